@@ -1,0 +1,203 @@
+/* omni_avsr.h — C ABI of libomniavsr_hip.so (MI355X / gfx950).
+ *
+ * This library is the drop-in for the tensor work behind the reference's Python boundary
+ *   AVSR_LLMs.forward(inputs, is_trainval=False, modality, test_ratio_matry_audio, test_ratio_matry_video)
+ *   (Omni_AVSR/modeling_OmniAVSR.py:263,308-323)  ->  llm.generate(...)  (:313-322).
+ * The reference has no FFI layer of its own; the Python shim `omni_avsr_amd.modeling.AVSR_LLMs`
+ * binds these entry points with ctypes (see INTEGRATION.md for the stub a maintainer would add).
+ *
+ * Conventions: every pointer named *_dev is device memory owned by the caller; *_host is host memory read
+ * before the call returns.  All calls are asynchronous on `stream` (a hipStream_t passed as void*), allocate
+ * nothing, never throw; return 0 on success, <0 on error (message: oavsr_last_error()).  One oavsr_model is
+ * immutable and shareable; one oavsr_workspace per stream.  One process per GPU.
+ */
+#ifndef OMNI_AVSR_H_
+#define OMNI_AVSR_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OAVSR_ABI_VERSION 1
+#define OAVSR_DT_F32 0  /* parity mode: exact-f32 MFMA */
+#define OAVSR_DT_BF16 1 /* throughput mode: bf16 storage, f32 accumulate (reference: bf16-true, eval_OmniAVSR.py:19) */
+#define OAVSR_MAX_RATES 8
+#define OAVSR_TASK_AUDIO 0
+#define OAVSR_TASK_VIDEO 1
+#define OAVSR_TASK_AUDIOVISUAL 2
+
+typedef struct oavsr_model oavsr_model;
+typedef struct oavsr_workspace oavsr_workspace;
+typedef void* oavsr_stream; /* hipStream_t */
+
+/* Mirrors the ctor arguments of AVSR_LLMs (modeling_OmniAVSR.py:28-34) + the HF configs it pulls in. */
+typedef struct oavsr_config {
+  int32_t dtype;
+  /* LLM (Llama_LoRA.py / Qwen_LoRA.py) */
+  int32_t llm_family; /* 0 llama, 1 qwen2 (no BOS, qkv bias) */
+  int32_t llm_hidden, llm_layers, llm_heads, llm_kv_heads, llm_head_dim, llm_mlp, llm_vocab;
+  float llm_rms_eps;
+  int32_t llm_qkv_bias;
+  int32_t lora_inner;         /* round(hidden / RANK), 0 = no LoRA (Llama_LoRA.py:125) */
+  int32_t lora_k2;            /* padded K of the fused LoRA segment (multiple of 64) */
+  int32_t lora_task_specific; /* IS_TASK_SPECIFIC */
+  /* Whisper encoder */
+  int32_t wh_dim, wh_layers, wh_heads, wh_ffn;
+  /* AV-HuBERT */
+  int32_t av_dim, av_layers, av_heads, av_ffn, av_conv_pos, av_conv_groups;
+  int32_t av_lora_k2; /* 0 = no LoRA on the video encoder (modeling_OmniAVSR.py:125-142) */
+  /* compressor + projector (modeling_OmniAVSR.py:86-111,171-196) */
+  int32_t proj_inter;
+  int32_t compression_stack; /* 0 avg-pooling, 1 stack */
+  int32_t n_rates_audio, rates_audio[OAVSR_MAX_RATES];
+  int32_t n_rates_video, rates_video[OAVSR_MAX_RATES];
+  int32_t proj_per_rate; /* 1: one projector per rate (ModuleList), 0: single projector */
+  int32_t proj_layernorm_audio, proj_layernorm_video; /* LayerNorm really present (index 3 of the Sequential) */
+  /* token ids (lightning_OmniAVSR.py:83-88, modeling_OmniAVSR.py:312-322) */
+  int32_t id_bos, id_eos, id_pad, id_audio_sos, id_audio_eos, id_video_sos, id_video_eos;
+  int32_t prompt_len[3]; /* tokens in prompt_audio / prompt_video / prompt_audiovisual buffers */
+} oavsr_config;
+
+typedef struct oavsr_tensor {
+  const char* name; /* packed-weight name, see omni_avsr_amd/weights.py */
+  uint64_t offset;  /* byte offset inside the device blob (256-byte aligned) */
+  uint64_t nbytes;
+} oavsr_tensor;
+
+int oavsr_abi_version(void);
+const char* oavsr_last_error(void);
+
+/* weights: one device blob + manifest (replaces AVSR_LLMs.load_state_dict, lightning_OmniAVSR.py:148-150) */
+int oavsr_model_create(const oavsr_config* cfg, const void* blob_dev, uint64_t blob_bytes, const oavsr_tensor* tensors,
+                       int32_t n_tensors, oavsr_model** out);
+void oavsr_model_destroy(oavsr_model* m);
+
+/* scratch + KV caches for batches of up to max_B utterances, max_Tv video frames / max_Ts samples each */
+int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, int32_t max_Ts, int32_t max_beams,
+                           int32_t max_new, oavsr_workspace** out);
+void oavsr_workspace_destroy(oavsr_workspace* ws);
+uint64_t oavsr_workspace_bytes(const oavsr_workspace* ws);
+
+/* ---- stage entry points (each replaces the reference function cited) ------------------------------------ */
+
+/* encode_video (modeling_OmniAVSR.py:461-483) = AVHubertModel.extract_finetune (hubert.py:695-755) + compressor.
+ * video_dev: f32 [sum(Tv)][88][88] (frames of all utterances back to back); out_dev: [sum(Tv/rate)][D or D*rate];
+ * enc_dev (optional): uncompressed encoder output [sum(Tv)][D]. */
+int oavsr_encode_video(const oavsr_model* m, oavsr_workspace* ws, const float* video_dev, const int32_t* Tv_host, int32_t B,
+                       int32_t rate, void* out_dev, void* enc_dev, oavsr_stream stream);
+
+/* encode_audio (modeling_OmniAVSR.py:528-558) = log-mel + WhisperEncoder + truncation (:537) + compressor.
+ * wav_dev: f32 [B][ld]; Ts_host: valid samples; keep_host: tokens kept per utterance (:537, computed by the shim);
+ * out_dev: [sum(keep/rate)][D or D*rate]; enc_dev (optional): [B][1500][D]; mel_dev (optional): [B][3000][80]. */
+int oavsr_encode_audio(const oavsr_model* m, oavsr_workspace* ws, const float* wav_dev, int64_t ld, const int32_t* Ts_host,
+                       const int32_t* keep_host, int32_t B, int32_t rate, void* out_dev, void* enc_dev, void* mel_dev,
+                       oavsr_stream stream);
+
+/* audio_proj / video_proj (modeling_OmniAVSR.py:429,447): which = 0 audio, 1 video */
+int oavsr_project(const oavsr_model* m, oavsr_workspace* ws, int32_t which, int32_t rate, const void* feats_dev, int32_t rows,
+                  void* out_dev, oavsr_stream stream);
+
+/* prepare_inputs, inference branch (modeling_OmniAVSR.py:406-458): splice BOS / <audio> A </audio> / <video> V </video> /
+ * prompt.  na_host / nv_host: projected tokens per utterance (NULL when the modality is absent).
+ * embeds_dev: [sum(S)][hidden]; S_host_out: prompt length per utterance. */
+int oavsr_build_prompt(const oavsr_model* m, oavsr_workspace* ws, int32_t task, int32_t B, const int32_t* na_host,
+                       const void* audio_tok_dev, const int32_t* nv_host, const void* video_tok_dev, void* embeds_dev,
+                       int32_t* S_host_out, oavsr_stream stream);
+
+/* LLM prompt pass (LlamaForCausalLM_lora.forward, Llama_LoRA.py:328-398; once per utterance, last-position logits
+ * only).  Fills the prefix KV cache of the workspace.  logits_dev (optional): f32 [B][vocab]. */
+int oavsr_prefill(const oavsr_model* m, oavsr_workspace* ws, int32_t task, int32_t B, const void* embeds_dev,
+                  const int32_t* S_host, float* logits_dev, oavsr_stream stream);
+
+/* generate (modeling_OmniAVSR.py:313-322) after oavsr_prefill: beams == 1 greedy, > 1 HF beam search.
+ * out_ids_dev: int32 [B][max_new] (pad-filled); out_len_dev: int32 [B].  force_len: suppress EOS (benchmarks). */
+int oavsr_decode(const oavsr_model* m, oavsr_workspace* ws, int32_t task, int32_t B, int32_t beams, int32_t max_new,
+                 int32_t force_len, int32_t* out_ids_dev, int32_t* out_len_dev, oavsr_stream stream);
+
+/* AVSR_LLMs.forward(inputs, is_trainval=False) end to end (modeling_OmniAVSR.py:308-323). */
+int oavsr_generate(const oavsr_model* m, oavsr_workspace* ws, int32_t task, const float* video_dev, const int32_t* Tv_host,
+                   const float* wav_dev, int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host, int32_t B,
+                   int32_t rate_audio, int32_t rate_video, int32_t beams, int32_t max_new, int32_t force_len,
+                   int32_t* out_ids_dev, int32_t* out_len_dev, oavsr_stream stream);
+
+/* ---- profiling hook (bench.py roofline): per-kernel-family HIP-event timing of every launch ---------------- */
+typedef struct oavsr_prof_entry {
+  char name[32];
+  uint64_t launches;
+  double ms;    /* summed HIP-event duration */
+  double flops; /* algorithmic flops (2*M*N*K) */
+  double bytes; /* algorithmic bytes */
+} oavsr_prof_entry;
+int oavsr_profile_enable(int32_t on); /* on=1: bracket launches with events (serialises the stream); 0: off */
+int oavsr_profile_reset(void);
+int oavsr_profile_read(oavsr_prof_entry* out, int32_t max_entries); /* returns number of entries, syncs events */
+
+/* ---- single-kernel entry points (parity tests of each HIP kernel through the C ABI) ------------------------- */
+typedef struct oavsr_gemm_desc {
+  int32_t dtype, M, N, K, K2;
+  const void *A, *W, *A2, *W2;
+  int64_t lda, ldw, lda2, ldw2;
+  void* C;
+  int64_t ldc;
+  int32_t out_f32;
+  const float *col_scale, *col_bias, *prelu;
+  int32_t act; /* 0 none, 1 gelu, 2 relu, 3 prelu, 4 silu */
+  const void* residual;
+  int64_t ldr;
+  int32_t res_after_act;
+  int32_t groups, a_goff;
+  int32_t amode; /* 0 dense, 1 conv2d NHWC, 2 conv1d token-major, 3 video stem */
+  int32_t H, W_, Cin, OH, OW, stride, pad, ksize;
+  const int32_t* rowinfo; /* int4 per output row */
+  int32_t taps, Kvalid;
+  const int32_t* frameinfo; /* int2 per frame */
+  int32_t skinny;           /* 1: decode kernel (M <= 128) */
+} oavsr_gemm_desc;
+int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream);
+
+typedef struct oavsr_attn_desc {
+  int32_t dtype, head_dim, n_heads, n_kv_heads, n_seqs, max_q, causal;
+  const void *Q, *K, *V;
+  void* O;
+  int64_t ldq, ldk, ldv, ldo;
+  const int32_t *cu_q, *cu_k;
+  float scale;
+} oavsr_attn_desc;
+int oavsr_op_attention(const oavsr_attn_desc* d, oavsr_stream stream);
+
+typedef struct oavsr_decode_attn_desc {
+  int32_t dtype, head_dim, n_heads, n_kv_heads, rows, beams, max_prefix, max_tail;
+  const void *Q, *Kp, *Vp, *Kt, *Vt;
+  void* O;
+  int64_t ldq, ldo;
+  const int32_t *prefix_len, *step, *anc;
+  float scale;
+} oavsr_decode_attn_desc;
+int oavsr_op_decode_attention(const oavsr_decode_attn_desc* d, oavsr_stream stream);
+
+/* mode: 0 LayerNorm, 1 RMSNorm, 2 LayerNorm over [zeros(D), x] */
+int oavsr_op_norm(int32_t mode, int32_t dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, const float* b,
+                  int32_t rows, int32_t D, float eps, oavsr_stream stream);
+int oavsr_op_maxpool3x3s2(int32_t dtype, const void* x, void* y, int32_t imgs, int32_t H, int32_t W, int32_t C, oavsr_stream stream);
+int oavsr_op_avgpool_hw(int32_t dtype, const void* x, void* y, int32_t imgs, int32_t HW, int32_t C, oavsr_stream stream);
+int oavsr_op_time_compress(int32_t dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const int32_t* seg_dev, int32_t n_seqs,
+                           int32_t max_out, int32_t rate, int32_t C, int32_t stack, oavsr_stream stream);
+int oavsr_op_copy_rows(int32_t dtype, const void* src, int64_t lds, const int32_t* map_dev, void* y, int64_t ldy, int32_t n,
+                       int32_t D, oavsr_stream stream);
+int oavsr_op_rope_kv(int32_t dtype, int32_t rows, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, void* qkv, int64_t ld,
+                     const float* inv_freq, const int32_t* pos, const int32_t* slot, const int32_t* cpos, void* kcache,
+                     void* vcache, int32_t max_ctx, oavsr_stream stream);
+int oavsr_op_swiglu(int32_t dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t I, oavsr_stream stream);
+int oavsr_op_argmax(const float* logits, int64_t ld, int32_t rows, int32_t V, int32_t banned, int32_t* out, oavsr_stream stream);
+int oavsr_op_build_rowinfo(const int32_t* cu_out, const int32_t* cu_in, int32_t n_seqs, int32_t stride, int32_t* rowinfo,
+                           int32_t rows, oavsr_stream stream);
+/* twiddle / mel filterbank come from the model (built at oavsr_model_create) */
+int oavsr_op_logmel(const oavsr_model* m, int32_t dtype, const float* wav, int64_t ld, const int32_t* lens_dev, int32_t B,
+                    float* mel_ws, float* max_ws, void* out, int64_t ldo, oavsr_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMNI_AVSR_H_ */

@@ -1,0 +1,143 @@
+// Internal launcher API of the gfx950 kernels (host side).  Every launcher is asynchronous on the
+// given stream, allocates nothing and never synchronises (hipGraph-capturable).
+#pragma once
+#include "common.h"
+
+namespace oavsr {
+
+enum AMode : int { A_DENSE = 0, A_CONV2D = 1, A_CONV1D = 2, A_STEM = 3 };
+enum Act : int { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_PRELU = 3, ACT_SILU = 4 };
+
+// C[M,N] = epi( A1[M,K1] . W1[N,K1]^T + A2[M,K2] . W2[N,K2]^T )
+// W is stored [N][K] (K contiguous) exactly like torch.nn.Linear.weight.
+struct GemmArgs {
+  int dtype = DT_BF16;       // element type of A, W, residual (and C unless out_f32)
+  int M = 0, N = 0;
+  const void* A = nullptr;  int64_t lda = 0;
+  const void* W = nullptr;  int64_t ldw = 0;  int K = 0;     // K1 (elements), multiple of 128B/elt
+  const void* A2 = nullptr; int64_t lda2 = 0;
+  const void* W2 = nullptr; int64_t ldw2 = 0; int K2 = 0;    // optional second K segment (LoRA)
+  void* C = nullptr; int64_t ldc = 0; int out_f32 = 0;
+  // epilogue: y = acc*col_scale[n] + col_bias[n]; then residual/activation
+  const float* col_scale = nullptr;
+  const float* col_bias = nullptr;
+  const float* prelu = nullptr;      // per-column slope (ACT_PRELU)
+  int act = ACT_NONE;
+  const void* residual = nullptr; int64_t ldr = 0;
+  int res_after_act = 0;             // 0: act(y + res)   1: res + act(y)
+  // grouped / batched: blockIdx.z = g; A channel offset g*a_goff, W row offset g*N, C col offset g*N
+  int groups = 1; int a_goff = 0;
+  // A gather
+  int amode = A_DENSE;
+  // A_CONV2D: NHWC input [img][H][Wd][C], ksize x ksize, stride, pad; M = imgs*OH*OW, K = ksize^2*C
+  int H = 0, Wd = 0, Cin = 0, OH = 0, OW = 0, stride = 1, pad = 0, ksize = 1;
+  // A_CONV1D: token-major input x[row][Cin_total]; K index = tap*Cin + c; rowinfo[m] = {center_row, t_center, len_in, 0}
+  const int4* rowinfo = nullptr; int taps = 0; int Kvalid = 0;   // Kvalid = taps*Cin (<= K, rest zero)
+  // A_STEM: input f32 video [frame][88][88]; frameinfo[frame] = {t, len}; M = frames*44*44, K = 256 (245 valid)
+  const int2* frameinfo = nullptr;
+};
+int launch_gemm(const GemmArgs& a, hipStream_t st);
+
+// Skinny (decode) GEMM: M <= 128 rows, weights streamed once.  Same math/epilogue subset.
+int launch_gemm_skinny(const GemmArgs& a, hipStream_t st);
+
+// ---- attention ---------------------------------------------------------------------------------
+struct AttnArgs {
+  int dtype = DT_BF16;
+  int head_dim = 64;                 // 64 or 128
+  int n_heads = 0, n_kv_heads = 0;
+  int n_seqs = 0;
+  const void* Q = nullptr; int64_t ldq = 0;     // Q[row][head*hd + d]
+  const void* K = nullptr; int64_t ldk = 0;     // K[row][kvhead*hd + d]
+  const void* V = nullptr; int64_t ldv = 0;
+  void* O = nullptr; int64_t ldo = 0;
+  const int* cu_q = nullptr;         // [n_seqs+1] row offsets of queries (device)
+  const int* cu_k = nullptr;         // [n_seqs+1] row offsets of keys
+  int max_q = 0;                     // max query length (host) -> grid
+  float scale = 1.f;
+  int causal = 0;                    // key j visible to query i iff j <= i + (klen - qlen)
+};
+int launch_attention(const AttnArgs& a, hipStream_t st);
+
+// Decode attention (one new token per row).  KV cache layout: [seq][kv_head][max_ctx][hd].
+// Beams: row r belongs to utterance r / beams; positions < prefix_len[utt] are read from the
+// utterance's shared prefix cache (slot = utt), later positions from tail caches through `anc`.
+struct DecodeAttnArgs {
+  int dtype = DT_BF16;
+  int head_dim = 64, n_heads = 0, n_kv_heads = 0;
+  int rows = 0, beams = 1;
+  const void* Q = nullptr; int64_t ldq = 0;
+  void* O = nullptr; int64_t ldo = 0;
+  const void* Kp = nullptr; const void* Vp = nullptr;   // prefix caches [utt][kvh][max_prefix][hd]
+  int max_prefix = 0;
+  const void* Kt = nullptr; const void* Vt = nullptr;   // tail caches   [row][kvh][max_tail][hd]
+  int max_tail = 0;
+  const int* prefix_len = nullptr;   // [utts] device
+  const int* step = nullptr;         // device scalar: number of tail tokens INCLUDING the current one
+  const int* anc = nullptr;          // [rows][max_tail] row that holds tail position t (null: own row)
+  float scale = 1.f;
+};
+int launch_decode_attention(const DecodeAttnArgs& a, hipStream_t st);
+
+// ---- normalisation / elementwise ----------------------------------------------------------------
+int launch_layernorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, const float* b,
+                     int rows, int D, float eps, hipStream_t st);
+// LayerNorm over the virtual concat [zeros(D), x[D]] -> y[2D]  (hubert.py:709-721)
+int launch_layernorm_zero_prefix(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w,
+                                 const float* b, int rows, int D, float eps, hipStream_t st);
+int launch_rmsnorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, int rows, int D,
+                   float eps, hipStream_t st);
+// 3x3 stride-2 pad-1 max pool, NHWC
+int launch_maxpool3x3s2(int dtype, const void* x, void* y, int imgs, int H, int W, int C, hipStream_t st);
+// global average pool over HW, NHWC -> [imgs][C]
+int launch_avgpool_hw(int dtype, const void* x, void* y, int imgs, int HW, int C, hipStream_t st);
+// Time compressor (modeling_OmniAVSR.py:480-483 / :507-514): per sequence, out row j = mean (or concat) of
+// in rows [in_off + j*rate, +rate).  seg[] = {in_off, out_off, n_out} per sequence (device).
+int launch_time_compress(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const int4* seg, int n_seqs,
+                         int max_out, int rate, int C, int stack, hipStream_t st);
+// gather rows: y[i] = table[ids[i]]
+int launch_embed(int dtype, const void* table, int64_t ldt, const int* ids, void* y, int64_t ldy, int n, int D,
+                 hipStream_t st);
+// copy rows with per-row source map: y[i] = src[map[i]] (map<0 -> skip)
+int launch_copy_rows(int dtype, const void* src, int64_t lds, const int* map, void* y, int64_t ldy, int n, int D,
+                     hipStream_t st);
+// RoPE (rotate-half, HF convention) applied in place to q and k slices of a fused qkv buffer; cos/sin computed
+// from inv_freq[hd/2] and pos[row].  Optionally scatters k,v rows into a KV cache [slot][kvh][max_ctx][hd].
+struct RopeArgs {
+  int dtype = DT_BF16; int rows = 0; int n_heads = 0, n_kv_heads = 0, head_dim = 64;
+  void* qkv = nullptr; int64_t ld = 0;          // [row][ (H + 2*KV) * hd ]
+  const float* inv_freq = nullptr;              // [hd/2]
+  const int* pos = nullptr;                     // [rows] absolute position
+  const int* slot = nullptr;                    // [rows] cache slot (sequence / row)
+  const int* cpos = nullptr;                    // [rows] position inside the cache
+  void* kcache = nullptr; void* vcache = nullptr; int max_ctx = 0;
+};
+int launch_rope_kv(const RopeArgs& a, hipStream_t st);
+// y[m][j] = silu(x[m][j]) * x[m][I + j]
+int launch_swiglu(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int rows, int I, hipStream_t st);
+// argmax over fp32 logits rows (ties -> lowest index, as torch.argmax); optional banned token
+int launch_argmax(const float* logits, int64_t ld, int rows, int V, int banned, int* out, hipStream_t st);
+// segment metadata
+int launch_build_rowinfo(const int* cu_out, const int* cu_in, int n_seqs, int stride, int4* rowinfo, int rows,
+                         hipStream_t st);
+
+// ---- audio front-end ----------------------------------------------------------------------------
+// Whisper log-mel (K10): wav f32 [B][ld] (first lens[b] samples valid, rest treated as the 30 s zero padding)
+// -> out [B][3000][80] in dtype.  twiddle = {cos,sin}(2*pi*k/400) as doubles [400][2]; melfb f32 [201][80];
+// mel_ws f32 [B][3000][80]; max_ws f32 [B].
+int launch_logmel(int dtype, const float* wav, int64_t ld, const int* lens, int B, const double* twiddle,
+                  const float* melfb, float* mel_ws, float* max_ws, void* out, int64_t ldo, hipStream_t st);
+
+// ---- greedy bookkeeping ---------------------------------------------------------------------------
+struct GreedyState {
+  int* tok;        // [B] current token per row (input of the next step)
+  int* finished;   // [B]
+  int* out_ids;    // [B][max_new]
+  int* out_len;    // [B]
+  int* step;       // scalar: number of generated tokens so far
+  int* pos;        // [B] absolute position of the next token
+  int* cpos;       // [B] cache position of the next token
+};
+int launch_greedy_update(const int* argmax, GreedyState s, int B, int max_new, int eos, int pad, hipStream_t st);
+
+}  // namespace oavsr

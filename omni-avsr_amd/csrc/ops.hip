@@ -1,0 +1,424 @@
+// HBM-bound kernels: normalisation, pooling, token compressor, row gathers, RoPE + KV-cache write, SwiGLU,
+// arg-max and greedy bookkeeping.  All loads/stores are 16-byte vectors (4 x f32 / 8 x bf16) per lane,
+// one wave (64 lanes) per row where a row reduction is needed, statistics in fp32.
+#include "kernels.h"
+
+namespace oavsr {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWavesPerBlock = 4;
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm / RMSNorm: one wave per row.  MODE 0 = LayerNorm, 1 = RMSNorm, 2 = LayerNorm over [zeros(D), x]
+// ---------------------------------------------------------------------------------------------
+template <typename T, int MODE>
+__global__ __launch_bounds__(kThreads) void norm_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy,
+                                                         const float* __restrict__ w, const float* __restrict__ b, int rows, int D,
+                                                         float eps) {
+  constexpr int VEC = TypeInfo<T>::kVec;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * kWavesPerBlock + wave;
+  if (row >= rows) return;
+  const T* xr = x + (int64_t)row * ldx;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane * VEC; c < D; c += 64 * VEC) {
+    float f[VEC];
+    chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(xr + c), f);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { s1 += f[e]; s2 += f[e] * f[e]; }
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  const float n = (MODE == 2) ? 2.f * D : (float)D;
+  float mean = (MODE == 1) ? 0.f : s1 / n;
+  float var = s2 / n - mean * mean;
+  if (MODE != 1) {
+    // two-pass variance for accuracy (matches torch's Welford result to fp32 rounding)
+    float v2 = 0.f;
+    for (int c = lane * VEC; c < D; c += 64 * VEC) {
+      float f[VEC];
+      chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(xr + c), f);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { float d = f[e] - mean; v2 += d * d; }
+    }
+    v2 = wave_sum(v2);
+    if (MODE == 2) v2 += (float)D * mean * mean;   // the D zero inputs
+    var = v2 / n;
+  }
+  const float rstd = rsqrtf(var + eps);
+  T* yr = y + (int64_t)row * ldy;
+  if (MODE == 2) {
+    const float z = -mean * rstd;
+    for (int c = lane * VEC; c < D; c += 64 * VEC) {
+      float o[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = z * w[c + e] + b[c + e];
+      *reinterpret_cast<Chunk16*>(yr + c) = chunk_from_f32<T>(o);
+    }
+    yr += D; w += D; b += D;
+  }
+  for (int c = lane * VEC; c < D; c += 64 * VEC) {
+    float f[VEC], o[VEC];
+    chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(xr + c), f);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      if (MODE == 1) o[e] = w[c + e] * (f[e] * rstd);
+      else o[e] = (f[e] - mean) * rstd * w[c + e] + b[c + e];
+    }
+    *reinterpret_cast<Chunk16*>(yr + c) = chunk_from_f32<T>(o);
+  }
+}
+
+template <int MODE>
+int launch_norm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, const float* b, int rows, int D,
+                float eps, hipStream_t st) {
+  if (rows <= 0) return 0;
+  const int vec = dtype == DT_F32 ? 4 : 8;
+  OAVSR_REQUIRE(D % vec == 0 && ldx % vec == 0 && ldy % vec == 0, "norm: D=%d and strides must be multiples of %d", D, vec);
+  dim3 grid(ceil_div(rows, kWavesPerBlock));
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL((norm_kernel<float, MODE>), grid, dim3(kThreads), 0, st, (const float*)x, ldx, (float*)y, ldy, w, b, rows, D, eps);
+  else
+    hipLaunchKernelGGL((norm_kernel<bf16_t, MODE>), grid, dim3(kThreads), 0, st, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, w, b, rows, D, eps);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NHWC pools
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kThreads) void maxpool3x3s2_kernel(const T* __restrict__ x, T* __restrict__ y, int imgs, int H, int W, int C) {
+  constexpr int VEC = TypeInfo<T>::kVec;
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1, CV = C / VEC;
+  const int64_t total = (int64_t)imgs * OH * OW * CV;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+    int cv = (int)(i % CV);
+    int64_t r = i / CV;
+    int ox = (int)(r % OW); r /= OW;
+    int oy = (int)(r % OH);
+    int img = (int)(r / OH);
+    float m[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) m[e] = -INFINITY;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      int iy = oy * 2 - 1 + ky;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        int ix = ox * 2 - 1 + kx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        float f[VEC];
+        chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(x + (((int64_t)img * H + iy) * W + ix) * C + cv * VEC), f);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) m[e] = fmaxf(m[e], f[e]);
+      }
+    }
+    *reinterpret_cast<Chunk16*>(y + (((int64_t)img * OH + oy) * OW + ox) * C + cv * VEC) = chunk_from_f32<T>(m);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void avgpool_hw_kernel(const T* __restrict__ x, T* __restrict__ y, int imgs, int HW, int C) {
+  constexpr int VEC = TypeInfo<T>::kVec;
+  const int CV = C / VEC;
+  const int64_t total = (int64_t)imgs * CV;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+    int cv = (int)(i % CV);
+    int img = (int)(i / CV);
+    float a[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) a[e] = 0.f;
+    for (int p = 0; p < HW; ++p) {
+      float f[VEC];
+      chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(x + ((int64_t)img * HW + p) * C + cv * VEC), f);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) a[e] += f[e];
+    }
+    const float inv = 1.f / HW;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) a[e] *= inv;
+    *reinterpret_cast<Chunk16*>(y + (int64_t)img * C + cv * VEC) = chunk_from_f32<T>(a);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Matryoshka time compressor: avg-pool (kernel = stride = rate, floor) or frame stacking.
+// grid = (max_out, n_seqs); one workgroup per output token, lanes stride the channel chunks.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kThreads) void time_compress_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy,
+                                                                  const int4* __restrict__ seg, int rate, int C, int stack) {
+  constexpr int VEC = TypeInfo<T>::kVec;
+  const int4 s = seg[blockIdx.y];
+  const int j = blockIdx.x;
+  if (j >= s.z) return;
+  const T* xr = x + (int64_t)(s.x + j * rate) * ldx;
+  T* yr = y + (int64_t)(s.y + j) * ldy;
+  const int CV = C / VEC;
+  if (stack) {
+    for (int i = threadIdx.x; i < rate * CV; i += kThreads) {
+      int r = i / CV, cv = i - r * CV;
+      *reinterpret_cast<Chunk16*>(yr + (int64_t)r * C + cv * VEC) = *reinterpret_cast<const Chunk16*>(xr + (int64_t)r * ldx + cv * VEC);
+    }
+  } else {
+    const float inv = 1.f / rate;
+    for (int cv = threadIdx.x; cv < CV; cv += kThreads) {
+      float a[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) a[e] = 0.f;
+      for (int r = 0; r < rate; ++r) {
+        float f[VEC];
+        chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(xr + (int64_t)r * ldx + cv * VEC), f);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] += f[e];
+      }
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) a[e] *= inv;
+      *reinterpret_cast<Chunk16*>(yr + cv * VEC) = chunk_from_f32<T>(a);
+    }
+  }
+}
+
+// y[i] = src[map[i]]  (map < 0: leave untouched).  One wave per row.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void copy_rows_kernel(const T* __restrict__ src, int64_t lds, const int* __restrict__ map,
+                                                              T* __restrict__ y, int64_t ldy, int n, int D) {
+  constexpr int VEC = TypeInfo<T>::kVec;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * kWavesPerBlock + wave;
+  if (row >= n) return;
+  const int s = map[row];
+  if (s < 0) return;
+  for (int c = lane * VEC; c < D; c += 64 * VEC)
+    *reinterpret_cast<Chunk16*>(y + (int64_t)row * ldy + c) = *reinterpret_cast<const Chunk16*>(src + (int64_t)s * lds + c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// RoPE (HF rotate_half convention) in place on the q and k slices of a fused [q|k|v] row, then scatter of
+// the rotated k and of v into the KV cache.  grid = rows, block = 256.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kThreads) void rope_kv_kernel(const RopeArgs p) {
+  const int row = blockIdx.x;
+  const int HD = p.head_dim, half = HD / 2;
+  T* base = reinterpret_cast<T*>(p.qkv) + (int64_t)row * p.ld;
+  const float pos = (float)p.pos[row];
+  const int nrot = (p.n_heads + p.n_kv_heads) * half;
+  for (int i = threadIdx.x; i < nrot; i += kThreads) {
+    int h = i / half, d = i - h * half;
+    float ang = pos * p.inv_freq[d];
+    float sn, cs;
+    sincosf(ang, &sn, &cs);
+    T* v = base + (int64_t)h * HD;
+    float x0 = to_f32(v[d]), x1 = to_f32(v[d + half]);
+    v[d] = from_f32<T>(x0 * cs - x1 * sn);
+    v[d + half] = from_f32<T>(x1 * cs + x0 * sn);
+  }
+  if (p.kcache == nullptr) return;
+  __syncthreads();
+  const int slot = p.slot[row], cp = p.cpos[row];
+  const T* k = base + (int64_t)p.n_heads * HD;
+  const T* v = k + (int64_t)p.n_kv_heads * HD;
+  T* kc = reinterpret_cast<T*>(p.kcache);
+  T* vc = reinterpret_cast<T*>(p.vcache);
+  for (int i = threadIdx.x; i < p.n_kv_heads * HD; i += kThreads) {
+    int h = i / HD, d = i - h * HD;
+    int64_t o = (((int64_t)slot * p.n_kv_heads + h) * p.max_ctx + cp) * HD + d;
+    kc[o] = k[i];
+    vc[o] = v[i];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void swiglu_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, int rows, int I) {
+  constexpr int VEC = TypeInfo<T>::kVec;
+  const int IV = I / VEC;
+  const int64_t total = (int64_t)rows * IV;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+    int cv = (int)(i % IV);
+    int64_t r = i / IV;
+    float g[VEC], u[VEC];
+    chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(x + r * ldx + cv * VEC), g);
+    chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(x + r * ldx + I + cv * VEC), u);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) g[e] = silu(g[e]) * u[e];
+    *reinterpret_cast<Chunk16*>(y + r * ldy + cv * VEC) = chunk_from_f32<T>(g);
+  }
+}
+
+// arg-max of one fp32 row per workgroup; ties resolve to the lowest index (torch.argmax on CPU / HF greedy).
+__global__ __launch_bounds__(kThreads) void argmax_kernel(const float* __restrict__ logits, int64_t ld, int V, int banned, int* __restrict__ out) {
+  __shared__ float sv[kWavesPerBlock];
+  __shared__ int si[kWavesPerBlock];
+  const float* r = logits + (int64_t)blockIdx.x * ld;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < V; i += kThreads) {
+    float v = r[i];
+    if (i == banned) v = -INFINITY;
+    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(best, o, 64);
+    int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sv[wave] = best; si[wave] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kWavesPerBlock; ++w)
+      if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+    out[blockIdx.x] = bi;
+  }
+}
+
+// Greedy bookkeeping, one thread per row (HF GenerationMixin greedy: finished rows emit pad).
+__global__ void greedy_update_kernel(const int* __restrict__ amax, GreedyState s, int B, int max_new, int eos, int pad) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int step = *s.step;
+  if (b < B) {
+    int tok = amax[b];
+    if (s.finished[b]) tok = pad;
+    else {
+      s.out_len[b] = step + 1;
+      if (tok == eos) s.finished[b] = 1;
+    }
+    if (step < max_new) s.out_ids[(int64_t)b * max_new + step] = tok;
+    s.tok[b] = tok;
+    s.pos[b] += 1;
+    s.cpos[b] += 1;
+  }
+  // all rows read `step` before anyone bumps it: single block launch guarantees this via the barrier below
+  __syncthreads();
+  if (b == 0) *s.step = step + 1;
+}
+
+__global__ void rowinfo_kernel(const int* __restrict__ cu_out, const int* __restrict__ cu_in, int n_seqs, int stride, int4* __restrict__ ri, int rows) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= rows) return;
+  int s = 0;
+  while (s + 1 < n_seqs && cu_out[s + 1] <= m) ++s;
+  int t = m - cu_out[s];
+  int len_in = cu_in[s + 1] - cu_in[s];
+  ri[m] = make_int4(cu_in[s] + t * stride, t * stride, len_in, s);
+}
+
+}  // namespace
+
+int launch_layernorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, const float* b, int rows, int D,
+                     float eps, hipStream_t st) {
+  return launch_norm<0>(dtype, x, ldx, y, ldy, w, b, rows, D, eps, st);
+}
+int launch_layernorm_zero_prefix(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, const float* b,
+                                 int rows, int D, float eps, hipStream_t st) {
+  return launch_norm<2>(dtype, x, ldx, y, ldy, w, b, rows, D, eps, st);
+}
+int launch_rmsnorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, int rows, int D, float eps,
+                   hipStream_t st) {
+  return launch_norm<1>(dtype, x, ldx, y, ldy, w, nullptr, rows, D, eps, st);
+}
+
+static int grid_for(int64_t total) {
+  int64_t g = (total + kThreads - 1) / kThreads;
+  if (g > 256 * 8) g = 256 * 8;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+int launch_maxpool3x3s2(int dtype, const void* x, void* y, int imgs, int H, int W, int C, hipStream_t st) {
+  if (imgs <= 0) return 0;
+  const int vec = dtype == DT_F32 ? 4 : 8;
+  OAVSR_REQUIRE(C % vec == 0, "maxpool: C=%d", C);
+  int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  int g = grid_for((int64_t)imgs * OH * OW * (C / vec));
+  if (dtype == DT_F32) hipLaunchKernelGGL(maxpool3x3s2_kernel<float>, dim3(g), dim3(kThreads), 0, st, (const float*)x, (float*)y, imgs, H, W, C);
+  else hipLaunchKernelGGL(maxpool3x3s2_kernel<bf16_t>, dim3(g), dim3(kThreads), 0, st, (const bf16_t*)x, (bf16_t*)y, imgs, H, W, C);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_avgpool_hw(int dtype, const void* x, void* y, int imgs, int HW, int C, hipStream_t st) {
+  if (imgs <= 0) return 0;
+  const int vec = dtype == DT_F32 ? 4 : 8;
+  OAVSR_REQUIRE(C % vec == 0, "avgpool: C=%d", C);
+  int g = grid_for((int64_t)imgs * (C / vec));
+  if (dtype == DT_F32) hipLaunchKernelGGL(avgpool_hw_kernel<float>, dim3(g), dim3(kThreads), 0, st, (const float*)x, (float*)y, imgs, HW, C);
+  else hipLaunchKernelGGL(avgpool_hw_kernel<bf16_t>, dim3(g), dim3(kThreads), 0, st, (const bf16_t*)x, (bf16_t*)y, imgs, HW, C);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_time_compress(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const int4* seg, int n_seqs, int max_out,
+                         int rate, int C, int stack, hipStream_t st) {
+  if (n_seqs <= 0 || max_out <= 0) return 0;
+  const int vec = dtype == DT_F32 ? 4 : 8;
+  OAVSR_REQUIRE(C % vec == 0 && ldx % vec == 0 && ldy % vec == 0 && rate >= 1, "time_compress: bad geometry");
+  dim3 grid(max_out, n_seqs);
+  if (dtype == DT_F32) hipLaunchKernelGGL(time_compress_kernel<float>, grid, dim3(kThreads), 0, st, (const float*)x, ldx, (float*)y, ldy, seg, rate, C, stack);
+  else hipLaunchKernelGGL(time_compress_kernel<bf16_t>, grid, dim3(kThreads), 0, st, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, seg, rate, C, stack);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_copy_rows(int dtype, const void* src, int64_t lds, const int* map, void* y, int64_t ldy, int n, int D, hipStream_t st) {
+  if (n <= 0) return 0;
+  const int vec = dtype == DT_F32 ? 4 : 8;
+  OAVSR_REQUIRE(D % vec == 0 && lds % vec == 0 && ldy % vec == 0, "copy_rows: D=%d", D);
+  dim3 grid(ceil_div(n, kWavesPerBlock));
+  if (dtype == DT_F32) hipLaunchKernelGGL(copy_rows_kernel<float>, grid, dim3(kThreads), 0, st, (const float*)src, lds, map, (float*)y, ldy, n, D);
+  else hipLaunchKernelGGL(copy_rows_kernel<bf16_t>, grid, dim3(kThreads), 0, st, (const bf16_t*)src, lds, map, (bf16_t*)y, ldy, n, D);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_embed(int dtype, const void* table, int64_t ldt, const int* ids, void* y, int64_t ldy, int n, int D, hipStream_t st) {
+  return launch_copy_rows(dtype, table, ldt, ids, y, ldy, n, D, st);
+}
+
+int launch_rope_kv(const RopeArgs& a, hipStream_t st) {
+  if (a.rows <= 0) return 0;
+  if (a.dtype == DT_F32) hipLaunchKernelGGL(rope_kv_kernel<float>, dim3(a.rows), dim3(kThreads), 0, st, a);
+  else hipLaunchKernelGGL(rope_kv_kernel<bf16_t>, dim3(a.rows), dim3(kThreads), 0, st, a);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_swiglu(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int rows, int I, hipStream_t st) {
+  if (rows <= 0) return 0;
+  const int vec = dtype == DT_F32 ? 4 : 8;
+  OAVSR_REQUIRE(I % vec == 0 && ldx % vec == 0 && ldy % vec == 0, "swiglu: I=%d", I);
+  int g = grid_for((int64_t)rows * (I / vec));
+  if (dtype == DT_F32) hipLaunchKernelGGL(swiglu_kernel<float>, dim3(g), dim3(kThreads), 0, st, (const float*)x, ldx, (float*)y, ldy, rows, I);
+  else hipLaunchKernelGGL(swiglu_kernel<bf16_t>, dim3(g), dim3(kThreads), 0, st, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, I);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_argmax(const float* logits, int64_t ld, int rows, int V, int banned, int* out, hipStream_t st) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(kThreads), 0, st, logits, ld, V, banned, out);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_greedy_update(const int* amax, GreedyState s, int B, int max_new, int eos, int pad, hipStream_t st) {
+  OAVSR_REQUIRE(B <= 1024, "greedy_update: B=%d > 1024", B);
+  int threads = ((B + 63) / 64) * 64;
+  hipLaunchKernelGGL(greedy_update_kernel, dim3(1), dim3(threads), 0, st, amax, s, B, max_new, eos, pad);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_build_rowinfo(const int* cu_out, const int* cu_in, int n_seqs, int stride, int4* rowinfo, int rows, hipStream_t st) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(rowinfo_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, st, cu_out, cu_in, n_seqs, stride, rowinfo, rows);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace oavsr
