@@ -1,0 +1,1006 @@
+// Host orchestration of the Omni-AVSR inference hot path + the C ABI (include/omni_avsr.h).
+//
+// Stage map (reference file:line each stage replaces is quoted in the header):
+//   encode_video  : stem conv3d (implicit GEMM) -> maxpool -> ResNet-18 trunk (implicit-GEMM convs, BN/PReLU/residual
+//                   fused) -> avgpool -> proj -> LN([0,x]) -> post_extract_proj -> grouped pos-conv (+GELU+res) ->
+//                   24 pre-LN layers (fused QKV + LoRA K-segment, flash attention, fused FFN epilogues) -> LN -> compressor
+//   encode_audio  : log-mel -> conv1/conv2 (implicit GEMM, GELU, +pos-emb) -> N pre-LN layers -> LN -> truncate -> compressor
+//   project       : Linear+ReLU, Linear(+LN)
+//   build_prompt  : row gathers into inputs_embeds
+//   prefill       : Llama/Qwen2 layers on all prompt rows of all utterances (var-len causal attention), KV prefix cache,
+//                   last-position logits only
+//   decode        : greedy loop, one skinny-GEMM step per token, no host sync inside the loop
+#include <stdarg.h>
+#include <math.h>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include <algorithm>
+
+#include "../../include/omni_avsr.h"
+#include "kernels.h"
+
+namespace oavsr {
+
+static thread_local char g_err[1024] = "";
+void set_last_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------------------
+// profiler: optional HIP-event bracket around every launch, aggregated per kernel family
+// ------------------------------------------------------------------------------------------------
+struct Profiler {
+  bool on = false;
+  struct Rec { int fam; hipEvent_t e0, e1; double flops, bytes; };
+  std::vector<Rec> recs;
+  std::vector<std::string> names;
+  std::vector<hipEvent_t> pool;
+  int family(const char* n) {
+    for (size_t i = 0; i < names.size(); ++i) if (names[i] == n) return (int)i;
+    names.push_back(n);
+    return (int)names.size() - 1;
+  }
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+  }
+  void reset() {
+    for (auto& r : recs) { pool.push_back(r.e0); pool.push_back(r.e1); }
+    recs.clear();
+  }
+};
+static Profiler g_prof;
+
+struct ProfScope {
+  hipStream_t st; int idx = -1;
+  ProfScope(const char* name, double flops, double bytes, hipStream_t s) : st(s) {
+    if (!g_prof.on) return;
+    Profiler::Rec r; r.fam = g_prof.family(name); r.e0 = g_prof.get(); r.e1 = g_prof.get(); r.flops = flops; r.bytes = bytes;
+    hipEventRecord(r.e0, st);
+    g_prof.recs.push_back(r);
+    idx = (int)g_prof.recs.size() - 1;
+  }
+  ~ProfScope() { if (idx >= 0) hipEventRecord(g_prof.recs[idx].e1, st); }
+};
+
+static const char* gemm_family(const GemmArgs& a, bool skinny) {
+  if (skinny) return a.dtype == DT_F32 ? "skinny_gemm_f32" : "skinny_gemm_bf16";
+  switch (a.amode) {
+    case A_DENSE: return a.dtype == DT_F32 ? "gemm_f32" : "gemm_bf16";
+    case A_CONV2D: return a.dtype == DT_F32 ? "conv2d_gemm_f32" : "conv2d_gemm_bf16";
+    case A_CONV1D: return a.dtype == DT_F32 ? "conv1d_gemm_f32" : "conv1d_gemm_bf16";
+    default: return a.dtype == DT_F32 ? "stem_gemm_f32" : "stem_gemm_bf16";
+  }
+}
+
+static int run_gemm(const GemmArgs& a, hipStream_t st, bool skinny = false) {
+  const double esz = a.dtype == DT_F32 ? 4 : 2;
+  const double kk = (double)a.K + a.K2;
+  const double flops = 2.0 * a.M * a.N * kk * a.groups;
+  const double bytes = esz * ((double)a.M * kk + (double)a.N * kk * a.groups) + (a.out_f32 ? 4 : esz) * (double)a.M * a.N * a.groups;
+  ProfScope ps(gemm_family(a, skinny), flops, bytes, st);
+  return skinny ? launch_gemm_skinny(a, st) : launch_gemm(a, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// model
+// ------------------------------------------------------------------------------------------------
+struct EncLayer {
+  const float *ln1w, *ln1b, *qkvb, *ob, *ln2w, *ln2b, *fc1b, *fc2b;
+  const void *qkvw, *lora_dn, *lora_up, *ow, *fc1w, *fc2w;
+};
+struct ConvBN { const void* w; const float *scale, *shift, *slope; };
+struct ResBlock { ConvBN c1, c2, down; bool has_down; int cin, cout, stride; };
+struct LlmLayer {
+  const float *ln1w, *ln2w, *qkvb;
+  const void *qkvw, *ow, *guw, *downw;
+  const void* lora_dn[3]; const void* lora_up[3];
+};
+struct Projector { const void *fc1w, *fc2w; const float *fc1b, *fc2b, *lnw, *lnb; };
+
+}  // namespace oavsr
+
+using namespace oavsr;
+
+struct oavsr_model {
+  oavsr_config cfg;
+  const char* blob = nullptr;
+  uint64_t blob_bytes = 0;
+  std::unordered_map<std::string, std::pair<uint64_t, uint64_t>> t;
+  int dtype = DT_BF16; size_t esz = 2;
+  // video
+  bool has_video = false, has_audio = false;
+  ConvBN stem; ResBlock blocks[8];
+  const void *vproj_w, *vpost_w, *vpos_w; const float *vproj_b, *vln_w, *vln_b, *vpost_b, *vpos_b, *vlnf_w, *vlnf_b;
+  std::vector<EncLayer> vlayers;
+  // audio
+  const void *aconv1_w, *aconv2_w, *apos; const float *aconv1_b, *aconv2_b, *alnf_w, *alnf_b;
+  std::vector<EncLayer> alayers;
+  std::vector<Projector> proj_a, proj_v;
+  // llm
+  const void *embed, *lm_head; const float *norm_w, *inv_freq;
+  std::vector<LlmLayer> llayers;
+  const void* prompt[3];
+  // constants built at create
+  double* twiddle = nullptr; float* melfb = nullptr;
+
+  const void* ptr(const std::string& n, bool required = true) const {
+    auto it = t.find(n);
+    if (it == t.end()) { if (required) set_last_error("missing packed tensor '%s'", n.c_str()); return nullptr; }
+    return blob + it->second.first;
+  }
+};
+
+struct oavsr_workspace {
+  const oavsr_model* m = nullptr;
+  int max_B = 0, max_Tv = 0, max_Ts = 0, max_beams = 1, max_new = 0;
+  char* arena = nullptr; size_t arena_bytes = 0, used = 0;
+  char* host_base = nullptr; char* host = nullptr; size_t host_bytes = 0, host_used = 0;   // pinned staging (2 halves)
+  hipEvent_t host_ev[2] = {nullptr, nullptr}; unsigned call_idx = 0;
+  // encoder scratch (shared by both encoders)
+  void *enc_x, *enc_h, *enc_qkv, *enc_attn, *enc_ffn, *enc_lora, *enc_out_v, *enc_out_a;
+  // video front
+  void *stem_out, *pool_out, *trunk[2], *feat512, *featproj, *ln2d;
+  int2* frameinfo; int4* rowinfo; int4* rowinfo2; int* cu_a; int* cu_b; int4* seg;
+  // audio front
+  void *mel, *conv1_out, *pos_rep; float *mel_ws, *max_ws; int* lens_dev;
+  // projector / prompt
+  void *comp_a, *comp_v, *proj_h, *tok_a, *tok_v, *embeds; int* maps;
+  // llm
+  void *lx, *lh, *lqkv, *lattn, *lgu, *lact, *llora, *lastx;
+  float* logits;
+  void *kpre, *vpre, *ktail, *vtail; int max_prefix = 0; size_t kpre_layer = 0, ktail_layer = 0;
+  int *pos, *slot, *cpos, *cu_s, *prefix_len, *last_rows;
+  int *amax; GreedyState gs;
+  int max_tok_enc = 0, max_S_total = 0;
+  int S_host[1024]; int B_cur = 0;
+
+  void* take(size_t bytes) {
+    size_t off = align_up(used, 256);
+    if (off + bytes > arena_bytes) return nullptr;
+    used = off + bytes;
+    return arena + off;
+  }
+  template <typename T> T* stage(size_t n) {   // pinned host staging (bump; reset per call)
+    size_t off = align_up(host_used, 64);
+    if (off + n * sizeof(T) > host_bytes) return nullptr;
+    host_used = off + n * sizeof(T);
+    return reinterpret_cast<T*>(host + off);
+  }
+};
+
+namespace oavsr {
+
+// Every API call stages its host metadata in one half of the pinned buffer; the half is reused two calls later, after
+// the event recorded at the end of the call that last used it (keeps back-to-back calls asynchronous).
+struct CallScope {
+  oavsr_workspace* ws; hipStream_t st; int half;
+  CallScope(oavsr_workspace* w, hipStream_t s) : ws(w), st(s) {
+    half = (int)(ws->call_idx++ & 1u);
+    hipEventSynchronize(ws->host_ev[half]);
+    ws->host = ws->host_base + (size_t)half * ws->host_bytes;
+    ws->host_used = 0;
+  }
+  ~CallScope() { hipEventRecord(ws->host_ev[half], st); }
+};
+
+static int h2d(void* dst, const void* src_pinned, size_t bytes, hipStream_t st) {
+  OAVSR_CHECK_HIP(hipMemcpyAsync(dst, src_pinned, bytes, hipMemcpyHostToDevice, st));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// slaney mel filterbank (librosa / transformers mel_filter_bank(norm="slaney", mel_scale="slaney")), [201][80]
+// ------------------------------------------------------------------------------------------------
+static void build_melfb(std::vector<float>& fb) {
+  const int nf = 201, nm = 80;
+  auto hz2mel = [](double f) { return f >= 1000.0 ? 15.0 + log(f / 1000.0) * (27.0 / log(6.4)) : 3.0 * f / 200.0; };
+  auto mel2hz = [](double m) { return m >= 15.0 ? 1000.0 * exp((log(6.4) / 27.0) * (m - 15.0)) : 200.0 * m / 3.0; };
+  std::vector<double> ff(nm + 2);
+  double m0 = hz2mel(0.0), m1 = hz2mel(8000.0);
+  for (int i = 0; i < nm + 2; ++i) ff[i] = mel2hz(m0 + (m1 - m0) * i / (nm + 1));
+  fb.assign((size_t)nf * nm, 0.f);
+  for (int f = 0; f < nf; ++f) {
+    double hz = 8000.0 * f / (nf - 1);
+    for (int m = 0; m < nm; ++m) {
+      double down = -(ff[m] - hz) / (ff[m + 1] - ff[m]);
+      double up = (ff[m + 2] - hz) / (ff[m + 2] - ff[m + 1]);
+      double v = std::max(0.0, std::min(down, up));
+      v *= 2.0 / (ff[m + 2] - ff[m]);
+      fb[(size_t)f * nm + m] = (float)v;
+    }
+  }
+}
+
+static int resolve_enc_layer(const oavsr_model* m, const std::string& p, bool lora, EncLayer& L) {
+#define GETP(field, name, req) L.field = (decltype(L.field))m->ptr(p + name, req); if (req && !L.field) return -1;
+  GETP(ln1w, "ln1.w", true) GETP(ln1b, "ln1.b", true) GETP(qkvw, "qkv.w", true) GETP(qkvb, "qkv.b", true)
+  GETP(ow, "o.w", true) GETP(ob, "o.b", true) GETP(ln2w, "ln2.w", true) GETP(ln2b, "ln2.b", true)
+  GETP(fc1w, "fc1.w", true) GETP(fc1b, "fc1.b", true) GETP(fc2w, "fc2.w", true) GETP(fc2b, "fc2.b", true)
+  GETP(lora_dn, "lora_dn.w", lora) GETP(lora_up, "lora_up.w", lora)
+#undef GETP
+  return 0;
+}
+
+static int resolve_convbn(const oavsr_model* m, const std::string& p, bool slope, ConvBN& c) {
+  c.w = m->ptr(p + ".w"); c.scale = (const float*)m->ptr(p + ".scale"); c.shift = (const float*)m->ptr(p + ".shift");
+  c.slope = slope ? (const float*)m->ptr(p + ".slope") : nullptr;
+  return (c.w && c.scale && c.shift && (!slope || c.slope)) ? 0 : -1;
+}
+
+static int resolve_model(oavsr_model* m) {
+  const oavsr_config& c = m->cfg;
+  m->has_video = m->t.count("v.stem.w") > 0;
+  m->has_audio = m->t.count("a.conv1.w") > 0;
+  if (m->has_video) {
+    OAVSR_TRY(resolve_convbn(m, "v.stem", true, m->stem));
+    const int chans[5] = {64, 64, 128, 256, 512};
+    for (int l = 1; l <= 4; ++l)
+      for (int b = 0; b < 2; ++b) {
+        ResBlock& rb = m->blocks[(l - 1) * 2 + b];
+        std::string p = "v.l" + std::to_string(l) + "." + std::to_string(b);
+        rb.cin = b == 0 ? chans[l - 1] : chans[l]; rb.cout = chans[l];
+        rb.stride = (b == 0 && l > 1) ? 2 : 1;
+        rb.has_down = (b == 0 && l > 1);
+        OAVSR_TRY(resolve_convbn(m, p + ".conv1", true, rb.c1));
+        OAVSR_TRY(resolve_convbn(m, p + ".conv2", true, rb.c2));
+        if (rb.has_down) OAVSR_TRY(resolve_convbn(m, p + ".down", false, rb.down));
+      }
+#define GETM(field, name) m->field = (decltype(m->field))m->ptr(name); if (!m->field) return -1;
+    GETM(vproj_w, "v.proj.w") GETM(vproj_b, "v.proj.b") GETM(vln_w, "v.ln.w") GETM(vln_b, "v.ln.b")
+    GETM(vpost_w, "v.post.w") GETM(vpost_b, "v.post.b") GETM(vpos_w, "v.pos.w") GETM(vpos_b, "v.pos.b")
+    GETM(vlnf_w, "v.lnf.w") GETM(vlnf_b, "v.lnf.b")
+    m->vlayers.resize(c.av_layers);
+    for (int i = 0; i < c.av_layers; ++i) OAVSR_TRY(resolve_enc_layer(m, "v.L" + std::to_string(i) + ".", c.av_lora_k2 > 0, m->vlayers[i]));
+  }
+  if (m->has_audio) {
+    GETM(aconv1_w, "a.conv1.w") GETM(aconv1_b, "a.conv1.b") GETM(aconv2_w, "a.conv2.w") GETM(aconv2_b, "a.conv2.b")
+    GETM(apos, "a.pos") GETM(alnf_w, "a.lnf.w") GETM(alnf_b, "a.lnf.b")
+    m->alayers.resize(c.wh_layers);
+    for (int i = 0; i < c.wh_layers; ++i) OAVSR_TRY(resolve_enc_layer(m, "a.L" + std::to_string(i) + ".", false, m->alayers[i]));
+  }
+  for (int which = 0; which < 2; ++which) {
+    bool have = which == 0 ? m->has_audio : m->has_video;
+    if (!have) continue;
+    int n = c.proj_per_rate ? (which == 0 ? c.n_rates_audio : c.n_rates_video) : 1;
+    auto& vec = which == 0 ? m->proj_a : m->proj_v;
+    bool ln = which == 0 ? c.proj_layernorm_audio : c.proj_layernorm_video;
+    vec.resize(n);
+    for (int i = 0; i < n; ++i) {
+      std::string p = std::string(which == 0 ? "pa." : "pv.") + std::to_string(i) + ".";
+      Projector& P = vec[i];
+      P.fc1w = m->ptr(p + "fc1.w"); P.fc1b = (const float*)m->ptr(p + "fc1.b");
+      P.fc2w = m->ptr(p + "fc2.w"); P.fc2b = (const float*)m->ptr(p + "fc2.b");
+      if (!P.fc1w || !P.fc1b || !P.fc2w || !P.fc2b) return -1;
+      P.lnw = ln ? (const float*)m->ptr(p + "ln.w") : nullptr; P.lnb = ln ? (const float*)m->ptr(p + "ln.b") : nullptr;
+      if (ln && (!P.lnw || !P.lnb)) return -1;
+    }
+  }
+  GETM(embed, "l.embed") GETM(lm_head, "l.lm_head") GETM(norm_w, "l.norm.w") GETM(inv_freq, "l.inv_freq")
+  m->llayers.resize(c.llm_layers);
+  for (int i = 0; i < c.llm_layers; ++i) {
+    LlmLayer& L = m->llayers[i];
+    std::string p = "l.L" + std::to_string(i) + ".";
+    L.ln1w = (const float*)m->ptr(p + "ln1.w"); L.ln2w = (const float*)m->ptr(p + "ln2.w");
+    L.qkvw = m->ptr(p + "qkv.w"); L.ow = m->ptr(p + "o.w"); L.guw = m->ptr(p + "gu.w"); L.downw = m->ptr(p + "down.w");
+    if (!L.ln1w || !L.ln2w || !L.qkvw || !L.ow || !L.guw || !L.downw) return -1;
+    L.qkvb = c.llm_qkv_bias ? (const float*)m->ptr(p + "qkv.b") : nullptr;
+    if (c.llm_qkv_bias && !L.qkvb) return -1;
+    for (int t = 0; t < 3; ++t) {
+      L.lora_dn[t] = L.lora_up[t] = nullptr;
+      if (c.lora_k2 > 0) {
+        std::string tn = c.lora_task_specific ? std::to_string(t) : "x";
+        L.lora_dn[t] = m->ptr(p + "lora_dn." + tn + ".w"); L.lora_up[t] = m->ptr(p + "lora_up." + tn + ".w");
+        if (!L.lora_dn[t] || !L.lora_up[t]) return -1;
+      }
+    }
+  }
+  for (int t = 0; t < 3; ++t) m->prompt[t] = c.prompt_len[t] > 0 ? m->ptr("l.prompt." + std::to_string(t), false) : nullptr;
+#undef GETM
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// shared transformer-encoder layer stack (AV-HuBERT wav2vec2.py:977-1006 / WhisperEncoderLayer), pre-LN
+// ------------------------------------------------------------------------------------------------
+static int run_encoder_layers(const oavsr_model* m, oavsr_workspace* ws, const std::vector<EncLayer>& layers, int rows, int D,
+                              int heads, int ffn, int lora_k2, const int* cu_dev, int n_seqs, int max_len, hipStream_t st) {
+  const int dt = m->dtype;
+  const int hd = D / heads;
+  for (const EncLayer& L : layers) {
+    { ProfScope ps("layernorm", 0, 2.0 * rows * D * m->esz, st);
+      OAVSR_TRY(launch_layernorm(dt, ws->enc_x, D, ws->enc_h, D, L.ln1w, L.ln1b, rows, D, 1e-5f, st)); }
+    GemmArgs g;
+    if (lora_k2 > 0) {   // t = h . [A_q; A_v]^T
+      g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = lora_k2; g.K = D; g.A = ws->enc_h; g.lda = D; g.W = L.lora_dn; g.ldw = D;
+      g.C = ws->enc_lora; g.ldc = lora_k2;
+      OAVSR_TRY(run_gemm(g, st));
+    }
+    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 3 * D; g.K = D; g.A = ws->enc_h; g.lda = D; g.W = L.qkvw; g.ldw = D;
+    if (lora_k2 > 0) { g.A2 = ws->enc_lora; g.lda2 = lora_k2; g.W2 = L.lora_up; g.ldw2 = lora_k2; g.K2 = lora_k2; }
+    g.col_bias = L.qkvb; g.C = ws->enc_qkv; g.ldc = 3 * D;
+    OAVSR_TRY(run_gemm(g, st));
+    AttnArgs a; a.dtype = dt; a.head_dim = hd; a.n_heads = heads; a.n_kv_heads = heads; a.n_seqs = n_seqs;
+    a.Q = ws->enc_qkv; a.K = (const char*)ws->enc_qkv + (size_t)D * m->esz; a.V = (const char*)ws->enc_qkv + (size_t)2 * D * m->esz;
+    a.ldq = a.ldk = a.ldv = 3 * D; a.O = ws->enc_attn; a.ldo = D; a.cu_q = cu_dev; a.cu_k = cu_dev; a.max_q = max_len;
+    a.scale = 1.0f / sqrtf((float)hd); a.causal = 0;
+    { double fl = 0; /* 4*T*T*D per sequence, upper bound with max_len */ fl = 4.0 * (double)rows * max_len * D;
+      ProfScope ps(dt == DT_F32 ? "attention_f32" : "attention_bf16", fl, 4.0 * rows * D * m->esz, st);
+      OAVSR_TRY(launch_attention(a, st)); }
+    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = D; g.K = D; g.A = ws->enc_attn; g.lda = D; g.W = L.ow; g.ldw = D; g.col_bias = L.ob;
+    g.residual = ws->enc_x; g.ldr = D; g.C = ws->enc_x; g.ldc = D;
+    OAVSR_TRY(run_gemm(g, st));
+    { ProfScope ps("layernorm", 0, 2.0 * rows * D * m->esz, st);
+      OAVSR_TRY(launch_layernorm(dt, ws->enc_x, D, ws->enc_h, D, L.ln2w, L.ln2b, rows, D, 1e-5f, st)); }
+    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = ffn; g.K = D; g.A = ws->enc_h; g.lda = D; g.W = L.fc1w; g.ldw = D; g.col_bias = L.fc1b;
+    g.act = ACT_GELU; g.C = ws->enc_ffn; g.ldc = ffn;
+    OAVSR_TRY(run_gemm(g, st));
+    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = D; g.K = ffn; g.A = ws->enc_ffn; g.lda = ffn; g.W = L.fc2w; g.ldw = ffn; g.col_bias = L.fc2b;
+    g.residual = ws->enc_x; g.ldr = D; g.C = ws->enc_x; g.ldc = D;
+    OAVSR_TRY(run_gemm(g, st));
+  }
+  return 0;
+}
+
+static int conv2d_gemm(const oavsr_model* m, const void* x, int imgs, int H, int W, int Cin, int Cout, int ks, int stride, const ConvBN& c,
+                       const void* residual, bool prelu, void* out, hipStream_t st) {
+  GemmArgs g; g.dtype = m->dtype; g.amode = A_CONV2D; g.H = H; g.Wd = W; g.Cin = Cin; g.ksize = ks; g.stride = stride; g.pad = ks / 2;
+  g.OH = (H + 2 * g.pad - ks) / stride + 1; g.OW = (W + 2 * g.pad - ks) / stride + 1;
+  g.M = imgs * g.OH * g.OW; g.N = Cout; g.K = ks * ks * Cin; g.A = x; g.W = c.w; g.ldw = g.K;
+  g.col_scale = c.scale; g.col_bias = c.shift; g.residual = residual; g.ldr = Cout;
+  if (prelu) { g.act = ACT_PRELU; g.prelu = c.slope; }
+  g.C = out; g.ldc = Cout;
+  return run_gemm(g, st);
+}
+
+static int time_compress(const oavsr_model* m, oavsr_workspace* ws, const void* x, int D, const std::vector<int>& in_off,
+                         const std::vector<int>& n_in, int rate, void* out, int* total_out, hipStream_t st) {
+  const int B = (int)in_off.size();
+  int4* seg_h = ws->stage<int4>(B);
+  OAVSR_REQUIRE(seg_h, "host staging exhausted");
+  int off = 0, mx = 0;
+  for (int b = 0; b < B; ++b) { int n = n_in[b] / rate; seg_h[b] = make_int4(in_off[b], off, n, 0); off += n; mx = std::max(mx, n); }
+  *total_out = off;
+  OAVSR_TRY(h2d(ws->seg, seg_h, sizeof(int4) * B, st));
+  const int stack = m->cfg.compression_stack;
+  ProfScope ps("time_compress", 0, (double)off * D * (rate + 1) * m->esz, st);
+  if (rate == 1 && !stack) {
+    // identity compress still goes through the kernel (rate 1 mean == copy)
+  }
+  return launch_time_compress(m->dtype, x, D, out, stack ? (int64_t)D * rate : D, ws->seg, B, mx, rate, D, stack, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// encode_video
+// ------------------------------------------------------------------------------------------------
+static int encode_video_impl(const oavsr_model* m, oavsr_workspace* ws, const float* video, const int32_t* Tv, int B, int rate,
+                             void* out_dev, void* enc_dev, int* n_out_host, hipStream_t st) {
+  OAVSR_REQUIRE(m->has_video, "model has no video encoder");
+  OAVSR_REQUIRE(B >= 1 && B <= ws->max_B, "encode_video: B=%d exceeds workspace (%d)", B, ws->max_B);
+  const oavsr_config& c = m->cfg;
+  const int dt = m->dtype, D = c.av_dim;
+  int F = 0, maxT = 0;
+  for (int b = 0; b < B; ++b) { OAVSR_REQUIRE(Tv[b] >= 1 && Tv[b] <= ws->max_Tv, "encode_video: Tv[%d]=%d out of range", b, Tv[b]); F += Tv[b]; maxT = std::max(maxT, Tv[b]); }
+  int2* fi = ws->stage<int2>(F); int* cu = ws->stage<int>(B + 1);
+  OAVSR_REQUIRE(fi && cu, "host staging exhausted");
+  { int f = 0; cu[0] = 0;
+    for (int b = 0; b < B; ++b) { for (int t = 0; t < Tv[b]; ++t) fi[f++] = make_int2(t, Tv[b]); cu[b + 1] = f; } }
+  OAVSR_TRY(h2d(ws->frameinfo, fi, sizeof(int2) * F, st));
+  OAVSR_TRY(h2d(ws->cu_a, cu, sizeof(int) * (B + 1), st));
+  // K1: stem conv3d + BN + PReLU (resnet.py:137-140) as implicit GEMM, then MaxPool3d (:141)
+  GemmArgs g; g.dtype = dt; g.amode = A_STEM; g.M = F * 1936; g.N = 64; g.K = 256; g.A = video; g.frameinfo = ws->frameinfo;
+  g.W = m->stem.w; g.ldw = 256; g.col_scale = m->stem.scale; g.col_bias = m->stem.shift; g.act = ACT_PRELU; g.prelu = m->stem.slope;
+  g.C = ws->stem_out; g.ldc = 64;
+  OAVSR_TRY(run_gemm(g, st));
+  { ProfScope ps("maxpool", 0, (double)F * (1936 + 484) * 64 * m->esz, st);
+    OAVSR_TRY(launch_maxpool3x3s2(dt, ws->stem_out, ws->pool_out, F, 44, 44, 64, st)); }
+  // K2: ResNet-18 trunk (resnet.py:61-74, 121-126)
+  // x lives in pool_out and is updated in place: conv2's epilogue reads residual[m][n] and writes C[m][n] from the
+  // same thread, and conv1 / downsample (the only readers of x as a GEMM operand) precede it in stream order.
+  void* x = ws->pool_out;
+  int H = 22;
+  for (int i = 0; i < 8; ++i) {
+    const ResBlock& rb = m->blocks[i];
+    void* tmp = ws->trunk[0]; void* res = ws->trunk[1];
+    const int OHo = (H - 1) / rb.stride + 1;
+    OAVSR_TRY(conv2d_gemm(m, x, F, H, H, rb.cin, rb.cout, 3, rb.stride, rb.c1, nullptr, true, tmp, st));
+    const void* residual = x;
+    if (rb.has_down) { OAVSR_TRY(conv2d_gemm(m, x, F, H, H, rb.cin, rb.cout, 1, rb.stride, rb.down, nullptr, false, res, st)); residual = res; }
+    OAVSR_TRY(conv2d_gemm(m, tmp, F, OHo, OHo, rb.cout, rb.cout, 3, 1, rb.c2, residual, true, x, st));
+    H = OHo;
+  }
+  // K3: avgpool -> Linear 512->D -> LN([0,x]) -> Linear 2D->D   (resnet.py:127-128, hubert.py:327,709-728)
+  { ProfScope ps("avgpool", 0, (double)F * (H * H + 1) * 512 * m->esz, st);
+    OAVSR_TRY(launch_avgpool_hw(dt, x, ws->feat512, F, H * H, 512, st)); }
+  g = GemmArgs(); g.dtype = dt; g.M = F; g.N = D; g.K = 512; g.A = ws->feat512; g.lda = 512; g.W = m->vproj_w; g.ldw = 512; g.col_bias = m->vproj_b;
+  g.C = ws->featproj; g.ldc = D;
+  OAVSR_TRY(run_gemm(g, st));
+  { ProfScope ps("layernorm", 0, 3.0 * F * D * m->esz, st);
+    OAVSR_TRY(launch_layernorm_zero_prefix(dt, ws->featproj, D, ws->ln2d, 2 * D, m->vln_w, m->vln_b, F, D, 1e-5f, st)); }
+  g = GemmArgs(); g.dtype = dt; g.M = F; g.N = D; g.K = 2 * D; g.A = ws->ln2d; g.lda = 2 * D; g.W = m->vpost_w; g.ldw = 2 * D; g.col_bias = m->vpost_b;
+  g.C = ws->enc_h; g.ldc = D;   // x0 in enc_h
+  OAVSR_TRY(run_gemm(g, st));
+  // K4: x = x0 + GELU(pos_conv(x0))  (wav2vec2.py:875-877)
+  OAVSR_TRY(launch_build_rowinfo(ws->cu_a, ws->cu_a, B, 1, ws->rowinfo, F, st));
+  const int G = c.av_conv_groups, Cg = D / G, taps = c.av_conv_pos;
+  g = GemmArgs(); g.dtype = dt; g.amode = A_CONV1D; g.M = F; g.N = Cg; g.K = taps * Cg; g.Kvalid = taps * Cg; g.taps = taps; g.pad = taps / 2;
+  g.Cin = Cg; g.A = ws->enc_h; g.lda = D; g.groups = G; g.a_goff = Cg; g.rowinfo = ws->rowinfo; g.W = m->vpos_w; g.ldw = g.K;
+  g.col_bias = m->vpos_b; g.act = ACT_GELU; g.residual = ws->enc_h; g.ldr = D; g.res_after_act = 1; g.C = ws->enc_x; g.ldc = D;
+  OAVSR_TRY(run_gemm(g, st));
+  OAVSR_TRY(run_encoder_layers(m, ws, m->vlayers, F, D, c.av_heads, c.av_ffn, c.av_lora_k2, ws->cu_a, B, maxT, st));
+  void* enc = ws->enc_out_v;
+  { ProfScope ps("layernorm", 0, 2.0 * F * D * m->esz, st);
+    OAVSR_TRY(launch_layernorm(dt, ws->enc_x, D, enc, D, m->vlnf_w, m->vlnf_b, F, D, 1e-5f, st)); }
+  if (enc_dev) OAVSR_CHECK_HIP(hipMemcpyAsync(enc_dev, enc, (size_t)F * D * m->esz, hipMemcpyDeviceToDevice, st));
+  std::vector<int> in_off(B), n_in(B);
+  for (int b = 0; b < B; ++b) { in_off[b] = cu[b]; n_in[b] = Tv[b]; }
+  int total = 0;
+  OAVSR_TRY(time_compress(m, ws, enc, D, in_off, n_in, rate, ws->comp_v, &total, st));
+  const int Dout = c.compression_stack ? D * rate : D;
+  if (out_dev) OAVSR_CHECK_HIP(hipMemcpyAsync(out_dev, ws->comp_v, (size_t)total * Dout * m->esz, hipMemcpyDeviceToDevice, st));
+  if (n_out_host) for (int b = 0; b < B; ++b) n_out_host[b] = Tv[b] / rate;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// encode_audio
+// ------------------------------------------------------------------------------------------------
+static int encode_audio_impl(const oavsr_model* m, oavsr_workspace* ws, const float* wav, int64_t ld, const int32_t* Ts, const int32_t* keep,
+                             int B, int rate, void* out_dev, void* enc_dev, void* mel_dev, int* n_out_host, hipStream_t st) {
+  OAVSR_REQUIRE(m->has_audio, "model has no audio encoder");
+  OAVSR_REQUIRE(B >= 1 && B <= ws->max_B, "encode_audio: B=%d exceeds workspace (%d)", B, ws->max_B);
+  const oavsr_config& c = m->cfg;
+  const int dt = m->dtype, D = c.wh_dim;
+  int* lens = ws->stage<int>(B); int* cu3000 = ws->stage<int>(B + 1); int* cu1500 = ws->stage<int>(B + 1);
+  OAVSR_REQUIRE(lens && cu3000 && cu1500, "host staging exhausted");
+  for (int b = 0; b < B; ++b) {
+    OAVSR_REQUIRE(Ts[b] >= 0 && Ts[b] <= ld, "encode_audio: Ts[%d]=%d exceeds row stride", b, Ts[b]);
+    OAVSR_REQUIRE(keep[b] >= 1 && keep[b] <= 1500, "encode_audio: keep[%d]=%d out of range", b, keep[b]);
+    lens[b] = Ts[b]; cu3000[b] = b * 3000; cu1500[b] = b * 1500;
+  }
+  cu3000[B] = B * 3000; cu1500[B] = B * 1500;
+  OAVSR_TRY(h2d(ws->lens_dev, lens, sizeof(int) * B, st));
+  OAVSR_TRY(h2d(ws->cu_a, cu3000, sizeof(int) * (B + 1), st));
+  OAVSR_TRY(h2d(ws->cu_b, cu1500, sizeof(int) * (B + 1), st));
+  { ProfScope ps("logmel", 2.0 * B * 3000.0 * 201 * 400 * 2, (double)B * 480000 * 4, st);
+    OAVSR_TRY(launch_logmel(dt, wav, ld, ws->lens_dev, B, m->twiddle, m->melfb, ws->mel_ws, ws->max_ws, ws->mel, 80, st)); }
+  if (mel_dev) OAVSR_CHECK_HIP(hipMemcpyAsync(mel_dev, ws->mel, (size_t)B * 3000 * 80 * m->esz, hipMemcpyDeviceToDevice, st));
+  // K9: conv1 (k3,p1)+GELU ; conv2 (k3,s2,p1)+GELU ; + embed_positions   (transformers WhisperEncoder.forward)
+  OAVSR_TRY(launch_build_rowinfo(ws->cu_a, ws->cu_a, B, 1, ws->rowinfo, B * 3000, st));
+  GemmArgs g; g.dtype = dt; g.amode = A_CONV1D; g.M = B * 3000; g.N = D; g.K = 256; g.Kvalid = 240; g.taps = 3; g.pad = 1; g.Cin = 80;
+  g.A = ws->mel; g.lda = 80; g.rowinfo = ws->rowinfo; g.W = m->aconv1_w; g.ldw = 256; g.col_bias = m->aconv1_b; g.act = ACT_GELU;
+  g.C = ws->conv1_out; g.ldc = D;
+  OAVSR_TRY(run_gemm(g, st));
+  OAVSR_TRY(launch_build_rowinfo(ws->cu_b, ws->cu_a, B, 2, ws->rowinfo2, B * 1500, st));
+  g = GemmArgs(); g.dtype = dt; g.amode = A_CONV1D; g.M = B * 1500; g.N = D; g.K = 3 * D; g.Kvalid = 3 * D; g.taps = 3; g.pad = 1; g.Cin = D;
+  g.A = ws->conv1_out; g.lda = D; g.rowinfo = ws->rowinfo2; g.W = m->aconv2_w; g.ldw = 3 * D; g.col_bias = m->aconv2_b; g.act = ACT_GELU;
+  g.residual = ws->pos_rep; g.ldr = D; g.res_after_act = 1; g.C = ws->enc_x; g.ldc = D;
+  OAVSR_TRY(run_gemm(g, st));
+  OAVSR_TRY(run_encoder_layers(m, ws, m->alayers, B * 1500, D, c.wh_heads, c.wh_ffn, 0, ws->cu_b, B, 1500, st));
+  void* enc = ws->enc_out_a;
+  { ProfScope ps("layernorm", 0, 2.0 * B * 1500 * D * m->esz, st);
+    OAVSR_TRY(launch_layernorm(dt, ws->enc_x, D, enc, D, m->alnf_w, m->alnf_b, B * 1500, D, 1e-5f, st)); }
+  if (enc_dev) OAVSR_CHECK_HIP(hipMemcpyAsync(enc_dev, enc, (size_t)B * 1500 * D * m->esz, hipMemcpyDeviceToDevice, st));
+  std::vector<int> in_off(B), n_in(B);
+  for (int b = 0; b < B; ++b) { in_off[b] = b * 1500; n_in[b] = keep[b]; }   // truncation modeling_OmniAVSR.py:537
+  int total = 0;
+  OAVSR_TRY(time_compress(m, ws, enc, D, in_off, n_in, rate, ws->comp_a, &total, st));
+  const int Dout = c.compression_stack ? D * rate : D;
+  if (out_dev) OAVSR_CHECK_HIP(hipMemcpyAsync(out_dev, ws->comp_a, (size_t)total * Dout * m->esz, hipMemcpyDeviceToDevice, st));
+  if (n_out_host) for (int b = 0; b < B; ++b) n_out_host[b] = keep[b] / rate;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// projector
+// ------------------------------------------------------------------------------------------------
+static int project_impl(const oavsr_model* m, oavsr_workspace* ws, int which, int rate, const void* feats, int rows, void* out, hipStream_t st) {
+  const oavsr_config& c = m->cfg;
+  const auto& vec = which == 0 ? m->proj_a : m->proj_v;
+  OAVSR_REQUIRE(!vec.empty(), "project: modality %d has no projector", which);
+  int idx = 0;
+  const int n_rates = which == 0 ? c.n_rates_audio : c.n_rates_video;
+  const int* rates = which == 0 ? c.rates_audio : c.rates_video;
+  int found = -1;
+  for (int i = 0; i < n_rates; ++i) if (rates[i] == rate) found = i;
+  // the reference looks the rate up in matry_map_* (modeling_OmniAVSR.py:429,447) -> KeyError for an unknown rate
+  OAVSR_REQUIRE(found >= 0, "KeyError: compression rate %d is not in the configured list", rate);
+  if (c.proj_per_rate) idx = found;
+  const Projector& P = vec[idx];
+  const int Denc = which == 0 ? c.wh_dim : c.av_dim;
+  const int Din = c.compression_stack ? Denc * rate : Denc;
+  const int I = c.proj_inter, d = c.llm_hidden, dt = m->dtype;
+  GemmArgs g; g.dtype = dt; g.M = rows; g.N = I; g.K = Din; g.A = feats; g.lda = Din; g.W = P.fc1w; g.ldw = Din; g.col_bias = P.fc1b; g.act = ACT_RELU;
+  g.C = ws->proj_h; g.ldc = I;
+  OAVSR_TRY(run_gemm(g, st));
+  g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = d; g.K = I; g.A = ws->proj_h; g.lda = I; g.W = P.fc2w; g.ldw = I; g.col_bias = P.fc2b;
+  g.C = out; g.ldc = d;
+  OAVSR_TRY(run_gemm(g, st));
+  if (P.lnw) { ProfScope ps("layernorm", 0, 2.0 * rows * d * m->esz, st);
+    OAVSR_TRY(launch_layernorm(dt, out, d, out, d, P.lnw, P.lnb, rows, d, 1e-5f, st)); }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// prompt splice (modeling_OmniAVSR.py:406-458)
+// ------------------------------------------------------------------------------------------------
+static int build_prompt_impl(const oavsr_model* m, oavsr_workspace* ws, int task, int B, const int32_t* na, const void* atok,
+                             const int32_t* nv, const void* vtok, void* embeds, int32_t* S_out, hipStream_t st) {
+  const oavsr_config& c = m->cfg;
+  OAVSR_REQUIRE(task >= 0 && task < 3, "bad task %d", task);
+  const int P = c.prompt_len[task], d = c.llm_hidden;
+  OAVSR_REQUIRE(P == 0 || m->prompt[task], "prompt buffer for task %d missing", task);
+  int total = 0;
+  for (int b = 0; b < B; ++b) {
+    int S = (c.llm_family == 0 ? 1 : 0) + (na ? na[b] + 2 : 0) + (nv ? nv[b] + 2 : 0) + P;
+    S_out[b] = S; total += S;
+  }
+  OAVSR_REQUIRE(total <= ws->max_S_total, "build_prompt: %d prompt rows exceed workspace (%d)", total, ws->max_S_total);
+  int* maps = ws->stage<int>((size_t)4 * total);
+  OAVSR_REQUIRE(maps, "host staging exhausted");
+  int* m_emb = maps; int* m_a = maps + total; int* m_v = maps + 2 * total; int* m_p = maps + 3 * total;
+  for (int i = 0; i < 4 * total; ++i) maps[i] = -1;
+  int r = 0, ao = 0, vo = 0;
+  for (int b = 0; b < B; ++b) {
+    // final order: [BOS] <audio> A </audio> <video> V </video> prompt   (Qwen: no BOS)  — :434-437,452-455
+    if (c.llm_family == 0) m_emb[r++] = c.id_bos;
+    if (na) { m_emb[r++] = c.id_audio_sos; for (int i = 0; i < na[b]; ++i) m_a[r++] = ao++; m_emb[r++] = c.id_audio_eos; }
+    if (nv) { m_emb[r++] = c.id_video_sos; for (int i = 0; i < nv[b]; ++i) m_v[r++] = vo++; m_emb[r++] = c.id_video_eos; }
+    for (int i = 0; i < P; ++i) m_p[r++] = i;
+  }
+  OAVSR_TRY(h2d(ws->maps, maps, sizeof(int) * 4 * total, st));
+  const int dt = m->dtype;
+  ProfScope ps("prompt_splice", 0, 2.0 * total * d * m->esz, st);
+  OAVSR_TRY(launch_copy_rows(dt, m->embed, d, ws->maps, embeds, d, total, d, st));
+  if (na) OAVSR_TRY(launch_copy_rows(dt, atok, d, ws->maps + total, embeds, d, total, d, st));
+  if (nv) OAVSR_TRY(launch_copy_rows(dt, vtok, d, ws->maps + 2 * total, embeds, d, total, d, st));
+  if (P) OAVSR_TRY(launch_copy_rows(dt, m->prompt[task], d, ws->maps + 3 * total, embeds, d, total, d, st));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LLM layer stack; rows = prompt rows (prefill, big GEMM) or decode rows (skinny GEMM)
+// ------------------------------------------------------------------------------------------------
+static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int rows, bool decode, int B, int beams, int max_S,
+                      const int* pos, const int* cpos, hipStream_t st) {
+  const oavsr_config& c = m->cfg;
+  const int dt = m->dtype, d = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, hd = c.llm_head_dim, I = c.llm_mlp;
+  const int nq = H * hd, nqkv = (H + 2 * KV) * hd;
+  const int tl = c.lora_task_specific ? task : 0;
+  for (int li = 0; li < c.llm_layers; ++li) {
+    const LlmLayer& L = m->llayers[li];
+    { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
+      OAVSR_TRY(launch_rmsnorm(dt, ws->lx, d, ws->lh, d, L.ln1w, rows, d, c.llm_rms_eps, st)); }
+    GemmArgs g;
+    if (c.lora_k2 > 0) {
+      g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = c.lora_k2; g.K = d; g.A = ws->lh; g.lda = d; g.W = L.lora_dn[tl]; g.ldw = d;
+      g.C = ws->llora; g.ldc = c.lora_k2;
+      OAVSR_TRY(run_gemm(g, st, decode));
+    }
+    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = nqkv; g.K = d; g.A = ws->lh; g.lda = d; g.W = L.qkvw; g.ldw = d; g.col_bias = L.qkvb;
+    if (c.lora_k2 > 0) { g.A2 = ws->llora; g.lda2 = c.lora_k2; g.W2 = L.lora_up[tl]; g.ldw2 = c.lora_k2; g.K2 = c.lora_k2; }
+    g.C = ws->lqkv; g.ldc = nqkv;
+    OAVSR_TRY(run_gemm(g, st, decode));
+    RopeArgs r; r.dtype = dt; r.rows = rows; r.n_heads = H; r.n_kv_heads = KV; r.head_dim = hd; r.qkv = ws->lqkv; r.ld = nqkv;
+    r.inv_freq = m->inv_freq; r.pos = pos; r.slot = ws->slot; r.cpos = cpos;
+    if (decode) { r.kcache = (char*)ws->ktail + li * ws->ktail_layer; r.vcache = (char*)ws->vtail + li * ws->ktail_layer; r.max_ctx = ws->max_new; }
+    else { r.kcache = (char*)ws->kpre + li * ws->kpre_layer; r.vcache = (char*)ws->vpre + li * ws->kpre_layer; r.max_ctx = ws->max_prefix; }
+    { ProfScope ps("rope_kv", 0, 2.0 * rows * nqkv * m->esz, st);
+      OAVSR_TRY(launch_rope_kv(r, st)); }
+    if (!decode) {
+      AttnArgs a; a.dtype = dt; a.head_dim = hd; a.n_heads = H; a.n_kv_heads = KV; a.n_seqs = B;
+      a.Q = ws->lqkv; a.K = (const char*)ws->lqkv + (size_t)nq * m->esz; a.V = (const char*)ws->lqkv + (size_t)(nq + KV * hd) * m->esz;
+      a.ldq = a.ldk = a.ldv = nqkv; a.O = ws->lattn; a.ldo = nq; a.cu_q = ws->cu_s; a.cu_k = ws->cu_s; a.max_q = max_S;
+      a.scale = 1.0f / sqrtf((float)hd); a.causal = 1;
+      ProfScope ps(dt == DT_F32 ? "attention_f32" : "attention_bf16", 2.0 * rows * max_S * nq, 4.0 * rows * nq * m->esz, st);
+      OAVSR_TRY(launch_attention(a, st));
+    } else {
+      DecodeAttnArgs a; a.dtype = dt; a.head_dim = hd; a.n_heads = H; a.n_kv_heads = KV; a.rows = rows; a.beams = beams;
+      a.Q = ws->lqkv; a.ldq = nqkv; a.O = ws->lattn; a.ldo = nq;
+      a.Kp = (char*)ws->kpre + li * ws->kpre_layer; a.Vp = (char*)ws->vpre + li * ws->kpre_layer; a.max_prefix = ws->max_prefix;
+      a.Kt = (char*)ws->ktail + li * ws->ktail_layer; a.Vt = (char*)ws->vtail + li * ws->ktail_layer; a.max_tail = ws->max_new;
+      a.prefix_len = ws->prefix_len; a.step = ws->gs.step; a.anc = nullptr; a.scale = 1.0f / sqrtf((float)hd);
+      ProfScope ps("decode_attention", 0, 2.0 * rows * max_S * KV * hd * m->esz, st);
+      OAVSR_TRY(launch_decode_attention(a, st));
+    }
+    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = d; g.K = nq; g.A = ws->lattn; g.lda = nq; g.W = L.ow; g.ldw = nq;
+    g.residual = ws->lx; g.ldr = d; g.C = ws->lx; g.ldc = d;
+    OAVSR_TRY(run_gemm(g, st, decode));
+    { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
+      OAVSR_TRY(launch_rmsnorm(dt, ws->lx, d, ws->lh, d, L.ln2w, rows, d, c.llm_rms_eps, st)); }
+    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 2 * I; g.K = d; g.A = ws->lh; g.lda = d; g.W = L.guw; g.ldw = d; g.C = ws->lgu; g.ldc = 2 * I;
+    OAVSR_TRY(run_gemm(g, st, decode));
+    { ProfScope ps("swiglu", 0, 3.0 * rows * I * m->esz, st);
+      OAVSR_TRY(launch_swiglu(dt, ws->lgu, 2 * I, ws->lact, I, rows, I, st)); }
+    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = d; g.K = I; g.A = ws->lact; g.lda = I; g.W = L.downw; g.ldw = I;
+    g.residual = ws->lx; g.ldr = d; g.C = ws->lx; g.ldc = d;
+    OAVSR_TRY(run_gemm(g, st, decode));
+  }
+  return 0;
+}
+
+static int lm_head_rows(const oavsr_model* m, oavsr_workspace* ws, const void* x, int rows, float* logits, hipStream_t st) {
+  const oavsr_config& c = m->cfg;
+  const int d = c.llm_hidden;
+  { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
+    OAVSR_TRY(launch_rmsnorm(m->dtype, x, d, ws->lh, d, m->norm_w, rows, d, c.llm_rms_eps, st)); }
+  GemmArgs g; g.dtype = m->dtype; g.M = rows; g.N = c.llm_vocab; g.K = d; g.A = ws->lh; g.lda = d; g.W = m->lm_head; g.ldw = d;
+  g.C = logits; g.ldc = c.llm_vocab; g.out_f32 = 1;
+  return run_gemm(g, st, rows <= 128);
+}
+
+static int prefill_impl(const oavsr_model* m, oavsr_workspace* ws, int task, int B, const void* embeds, const int32_t* S, float* logits_out,
+                        hipStream_t st) {
+  const oavsr_config& c = m->cfg;
+  OAVSR_REQUIRE(B >= 1 && B <= ws->max_B, "prefill: B=%d exceeds workspace (%d)", B, ws->max_B);
+  int total = 0, maxS = 0;
+  for (int b = 0; b < B; ++b) { OAVSR_REQUIRE(S[b] >= 1 && S[b] <= ws->max_prefix, "prefill: S[%d]=%d exceeds prefix cache (%d)", b, S[b], ws->max_prefix); total += S[b]; maxS = std::max(maxS, S[b]); }
+  OAVSR_REQUIRE(total <= ws->max_S_total, "prefill: too many prompt rows");
+  int* pos = ws->stage<int>(total); int* slot = ws->stage<int>(total); int* cu = ws->stage<int>(B + 1); int* last = ws->stage<int>(B);
+  int* plen = ws->stage<int>(B);
+  OAVSR_REQUIRE(pos && slot && cu && last && plen, "host staging exhausted");
+  int r = 0; cu[0] = 0;
+  for (int b = 0; b < B; ++b) { for (int i = 0; i < S[b]; ++i) { pos[r] = i; slot[r] = b; ++r; } cu[b + 1] = r; last[b] = r - 1; plen[b] = S[b]; ws->S_host[b] = S[b]; }
+  ws->B_cur = B;
+  OAVSR_TRY(h2d(ws->pos, pos, sizeof(int) * total, st));
+  OAVSR_TRY(h2d(ws->cpos, pos, sizeof(int) * total, st));
+  OAVSR_TRY(h2d(ws->slot, slot, sizeof(int) * total, st));
+  OAVSR_TRY(h2d(ws->cu_s, cu, sizeof(int) * (B + 1), st));
+  OAVSR_TRY(h2d(ws->last_rows, last, sizeof(int) * B, st));
+  OAVSR_TRY(h2d(ws->prefix_len, plen, sizeof(int) * B, st));
+  if (embeds != ws->lx) OAVSR_CHECK_HIP(hipMemcpyAsync(ws->lx, embeds, (size_t)total * c.llm_hidden * m->esz, hipMemcpyDeviceToDevice, st));
+  OAVSR_TRY(llm_layers(m, ws, task, total, false, B, 1, maxS, ws->pos, ws->cpos, st));
+  // last position of every utterance only (the reference materialises all positions, Llama_LoRA.py:372-373)
+  OAVSR_TRY(launch_copy_rows(m->dtype, ws->lx, c.llm_hidden, ws->last_rows, ws->lastx, c.llm_hidden, B, c.llm_hidden, st));
+  OAVSR_TRY(lm_head_rows(m, ws, ws->lastx, B, ws->logits, st));
+  if (logits_out) OAVSR_CHECK_HIP(hipMemcpyAsync(logits_out, ws->logits, (size_t)B * c.llm_vocab * 4, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+static int decode_greedy(const oavsr_model* m, oavsr_workspace* ws, int task, int B, int max_new, int force_len, int32_t* out_ids, int32_t* out_len,
+                         hipStream_t st) {
+  const oavsr_config& c = m->cfg;
+  OAVSR_REQUIRE(B == ws->B_cur, "decode: call oavsr_prefill for this batch first");
+  OAVSR_REQUIRE(max_new >= 1 && max_new <= ws->max_new, "decode: max_new=%d exceeds workspace (%d)", max_new, ws->max_new);
+  // state: pos = S-1, cpos = -1, step = 0, finished = 0, out_len = 0, out_ids = pad
+  int* init = ws->stage<int>((size_t)B * 4 + 1 + (size_t)B * max_new);
+  OAVSR_REQUIRE(init, "host staging exhausted");
+  int* ipos = init; int* icpos = init + B; int* ifin = init + 2 * B; int* ilen = init + 3 * B; int* istep = init + 4 * B; int* iout = istep + 1;
+  int maxS = 0;
+  for (int b = 0; b < B; ++b) { ipos[b] = ws->S_host[b] - 1; icpos[b] = -1; ifin[b] = 0; ilen[b] = 0; maxS = std::max(maxS, ws->S_host[b]); }
+  *istep = 0;
+  for (int i = 0; i < B * max_new; ++i) iout[i] = c.id_pad;
+  GreedyState gs = ws->gs;
+  gs.out_ids = out_ids; gs.out_len = out_len;
+  OAVSR_TRY(h2d(gs.pos, ipos, sizeof(int) * B, st));
+  OAVSR_TRY(h2d(gs.cpos, icpos, sizeof(int) * B, st));
+  OAVSR_TRY(h2d(gs.finished, ifin, sizeof(int) * B, st));
+  OAVSR_TRY(h2d(gs.out_len, ilen, sizeof(int) * B, st));
+  OAVSR_TRY(h2d(gs.step, istep, sizeof(int), st));
+  OAVSR_TRY(h2d(gs.out_ids, iout, sizeof(int) * B * max_new, st));
+  // decode rows use slot = row index
+  int* slot = ws->stage<int>(B);
+  OAVSR_REQUIRE(slot, "host staging exhausted");
+  for (int b = 0; b < B; ++b) slot[b] = b;
+  OAVSR_TRY(h2d(ws->slot, slot, sizeof(int) * B, st));
+  const int banned = force_len ? c.id_eos : -1;
+  OAVSR_TRY(launch_argmax(ws->logits, c.llm_vocab, B, c.llm_vocab, banned, ws->amax, st));
+  OAVSR_TRY(launch_greedy_update(ws->amax, gs, B, max_new, c.id_eos, c.id_pad, st));
+  for (int step = 1; step < max_new; ++step) {
+    OAVSR_TRY(launch_embed(m->dtype, m->embed, c.llm_hidden, gs.tok, ws->lx, c.llm_hidden, B, c.llm_hidden, st));
+    OAVSR_TRY(llm_layers(m, ws, task, B, true, B, 1, maxS + max_new, gs.pos, gs.cpos, st));
+    OAVSR_TRY(lm_head_rows(m, ws, ws->lx, B, ws->logits, st));
+    OAVSR_TRY(launch_argmax(ws->logits, c.llm_vocab, B, c.llm_vocab, banned, ws->amax, st));
+    OAVSR_TRY(launch_greedy_update(ws->amax, gs, B, max_new, c.id_eos, c.id_pad, st));
+  }
+  return 0;
+}
+
+}  // namespace oavsr
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int oavsr_abi_version(void) { return OAVSR_ABI_VERSION; }
+const char* oavsr_last_error(void) { return g_err; }
+
+int oavsr_model_create(const oavsr_config* cfg, const void* blob_dev, uint64_t blob_bytes, const oavsr_tensor* tensors, int32_t n_tensors,
+                       oavsr_model** out) {
+  OAVSR_REQUIRE(cfg && blob_dev && tensors && out, "model_create: null argument");
+  OAVSR_REQUIRE(cfg->dtype == DT_F32 || cfg->dtype == DT_BF16, "model_create: bad dtype");
+  OAVSR_REQUIRE(cfg->llm_head_dim == 64 || cfg->llm_head_dim == 128, "model_create: llm head_dim %d unsupported", cfg->llm_head_dim);
+  OAVSR_REQUIRE(cfg->llm_heads % cfg->llm_kv_heads == 0 && cfg->llm_heads / cfg->llm_kv_heads <= 8, "model_create: GQA group must be <= 8");
+  oavsr_model* m = new oavsr_model();
+  m->cfg = *cfg; m->blob = (const char*)blob_dev; m->blob_bytes = blob_bytes; m->dtype = cfg->dtype; m->esz = cfg->dtype == DT_F32 ? 4 : 2;
+  for (int i = 0; i < n_tensors; ++i) {
+    if (tensors[i].offset + tensors[i].nbytes > blob_bytes || (tensors[i].offset & 255)) {
+      set_last_error("model_create: tensor '%s' out of bounds or misaligned", tensors[i].name); delete m; return -1;
+    }
+    m->t[tensors[i].name] = {tensors[i].offset, tensors[i].nbytes};
+  }
+  if (resolve_model(m) != 0) { delete m; return -1; }
+  // constants for the log-mel front-end
+  std::vector<double> tw(800);
+  for (int k = 0; k < 400; ++k) { tw[2 * k] = cos(2.0 * M_PI * k / 400.0); tw[2 * k + 1] = sin(2.0 * M_PI * k / 400.0); }
+  std::vector<float> fb; build_melfb(fb);
+  if (hipMalloc(&m->twiddle, 800 * sizeof(double)) != hipSuccess || hipMalloc(&m->melfb, fb.size() * sizeof(float)) != hipSuccess) {
+    set_last_error("model_create: hipMalloc failed"); delete m; return -2;
+  }
+  hipMemcpy(m->twiddle, tw.data(), 800 * sizeof(double), hipMemcpyHostToDevice);
+  hipMemcpy(m->melfb, fb.data(), fb.size() * sizeof(float), hipMemcpyHostToDevice);
+  *out = m;
+  return 0;
+}
+
+void oavsr_model_destroy(oavsr_model* m) {
+  if (!m) return;
+  if (m->twiddle) hipFree(m->twiddle);
+  if (m->melfb) hipFree(m->melfb);
+  delete m;
+}
+
+int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, int32_t max_Ts, int32_t max_beams, int32_t max_new,
+                           oavsr_workspace** out) {
+  OAVSR_REQUIRE(m && out, "workspace_create: null argument");
+  OAVSR_REQUIRE(max_B >= 1 && max_B <= 1024 && max_new >= 1 && max_beams >= 1, "workspace_create: bad sizes");
+  const oavsr_config& c = m->cfg;
+  oavsr_workspace* ws = new oavsr_workspace();
+  ws->m = m; ws->max_B = max_B; ws->max_Tv = max_Tv; ws->max_Ts = max_Ts; ws->max_beams = max_beams; ws->max_new = max_new;
+  const size_t e = m->esz;
+  const size_t F = m->has_video ? (size_t)max_B * max_Tv : 0;
+  const size_t TA = m->has_audio ? (size_t)max_B * 1500 : 0;
+  const size_t NT = std::max(F, TA);
+  const int Dv = m->has_video ? c.av_dim : 0, Da = m->has_audio ? c.wh_dim : 0;
+  const size_t De = std::max(Dv, Da);
+  const size_t Fe = std::max(m->has_video ? c.av_ffn : 0, m->has_audio ? c.wh_ffn : 0);
+  const int d = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, hd = c.llm_head_dim, I = c.llm_mlp;
+  const size_t nqkv = (size_t)(H + 2 * KV) * hd;
+  // longest prompt: BOS + audio(1500/1 + 2) + video(max_Tv + 2) + prompt
+  int maxP = std::max(c.prompt_len[0], std::max(c.prompt_len[1], c.prompt_len[2]));
+  int min_ra = 1 << 30, min_rv = 1 << 30;
+  for (int i = 0; i < c.n_rates_audio; ++i) min_ra = std::min(min_ra, c.rates_audio[i]);
+  for (int i = 0; i < c.n_rates_video; ++i) min_rv = std::min(min_rv, c.rates_video[i]);
+  int max_keep = std::min(1500, std::max(25, (int)((double)max_Ts / 16000.0 * 50.0) + 1));
+  int max_na = m->has_audio ? max_keep / std::max(1, min_ra == (1 << 30) ? 1 : min_ra) : 0;
+  int max_nv = m->has_video ? max_Tv / std::max(1, min_rv == (1 << 30) ? 1 : min_rv) : 0;
+  ws->max_prefix = 1 + (m->has_audio ? max_na + 2 : 0) + (m->has_video ? max_nv + 2 : 0) + maxP;
+  ws->max_prefix = (ws->max_prefix + 63) / 64 * 64;
+  ws->max_S_total = ws->max_prefix * max_B;
+  const size_t ST = (size_t)ws->max_S_total;
+  const size_t rows_dec = (size_t)max_B * max_beams;
+  const size_t Rl = std::max(ST, rows_dec);
+  struct Req { void** p; size_t bytes; };
+  std::vector<Req> reqs;
+  auto want = [&](void** p, size_t bytes) { reqs.push_back({p, bytes}); };
+#define WANT(field, bytes) want((void**)&ws->field, (bytes))
+  const int stackmul_a = c.compression_stack ? 1 : 1;
+  (void)stackmul_a;
+  WANT(enc_x, NT * De * e); WANT(enc_h, NT * De * e); WANT(enc_qkv, NT * 3 * De * e); WANT(enc_attn, NT * De * e);
+  WANT(enc_ffn, NT * Fe * e); WANT(enc_lora, NT * (size_t)std::max(64, c.av_lora_k2) * e);
+  WANT(enc_out_v, F * Dv * e); WANT(enc_out_a, TA * Da * e);
+  if (m->has_video) {
+    WANT(stem_out, F * 1936 * 64 * e); WANT(pool_out, F * 484 * 64 * e);
+    for (int i = 0; i < 2; ++i) WANT(trunk[i], F * 484 * 64 * e);
+    WANT(feat512, F * 512 * e); WANT(featproj, F * Dv * e); WANT(ln2d, F * 2 * Dv * e);
+    WANT(frameinfo, F * sizeof(int2));
+    WANT(comp_v, F * Dv * e); WANT(tok_v, F * (size_t)d * e);
+  }
+  WANT(rowinfo, std::max(F, (size_t)max_B * 3000) * sizeof(int4)); WANT(rowinfo2, ((size_t)max_B * 1500 + 16) * sizeof(int4));
+  WANT(cu_a, (max_B + 1) * sizeof(int)); WANT(cu_b, (max_B + 1) * sizeof(int)); WANT(seg, max_B * sizeof(int4));
+  if (m->has_audio) {
+    WANT(mel, (size_t)max_B * 3000 * 80 * e); WANT(mel_ws, (size_t)max_B * 3000 * 80 * 4); WANT(max_ws, max_B * 4); WANT(lens_dev, max_B * 4);
+    WANT(conv1_out, (size_t)max_B * 3000 * Da * e); WANT(pos_rep, TA * Da * e);
+    WANT(comp_a, TA * Da * e); WANT(tok_a, TA * (size_t)d * e);
+  }
+  WANT(proj_h, std::max(F, TA) * (size_t)c.proj_inter * e);
+  WANT(embeds, ST * d * e); WANT(maps, ST * 4 * sizeof(int));
+  WANT(lx, Rl * d * e); WANT(lh, Rl * d * e); WANT(lqkv, Rl * nqkv * e); WANT(lattn, Rl * (size_t)H * hd * e);
+  WANT(lgu, Rl * 2 * I * e); WANT(lact, Rl * (size_t)I * e); WANT(llora, Rl * (size_t)std::max(64, c.lora_k2) * e);
+  WANT(lastx, rows_dec * d * e); WANT(logits, rows_dec * (size_t)c.llm_vocab * 4);
+  ws->kpre_layer = (size_t)max_B * KV * ws->max_prefix * hd * e;
+  ws->ktail_layer = rows_dec * KV * (size_t)max_new * hd * e;
+  WANT(kpre, ws->kpre_layer * c.llm_layers); WANT(vpre, ws->kpre_layer * c.llm_layers);
+  WANT(ktail, ws->ktail_layer * c.llm_layers); WANT(vtail, ws->ktail_layer * c.llm_layers);
+  WANT(pos, Rl * 4); WANT(slot, Rl * 4); WANT(cpos, Rl * 4); WANT(cu_s, (max_B + 1) * 4); WANT(prefix_len, max_B * 4); WANT(last_rows, max_B * 4);
+  WANT(amax, rows_dec * 4);
+  WANT(gs.tok, rows_dec * 4); WANT(gs.finished, rows_dec * 4); WANT(gs.out_ids, rows_dec * (size_t)max_new * 4); WANT(gs.out_len, rows_dec * 4);
+  WANT(gs.step, 256); WANT(gs.pos, rows_dec * 4); WANT(gs.cpos, rows_dec * 4);
+#undef WANT
+  size_t total = 0;
+  for (auto& r : reqs) total = align_up(total, 256) + std::max<size_t>(r.bytes, 256);
+  total += 4096;
+  if (hipMalloc((void**)&ws->arena, total) != hipSuccess) { set_last_error("workspace_create: hipMalloc(%zu bytes) failed", total); delete ws; return -2; }
+  ws->arena_bytes = total;
+  for (auto& r : reqs) { *r.p = ws->take(std::max<size_t>(r.bytes, 256)); if (!*r.p) { set_last_error("workspace arena overflow"); hipFree(ws->arena); delete ws; return -1; } }
+  // decode uses gs.pos / gs.cpos as the row position arrays of the layer stack
+  ws->host_bytes = (size_t)(F * sizeof(int2) + ST * 8 * sizeof(int) + rows_dec * (size_t)(max_new + 16) * sizeof(int) + 1 * 1024 * 1024);
+  if (hipHostMalloc((void**)&ws->host_base, 2 * ws->host_bytes) != hipSuccess) { set_last_error("workspace_create: hipHostMalloc failed"); hipFree(ws->arena); delete ws; return -2; }
+  if (m->has_audio) {   // replicate embed_positions for every utterance slot (residual operand of conv2's epilogue)
+    for (int b = 0; b < max_B; ++b)
+      hipMemcpy((char*)ws->pos_rep + (size_t)b * 1500 * Da * e, m->apos, (size_t)1500 * Da * e, hipMemcpyDeviceToDevice);
+  }
+  ws->host = ws->host_base;
+  hipEventCreateWithFlags(&ws->host_ev[0], hipEventDisableTiming);
+  hipEventCreateWithFlags(&ws->host_ev[1], hipEventDisableTiming);
+  *out = ws;
+  return 0;
+}
+
+void oavsr_workspace_destroy(oavsr_workspace* ws) {
+  if (!ws) return;
+  if (ws->arena) hipFree(ws->arena);
+  if (ws->host_base) hipHostFree(ws->host_base);
+  for (int i = 0; i < 2; ++i) if (ws->host_ev[i]) hipEventDestroy(ws->host_ev[i]);
+  delete ws;
+}
+uint64_t oavsr_workspace_bytes(const oavsr_workspace* ws) { return ws ? ws->arena_bytes : 0; }
+
+int oavsr_encode_video(const oavsr_model* m, oavsr_workspace* ws, const float* video_dev, const int32_t* Tv_host, int32_t B, int32_t rate,
+                       void* out_dev, void* enc_dev, oavsr_stream stream) {
+  OAVSR_REQUIRE(m && ws && video_dev && Tv_host, "encode_video: null argument");
+  CallScope cs(ws, (hipStream_t)stream);
+  return encode_video_impl(m, ws, video_dev, Tv_host, B, rate, out_dev, enc_dev, nullptr, (hipStream_t)stream);
+}
+
+int oavsr_encode_audio(const oavsr_model* m, oavsr_workspace* ws, const float* wav_dev, int64_t ld, const int32_t* Ts_host,
+                       const int32_t* keep_host, int32_t B, int32_t rate, void* out_dev, void* enc_dev, void* mel_dev, oavsr_stream stream) {
+  OAVSR_REQUIRE(m && ws && wav_dev && Ts_host && keep_host, "encode_audio: null argument");
+  CallScope cs(ws, (hipStream_t)stream);
+  return encode_audio_impl(m, ws, wav_dev, ld, Ts_host, keep_host, B, rate, out_dev, enc_dev, mel_dev, nullptr, (hipStream_t)stream);
+}
+
+int oavsr_project(const oavsr_model* m, oavsr_workspace* ws, int32_t which, int32_t rate, const void* feats_dev, int32_t rows, void* out_dev,
+                  oavsr_stream stream) {
+  OAVSR_REQUIRE(m && ws && feats_dev && out_dev, "project: null argument");
+  return project_impl(m, ws, which, rate, feats_dev, rows, out_dev, (hipStream_t)stream);
+}
+
+int oavsr_build_prompt(const oavsr_model* m, oavsr_workspace* ws, int32_t task, int32_t B, const int32_t* na_host, const void* audio_tok_dev,
+                       const int32_t* nv_host, const void* video_tok_dev, void* embeds_dev, int32_t* S_host_out, oavsr_stream stream) {
+  OAVSR_REQUIRE(m && ws && embeds_dev && S_host_out, "build_prompt: null argument");
+  CallScope cs(ws, (hipStream_t)stream);
+  return build_prompt_impl(m, ws, task, B, na_host, audio_tok_dev, nv_host, video_tok_dev, embeds_dev, S_host_out, (hipStream_t)stream);
+}
+
+int oavsr_prefill(const oavsr_model* m, oavsr_workspace* ws, int32_t task, int32_t B, const void* embeds_dev, const int32_t* S_host,
+                  float* logits_dev, oavsr_stream stream) {
+  OAVSR_REQUIRE(m && ws && embeds_dev && S_host, "prefill: null argument");
+  CallScope cs(ws, (hipStream_t)stream);
+  return prefill_impl(m, ws, task, B, embeds_dev, S_host, logits_dev, (hipStream_t)stream);
+}
+
+int oavsr_decode(const oavsr_model* m, oavsr_workspace* ws, int32_t task, int32_t B, int32_t beams, int32_t max_new, int32_t force_len,
+                 int32_t* out_ids_dev, int32_t* out_len_dev, oavsr_stream stream) {
+  OAVSR_REQUIRE(m && ws && out_ids_dev && out_len_dev, "decode: null argument");
+  OAVSR_REQUIRE(beams == 1, "decode: beam search (num_beams=%d) is not built yet; use num_beams=1", beams);
+  CallScope cs(ws, (hipStream_t)stream);
+  return decode_greedy(m, ws, task, B, max_new, force_len, out_ids_dev, out_len_dev, (hipStream_t)stream);
+}
+
+int oavsr_generate(const oavsr_model* m, oavsr_workspace* ws, int32_t task, const float* video_dev, const int32_t* Tv_host, const float* wav_dev,
+                   int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host, int32_t B, int32_t rate_audio, int32_t rate_video,
+                   int32_t beams, int32_t max_new, int32_t force_len, int32_t* out_ids_dev, int32_t* out_len_dev, oavsr_stream stream) {
+  OAVSR_REQUIRE(m && ws && out_ids_dev && out_len_dev, "generate: null argument");
+  OAVSR_REQUIRE(beams == 1, "generate: beam search (num_beams=%d) is not built yet; use num_beams=1", beams);
+  OAVSR_REQUIRE(B >= 1 && B <= ws->max_B, "generate: B=%d exceeds workspace (%d)", B, ws->max_B);
+  hipStream_t st = (hipStream_t)stream;
+  CallScope cs(ws, st);
+  const bool use_a = task == OAVSR_TASK_AUDIO || task == OAVSR_TASK_AUDIOVISUAL;
+  const bool use_v = task == OAVSR_TASK_VIDEO || task == OAVSR_TASK_AUDIOVISUAL;
+  std::vector<int> na(B), nv(B);
+  int tot_a = 0, tot_v = 0;
+  if (use_a) {
+    OAVSR_REQUIRE(wav_dev && Ts_host && keep_host, "generate: audio inputs missing");
+    OAVSR_TRY(encode_audio_impl(m, ws, wav_dev, wav_ld, Ts_host, keep_host, B, rate_audio, nullptr, nullptr, nullptr, na.data(), st));
+    for (int b = 0; b < B; ++b) tot_a += na[b];
+    OAVSR_TRY(project_impl(m, ws, 0, rate_audio, ws->comp_a, tot_a, ws->tok_a, st));
+  }
+  if (use_v) {
+    OAVSR_REQUIRE(video_dev && Tv_host, "generate: video inputs missing");
+    OAVSR_TRY(encode_video_impl(m, ws, video_dev, Tv_host, B, rate_video, nullptr, nullptr, nv.data(), st));
+    for (int b = 0; b < B; ++b) tot_v += nv[b];
+    OAVSR_TRY(project_impl(m, ws, 1, rate_video, ws->comp_v, tot_v, ws->tok_v, st));
+  }
+  std::vector<int> S(B);
+  OAVSR_TRY(build_prompt_impl(m, ws, task, B, use_a ? na.data() : nullptr, ws->tok_a, use_v ? nv.data() : nullptr, ws->tok_v, ws->lx, S.data(), st));
+  OAVSR_TRY(prefill_impl(m, ws, task, B, ws->lx, S.data(), nullptr, st));
+  return decode_greedy(m, ws, task, B, max_new, force_len, out_ids_dev, out_len_dev, st);
+}
+
+int oavsr_profile_enable(int32_t on) { g_prof.on = on != 0; return 0; }
+int oavsr_profile_reset(void) { hipDeviceSynchronize(); g_prof.reset(); return 0; }
+int oavsr_profile_read(oavsr_prof_entry* out, int32_t max_entries) {
+  if (hipDeviceSynchronize() != hipSuccess) { set_last_error("profile_read: device sync failed"); return -2; }
+  const int nf = (int)g_prof.names.size();
+  std::vector<oavsr_prof_entry> agg(nf);
+  for (int i = 0; i < nf; ++i) { memset(&agg[i], 0, sizeof(oavsr_prof_entry)); strncpy(agg[i].name, g_prof.names[i].c_str(), 31); }
+  for (auto& r : g_prof.recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+    agg[r.fam].launches += 1; agg[r.fam].ms += ms; agg[r.fam].flops += r.flops; agg[r.fam].bytes += r.bytes;
+  }
+  int n = std::min(nf, (int)max_entries);
+  for (int i = 0; i < n; ++i) out[i] = agg[i];
+  return n;
+}
+
+// ---- single-kernel entry points --------------------------------------------------------------------
+int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream) {
+  OAVSR_REQUIRE(d, "op_gemm: null desc");
+  GemmArgs g; g.dtype = d->dtype; g.M = d->M; g.N = d->N; g.K = d->K; g.K2 = d->K2; g.A = d->A; g.W = d->W; g.A2 = d->A2; g.W2 = d->W2;
+  g.lda = d->lda; g.ldw = d->ldw; g.lda2 = d->lda2; g.ldw2 = d->ldw2; g.C = d->C; g.ldc = d->ldc; g.out_f32 = d->out_f32;
+  g.col_scale = d->col_scale; g.col_bias = d->col_bias; g.prelu = d->prelu; g.act = d->act; g.residual = d->residual; g.ldr = d->ldr;
+  g.res_after_act = d->res_after_act; g.groups = d->groups < 1 ? 1 : d->groups; g.a_goff = d->a_goff; g.amode = d->amode;
+  g.H = d->H; g.Wd = d->W_; g.Cin = d->Cin; g.OH = d->OH; g.OW = d->OW; g.stride = d->stride; g.pad = d->pad; g.ksize = d->ksize;
+  g.rowinfo = (const int4*)d->rowinfo; g.taps = d->taps; g.Kvalid = d->Kvalid; g.frameinfo = (const int2*)d->frameinfo;
+  return d->skinny ? launch_gemm_skinny(g, (hipStream_t)stream) : launch_gemm(g, (hipStream_t)stream);
+}
+
+int oavsr_op_attention(const oavsr_attn_desc* d, oavsr_stream stream) {
+  OAVSR_REQUIRE(d, "op_attention: null desc");
+  AttnArgs a; a.dtype = d->dtype; a.head_dim = d->head_dim; a.n_heads = d->n_heads; a.n_kv_heads = d->n_kv_heads; a.n_seqs = d->n_seqs;
+  a.max_q = d->max_q; a.causal = d->causal; a.Q = d->Q; a.K = d->K; a.V = d->V; a.O = d->O; a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv;
+  a.ldo = d->ldo; a.cu_q = d->cu_q; a.cu_k = d->cu_k; a.scale = d->scale;
+  return launch_attention(a, (hipStream_t)stream);
+}
+
+int oavsr_op_decode_attention(const oavsr_decode_attn_desc* d, oavsr_stream stream) {
+  OAVSR_REQUIRE(d, "op_decode_attention: null desc");
+  DecodeAttnArgs a; a.dtype = d->dtype; a.head_dim = d->head_dim; a.n_heads = d->n_heads; a.n_kv_heads = d->n_kv_heads; a.rows = d->rows;
+  a.beams = d->beams; a.max_prefix = d->max_prefix; a.max_tail = d->max_tail; a.Q = d->Q; a.Kp = d->Kp; a.Vp = d->Vp; a.Kt = d->Kt; a.Vt = d->Vt;
+  a.O = d->O; a.ldq = d->ldq; a.ldo = d->ldo; a.prefix_len = d->prefix_len; a.step = d->step; a.anc = d->anc; a.scale = d->scale;
+  return launch_decode_attention(a, (hipStream_t)stream);
+}
+
+int oavsr_op_norm(int32_t mode, int32_t dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, const float* b, int32_t rows,
+                  int32_t D, float eps, oavsr_stream stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 0) return launch_layernorm(dtype, x, ldx, y, ldy, w, b, rows, D, eps, st);
+  if (mode == 1) return launch_rmsnorm(dtype, x, ldx, y, ldy, w, rows, D, eps, st);
+  if (mode == 2) return launch_layernorm_zero_prefix(dtype, x, ldx, y, ldy, w, b, rows, D, eps, st);
+  set_last_error("op_norm: bad mode %d", mode);
+  return -1;
+}
+int oavsr_op_maxpool3x3s2(int32_t dtype, const void* x, void* y, int32_t imgs, int32_t H, int32_t W, int32_t C, oavsr_stream stream) {
+  return launch_maxpool3x3s2(dtype, x, y, imgs, H, W, C, (hipStream_t)stream);
+}
+int oavsr_op_avgpool_hw(int32_t dtype, const void* x, void* y, int32_t imgs, int32_t HW, int32_t C, oavsr_stream stream) {
+  return launch_avgpool_hw(dtype, x, y, imgs, HW, C, (hipStream_t)stream);
+}
+int oavsr_op_time_compress(int32_t dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const int32_t* seg_dev, int32_t n_seqs, int32_t max_out,
+                           int32_t rate, int32_t C, int32_t stack, oavsr_stream stream) {
+  return launch_time_compress(dtype, x, ldx, y, ldy, (const int4*)seg_dev, n_seqs, max_out, rate, C, stack, (hipStream_t)stream);
+}
+int oavsr_op_copy_rows(int32_t dtype, const void* src, int64_t lds, const int32_t* map_dev, void* y, int64_t ldy, int32_t n, int32_t D,
+                       oavsr_stream stream) {
+  return launch_copy_rows(dtype, src, lds, map_dev, y, ldy, n, D, (hipStream_t)stream);
+}
+int oavsr_op_rope_kv(int32_t dtype, int32_t rows, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, void* qkv, int64_t ld, const float* inv_freq,
+                     const int32_t* pos, const int32_t* slot, const int32_t* cpos, void* kcache, void* vcache, int32_t max_ctx, oavsr_stream stream) {
+  RopeArgs r; r.dtype = dtype; r.rows = rows; r.n_heads = n_heads; r.n_kv_heads = n_kv_heads; r.head_dim = head_dim; r.qkv = qkv; r.ld = ld;
+  r.inv_freq = inv_freq; r.pos = pos; r.slot = slot; r.cpos = cpos; r.kcache = kcache; r.vcache = vcache; r.max_ctx = max_ctx;
+  return launch_rope_kv(r, (hipStream_t)stream);
+}
+int oavsr_op_swiglu(int32_t dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t I, oavsr_stream stream) {
+  return launch_swiglu(dtype, x, ldx, y, ldy, rows, I, (hipStream_t)stream);
+}
+int oavsr_op_argmax(const float* logits, int64_t ld, int32_t rows, int32_t V, int32_t banned, int32_t* out, oavsr_stream stream) {
+  return launch_argmax(logits, ld, rows, V, banned, out, (hipStream_t)stream);
+}
+int oavsr_op_build_rowinfo(const int32_t* cu_out, const int32_t* cu_in, int32_t n_seqs, int32_t stride, int32_t* rowinfo, int32_t rows,
+                           oavsr_stream stream) {
+  return launch_build_rowinfo(cu_out, cu_in, n_seqs, stride, (int4*)rowinfo, rows, (hipStream_t)stream);
+}
+int oavsr_op_logmel(const oavsr_model* m, int32_t dtype, const float* wav, int64_t ld, const int32_t* lens_dev, int32_t B, float* mel_ws,
+                    float* max_ws, void* out, int64_t ldo, oavsr_stream stream) {
+  OAVSR_REQUIRE(m, "op_logmel: null model");
+  return launch_logmel(dtype, wav, ld, lens_dev, B, m->twiddle, m->melfb, mel_ws, max_ws, out, ldo, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,341 @@
+"""Python shim that keeps the reference's boundary: `AVSR_LLMs(...)`, `.load_state_dict(ckpt)`, `.modality`,
+`.forward(inputs, is_trainval=False, modality=None, test_ratio_matry_audio=None, test_ratio_matry_video=None)`
+(Omni_AVSR/modeling_OmniAVSR.py:27-34,263,308-323).  All tensor work happens in libomniavsr_hip.so; torch is only
+the owner of device memory and of the HIP stream.
+
+Differences from the reference that are deliberate:
+  * batches > 1 are allowed; every utterance is computed exactly as if it were alone (no padded attention), which is
+    what the reference's batch-1 evaluation does.  Optional `inputs["video_lengths"]` gives frames per utterance.
+  * `num_beams == 1` runs the hipGraph-free greedy loop with `do_sample=False` (the north-star decode); HF beam search
+    is the next row of SURVEY.md §8(f) and raises NotImplementedError for now.
+  * `is_trainval=True` (loss computation) is training and out of scope: NotImplementedError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .config import (LLM_SPECS, LoRA_config, OmniSpec, QwenLoRA_config, spec_from_names)
+from .weights import av_lora_k2, build_blob, lora_k2, pack_state_dict
+
+
+def _i32arr(xs: Sequence[int]):
+    return (C.c_int32 * len(xs))(*[int(x) for x in xs])
+
+
+def whisper_keep_tokens(max_len: int) -> int:
+    """modeling_OmniAVSR.py:537 — `max(int(max_len/16000*50), 25)` evaluated with Python float semantics."""
+    return max(int(max_len / 16000 * 50), 25)
+
+
+class OmniEngine:
+    """Owns the device blob, the oavsr_model and one workspace; thin typed wrappers over the C ABI."""
+
+    def __init__(self, spec: OmniSpec, dtype: str = "bf16", device: str = "cuda:0"):
+        self.spec, self.dtype, self.device = spec, dtype, torch.device(device)
+        self.tdtype = torch.bfloat16 if dtype == "bf16" else torch.float32
+        self.lib = L.load()
+        self._model = C.c_void_p(None)
+        self._ws = C.c_void_p(None)
+        self._ws_key = None
+        self._blob = None
+        self._names = None
+
+    # ---- construction ------------------------------------------------------------------------------
+    def _config(self, packed_names) -> L.OavsrConfig:
+        s, l = self.spec, self.spec.llm
+        c = L.OavsrConfig()
+        c.dtype = L.DT_BF16 if self.dtype == "bf16" else L.DT_F32
+        c.llm_family = 0 if l.family == "llama" else 1
+        c.llm_hidden, c.llm_layers, c.llm_heads, c.llm_kv_heads = l.hidden, l.layers, l.heads, l.kv_heads
+        c.llm_head_dim, c.llm_mlp, c.llm_vocab, c.llm_rms_eps, c.llm_qkv_bias = l.head_dim, l.mlp, l.vocab, l.rms_eps, int(l.qkv_bias)
+        c.lora_inner, c.lora_k2, c.lora_task_specific = s.lora_inner(), lora_k2(s), int(s.is_task_specific)
+        if s.whisper is not None:
+            c.wh_dim, c.wh_layers, c.wh_heads, c.wh_ffn = s.whisper.dim, s.whisper.layers, s.whisper.heads, s.whisper.ffn
+        if s.avhubert is not None:
+            a = s.avhubert
+            c.av_dim, c.av_layers, c.av_heads, c.av_ffn = a.dim, a.layers, a.heads, a.ffn
+            c.av_conv_pos, c.av_conv_groups, c.av_lora_k2 = a.conv_pos, a.conv_pos_groups, av_lora_k2(s)
+        c.proj_inter = s.intermediate_size
+        c.compression_stack = int(s.compression_mode == "stack")
+        ra, rv = s.rates("audio"), s.rates("video")
+        c.n_rates_audio, c.n_rates_video = len(ra), len(rv)
+        for i, r in enumerate(ra):
+            c.rates_audio[i] = r
+        for i, r in enumerate(rv):
+            c.rates_video[i] = r
+        c.proj_per_rate = int(s.proj_per_rate())
+        c.proj_layernorm_audio = int("pa.0.ln.w" in packed_names)
+        c.proj_layernorm_video = int("pv.0.ln.w" in packed_names)
+        ids = s.ids
+        c.id_bos, c.id_eos, c.id_pad = ids["bos"], ids["eos"], ids["pad"]
+        c.id_audio_sos, c.id_audio_eos, c.id_video_sos, c.id_video_eos = ids["audio_sos"], ids["audio_eos"], ids["video_sos"], ids["video_eos"]
+        for t, name in enumerate(("audio", "video", "audiovisual")):
+            c.prompt_len[t] = s.prompt_len[name] if f"l.prompt.{t}" in packed_names else 0
+        return c
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        """Accepts the reference's checkpoint layout (strict for the modules the spec declares)."""
+        if not torch.cuda.is_available():
+            raise RuntimeError("omni_avsr_amd needs a ROCm GPU (MI355X); there is no CPU path")
+        packed = pack_state_dict(sd, self.spec, self.dtype)
+        # keep the true prompt lengths of the checkpoint
+        for t, name in enumerate(("audio", "video", "audiovisual")):
+            if f"l.prompt.{t}" in packed:
+                self.spec.prompt_len[name] = int(packed[f"l.prompt.{t}"].shape[0])
+        blob, manifest = build_blob(packed, device=self.device)
+        self._blob = blob
+        self._names = [n.encode() for n, _, _ in manifest]
+        arr = (L.OavsrTensor * len(manifest))()
+        for i, (n, off, nb) in enumerate(manifest):
+            arr[i].name, arr[i].offset, arr[i].nbytes = self._names[i], off, nb
+        cfg = self._config({n for n, _, _ in manifest})
+        self.close()
+        torch.cuda.synchronize(self.device)
+        L.check(self.lib.oavsr_model_create(C.byref(cfg), C.c_void_p(blob.data_ptr()), blob.numel(), arr, len(manifest), C.byref(self._model)))
+        self.blob_bytes = blob.numel()
+        return self
+
+    def ensure_workspace(self, B: int, Tv: int, Ts: int, beams: int = 1, max_new: Optional[int] = None):
+        max_new = max_new or self.spec.max_dec_tokens
+        key = self._ws_key
+        if key is not None and key[0] >= B and key[1] >= Tv and key[2] >= Ts and key[3] >= beams and key[4] >= max_new:
+            return
+        if self._ws:
+            torch.cuda.synchronize(self.device)
+            self.lib.oavsr_workspace_destroy(self._ws)
+            self._ws = C.c_void_p(None)
+        L.check(self.lib.oavsr_workspace_create(self._model, B, max(Tv, 1), max(Ts, 1), beams, max_new, C.byref(self._ws)))
+        self._ws_key = (B, Tv, Ts, beams, max_new)
+
+    def workspace_bytes(self) -> int:
+        return int(self.lib.oavsr_workspace_bytes(self._ws)) if self._ws else 0
+
+    def close(self):
+        if self._ws:
+            self.lib.oavsr_workspace_destroy(self._ws)
+            self._ws = C.c_void_p(None)
+            self._ws_key = None
+        if self._model:
+            self.lib.oavsr_model_destroy(self._model)
+            self._model = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- stage wrappers (parity tests call these) ----------------------------------------------------
+    def _flat_video(self, video: torch.Tensor, Tv: Sequence[int]) -> torch.Tensor:
+        """[B,T,1,88,88] (padded) -> contiguous f32 [sum(Tv),88,88]"""
+        v = video.to(self.device, torch.float32)
+        return torch.cat([v[b, : Tv[b], 0] for b in range(v.shape[0])], 0).contiguous()
+
+    def encode_video(self, video: torch.Tensor, Tv: Sequence[int], rate: int, return_enc: bool = False):
+        B = len(Tv)
+        self.ensure_workspace(max(B, self._ws_key[0] if self._ws_key else 0), max(max(Tv), self._ws_key[1] if self._ws_key else 0), self._ws_key[2] if self._ws_key else 16000)
+        flat = self._flat_video(video, Tv)
+        D = self.spec.avhubert.dim
+        n_out = [t // rate for t in Tv]
+        Dout = D * rate if self.spec.compression_mode == "stack" else D
+        out = torch.empty(sum(n_out), Dout, dtype=self.tdtype, device=self.device)
+        enc = torch.empty(sum(Tv), D, dtype=self.tdtype, device=self.device) if return_enc else None
+        L.check(self.lib.oavsr_encode_video(self._model, self._ws, C.c_void_p(flat.data_ptr()), _i32arr(Tv), B, rate, C.c_void_p(out.data_ptr()),
+                                            C.c_void_p(enc.data_ptr()) if enc is not None else None, self._stream()))
+        return (out, enc, n_out) if return_enc else (out, n_out)
+
+    def encode_audio(self, audio: torch.Tensor, lengths: Sequence[int], rate: int, return_enc: bool = False, keep: Optional[Sequence[int]] = None):
+        """audio [B,T_s] or [B,T_s,1] f32; lengths = valid samples per utterance."""
+        a = audio.to(self.device, torch.float32)
+        if a.dim() == 3:
+            a = a[..., 0]
+        a = a.contiguous()
+        B = a.shape[0]
+        keep = list(keep) if keep is not None else [whisper_keep_tokens(int(n)) for n in lengths]
+        self.ensure_workspace(max(B, self._ws_key[0] if self._ws_key else 0), self._ws_key[1] if self._ws_key else 1, max(int(max(lengths)), self._ws_key[2] if self._ws_key else 0))
+        D = self.spec.whisper.dim
+        n_out = [k // rate for k in keep]
+        Dout = D * rate if self.spec.compression_mode == "stack" else D
+        out = torch.empty(sum(n_out), Dout, dtype=self.tdtype, device=self.device)
+        enc = torch.empty(B, 1500, D, dtype=self.tdtype, device=self.device) if return_enc else None
+        mel = torch.empty(B, 3000, 80, dtype=self.tdtype, device=self.device) if return_enc else None
+        L.check(self.lib.oavsr_encode_audio(self._model, self._ws, C.c_void_p(a.data_ptr()), a.stride(0), _i32arr(lengths), _i32arr(keep), B, rate,
+                                            C.c_void_p(out.data_ptr()), C.c_void_p(enc.data_ptr()) if enc is not None else None,
+                                            C.c_void_p(mel.data_ptr()) if mel is not None else None, self._stream()))
+        return (out, enc, mel, n_out) if return_enc else (out, n_out)
+
+    def project(self, which: str, rate: int, feats: torch.Tensor) -> torch.Tensor:
+        out = torch.empty(feats.shape[0], self.spec.llm.hidden, dtype=self.tdtype, device=self.device)
+        L.check(self.lib.oavsr_project(self._model, self._ws, 0 if which == "audio" else 1, rate, C.c_void_p(feats.data_ptr()), feats.shape[0],
+                                       C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
+    def build_prompt(self, task: str, B: int, na, atok, nv, vtok):
+        P = self.spec.prompt_len[task]
+        bos = 1 if self.spec.llm.family == "llama" else 0
+        S = [bos + (na[b] + 2 if na is not None else 0) + (nv[b] + 2 if nv is not None else 0) + P for b in range(B)]
+        emb = torch.empty(sum(S), self.spec.llm.hidden, dtype=self.tdtype, device=self.device)
+        S_out = (C.c_int32 * B)()
+        L.check(self.lib.oavsr_build_prompt(self._model, self._ws, L.TASK_ID[task], B, _i32arr(na) if na is not None else None,
+                                            C.c_void_p(atok.data_ptr()) if atok is not None else None, _i32arr(nv) if nv is not None else None,
+                                            C.c_void_p(vtok.data_ptr()) if vtok is not None else None, C.c_void_p(emb.data_ptr()), S_out, self._stream()))
+        assert list(S_out) == S
+        return emb, S
+
+    def prefill(self, task: str, embeds: torch.Tensor, S: Sequence[int]) -> torch.Tensor:
+        B = len(S)
+        logits = torch.empty(B, self.spec.llm.vocab, dtype=torch.float32, device=self.device)
+        L.check(self.lib.oavsr_prefill(self._model, self._ws, L.TASK_ID[task], B, C.c_void_p(embeds.data_ptr()), _i32arr(S), C.c_void_p(logits.data_ptr()), self._stream()))
+        return logits
+
+    def decode(self, task: str, B: int, beams: int, max_new: int, force_len: bool = False):
+        ids = torch.empty(B, max_new, dtype=torch.int32, device=self.device)
+        lens = torch.empty(B, dtype=torch.int32, device=self.device)
+        L.check(self.lib.oavsr_decode(self._model, self._ws, L.TASK_ID[task], B, beams, max_new, int(force_len), C.c_void_p(ids.data_ptr()),
+                                      C.c_void_p(lens.data_ptr()), self._stream()))
+        return ids, lens
+
+    def generate(self, task: str, video: Optional[torch.Tensor], Tv: Optional[Sequence[int]], audio: Optional[torch.Tensor],
+                 lengths: Optional[Sequence[int]], rate_a: int, rate_v: int, beams: int = 1, max_new: Optional[int] = None,
+                 force_len: bool = False, video_is_flat: bool = False):
+        """End-to-end `forward(is_trainval=False)`: returns (ids int32 [B,max_new] pad-filled, lens int32 [B]) on device.
+        No host synchronisation happens inside."""
+        max_new = max_new or self.spec.max_dec_tokens
+        use_a, use_v = task in ("audio", "audiovisual"), task in ("video", "audiovisual")
+        B = len(Tv) if use_v else len(lengths)
+        flat = a = None
+        keep = None
+        if use_v:
+            flat = video if video_is_flat else self._flat_video(video, Tv)
+        if use_a:
+            a = audio if audio.dim() == 2 else audio[..., 0]
+            if a.device != self.device or a.dtype != torch.float32 or not a.is_contiguous():
+                a = a.to(self.device, torch.float32).contiguous()
+            keep = [whisper_keep_tokens(int(n)) for n in lengths]
+        self.ensure_workspace(B, max(Tv) if use_v else 1, int(max(lengths)) if use_a else 16000, beams, max_new)
+        ids = torch.empty(B, max_new, dtype=torch.int32, device=self.device)
+        lens = torch.empty(B, dtype=torch.int32, device=self.device)
+        L.check(self.lib.oavsr_generate(
+            self._model, self._ws, L.TASK_ID[task],
+            C.c_void_p(flat.data_ptr()) if use_v else None, _i32arr(Tv) if use_v else None,
+            C.c_void_p(a.data_ptr()) if use_a else None, a.stride(0) if use_a else 0,
+            _i32arr(lengths) if use_a else None, _i32arr(keep) if use_a else None,
+            B, int(rate_a or 1), int(rate_v or 1), beams, max_new, int(force_len),
+            C.c_void_p(ids.data_ptr()), C.c_void_p(lens.data_ptr()), self._stream()))
+        self._keepalive = (flat, a)
+        return ids, lens
+
+    # ---- profiling (bench.py roofline) ------------------------------------------------------------------
+    def profile(self, on: bool):
+        self.lib.oavsr_profile_enable(int(on))
+        self.lib.oavsr_profile_reset()
+
+    def profile_read(self) -> List[dict]:
+        arr = (L.OavsrProfEntry * 64)()
+        n = self.lib.oavsr_profile_read(arr, 64)
+        return [dict(name=arr[i].name.decode(), launches=int(arr[i].launches), ms=float(arr[i].ms), flops=float(arr[i].flops),
+                     bytes=float(arr[i].bytes)) for i in range(max(n, 0))]
+
+
+class AVSR_LLMs:
+    """Drop-in for `Omni_AVSR.modeling_OmniAVSR.AVSR_LLMs` (inference branch).  Same ctor arguments (:28-34); because
+    no hub / tokenizer is reachable offline, `tokenizer` may be None (ids then come from the model family's published
+    vocabulary) and the pretrained encoders are not downloaded: weights arrive through `load_state_dict`, exactly like
+    `lightning_OmniAVSR.py:148-150`."""
+
+    def __init__(self, modality, pretrain_avhubert_enc_video, use_lora_avhubert, llm_model, hidden_size, intermediate_size, tokenizer,
+                 prompt_audio, prompt_video, prompt_audiovisual, pad_id, downsample_ratio_audio, downsample_ratio_video,
+                 audio_encoder_name, compression_mode, unfrozen_modules, max_dec_tokens, num_beams, PETF_LLM_name=None,
+                 peft_config_llm=None, remove_layernorm_from_projector=False, matry_weights=None, is_task_specific=None,
+                 is_matryoshka=False, is_single_matry_projector=False, *, spec: Optional[OmniSpec] = None, dtype: str = "bf16",
+                 device: str = "cuda:0"):
+        self.modality = modality
+        self.max_dec_tokens, self.num_beams = max_dec_tokens, num_beams
+        self.llm_model, self.tokenizer = llm_model, tokenizer
+        self.is_matryoshka, self.is_task_specific = is_matryoshka, bool(is_task_specific)
+        self.downsample_ratio_audio, self.downsample_ratio_video = downsample_ratio_audio, downsample_ratio_video
+        if spec is None:
+            rank = alpha = 0
+            shared = False
+            if PETF_LLM_name is not None:
+                assert PETF_LLM_name == "lora"                                              # modeling_OmniAVSR.py:202
+                rank, alpha = peft_config_llm.RANK, peft_config_llm.ALPHA
+                shared = bool(peft_config_llm.SHARED_LORA)
+                if shared and not peft_config_llm.IS_TASK_SPECIFIC:
+                    raise ValueError("SHARED_LORA without IS_TASK_SPECIFIC is invalid in the reference (Llama_LoRA.py:138-142,254-256)")
+            spec = spec_from_names(
+                llm_model, audio_encoder_name if modality in ("audio", "audiovisual") else None,
+                pretrain_avhubert_enc_video if modality in ("video", "audiovisual") else None,
+                use_lora_avhubert=bool(use_lora_avhubert), intermediate_size=intermediate_size, compression_mode=compression_mode,
+                downsample_ratio_audio=downsample_ratio_audio, downsample_ratio_video=downsample_ratio_video,
+                is_matryoshka=bool(is_matryoshka), is_single_matry_projector=bool(is_single_matry_projector),
+                remove_layernorm_from_projector=bool(remove_layernorm_from_projector), lora_rank=rank, lora_alpha=alpha,
+                is_task_specific=bool(is_task_specific), shared_lora=shared, max_dec_tokens=max_dec_tokens, num_beams=num_beams)
+            assert spec.llm.hidden == hidden_size, "hidden_size does not match the LLM (lightning_OmniAVSR.py:28-37)"
+            if tokenizer is not None:
+                v = tokenizer.vocab
+                spec.ids.update(audio_sos=v["<audio>"], audio_eos=v["</audio>"], video_sos=v["<video>"], video_eos=v["</video>"])
+        self.spec = spec
+        self.engine = OmniEngine(spec, dtype=dtype, device=device)
+
+    # nn.Module-ish surface used by the reference's callers
+    def load_state_dict(self, state_dict, strict: bool = True):
+        self.engine.load_state_dict(state_dict)
+        return self
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def requires_grad_(self, *a, **k):
+        return self
+
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)
+
+    def forward(self, inputs, is_trainval=True, modality=None, test_ratio_matry_audio=None, test_ratio_matry_video=None,
+                force_len: bool = False):
+        if is_trainval:
+            raise NotImplementedError("training branch (modeling_OmniAVSR.py:265-306) is out of scope of the inference hot path")
+        task = self.modality
+        if self.is_task_specific and modality is None:
+            raise KeyError(None)      # reference: lora_up_Q[None] (Llama_LoRA.py:250)
+        if self.is_matryoshka:
+            ra, rv = test_ratio_matry_audio, test_ratio_matry_video
+        else:
+            ra, rv = self.downsample_ratio_audio, self.downsample_ratio_video
+        lora_task = modality if self.is_task_specific else task
+        if lora_task != task:
+            raise NotImplementedError("LoRA task different from the input modality is not supported")
+        use_a, use_v = task in ("audio", "audiovisual"), task in ("video", "audiovisual")
+        if use_a and ra not in self.spec.rates("audio"):
+            raise KeyError(ra)        # matry_map_audio[...] modeling_OmniAVSR.py:447,556
+        if use_v and rv not in self.spec.rates("video"):
+            raise KeyError(rv)
+        if self.num_beams != 1:
+            raise NotImplementedError("HF beam search (num_beams>1) is the next row of SURVEY.md §8(f); use num_beams=1")
+        video = inputs.get("video") if use_v else None
+        audio = inputs.get("audio") if use_a else None
+        Tv = lengths = None
+        if use_v:
+            Tv = [int(x) for x in inputs["video_lengths"]] if "video_lengths" in inputs else [video.shape[1]] * video.shape[0]
+        if use_a:
+            B = audio.shape[0]
+            if B == 1:
+                lengths = [int(max(inputs["lengths"]))]                                   # modeling_OmniAVSR.py:399
+            else:
+                lengths = [int(x) for x in inputs["lengths"]]
+        ids, lens = self.engine.generate(task, video, Tv, audio, lengths, ra, rv, self.num_beams, self.max_dec_tokens, force_len)
+        lens_h = lens.cpu()
+        n = int(lens_h.max())
+        return ids[:, :n].to(torch.long)

@@ -1,0 +1,61 @@
+"""Helpers for the -m gpu parity tests: call single kernels through the C ABI with torch-owned device memory."""
+import ctypes as C
+
+import torch
+
+from omni_avsr_amd import lib as L
+
+DEV = "cuda:0"
+
+
+def tdt(dtype):
+    return torch.bfloat16 if dtype == "bf16" else torch.float32
+
+
+def dcode(dtype):
+    return L.DT_BF16 if dtype == "bf16" else L.DT_F32
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def tol(dtype, k=1):
+    """abs tolerance relative to unit-scale outputs"""
+    return 2e-2 if dtype == "bf16" else 1e-4
+
+
+def gemm(dtype, A, W, *, A2=None, W2=None, scale=None, bias=None, prelu=None, act=0, residual=None, res_after_act=0,
+         out_f32=False, skinny=False, M=None, N=None, K=None, C_out=None, **geom):
+    lib = L.load()
+    d = L.GemmDesc()
+    d.dtype = dcode(dtype)
+    d.M = M if M is not None else A.shape[0]
+    d.N = N if N is not None else W.shape[0]
+    d.K = K if K is not None else W.shape[1]
+    d.A, d.W = P(A), P(W)
+    d.lda = geom.pop("lda", A.stride(0) if A.dim() == 2 else 0)
+    d.ldw = W.stride(0)
+    if A2 is not None:
+        d.A2, d.W2, d.K2, d.lda2, d.ldw2 = P(A2), P(W2), W2.shape[1], A2.stride(0), W2.stride(0)
+    groups = geom.get("groups", 1)
+    ncols = d.N * groups
+    out = C_out if C_out is not None else torch.empty(d.M, ncols, dtype=torch.float32 if out_f32 else tdt(dtype), device=DEV)
+    d.C, d.ldc, d.out_f32 = P(out), out.stride(0), int(out_f32)
+    d.col_scale, d.col_bias, d.prelu = P(scale), P(bias), P(prelu)
+    d.act, d.res_after_act = act, res_after_act
+    if residual is not None:
+        d.residual, d.ldr = P(residual), residual.stride(0)
+    d.groups = groups
+    d.skinny = int(skinny)
+    for k, v in geom.items():
+        if k in ("rowinfo", "frameinfo"):
+            setattr(d, k, P(v))
+        elif k != "groups":
+            setattr(d, k, v)
+    L.check(lib.oavsr_op_gemm(C.byref(d), stream()))
+    return out

@@ -1,0 +1,414 @@
+"""-m gpu: every HIP kernel, called through the C ABI, against a plain PyTorch fp32 reference of the same op.
+Tolerances: f32 (exact-f32 MFMA) 1e-4 abs on unit-scale outputs; bf16 2e-2 (8-bit mantissa inputs)."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from omni_avsr_amd import lib as L  # noqa: E402
+from gpu_util import DEV, P, dcode, gemm, stream, tdt, tol  # noqa: E402
+
+DTYPES = ["f32", "bf16"]
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def q(x, dtype):
+    """round to the compute dtype, return (device tensor in dtype, fp32 CPU view of the rounded values)"""
+    xd = x.to(tdt(dtype))
+    return xd.to(DEV).contiguous(), xd.float()
+
+
+def close(out, ref, atol, rtol=0.0, what=""):
+    out = out.float().cpu()
+    err = (out - ref).abs()
+    lim = atol + rtol * ref.abs()
+    bad = err > lim
+    assert not bad.any(), f"{what}: max err {err.max().item():.3e} (limit {atol}), {int(bad.sum())} / {bad.numel()} bad, worst idx {int(err.argmax())}"
+    assert torch.isfinite(out).all(), f"{what}: non-finite output"
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (200, 96, 256), (1, 64, 128), (333, 300, 384), (64, 1000, 128)])
+def test_gemm_dense(dtype, M, N, K):
+    a, ar = q(rnd(M, K, seed=1), dtype)
+    w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
+    out = gemm(dtype, a, w)
+    close(out, ar @ wr.T, tol(dtype), what="gemm")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_asymmetric_identity(dtype):
+    """A = I with an asymmetric W catches row/col swaps of the MFMA C layout."""
+    n = 128
+    a, _ = q(torch.eye(n), dtype)
+    wv = torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 / 64.0
+    w, wr = q(wv, dtype)
+    out = gemm(dtype, a, w)
+    close(out, wr.T, 1e-6, what="gemm identity")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("act", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("res_after", [0, 1])
+def test_gemm_epilogue(dtype, act, res_after):
+    M, N, K = 150, 200, 128
+    a, ar = q(rnd(M, K, seed=3), dtype)
+    w, wr = q(rnd(N, K, seed=4) / math.sqrt(K), dtype)
+    r, rr = q(rnd(M, N, seed=5), dtype)
+    scale = (rnd(N, seed=6) * 0.1 + 1).to(DEV)
+    bias = rnd(N, seed=7).to(DEV)
+    slope = (rnd(N, seed=8) * 0.05 + 0.25).to(DEV)
+    out = gemm(dtype, a, w, scale=scale, bias=bias, prelu=slope if act == 3 else None, act=act, residual=r, res_after_act=res_after)
+    y = (ar @ wr.T) * scale.cpu() + bias.cpu()
+    if not res_after:
+        y = y + rr
+    y = {0: lambda v: v, 1: F.gelu, 2: F.relu, 3: lambda v: torch.where(v >= 0, v, slope.cpu() * v), 4: F.silu}[act](y)
+    if res_after:
+        y = y + rr
+    close(out, y, tol(dtype) * 2, what="gemm epilogue")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("skinny", [False, True])
+def test_gemm_lora_segment(dtype, skinny):
+    """C = A1 W1^T + A2 W2^T (fused W + BA), fp32 logits output."""
+    M, N, K, K2 = (8 if skinny else 100), 320, 256, 64
+    a, ar = q(rnd(M, K, seed=1), dtype)
+    w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
+    a2, a2r = q(rnd(M, K2, seed=3), dtype)
+    w2, w2r = q(rnd(N, K2, seed=4) / math.sqrt(K2), dtype)
+    bias = rnd(N, seed=9).to(DEV)
+    out = gemm(dtype, a, w, A2=a2, W2=w2, bias=bias, out_f32=True, skinny=skinny)
+    close(out, ar @ wr.T + a2r @ w2r.T + bias.cpu(), tol(dtype), what="gemm 2-segment")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(1, 64, 64), (8, 1000, 256), (16, 16384 + 48, 128), (17, 200, 512), (40, 96, 256), (120, 333, 192)])
+def test_gemm_skinny(dtype, M, N, K):
+    a, ar = q(rnd(M, K, seed=1), dtype)
+    w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
+    r, rr = q(rnd(M, N, seed=5), dtype)
+    out = gemm(dtype, a, w, residual=r, skinny=True)
+    close(out, ar @ wr.T + rr, tol(dtype), what="skinny gemm")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Cin,Cout,H,stride,ks", [(64, 64, 22, 1, 3), (64, 128, 22, 2, 3), (64, 128, 22, 2, 1), (128, 256, 11, 2, 3), (256, 512, 6, 2, 3), (512, 512, 3, 1, 3)])
+def test_conv2d_implicit_gemm(dtype, Cin, Cout, H, stride, ks):
+    imgs = 5
+    x = rnd(imgs, Cin, H, H, seed=1)
+    w = rnd(Cout, Cin, ks, ks, seed=2) / math.sqrt(Cin * ks * ks)
+    xd, xr = q(x.permute(0, 2, 3, 1).contiguous(), dtype)            # NHWC
+    wd, wr = q(w.permute(0, 2, 3, 1).reshape(Cout, -1), dtype)
+    pad = ks // 2
+    OH = (H + 2 * pad - ks) // stride + 1
+    out = gemm(dtype, xd, wd, M=imgs * OH * OH, amode=1, H=H, W_=H, Cin=Cin, OH=OH, OW=OH, stride=stride, pad=pad, ksize=ks, lda=0)
+    ref = F.conv2d(xr.permute(0, 3, 1, 2), wr.reshape(Cout, ks, ks, Cin).permute(0, 3, 1, 2), stride=stride, padding=pad)
+    close(out.reshape(imgs, OH, OH, Cout), ref.permute(0, 2, 3, 1), tol(dtype), what="conv2d")
+
+
+def _rowinfo(cu_out, cu_in, stride):
+    lib = L.load()
+    n = len(cu_out) - 1
+    rows = cu_out[-1]
+    co = torch.tensor(cu_out, dtype=torch.int32, device=DEV)
+    ci = torch.tensor(cu_in, dtype=torch.int32, device=DEV)
+    ri = torch.empty(rows, 4, dtype=torch.int32, device=DEV)
+    L.check(lib.oavsr_op_build_rowinfo(P(co), P(ci), n, stride, P(ri), rows, stream()))
+    return ri
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv1d_posconv_grouped_varlen(dtype):
+    """AV-HuBERT positional conv: groups, even kernel with SamePad, GELU, residual, per-utterance zero halo."""
+    D, G, taps = 128, 4, 16
+    Cg = D // G
+    lens = [37, 5, 64]
+    cu = [0]
+    for n in lens:
+        cu.append(cu[-1] + n)
+    x = rnd(cu[-1], D, seed=1)
+    w = rnd(D, Cg, taps, seed=2) / math.sqrt(Cg * taps)
+    b = rnd(D, seed=3)
+    xd, xr = q(x, dtype)
+    wd, wr = q(w.permute(0, 2, 1).reshape(D, -1), dtype)
+    ri = _rowinfo(cu, cu, 1)
+    out = gemm(dtype, xd, wd, M=cu[-1], N=Cg, K=taps * Cg, amode=2, Cin=Cg, taps=taps, Kvalid=taps * Cg, pad=taps // 2, groups=G, a_goff=Cg,
+               rowinfo=ri, bias=b.to(DEV), act=1, residual=xd, res_after_act=1, lda=D)
+    refs = []
+    wref = wr.reshape(D, taps, Cg).permute(0, 2, 1)
+    for i, n in enumerate(lens):
+        xi = xr[cu[i]:cu[i + 1]].T[None]
+        y = F.conv1d(xi, wref, b, padding=taps // 2, groups=G)[:, :, :-1]
+        refs.append((xi + F.gelu(y))[0].T)
+    close(out, torch.cat(refs), tol(dtype) * 2, what="posconv")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("stride,Cin", [(1, 80), (2, 128)])
+def test_conv1d_whisper(dtype, stride, Cin):
+    B, Tin, D = 2, 40, 64
+    Tout = Tin // stride
+    x = rnd(B * Tin, Cin, seed=1)
+    w = rnd(D, Cin, 3, seed=2) / math.sqrt(3 * Cin)
+    b = rnd(D, seed=3)
+    xd, xr = q(x, dtype)
+    Kp = 256 if Cin == 80 else 3 * Cin
+    wp = torch.zeros(D, Kp)
+    wp[:, : 3 * Cin] = w.permute(0, 2, 1).reshape(D, -1)
+    wd, wr = q(wp, dtype)
+    cu_in = [i * Tin for i in range(B + 1)]
+    cu_out = [i * Tout for i in range(B + 1)]
+    ri = _rowinfo(cu_out, cu_in, stride)
+    out = gemm(dtype, xd, wd, M=B * Tout, N=D, K=Kp, amode=2, Cin=Cin, taps=3, Kvalid=3 * Cin, pad=1, rowinfo=ri, bias=b.to(DEV), act=1, lda=Cin)
+    wref = wr[:, : 3 * Cin].reshape(D, 3, Cin).permute(0, 2, 1)
+    ref = F.gelu(F.conv1d(xr.reshape(B, Tin, Cin).transpose(1, 2), wref, b, stride=stride, padding=1)).transpose(1, 2).reshape(B * Tout, D)
+    close(out, ref, tol(dtype) * 2, what="whisper conv")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_stem_conv3d(dtype):
+    """5x7x7 stride (1,2,2) conv on f32 video with per-utterance temporal zero padding + BN affine + PReLU."""
+    lens = [3, 4]
+    Fr = sum(lens)
+    vid = rnd(Fr, 88, 88, seed=1)
+    w = rnd(64, 1, 5, 7, 7, seed=2) / math.sqrt(245)
+    scale = (rnd(64, seed=3) * 0.1 + 1)
+    shift = rnd(64, seed=4) * 0.1
+    slope = rnd(64, seed=5) * 0.05 + 0.25
+    wp = torch.zeros(64, 256)
+    wp[:, :245] = w.reshape(64, 245)
+    wd, wr = q(wp, dtype)
+    fi = torch.tensor([[t, n] for n in lens for t in range(n)], dtype=torch.int32, device=DEV)
+    out = gemm(dtype, vid.to(DEV), wd, M=Fr * 1936, N=64, K=256, amode=3, frameinfo=fi, scale=scale.to(DEV), bias=shift.to(DEV), prelu=slope.to(DEV), act=3, lda=0)
+    refs = []
+    o = 0
+    vq = vid.to(tdt(dtype)).float()          # the loader rounds the video to the compute dtype
+    for n in lens:
+        v = vq[o:o + n][None, None]
+        y = F.conv3d(v, wr[:, :245].reshape(64, 1, 5, 7, 7), stride=(1, 2, 2), padding=(2, 3, 3))
+        y = y * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)
+        y = torch.where(y >= 0, y, slope.view(1, -1, 1, 1, 1) * y)
+        refs.append(y[0].permute(1, 2, 3, 0).reshape(n * 1936, 64))
+        o += n
+    close(out, torch.cat(refs), tol(dtype) * 2, what="stem")
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_ref(qr, kr, vr, cu_q, cu_k, H, KV, hd, scale, causal):
+    outs = []
+    for s in range(len(cu_q) - 1):
+        qs = qr[cu_q[s]:cu_q[s + 1]].reshape(-1, H, hd).transpose(0, 1)
+        ks = kr[cu_k[s]:cu_k[s + 1]].reshape(-1, KV, hd).transpose(0, 1).repeat_interleave(H // KV, 0)
+        vs = vr[cu_k[s]:cu_k[s + 1]].reshape(-1, KV, hd).transpose(0, 1).repeat_interleave(H // KV, 0)
+        w = qs @ ks.transpose(1, 2) * scale
+        if causal:
+            ql, kl = qs.shape[1], ks.shape[1]
+            mask = torch.arange(kl)[None, :] > (torch.arange(ql)[:, None] + (kl - ql))
+            w = w.masked_fill(mask, float("-inf"))
+        o = torch.softmax(w, -1) @ vs
+        outs.append(o.transpose(0, 1).reshape(-1, H * hd))
+    return torch.cat(outs)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hd,H,KV", [(64, 4, 4), (64, 8, 2), (128, 4, 1)])
+@pytest.mark.parametrize("causal", [0, 1])
+def test_attention_varlen(dtype, hd, H, KV, causal):
+    lens = [70, 1, 130, 64]
+    cu = [0]
+    for n in lens:
+        cu.append(cu[-1] + n)
+    rows = cu[-1]
+    nq, nkv = H * hd, KV * hd
+    qkv = rnd(rows, nq + 2 * nkv, seed=11)
+    qkvd, qkvr = q(qkv, dtype)
+    out = torch.empty(rows, nq, dtype=tdt(dtype), device=DEV)
+    cud = torch.tensor(cu, dtype=torch.int32, device=DEV)
+    d = L.AttnDesc()
+    d.dtype, d.head_dim, d.n_heads, d.n_kv_heads, d.n_seqs, d.max_q, d.causal = dcode(dtype), hd, H, KV, len(lens), max(lens), causal
+    esz = qkvd.element_size()
+    d.Q, d.K, d.V, d.O = qkvd.data_ptr(), qkvd.data_ptr() + nq * esz, qkvd.data_ptr() + (nq + nkv) * esz, out.data_ptr()
+    d.ldq = d.ldk = d.ldv = nq + 2 * nkv
+    d.ldo = nq
+    d.cu_q, d.cu_k, d.scale = cud.data_ptr(), cud.data_ptr(), 1.0 / math.sqrt(hd)
+    L.check(L.load().oavsr_op_attention(C.byref(d), stream()))
+    ref = _attn_ref(qkvr[:, :nq], qkvr[:, nq:nq + nkv], qkvr[:, nq + nkv:], cu, cu, H, KV, hd, 1.0 / math.sqrt(hd), causal)
+    close(out, ref, tol(dtype), what="attention")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_softmax_spike(dtype):
+    """One key dominates late in the sequence: exercises the online-softmax rescale branch."""
+    hd, H, n = 64, 2, 200
+    qv = rnd(n, H * hd, seed=1)
+    kv = rnd(n, H * hd, seed=2)
+    vv = rnd(n, H * hd, seed=3)
+    kv[150] = qv[10] * 3.0
+    qkvd, qkvr = q(torch.cat([qv, kv, vv], 1), dtype)
+    out = torch.empty(n, H * hd, dtype=tdt(dtype), device=DEV)
+    cud = torch.tensor([0, n], dtype=torch.int32, device=DEV)
+    d = L.AttnDesc()
+    d.dtype, d.head_dim, d.n_heads, d.n_kv_heads, d.n_seqs, d.max_q, d.causal = dcode(dtype), hd, H, H, 1, n, 0
+    esz = qkvd.element_size()
+    d.Q, d.K, d.V, d.O = qkvd.data_ptr(), qkvd.data_ptr() + H * hd * esz, qkvd.data_ptr() + 2 * H * hd * esz, out.data_ptr()
+    d.ldq = d.ldk = d.ldv = 3 * H * hd
+    d.ldo = H * hd
+    d.cu_q, d.cu_k, d.scale = cud.data_ptr(), cud.data_ptr(), 1.0 / math.sqrt(hd)
+    L.check(L.load().oavsr_op_attention(C.byref(d), stream()))
+    ref = _attn_ref(qkvr[:, :H * hd], qkvr[:, H * hd:2 * H * hd], qkvr[:, 2 * H * hd:], [0, n], [0, n], H, H, hd, 1.0 / math.sqrt(hd), 0)
+    close(out, ref, tol(dtype), what="attention spike")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hd,H,KV", [(64, 8, 2), (128, 7, 1)])
+def test_decode_attention(dtype, hd, H, KV):
+    utts, beams, maxp, maxt = 3, 1, 96, 8
+    rows = utts * beams
+    plen = [50, 96, 1]
+    step = 5
+    qd, qr = q(rnd(rows, H * hd, seed=1), dtype)
+    kp, kpr = q(rnd(utts, KV, maxp, hd, seed=2), dtype)
+    vp, vpr = q(rnd(utts, KV, maxp, hd, seed=3), dtype)
+    kt, ktr = q(rnd(rows, KV, maxt, hd, seed=4), dtype)
+    vt, vtr = q(rnd(rows, KV, maxt, hd, seed=5), dtype)
+    out = torch.empty(rows, H * hd, dtype=tdt(dtype), device=DEV)
+    pl = torch.tensor(plen, dtype=torch.int32, device=DEV)
+    st = torch.tensor([step], dtype=torch.int32, device=DEV)
+    d = L.DecodeAttnDesc()
+    d.dtype, d.head_dim, d.n_heads, d.n_kv_heads, d.rows, d.beams, d.max_prefix, d.max_tail = dcode(dtype), hd, H, KV, rows, beams, maxp, maxt
+    d.Q, d.Kp, d.Vp, d.Kt, d.Vt, d.O = qd.data_ptr(), kp.data_ptr(), vp.data_ptr(), kt.data_ptr(), vt.data_ptr(), out.data_ptr()
+    d.ldq = d.ldo = H * hd
+    d.prefix_len, d.step, d.anc, d.scale = pl.data_ptr(), st.data_ptr(), None, 1.0 / math.sqrt(hd)
+    L.check(L.load().oavsr_op_decode_attention(C.byref(d), stream()))
+    refs = []
+    G = H // KV
+    for r in range(rows):
+        k = torch.cat([kpr[r, :, :plen[r]], ktr[r, :, :step]], 1).repeat_interleave(G, 0)      # [H,ctx,hd]
+        v = torch.cat([vpr[r, :, :plen[r]], vtr[r, :, :step]], 1).repeat_interleave(G, 0)
+        qq = qr[r].reshape(H, 1, hd)
+        w = torch.softmax(qq @ k.transpose(1, 2) / math.sqrt(hd), -1)
+        refs.append((w @ v).reshape(H * hd))
+    close(out, torch.stack(refs), tol(dtype), what="decode attention")
+
+
+# ------------------------------------------------------------------------------------------------ norms & elementwise
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("D", [128, 1024, 3584])
+def test_norms(dtype, mode, D):
+    rows = 37
+    xd, xr = q(rnd(rows, D, seed=1) * 2 + 0.3, dtype)
+    Dw = 2 * D if mode == 2 else D
+    w = (rnd(Dw, seed=2) * 0.1 + 1).to(DEV)
+    b = (rnd(Dw, seed=3) * 0.1).to(DEV)
+    y = torch.empty(rows, Dw, dtype=tdt(dtype), device=DEV)
+    eps = 1e-5
+    L.check(L.load().oavsr_op_norm(mode, dcode(dtype), P(xd), D, P(y), Dw, P(w), P(b), rows, D, eps, stream()))
+    if mode == 0:
+        ref = F.layer_norm(xr, (D,), w.cpu(), b.cpu(), eps)
+    elif mode == 1:
+        ref = w.cpu() * (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + eps))
+    else:
+        ref = F.layer_norm(torch.cat([torch.zeros_like(xr), xr], -1), (2 * D,), w.cpu(), b.cpu(), eps)
+    close(y, ref, tol(dtype) * 2, what=f"norm mode {mode}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pools(dtype):
+    imgs, H, Cc = 3, 44, 64
+    xd, xr = q(rnd(imgs, H, H, Cc, seed=1), dtype)
+    y = torch.empty(imgs, 22, 22, Cc, dtype=tdt(dtype), device=DEV)
+    L.check(L.load().oavsr_op_maxpool3x3s2(dcode(dtype), P(xd), P(y), imgs, H, H, Cc, stream()))
+    ref = F.max_pool2d(xr.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    close(y, ref, 1e-6, what="maxpool")
+    x2d, x2r = q(rnd(imgs, 9, 512, seed=2), dtype)
+    y2 = torch.empty(imgs, 512, dtype=tdt(dtype), device=DEV)
+    L.check(L.load().oavsr_op_avgpool_hw(dcode(dtype), P(x2d), P(y2), imgs, 9, 512, stream()))
+    close(y2, x2r.mean(1), tol(dtype), what="avgpool")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("stack", [0, 1])
+@pytest.mark.parametrize("rate", [1, 2, 5])
+def test_time_compress(dtype, stack, rate):
+    D = 128
+    lens = [13, 25, 4]
+    offs = [0, 20, 50]              # sequences with gaps in the input buffer (Whisper: 1500-token slots, keep < 1500)
+    xd, xr = q(rnd(60, D, seed=1), dtype)
+    nout = [n // rate for n in lens]
+    seg = torch.tensor([[offs[i], sum(nout[:i]), nout[i], 0] for i in range(3)], dtype=torch.int32, device=DEV)
+    Do = D * rate if stack else D
+    y = torch.zeros(sum(nout), Do, dtype=tdt(dtype), device=DEV)
+    L.check(L.load().oavsr_op_time_compress(dcode(dtype), P(xd), D, P(y), Do, P(seg), 3, max(nout), rate, D, stack, stream()))
+    refs = []
+    for i, n in enumerate(lens):
+        blk = xr[offs[i]:offs[i] + nout[i] * rate].reshape(nout[i], rate, D)
+        refs.append(blk.reshape(nout[i], rate * D) if stack else blk.mean(1))
+    close(y, torch.cat(refs), tol(dtype), what="time compress")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_copy_rows_and_swiglu_and_argmax(dtype):
+    lib = L.load()
+    D = 256
+    td, tr = q(rnd(50, D, seed=1), dtype)
+    mp = torch.tensor([3, -1, 49, 0, 7], dtype=torch.int32, device=DEV)
+    y = torch.full((5, D), 7.0, dtype=tdt(dtype), device=DEV)
+    L.check(lib.oavsr_op_copy_rows(dcode(dtype), P(td), D, P(mp), P(y), D, 5, D, stream()))
+    ref = torch.stack([tr[3], torch.full((D,), 7.0), tr[49], tr[0], tr[7]])
+    close(y, ref, 0.0, what="copy_rows")
+    I = 384
+    xd, xr = q(rnd(9, 2 * I, seed=2), dtype)
+    y2 = torch.empty(9, I, dtype=tdt(dtype), device=DEV)
+    L.check(lib.oavsr_op_swiglu(dcode(dtype), P(xd), 2 * I, P(y2), I, 9, I, stream()))
+    close(y2, F.silu(xr[:, :I]) * xr[:, I:], tol(dtype), what="swiglu")
+    lg = rnd(6, 5000, seed=3).to(DEV)
+    lg[2, 100] = lg[2, 4000] = 50.0     # tie -> lowest index
+    lg[4, 77] = 99.0
+    o = torch.empty(6, dtype=torch.int32, device=DEV)
+    L.check(lib.oavsr_op_argmax(P(lg), 5000, 6, 5000, 77, P(o), stream()))
+    lgc = lg.cpu().clone()
+    lgc[:, 77] = float("-inf")
+    assert o.cpu().tolist() == lgc.argmax(-1).tolist()
+    assert o[2].item() == 100
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hd", [64, 128])
+def test_rope_kv(dtype, hd):
+    from omni_avsr_amd.weights import rope_inv_freq
+    H, KV, rows, maxc = 4, 2, 10, 16
+    ld = (H + 2 * KV) * hd
+    xd, xr = q(rnd(rows, ld, seed=1), dtype)
+    inv = rope_inv_freq(hd, 500000.0, dict(factor=32.0, low_freq_factor=1.0, high_freq_factor=4.0, original_max_position_embeddings=8192))
+    pos = torch.tensor([0, 1, 2, 3, 4, 300, 301, 7, 8, 9], dtype=torch.int32)
+    slot = torch.tensor([0, 0, 0, 0, 0, 1, 1, 2, 2, 2], dtype=torch.int32)
+    cpos = torch.tensor([0, 1, 2, 3, 4, 0, 1, 5, 6, 7], dtype=torch.int32)
+    kc = torch.zeros(3, KV, maxc, hd, dtype=tdt(dtype), device=DEV)
+    vc = torch.zeros_like(kc)
+    L.check(L.load().oavsr_op_rope_kv(dcode(dtype), rows, H, KV, hd, P(xd), ld, P(inv.to(DEV)), P(pos.to(DEV)), P(slot.to(DEV)), P(cpos.to(DEV)), P(kc), P(vc), maxc, stream()))
+    ang = pos.float()[:, None] * inv[None]
+    cos, sin = torch.cat([ang, ang], -1).cos(), torch.cat([ang, ang], -1).sin()
+    qk = xr[:, :(H + KV) * hd].reshape(rows, H + KV, hd)
+    rot = torch.cat([-qk[..., hd // 2:], qk[..., :hd // 2]], -1)
+    ref = xr.clone()
+    ref[:, :(H + KV) * hd] = (qk * cos[:, None] + rot * sin[:, None]).reshape(rows, -1)
+    close(xd, ref, tol(dtype), what="rope")
+    kref = torch.zeros(3, KV, maxc, hd)
+    vref = torch.zeros(3, KV, maxc, hd)
+    refq = ref.to(tdt(dtype)).float()
+    for r in range(rows):
+        kref[slot[r], :, cpos[r]] = refq[r, H * hd:(H + KV) * hd].reshape(KV, hd)
+        vref[slot[r], :, cpos[r]] = refq[r, (H + KV) * hd:].reshape(KV, hd)
+    close(kc, kref, tol(dtype), what="k cache")
+    close(vc, vref, tol(dtype), what="v cache")

