@@ -396,7 +396,8 @@ def test_rope_kv(dtype, hd):
     cpos = torch.tensor([0, 1, 2, 3, 4, 0, 1, 5, 6, 7], dtype=torch.int32)
     kc = torch.zeros(3, KV, maxc, hd, dtype=tdt(dtype), device=DEV)
     vc = torch.zeros_like(kc)
-    L.check(L.load().oavsr_op_rope_kv(dcode(dtype), rows, H, KV, hd, P(xd), ld, P(inv.to(DEV)), P(pos.to(DEV)), P(slot.to(DEV)), P(cpos.to(DEV)), P(kc), P(vc), maxc, stream()))
+    invd, posd, slotd, cposd = inv.to(DEV), pos.to(DEV), slot.to(DEV), cpos.to(DEV)     # keep the device buffers alive
+    L.check(L.load().oavsr_op_rope_kv(dcode(dtype), rows, H, KV, hd, P(xd), ld, P(invd), P(posd), P(slotd), P(cposd), P(kc), P(vc), maxc, stream()))
     ang = pos.float()[:, None] * inv[None]
     cos, sin = torch.cat([ang, ang], -1).cos(), torch.cat([ang, ang], -1).sin()
     qk = xr[:, :(H + KV) * hd].reshape(rows, H + KV, hd)
