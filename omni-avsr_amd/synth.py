@@ -16,20 +16,22 @@ from .config import OmniSpec
 
 
 class _Gen:
-    def __init__(self, seed: int):
-        self.seed, self.i = seed, 0
+    def __init__(self, seed: int, device="cpu", dtype=torch.float32):
+        self.seed, self.i, self.device, self.dtype = seed, 0, torch.device(device), dtype
+
+    def _g(self):
+        g = torch.Generator(device=self.device)
+        g.manual_seed(self.seed + self.i)
+        self.i += 1
+        return g
 
     def normal(self, *shape, std=0.02, mean=0.0):
-        g = torch.Generator(device="cpu")
-        g.manual_seed(self.seed + self.i)
-        self.i += 1
-        return torch.randn(*shape, generator=g, dtype=torch.float32) * std + mean
+        x = torch.randn(*shape, generator=self._g(), dtype=torch.float32, device=self.device)
+        return x.mul_(std).add_(mean).to(self.dtype)
 
     def uniform(self, *shape, lo=0.0, hi=1.0):
-        g = torch.Generator(device="cpu")
-        g.manual_seed(self.seed + self.i)
-        self.i += 1
-        return torch.rand(*shape, generator=g, dtype=torch.float32) * (hi - lo) + lo
+        x = torch.rand(*shape, generator=self._g(), dtype=torch.float32, device=self.device)
+        return x.mul_(hi - lo).add_(lo).to(self.dtype)
 
 
 def _linear(sd, g, key, out_f, in_f, bias=True, std=None):
@@ -49,11 +51,14 @@ def _bn(sd, g, key, c):
     sd[key + ".bias"] = g.normal(c, std=0.1)
     sd[key + ".running_mean"] = g.normal(c, std=0.1)
     sd[key + ".running_var"] = g.uniform(c, lo=0.8, hi=1.2)
-    sd[key + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+    sd[key + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long, device=g.device)
 
 
-def synth_state_dict(spec: OmniSpec, seed: int = 1234, modalities=("audio", "video")) -> Dict[str, torch.Tensor]:
-    g = _Gen(seed)
+def synth_state_dict(spec: OmniSpec, seed: int = 1234, modalities=("audio", "video"), device="cpu",
+                     dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """device='cuda' draws the tensors on the GPU (bench.py at full size; values then differ from the CPU stream).
+    dtype=torch.bfloat16 halves the footprint when only the bf16 engine consumes the checkpoint."""
+    g = _Gen(seed, device, dtype)
     sd: Dict[str, torch.Tensor] = OrderedDict()
     d = spec.llm.hidden
     # ---- audio_encoder.* : HF WhisperEncoder -------------------------------------------------------

@@ -42,7 +42,7 @@ def rope_inv_freq(head_dim: int, theta: float, scaling) -> torch.Tensor:
 def _pad_cols(w: torch.Tensor, k: int) -> torch.Tensor:
     if w.shape[1] == k:
         return w
-    out = torch.zeros(w.shape[0], k, dtype=w.dtype)
+    out = torch.zeros(w.shape[0], k, dtype=w.dtype, device=w.device)
     out[:, : w.shape[1]] = w
     return out
 
@@ -61,6 +61,7 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], spec: OmniSpec, dtype: str = "b
     """Returns {packed_name: tensor}; GEMM operands in `dtype`, everything else fp32."""
     T = torch.bfloat16 if dtype == "bf16" else torch.float32
     out: Dict[str, torch.Tensor] = {}
+    dev = next(iter(sd.values())).device
 
     def W(name, t):           # GEMM operand
         out[name] = t.to(T).contiguous()
@@ -68,18 +69,19 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], spec: OmniSpec, dtype: str = "b
     def F(name, t):           # fp32 side parameter
         out[name] = t.float().contiguous()
 
+
     def enc_layer(dst: str, src: str, attn: str, dim: int, lora_k2: int, lora_scale: float, k_bias: bool):
         q, k, v = (sd[f"{src}{attn}{n}_proj.weight"].float() for n in "qkv")
         W(dst + "qkv.w", torch.cat([q, k, v], 0))
-        kb = sd[f"{src}{attn}k_proj.bias"].float() if k_bias else torch.zeros(dim)
+        kb = sd[f"{src}{attn}k_proj.bias"].float() if k_bias else torch.zeros(dim, device=dev)
         F(dst + "qkv.b", torch.cat([sd[f"{src}{attn}q_proj.bias"].float(), kb, sd[f"{src}{attn}v_proj.bias"].float()]))
         if lora_k2:
             aq, av = sd[f"{src}{attn}lora_down_Q.weight"].float(), sd[f"{src}{attn}lora_down_V.weight"].float()
             bq, bv = sd[f"{src}{attn}lora_up_Q.weight"].float(), sd[f"{src}{attn}lora_up_V.weight"].float()
             r = aq.shape[0]
-            dn = torch.zeros(lora_k2, dim)
+            dn = torch.zeros(lora_k2, dim, device=dev)
             dn[:r], dn[r:2 * r] = aq, av
-            up = torch.zeros(3 * dim, lora_k2)
+            up = torch.zeros(3 * dim, lora_k2, device=dev)
             up[:dim, :r] = bq * lora_scale
             up[2 * dim:, r:2 * r] = bv * lora_scale
             W(dst + "lora_dn.w", dn)
@@ -159,7 +161,7 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], spec: OmniSpec, dtype: str = "b
     else:
         W("l.lm_head", head)
     F("l.norm.w", sd["llm.model.norm.weight"])
-    F("l.inv_freq", rope_inv_freq(l.head_dim, l.rope_theta, l.rope_scaling))
+    F("l.inv_freq", rope_inv_freq(l.head_dim, l.rope_theta, l.rope_scaling).to(dev))
     inner, scale = spec.lora_inner(), spec.lora_scale()
     n_ad = (2 if spec.shared_lora else 1)
     k2 = round_up(2 * n_ad * inner, 64) if inner else 0
@@ -176,8 +178,8 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], spec: OmniSpec, dtype: str = "b
         if inner:
             variants = [(str(t), f".{name}") for t, name in enumerate(TASKS)] if spec.is_task_specific else [("x", "")]
             for tag, suffix in variants:
-                dn = torch.zeros(k2, d)
-                up = torch.zeros(nq + 2 * kvd, k2)
+                dn = torch.zeros(k2, d, device=dev)
+                up = torch.zeros(nq + 2 * kvd, k2, device=dev)
                 col = 0
                 for which, row0, rows in (("Q", 0, nq), ("V", nq + kvd, kvd)):
                     srcs = [suffix] + (["_shared"] if spec.shared_lora else [])
