@@ -154,6 +154,10 @@ typedef struct oavsr_gemm_desc {
   int32_t taps, Kvalid;
   const int32_t* frameinfo; /* int2 per frame */
   int32_t skinny;           /* 1: decode kernel (M <= 128) */
+  /* skinny only: fused RMSNorm prologue (y = rstd * ((x*gain) W^T) + seg2) and SwiGLU epilogue (16-row interleaved gate/up) */
+  const float* norm_gain;
+  float norm_eps;
+  int32_t swiglu_pairs;
 } oavsr_gemm_desc;
 int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream);
 
@@ -189,8 +193,12 @@ int oavsr_op_copy_rows(int32_t dtype, const void* src, int64_t lds, const int32_
 int oavsr_op_rope_kv(int32_t dtype, int32_t rows, int32_t n_heads, int32_t n_kv_heads, int32_t head_dim, void* qkv, int64_t ld,
                      const float* inv_freq, const int32_t* pos, const int32_t* slot, const int32_t* cpos, void* kcache,
                      void* vcache, int32_t max_ctx, oavsr_stream stream);
-int oavsr_op_swiglu(int32_t dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t I, oavsr_stream stream);
-int oavsr_op_argmax(const float* logits, int64_t ld, int32_t rows, int32_t V, int32_t banned, int32_t* out, oavsr_stream stream);
+/* interleaved: 0 = [gate | up], 1 = 16-column blocks g0 u0 g1 u1 ... (the packed gate/up weight layout) */
+int oavsr_op_swiglu(int32_t dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t I, int32_t interleaved,
+                    oavsr_stream stream);
+/* scratch: NULL (one workgroup per row) or rows*64*8 bytes (two-stage, fills the chip for 128k-entry vocabularies) */
+int oavsr_op_argmax(const float* logits, int64_t ld, int32_t rows, int32_t V, int32_t banned, int32_t* out, void* scratch,
+                    oavsr_stream stream);
 int oavsr_op_build_rowinfo(const int32_t* cu_out, const int32_t* cu_in, int32_t n_seqs, int32_t stride, int32_t* rowinfo,
                            int32_t rows, oavsr_stream stream);
 /* twiddle / mel filterbank come from the model (built at oavsr_model_create) */

@@ -35,6 +35,9 @@ struct GemmArgs {
   const int4* rowinfo = nullptr; int taps = 0; int Kvalid = 0;   // Kvalid = taps*Cin (<= K, rest zero)
   // A_STEM: input f32 video [frame][88][88]; frameinfo[frame] = {t, len}; M = frames*44*44, K = 256 (245 valid)
   const int2* frameinfo = nullptr;
+  // skinny kernel only: fused RMSNorm prologue (gain[K], eps) and SwiGLU epilogue on 16-row interleaved gate/up weights
+  const float* norm_gain = nullptr; float norm_eps = 0.f;
+  int swiglu_pairs = 0;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t st);
 
@@ -113,10 +116,11 @@ struct RopeArgs {
   void* kcache = nullptr; void* vcache = nullptr; int max_ctx = 0;
 };
 int launch_rope_kv(const RopeArgs& a, hipStream_t st);
-// y[m][j] = silu(x[m][j]) * x[m][I + j]
-int launch_swiglu(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int rows, int I, hipStream_t st);
+// y[m][j] = silu(gate[m][j]) * up[m][j]; x = [gate | up] (interleaved = 0) or 16-column blocks g0 u0 g1 u1 ... (interleaved = 1)
+int launch_swiglu(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int rows, int I, int interleaved, hipStream_t st);
 // argmax over fp32 logits rows (ties -> lowest index, as torch.argmax); optional banned token
-int launch_argmax(const float* logits, int64_t ld, int rows, int V, int banned, int* out, hipStream_t st);
+// scratch: optional [rows][64] float2 for the two-stage variant
+int launch_argmax(const float* logits, int64_t ld, int rows, int V, int banned, int* out, void* scratch, hipStream_t st);
 // segment metadata
 int launch_build_rowinfo(const int* cu_out, const int* cu_in, int n_seqs, int stride, int4* rowinfo, int rows,
                          hipStream_t st);

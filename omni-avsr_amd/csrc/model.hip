@@ -155,7 +155,7 @@ struct oavsr_workspace {
   float* logits;
   void *kpre, *vpre, *ktail, *vtail; int max_prefix = 0; size_t kpre_layer = 0, ktail_layer = 0;
   int *pos, *slot, *cpos, *cu_s, *prefix_len, *last_rows;
-  int *amax; GreedyState gs;
+  int *amax; void* amax_scratch; GreedyState gs;
   int max_tok_enc = 0, max_S_total = 0;
   int S_host[1024]; int B_cur = 0;
 
@@ -573,16 +573,21 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
   const int tl = c.lora_task_specific ? task : 0;
   for (int li = 0; li < c.llm_layers; ++li) {
     const LlmLayer& L = m->llayers[li];
-    { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
+    // prefill: RMSNorm kernel + big GEMMs.  decode: the norm is fused into the skinny GEMMs (gain on the A fragments,
+    // rstd in the epilogue), so the raw residual stream lx is the A operand.
+    if (!decode) { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
       OAVSR_TRY(launch_rmsnorm(dt, ws->lx, d, ws->lh, d, L.ln1w, rows, d, c.llm_rms_eps, st)); }
+    const void* hin = decode ? ws->lx : ws->lh;
     GemmArgs g;
     if (c.lora_k2 > 0) {
-      g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = c.lora_k2; g.K = d; g.A = ws->lh; g.lda = d; g.W = L.lora_dn[tl]; g.ldw = d;
+      g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = c.lora_k2; g.K = d; g.A = hin; g.lda = d; g.W = L.lora_dn[tl]; g.ldw = d;
       g.C = ws->llora; g.ldc = c.lora_k2;
+      if (decode) { g.norm_gain = L.ln1w; g.norm_eps = c.llm_rms_eps; }
       OAVSR_TRY(run_gemm(g, st, decode));
     }
-    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = nqkv; g.K = d; g.A = ws->lh; g.lda = d; g.W = L.qkvw; g.ldw = d; g.col_bias = L.qkvb;
+    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = nqkv; g.K = d; g.A = hin; g.lda = d; g.W = L.qkvw; g.ldw = d; g.col_bias = L.qkvb;
     if (c.lora_k2 > 0) { g.A2 = ws->llora; g.lda2 = c.lora_k2; g.W2 = L.lora_up[tl]; g.ldw2 = c.lora_k2; g.K2 = c.lora_k2; }
+    if (decode) { g.norm_gain = L.ln1w; g.norm_eps = c.llm_rms_eps; }
     g.C = ws->lqkv; g.ldc = nqkv;
     OAVSR_TRY(run_gemm(g, st, decode));
     RopeArgs r; r.dtype = dt; r.rows = rows; r.n_heads = H; r.n_kv_heads = KV; r.head_dim = hd; r.qkv = ws->lqkv; r.ld = nqkv;
@@ -610,12 +615,19 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
     g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = d; g.K = nq; g.A = ws->lattn; g.lda = nq; g.W = L.ow; g.ldw = nq;
     g.residual = ws->lx; g.ldr = d; g.C = ws->lx; g.ldc = d;
     OAVSR_TRY(run_gemm(g, st, decode));
-    { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
-      OAVSR_TRY(launch_rmsnorm(dt, ws->lx, d, ws->lh, d, L.ln2w, rows, d, c.llm_rms_eps, st)); }
-    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 2 * I; g.K = d; g.A = ws->lh; g.lda = d; g.W = L.guw; g.ldw = d; g.C = ws->lgu; g.ldc = 2 * I;
-    OAVSR_TRY(run_gemm(g, st, decode));
-    { ProfScope ps("swiglu", 0, 3.0 * rows * I * m->esz, st);
-      OAVSR_TRY(launch_swiglu(dt, ws->lgu, 2 * I, ws->lact, I, rows, I, st)); }
+    if (decode && rows <= 32) {   // RMSNorm + gate/up + SwiGLU in one launch
+      g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 2 * I; g.K = d; g.A = ws->lx; g.lda = d; g.W = L.guw; g.ldw = d;
+      g.norm_gain = L.ln2w; g.norm_eps = c.llm_rms_eps; g.swiglu_pairs = 1; g.C = ws->lact; g.ldc = I;
+      OAVSR_TRY(run_gemm(g, st, true));
+    } else {
+      if (!decode) { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
+        OAVSR_TRY(launch_rmsnorm(dt, ws->lx, d, ws->lh, d, L.ln2w, rows, d, c.llm_rms_eps, st)); }
+      g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 2 * I; g.K = d; g.A = decode ? ws->lx : ws->lh; g.lda = d; g.W = L.guw; g.ldw = d; g.C = ws->lgu; g.ldc = 2 * I;
+      if (decode) { g.norm_gain = L.ln2w; g.norm_eps = c.llm_rms_eps; }
+      OAVSR_TRY(run_gemm(g, st, decode));
+      { ProfScope ps("swiglu", 0, 3.0 * rows * I * m->esz, st);
+        OAVSR_TRY(launch_swiglu(dt, ws->lgu, 2 * I, ws->lact, I, rows, I, 1, st)); }
+    }
     g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = d; g.K = I; g.A = ws->lact; g.lda = I; g.W = L.downw; g.ldw = I;
     g.residual = ws->lx; g.ldr = d; g.C = ws->lx; g.ldc = d;
     OAVSR_TRY(run_gemm(g, st, decode));
@@ -626,11 +638,16 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
 static int lm_head_rows(const oavsr_model* m, oavsr_workspace* ws, const void* x, int rows, float* logits, hipStream_t st) {
   const oavsr_config& c = m->cfg;
   const int d = c.llm_hidden;
+  GemmArgs g; g.dtype = m->dtype; g.M = rows; g.N = c.llm_vocab; g.K = d; g.W = m->lm_head; g.ldw = d;
+  g.C = logits; g.ldc = c.llm_vocab; g.out_f32 = 1;
+  if (rows <= 128) {          // final RMSNorm fused into the weight-streaming kernel
+    g.A = x; g.lda = d; g.norm_gain = m->norm_w; g.norm_eps = c.llm_rms_eps;
+    return run_gemm(g, st, true);
+  }
   { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
     OAVSR_TRY(launch_rmsnorm(m->dtype, x, d, ws->lh, d, m->norm_w, rows, d, c.llm_rms_eps, st)); }
-  GemmArgs g; g.dtype = m->dtype; g.M = rows; g.N = c.llm_vocab; g.K = d; g.A = ws->lh; g.lda = d; g.W = m->lm_head; g.ldw = d;
-  g.C = logits; g.ldc = c.llm_vocab; g.out_f32 = 1;
-  return run_gemm(g, st, rows <= 128);
+  g.A = ws->lh; g.lda = d;
+  return run_gemm(g, st, false);
 }
 
 static int prefill_impl(const oavsr_model* m, oavsr_workspace* ws, int task, int B, const void* embeds, const int32_t* S, float* logits_out,
@@ -688,13 +705,13 @@ static int decode_greedy(const oavsr_model* m, oavsr_workspace* ws, int task, in
   for (int b = 0; b < B; ++b) slot[b] = b;
   OAVSR_TRY(h2d(ws->slot, slot, sizeof(int) * B, st));
   const int banned = force_len ? c.id_eos : -1;
-  OAVSR_TRY(launch_argmax(ws->logits, c.llm_vocab, B, c.llm_vocab, banned, ws->amax, st));
+  OAVSR_TRY(launch_argmax(ws->logits, c.llm_vocab, B, c.llm_vocab, banned, ws->amax, ws->amax_scratch, st));
   OAVSR_TRY(launch_greedy_update(ws->amax, gs, B, max_new, c.id_eos, c.id_pad, st));
   for (int step = 1; step < max_new; ++step) {
     OAVSR_TRY(launch_embed(m->dtype, m->embed, c.llm_hidden, gs.tok, ws->lx, c.llm_hidden, B, c.llm_hidden, st));
     OAVSR_TRY(llm_layers(m, ws, task, B, true, B, 1, maxS + max_new, gs.pos, gs.cpos, st));
     OAVSR_TRY(lm_head_rows(m, ws, ws->lx, B, ws->logits, st));
-    OAVSR_TRY(launch_argmax(ws->logits, c.llm_vocab, B, c.llm_vocab, banned, ws->amax, st));
+    OAVSR_TRY(launch_argmax(ws->logits, c.llm_vocab, B, c.llm_vocab, banned, ws->amax, ws->amax_scratch, st));
     OAVSR_TRY(launch_greedy_update(ws->amax, gs, B, max_new, c.id_eos, c.id_pad, st));
   }
   return 0;
@@ -808,7 +825,7 @@ int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, 
   WANT(kpre, ws->kpre_layer * c.llm_layers); WANT(vpre, ws->kpre_layer * c.llm_layers);
   WANT(ktail, ws->ktail_layer * c.llm_layers); WANT(vtail, ws->ktail_layer * c.llm_layers);
   WANT(pos, Rl * 4); WANT(slot, Rl * 4); WANT(cpos, Rl * 4); WANT(cu_s, (max_B + 1) * 4); WANT(prefix_len, max_B * 4); WANT(last_rows, max_B * 4);
-  WANT(amax, rows_dec * 4);
+  WANT(amax, rows_dec * 4); WANT(amax_scratch, rows_dec * 64 * 8);
   WANT(gs.tok, rows_dec * 4); WANT(gs.finished, rows_dec * 4); WANT(gs.out_ids, rows_dec * (size_t)max_new * 4); WANT(gs.out_len, rows_dec * 4);
   WANT(gs.step, 256); WANT(gs.pos, rows_dec * 4); WANT(gs.cpos, rows_dec * 4);
 #undef WANT
@@ -939,6 +956,7 @@ int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream) {
   g.res_after_act = d->res_after_act; g.groups = d->groups < 1 ? 1 : d->groups; g.a_goff = d->a_goff; g.amode = d->amode;
   g.H = d->H; g.Wd = d->W_; g.Cin = d->Cin; g.OH = d->OH; g.OW = d->OW; g.stride = d->stride; g.pad = d->pad; g.ksize = d->ksize;
   g.rowinfo = (const int4*)d->rowinfo; g.taps = d->taps; g.Kvalid = d->Kvalid; g.frameinfo = (const int2*)d->frameinfo;
+  g.norm_gain = d->norm_gain; g.norm_eps = d->norm_eps; g.swiglu_pairs = d->swiglu_pairs;
   return d->skinny ? launch_gemm_skinny(g, (hipStream_t)stream) : launch_gemm(g, (hipStream_t)stream);
 }
 
@@ -987,11 +1005,12 @@ int oavsr_op_rope_kv(int32_t dtype, int32_t rows, int32_t n_heads, int32_t n_kv_
   r.inv_freq = inv_freq; r.pos = pos; r.slot = slot; r.cpos = cpos; r.kcache = kcache; r.vcache = vcache; r.max_ctx = max_ctx;
   return launch_rope_kv(r, (hipStream_t)stream);
 }
-int oavsr_op_swiglu(int32_t dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t I, oavsr_stream stream) {
-  return launch_swiglu(dtype, x, ldx, y, ldy, rows, I, (hipStream_t)stream);
+int oavsr_op_swiglu(int32_t dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t I, int32_t interleaved,
+                    oavsr_stream stream) {
+  return launch_swiglu(dtype, x, ldx, y, ldy, rows, I, interleaved, (hipStream_t)stream);
 }
-int oavsr_op_argmax(const float* logits, int64_t ld, int32_t rows, int32_t V, int32_t banned, int32_t* out, oavsr_stream stream) {
-  return launch_argmax(logits, ld, rows, V, banned, out, (hipStream_t)stream);
+int oavsr_op_argmax(const float* logits, int64_t ld, int32_t rows, int32_t V, int32_t banned, int32_t* out, void* scratch, oavsr_stream stream) {
+  return launch_argmax(logits, ld, rows, V, banned, out, scratch, (hipStream_t)stream);
 }
 int oavsr_op_build_rowinfo(const int32_t* cu_out, const int32_t* cu_in, int32_t n_seqs, int32_t stride, int32_t* rowinfo, int32_t rows,
                            oavsr_stream stream) {

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kThreads) void rope_kv_kernel(const RopeArgs p) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(kThreads) void swiglu_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, int rows, int I) {
+__global__ __launch_bounds__(kThreads) void swiglu_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, int rows, int I, int interleaved) {
   constexpr int VEC = TypeInfo<T>::kVec;
   const int IV = I / VEC;
   const int64_t total = (int64_t)rows * IV;
@@ -241,40 +241,72 @@ __global__ __launch_bounds__(kThreads) void swiglu_kernel(const T* __restrict__ 
     int cv = (int)(i % IV);
     int64_t r = i / IV;
     float g[VEC], u[VEC];
-    chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(x + r * ldx + cv * VEC), g);
-    chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(x + r * ldx + I + cv * VEC), u);
+    const int c0 = cv * VEC;
+    const int go = interleaved ? ((c0 >> 4) << 5) + (c0 & 15) : c0;
+    const int uo = interleaved ? go + 16 : I + c0;
+    chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(x + r * ldx + go), g);
+    chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(x + r * ldx + uo), u);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) g[e] = silu(g[e]) * u[e];
     *reinterpret_cast<Chunk16*>(y + r * ldy + cv * VEC) = chunk_from_f32<T>(g);
   }
 }
 
-// arg-max of one fp32 row per workgroup; ties resolve to the lowest index (torch.argmax on CPU / HF greedy).
-__global__ __launch_bounds__(kThreads) void argmax_kernel(const float* __restrict__ logits, int64_t ld, int V, int banned, int* __restrict__ out) {
+// arg-max over fp32 logits; ties resolve to the lowest index (torch.argmax on CPU / HF greedy).
+// Two stages so a [B x 128k] logits block fills the chip: grid (kArgChunks, rows) partial (value, index) pairs, then one
+// wave per row combines them.  scratch == nullptr: single-stage (one workgroup per row).
+constexpr int kArgChunks = 64;
+
+__device__ __forceinline__ void argmax_combine(float& best, int& bi, float ov, int oi) {
+  if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+}
+
+__global__ __launch_bounds__(kThreads) void argmax_kernel(const float* __restrict__ logits, int64_t ld, int V, int banned,
+                                                          int* __restrict__ out, float2* __restrict__ scratch) {
   __shared__ float sv[kWavesPerBlock];
   __shared__ int si[kWavesPerBlock];
-  const float* r = logits + (int64_t)blockIdx.x * ld;
+  const int row = blockIdx.y;
+  const float* r = logits + (int64_t)row * ld;
+  int lo = 0, hi = V;
+  if (scratch) {
+    const int ch = ((V + kArgChunks - 1) / kArgChunks + 3) & ~3;
+    lo = blockIdx.x * ch; hi = lo + ch < V ? lo + ch : V;
+  }
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int i = threadIdx.x; i < V; i += kThreads) {
+  for (int i = lo + threadIdx.x; i < hi; i += kThreads) {
     float v = r[i];
     if (i == banned) v = -INFINITY;
-    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    argmax_combine(best, bi, v, i);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     float ov = __shfl_xor(best, o, 64);
     int oi = __shfl_xor(bi, o, 64);
-    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    argmax_combine(best, bi, ov, oi);
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) { sv[wave] = best; si[wave] = bi; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < kWavesPerBlock; ++w)
-      if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
-    out[blockIdx.x] = bi;
+    for (int w = 1; w < kWavesPerBlock; ++w) argmax_combine(best, bi, sv[w], si[w]);
+    if (scratch) scratch[row * kArgChunks + blockIdx.x] = make_float2(best, __int_as_float(bi));
+    else out[row] = bi;
   }
+}
+
+__global__ __launch_bounds__(64) void argmax_final_kernel(const float2* __restrict__ scratch, int* __restrict__ out) {
+  const int row = blockIdx.x;
+  float2 p = scratch[row * kArgChunks + threadIdx.x];
+  float best = p.x;
+  int bi = __float_as_int(p.y);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(best, o, 64);
+    int oi = __shfl_xor(bi, o, 64);
+    argmax_combine(best, bi, ov, oi);
+  }
+  if (threadIdx.x == 0) out[row] = bi;
 }
 
 // Greedy bookkeeping, one thread per row (HF GenerationMixin greedy: finished rows emit pad).
@@ -388,20 +420,25 @@ int launch_rope_kv(const RopeArgs& a, hipStream_t st) {
   return 0;
 }
 
-int launch_swiglu(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int rows, int I, hipStream_t st) {
+int launch_swiglu(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int rows, int I, int interleaved, hipStream_t st) {
   if (rows <= 0) return 0;
   const int vec = dtype == DT_F32 ? 4 : 8;
-  OAVSR_REQUIRE(I % vec == 0 && ldx % vec == 0 && ldy % vec == 0, "swiglu: I=%d", I);
+  OAVSR_REQUIRE(I % 16 == 0 && ldx % vec == 0 && ldy % vec == 0, "swiglu: I=%d", I);
   int g = grid_for((int64_t)rows * (I / vec));
-  if (dtype == DT_F32) hipLaunchKernelGGL(swiglu_kernel<float>, dim3(g), dim3(kThreads), 0, st, (const float*)x, ldx, (float*)y, ldy, rows, I);
-  else hipLaunchKernelGGL(swiglu_kernel<bf16_t>, dim3(g), dim3(kThreads), 0, st, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, I);
+  if (dtype == DT_F32) hipLaunchKernelGGL(swiglu_kernel<float>, dim3(g), dim3(kThreads), 0, st, (const float*)x, ldx, (float*)y, ldy, rows, I, interleaved);
+  else hipLaunchKernelGGL(swiglu_kernel<bf16_t>, dim3(g), dim3(kThreads), 0, st, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, I, interleaved);
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
-int launch_argmax(const float* logits, int64_t ld, int rows, int V, int banned, int* out, hipStream_t st) {
+int launch_argmax(const float* logits, int64_t ld, int rows, int V, int banned, int* out, void* scratch, hipStream_t st) {
   if (rows <= 0) return 0;
-  hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(kThreads), 0, st, logits, ld, V, banned, out);
+  if (scratch && V >= 4096) {
+    hipLaunchKernelGGL(argmax_kernel, dim3(kArgChunks, rows), dim3(kThreads), 0, st, logits, ld, V, banned, out, (float2*)scratch);
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(rows), dim3(64), 0, st, (const float2*)scratch, out);
+  } else {
+    hipLaunchKernelGGL(argmax_kernel, dim3(1, rows), dim3(kThreads), 0, st, logits, ld, V, banned, out, (float2*)nullptr);
+  }
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -2,15 +2,23 @@
 //
 // Weight-streaming regime: every weight byte is read exactly once per step, straight from HBM into the MFMA
 // B-operand registers (lane l holds W[n0 + (l&15)][k + 8*(l>>4) ..] = one 16-byte global load, no LDS round
-// trip); the (tiny, L2-resident) activations are the A operand.  The four waves of a workgroup interleave the
-// 64-byte k blocks of the same NT*16 output columns and combine their partial sums through LDS, then apply the
-// same fused epilogue as the big GEMM.  The optional second K segment adds the LoRA term (W + BA fused).
+// trip); the (tiny, L2-resident) activations are the A operand.  A workgroup is 8 waves that interleave the
+// 64-byte k blocks of the same NT*16 output columns (8 x U x NT KiB of weights in flight per workgroup) and combine
+// their partial sums through LDS, then apply the fused epilogue.
+//
+// Fusions (decode only, all optional):
+//   * second K segment = LoRA term (x A^T)(s B)^T  (Llama_LoRA.py:250-259)
+//   * RMSNorm prologue: A1 rows are multiplied by the norm gain on the fly, sum(x^2) is accumulated from the very
+//     same fragments, and rstd scales the segment-1 accumulator in the epilogue:  y = rstd * ((x*g) W^T) + t B^T
+//     (LlamaRMSNorm -> q/k/v_proj, Llama_LoRA.py:624-645 via transformers)
+//   * SwiGLU epilogue on a gate/up weight whose rows are interleaved in blocks of 16: out = silu(gate) * up
 #include "kernels.h"
 
 namespace oavsr {
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 512;
+constexpr int kWaves = 8;
 
 __device__ __forceinline__ Chunk16 zchunk() { Chunk16 c; c.v = u32x4{0u, 0u, 0u, 0u}; return c; }
 
@@ -28,33 +36,42 @@ template <> struct MmaS<float> {
   }
 };
 
-template <typename T, int MT, int NT>
+template <typename T, int MT, int NT, bool NORM>
 __global__ __launch_bounds__(kThreads) void skinny_kernel(const GemmArgs p) {
   constexpr int KBE = 64 / (int)sizeof(T);       // elements per 64-byte k block
   constexpr int VEC = TypeInfo<T>::kVec;
-  constexpr int U = 4;                            // k blocks in flight per wave
+  constexpr int U = (NT >= 4) ? 4 : 8;            // k blocks in flight per wave
+  constexpr int MR = MT * 16, NC = NT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sred = reinterpret_cast<float*>(smem);   // [4][MT*16][NT*16]
+  float* sred = reinterpret_cast<float*>(smem);   // [8][MR][NC]
+  float* sred2 = sred + kWaves * MR * NC;         // [8][MR][NC]   (NORM && K2)
+  float* sssq = sred2 + (NORM ? kWaves * MR * NC : 0);   // [8][MR]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * (NT * 16);
+  const int n0 = blockIdx.x * NC;
   const T* A1 = reinterpret_cast<const T*>(p.A);
   const T* A2 = reinterpret_cast<const T*>(p.A2);
   const T* W1 = reinterpret_cast<const T*>(p.W);
   const T* W2 = reinterpret_cast<const T*>(p.W2);
   const int nkb1 = p.K / KBE, nkb = nkb1 + p.K2 / KBE;
 
-  f32x4 acc[MT][NT];
+  f32x4 acc[MT][NT], acc2[NORM ? MT : 1][NORM ? NT : 1];
+  float ssq[MT];
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int i = 0; i < MT; ++i) {
+    ssq[i] = 0.f;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT; ++j) {
+      acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (NORM) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
 
-  for (int kb0 = wave; kb0 < nkb; kb0 += 4 * U) {
+  for (int kb0 = wave; kb0 < nkb; kb0 += kWaves * U) {
     Chunk16 bf[U][NT], af[U][MT];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int kb = kb0 + 4 * u;
+      const int kb = kb0 + kWaves * u;
       const bool in = kb < nkb;
       const bool s1 = kb < nkb1;
       const T* Ab = s1 ? A1 : A2;
@@ -73,11 +90,34 @@ __global__ __launch_bounds__(kThreads) void skinny_kernel(const GemmArgs p) {
       }
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+    for (int u = 0; u < U; ++u) {
+      const int kb = kb0 + kWaves * u;
+      const bool s1 = kb < nkb1;
+      if (NORM && s1 && kb < nkb) {
+        const int k = kb * KBE + g * VEC;
+        float gn[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e += 4) {
+          f32x4 t = *reinterpret_cast<const f32x4*>(p.norm_gain + k + e);
+          gn[e] = t[0]; gn[e + 1] = t[1]; gn[e + 2] = t[2]; gn[e + 3] = t[3];
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          float f[VEC];
+          chunk_to_f32<T>(af[u][i], f);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) { ssq[i] += f[e] * f[e]; f[e] *= gn[e]; }
+          af[u][i] = chunk_from_f32<T>(f);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) MmaS<T>::run(af[u][i], bf[u][j], acc[i][j]);
+        for (int j = 0; j < NT; ++j) {
+          if (NORM && !s1) MmaS<T>::run(af[u][i], bf[u][j], acc2[i][j]);
+          else MmaS<T>::run(af[u][i], bf[u][j], acc[i][j]);
+        }
+    }
   }
   // partial sums -> LDS (C layout: col = lane&15, row = 4*(lane>>4)+r)
 #pragma unroll
@@ -85,19 +125,55 @@ __global__ __launch_bounds__(kThreads) void skinny_kernel(const GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        sred[(wave * (MT * 16) + i * 16 + g * 4 + r) * (NT * 16) + j * 16 + r16] = acc[i][j][r];
+      for (int r = 0; r < 4; ++r) {
+        const int o = (wave * MR + i * 16 + g * 4 + r) * NC + j * 16 + r16;
+        sred[o] = acc[i][j][r];
+        if (NORM) sred2[o] = acc2[i][j][r];
+      }
+  if (NORM) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float v = ssq[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (g == 0) sssq[wave * MR + i * 16 + r16] = v;
+    }
+  }
   __syncthreads();
   const T* R = reinterpret_cast<const T*>(p.residual);
-  for (int idx = tid; idx < MT * 16 * NT * 16; idx += kThreads) {
-    const int m = idx / (NT * 16), nn = idx - m * (NT * 16);
-    const int n = n0 + nn;
-    if (m >= p.M || n >= p.N) continue;
+  auto value = [&](int m, int nn) -> float {
     float y = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) y += sred[(w * (MT * 16) + m) * (NT * 16) + nn];
+    for (int w = 0; w < kWaves; ++w) y += sred[(w * MR + m) * NC + nn];
+    if (NORM) {
+      float s = 0.f, y2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) { s += sssq[w * MR + m]; y2 += sred2[(w * MR + m) * NC + nn]; }
+      y = y * rsqrtf(s / (float)p.K + p.norm_eps) + y2;
+    }
+    const int n = n0 + nn;
     if (p.col_scale) y *= p.col_scale[n];
     if (p.col_bias) y += p.col_bias[n];
+    return y;
+  };
+  if (p.swiglu_pairs) {
+    // weight rows interleaved [gate block b | up block b] in 16-row blocks; out column = (n0/32 + pblk)*16 + i
+    for (int idx = tid; idx < MR * (NC / 2); idx += kThreads) {
+      const int m = idx / (NC / 2), q = idx - m * (NC / 2);
+      const int pblk = q >> 4, i = q & 15;
+      const int ncol = (n0 >> 1) + q;
+      if (m >= p.M || n0 + pblk * 32 + i >= p.N) continue;
+      float y = silu(value(m, pblk * 32 + i)) * value(m, pblk * 32 + 16 + i);
+      if (p.out_f32) reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + ncol] = y;
+      else reinterpret_cast<T*>(p.C)[(int64_t)m * p.ldc + ncol] = from_f32<T>(y);
+    }
+    return;
+  }
+  for (int idx = tid; idx < MR * NC; idx += kThreads) {
+    const int m = idx / NC, nn = idx - m * NC;
+    const int n = n0 + nn;
+    if (m >= p.M || n >= p.N) continue;
+    float y = value(m, nn);
     float res = R ? to_f32(R[(int64_t)m * p.ldr + n]) : 0.f;
     if (!p.res_after_act) y += res;
     switch (p.act) {
@@ -113,10 +189,11 @@ __global__ __launch_bounds__(kThreads) void skinny_kernel(const GemmArgs p) {
   }
 }
 
-template <typename T, int MT, int NT>
+template <typename T, int MT, int NT, bool NORM>
 int launch_sk(const GemmArgs& a, hipStream_t st) {
-  constexpr int smem = 4 * MT * 16 * NT * 16 * 4;
-  auto kern = skinny_kernel<T, MT, NT>;
+  constexpr int smem = kWaves * MT * 16 * NT * 16 * 4 * (NORM ? 2 : 1) + (NORM ? kWaves * MT * 16 * 4 : 0);
+  static_assert(smem <= 160 * 1024, "LDS");
+  auto kern = skinny_kernel<T, MT, NT, NORM>;
   static bool attr_set = false;
   if (!attr_set && smem > 48 * 1024) {
     OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -127,14 +204,19 @@ int launch_sk(const GemmArgs& a, hipStream_t st) {
   return 0;
 }
 
-template <typename T>
+template <typename T, bool NORM>
 int launch_sk_t(const GemmArgs& a, hipStream_t st) {
   const int mt = ceil_div(a.M, 16);
-  const bool wide = a.N >= 16384;          // enough columns to fill the chip with 64-column workgroups
-  if (mt <= 1) return wide ? launch_sk<T, 1, 4>(a, st) : launch_sk<T, 1, 1>(a, st);
-  if (mt <= 2) return wide ? launch_sk<T, 2, 4>(a, st) : launch_sk<T, 2, 1>(a, st);
-  if (mt <= 4) return launch_sk<T, 4, 1>(a, st);
-  return launch_sk<T, 8, 1>(a, st);
+  const bool wide = a.N >= 8192;           // enough columns to fill the chip with 64-column workgroups
+  if (a.swiglu_pairs) {
+    OAVSR_REQUIRE(mt <= 2 && a.N % 32 == 0, "skinny gemm: fused SwiGLU needs M <= 32 and N %% 32 == 0");
+    if (mt <= 1) return wide ? launch_sk<T, 1, 4, NORM>(a, st) : launch_sk<T, 1, 2, NORM>(a, st);
+    return wide ? launch_sk<T, 2, 4, NORM>(a, st) : launch_sk<T, 2, 2, NORM>(a, st);
+  }
+  if (mt <= 1) return wide ? launch_sk<T, 1, 4, NORM>(a, st) : launch_sk<T, 1, 1, NORM>(a, st);
+  if (mt <= 2) return wide ? launch_sk<T, 2, 4, NORM>(a, st) : launch_sk<T, 2, 1, NORM>(a, st);
+  if (mt <= 4) return launch_sk<T, 4, 1, NORM>(a, st);
+  return launch_sk<T, 8, 1, NORM>(a, st);
 }
 
 }  // namespace
@@ -148,7 +230,12 @@ int launch_gemm_skinny(const GemmArgs& a, hipStream_t st) {
   OAVSR_REQUIRE(a.K > 0 && a.K % kbe == 0 && a.K2 % kbe == 0, "skinny gemm: K=%d/K2=%d must be multiples of %d", a.K, a.K2, kbe);
   OAVSR_REQUIRE(a.lda % vec == 0 && a.ldw % vec == 0 && (((uintptr_t)a.A | (uintptr_t)a.W) & 15) == 0, "skinny gemm: operands must be 16-byte aligned");
   if (a.K2) OAVSR_REQUIRE(a.lda2 % vec == 0 && a.ldw2 % vec == 0 && (((uintptr_t)a.A2 | (uintptr_t)a.W2) & 15) == 0, "skinny gemm: segment-2 operands must be 16-byte aligned");
-  return a.dtype == DT_F32 ? launch_sk_t<float>(a, st) : launch_sk_t<bf16_t>(a, st);
+  OAVSR_REQUIRE(!a.swiglu_pairs || (!a.residual && a.act == ACT_NONE), "skinny gemm: SwiGLU epilogue excludes residual/activation");
+  if (a.norm_gain) {
+    OAVSR_REQUIRE(((uintptr_t)a.norm_gain & 15) == 0, "skinny gemm: norm gain must be 16-byte aligned");
+    return a.dtype == DT_F32 ? launch_sk_t<float, true>(a, st) : launch_sk_t<bf16_t, true>(a, st);
+  }
+  return a.dtype == DT_F32 ? launch_sk_t<float, false>(a, st) : launch_sk_t<bf16_t, false>(a, st);
 }
 
 }  // namespace oavsr

@@ -54,7 +54,7 @@ class GemmDesc(C.Structure):
         ("H", C.c_int32), ("W_", C.c_int32), ("Cin", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32),
         ("stride", C.c_int32), ("pad", C.c_int32), ("ksize", C.c_int32),
         ("rowinfo", C.c_void_p), ("taps", C.c_int32), ("Kvalid", C.c_int32), ("frameinfo", C.c_void_p),
-        ("skinny", C.c_int32),
+        ("skinny", C.c_int32), ("norm_gain", C.c_void_p), ("norm_eps", C.c_float), ("swiglu_pairs", C.c_int32),
     ]
 
 
@@ -107,8 +107,8 @@ SYMBOLS = {
     "oavsr_op_time_compress": (C.c_int, [_I, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _P]),
     "oavsr_op_copy_rows": (C.c_int, [_I, _P, _L, _P, _P, _L, _I, _I, _P]),
     "oavsr_op_rope_kv": (C.c_int, [_I, _I, _I, _I, _I, _P, _L, _P, _P, _P, _P, _P, _P, _I, _P]),
-    "oavsr_op_swiglu": (C.c_int, [_I, _P, _L, _P, _L, _I, _I, _P]),
-    "oavsr_op_argmax": (C.c_int, [_P, _L, _I, _I, _I, _P, _P]),
+    "oavsr_op_swiglu": (C.c_int, [_I, _P, _L, _P, _L, _I, _I, _I, _P]),
+    "oavsr_op_argmax": (C.c_int, [_P, _L, _I, _I, _I, _P, _P, _P]),
     "oavsr_op_build_rowinfo": (C.c_int, [_P, _P, _I, _I, _P, _I, _P]),
     "oavsr_op_logmel": (C.c_int, [_P, _I, _P, _L, _P, _I, _P, _P, _P, _L, _P]),
 }

@@ -172,7 +172,10 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], spec: OmniSpec, dtype: str = "b
         if l.qkv_bias:
             F(dp + "qkv.b", torch.cat([sd[ap + f"{n}_proj.bias"].float() for n in "qkv"]))
         W(dp + "o.w", sd[ap + "o_proj.weight"])
-        W(dp + "gu.w", torch.cat([sd[sp + "mlp.gate_proj.weight"].float(), sd[sp + "mlp.up_proj.weight"].float()], 0))
+        gw, uw = sd[sp + "mlp.gate_proj.weight"].float(), sd[sp + "mlp.up_proj.weight"].float()
+        # gate / up rows interleaved in blocks of 16 (g0 u0 g1 u1 ...): one MFMA lane then holds gate_j and up_j of the
+        # same column, so SwiGLU is a register-local epilogue
+        W(dp + "gu.w", torch.stack([gw.reshape(-1, 16, d), uw.reshape(-1, 16, d)], 1).reshape(2 * l.mlp, d))
         W(dp + "down.w", sd[sp + "mlp.down_proj.weight"])
         F(dp + "ln1.w", sd[sp + "input_layernorm.weight"]); F(dp + "ln2.w", sd[sp + "post_attention_layernorm.weight"])
         if inner:

@@ -43,7 +43,7 @@ def gemm(dtype, A, W, *, A2=None, W2=None, scale=None, bias=None, prelu=None, ac
     if A2 is not None:
         d.A2, d.W2, d.K2, d.lda2, d.ldw2 = P(A2), P(W2), W2.shape[1], A2.stride(0), W2.stride(0)
     groups = geom.get("groups", 1)
-    ncols = d.N * groups
+    ncols = d.N * groups // (2 if geom.get("swiglu_pairs") else 1)
     out = C_out if C_out is not None else torch.empty(d.M, ncols, dtype=torch.float32 if out_f32 else tdt(dtype), device=DEV)
     d.C, d.ldc, d.out_f32 = P(out), out.stride(0), int(out_f32)
     d.col_scale, d.col_bias, d.prelu = P(scale), P(bias), P(prelu)
@@ -53,7 +53,7 @@ def gemm(dtype, A, W, *, A2=None, W2=None, scale=None, bias=None, prelu=None, ac
     d.groups = groups
     d.skinny = int(skinny)
     for k, v in geom.items():
-        if k in ("rowinfo", "frameinfo"):
+        if k in ("rowinfo", "frameinfo", "norm_gain"):
             setattr(d, k, P(v))
         elif k != "groups":
             setattr(d, k, v)

@@ -102,6 +102,44 @@ def test_gemm_skinny(dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,K2", [(8, 320, 256, 64), (20, 96, 512, 0), (8, 16384, 128, 0), (100, 64, 256, 64)])
+def test_gemm_skinny_fused_rmsnorm(dtype, M, N, K, K2):
+    """y = rstd * ((x*g) W^T) + t B^T  ==  rmsnorm(x) W^T + t B^T   (decode-step fusion)."""
+    x, xr = q(rnd(M, K, seed=1) * 1.7, dtype)
+    w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
+    gain = (rnd(K, seed=3) * 0.1 + 1)
+    bias = rnd(N, seed=4)
+    eps = 1e-5
+    kw = {}
+    ref = (gain * xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + eps)) @ wr.T
+    if K2:
+        a2, a2r = q(rnd(M, K2, seed=5), dtype)
+        w2, w2r = q(rnd(N, K2, seed=6) / math.sqrt(K2), dtype)
+        kw = dict(A2=a2, W2=w2)
+        ref = ref + a2r @ w2r.T
+    gd = gain.to(DEV)
+    out = gemm(dtype, x, w, bias=bias.to(DEV), skinny=True, norm_gain=gd, norm_eps=eps, **kw)
+    close(out, ref + bias, tol(dtype) * 2, what="skinny fused rmsnorm")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,I,K", [(8, 8192, 128), (3, 256, 256), (24, 512, 128), (32, 4096 + 16, 64)])
+def test_gemm_skinny_fused_rmsnorm_swiglu(dtype, M, I, K):
+    x, xr = q(rnd(M, K, seed=1), dtype)
+    wg, wgr = q(rnd(I, K, seed=2) / math.sqrt(K), dtype)
+    wu, wur = q(rnd(I, K, seed=3) / math.sqrt(K), dtype)
+    inter = torch.stack([wg.reshape(-1, 16, K), wu.reshape(-1, 16, K)], 1).reshape(2 * I, K).contiguous()
+    gain = (rnd(K, seed=4) * 0.1 + 1)
+    eps = 1e-6
+    h = gain * xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + eps)
+    ref = F.silu(h @ wgr.T) * (h @ wur.T)
+    gd = gain.to(DEV)
+    out = gemm(dtype, x, inter, skinny=True, norm_gain=gd, norm_eps=eps, swiglu_pairs=1)
+    assert out.shape == (M, I)
+    close(out, ref, tol(dtype) * 2, what="skinny fused rmsnorm+swiglu")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("Cin,Cout,H,stride,ks", [(64, 64, 22, 1, 3), (64, 128, 22, 2, 3), (64, 128, 22, 2, 1), (128, 256, 11, 2, 3), (256, 512, 6, 2, 3), (512, 512, 3, 1, 3)])
 def test_conv2d_implicit_gemm(dtype, Cin, Cout, H, stride, ks):
     imgs = 5
@@ -370,17 +408,22 @@ def test_copy_rows_and_swiglu_and_argmax(dtype):
     I = 384
     xd, xr = q(rnd(9, 2 * I, seed=2), dtype)
     y2 = torch.empty(9, I, dtype=tdt(dtype), device=DEV)
-    L.check(lib.oavsr_op_swiglu(dcode(dtype), P(xd), 2 * I, P(y2), I, 9, I, stream()))
+    L.check(lib.oavsr_op_swiglu(dcode(dtype), P(xd), 2 * I, P(y2), I, 9, I, 0, stream()))
     close(y2, F.silu(xr[:, :I]) * xr[:, I:], tol(dtype), what="swiglu")
+    L.check(lib.oavsr_op_swiglu(dcode(dtype), P(xd), 2 * I, P(y2), I, 9, I, 1, stream()))
+    xi = xr.reshape(9, I // 16, 2, 16)
+    close(y2, (F.silu(xi[:, :, 0]) * xi[:, :, 1]).reshape(9, I), tol(dtype), what="swiglu interleaved")
     lg = rnd(6, 5000, seed=3).to(DEV)
     lg[2, 100] = lg[2, 4000] = 50.0     # tie -> lowest index
     lg[4, 77] = 99.0
-    o = torch.empty(6, dtype=torch.int32, device=DEV)
-    L.check(lib.oavsr_op_argmax(P(lg), 5000, 6, 5000, 77, P(o), stream()))
     lgc = lg.cpu().clone()
     lgc[:, 77] = float("-inf")
-    assert o.cpu().tolist() == lgc.argmax(-1).tolist()
-    assert o[2].item() == 100
+    scratch = torch.empty(6 * 64 * 2, dtype=torch.float32, device=DEV)
+    for scr in (None, scratch):             # single-stage and two-stage variants
+        o = torch.full((6,), -1, dtype=torch.int32, device=DEV)
+        L.check(lib.oavsr_op_argmax(P(lg), 5000, 6, 5000, 77, P(o), P(scr), stream()))
+        assert o.cpu().tolist() == lgc.argmax(-1).tolist()
+        assert o[2].item() == 100
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
