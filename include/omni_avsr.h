@@ -178,6 +178,9 @@ typedef struct oavsr_decode_attn_desc {
   int64_t ldq, ldo;
   const int32_t *prefix_len, *step, *anc;
   float scale;
+  /* fused RoPE + cache append when inv_freq != NULL: Q = fused [q|k|v] rows, rotated with pos[row], k/v appended at cpos[row] */
+  const float* inv_freq;
+  const int32_t *pos, *cpos;
 } oavsr_decode_attn_desc;
 int oavsr_op_decode_attention(const oavsr_decode_attn_desc* d, oavsr_stream stream);
 

@@ -202,114 +202,203 @@ __global__ __launch_bounds__(kThreads) void attn_varlen_kernel(const AttnArgs p)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Decode attention (q_len = 1 per row), flash-decoding inside one workgroup per (row, kv head):
+//   * the G query heads that share the kv head are the 16 "query columns" of the 16x16 MFMA (G <= 8 valid)
+//   * optional fused RoPE + KV-cache append (inv_freq != nullptr): q and the new k are rotated on load, the new k / v row
+//     is written to the tail cache first and then read back like any other key (workgroup-scope visibility via the barrier)
+//   * the 4 waves split the 64-key tiles; K fragments go HBM -> VGPR directly (A operand), V tiles go through a per-wave
+//     LDS image for the transposed reads; per-wave (m, l, O^T) partials are merged through LDS at the end.
 template <typename T, int HD>
 __global__ __launch_bounds__(kThreads) void decode_attn_kernel(const DecodeAttnArgs p) {
+  constexpr int RB = HD * (int)sizeof(T);
+  constexpr int NCH = RB / 16;
+  constexpr int SWZ = (RB == 128) ? 7 : 15;
+  constexpr int NBLK = RB / 64;
+  constexpr int NDT = HD / 16;
   constexpr int VEC = TypeInfo<T>::kVec;
-  constexpr int NCH = HD / VEC;                  // chunks per row: 8 (bf16 64), 16, 32
-  constexpr int MAXG = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sq = smem;                                   // [16][RB]  rotated queries (rows >= G are zero)
+  char* sv = smem + 16 * RB;                         // [4 waves][64][RB]  V tiles; reused for the merge
   const int row = blockIdx.x, kvh = blockIdx.y;
   const int G = p.n_heads / p.n_kv_heads;
   const int utt = row / p.beams;
   const int plen = p.prefix_len[utt];
   const int ntail = *p.step;
   const int ctx = plen + ntail;
-  const int ctx_cap = p.max_prefix + p.max_tail;
-  float* sq = reinterpret_cast<float*>(smem);            // [G][HD]
-  float* ss = sq + MAXG * HD;                            // [G][ctx_cap]
-  float* sred = ss + MAXG * ctx_cap;                     // [4][G][HD]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const T* Q = reinterpret_cast<const T*>(p.Q) + (int64_t)row * p.ldq + (int64_t)kvh * G * HD;
-  for (int i = tid; i < G * HD; i += kThreads) sq[i] = to_f32(Q[i]) * p.scale;
+  const int qi = lane & 15, g = lane >> 4;
+  const T* qrow = reinterpret_cast<const T*>(p.Q) + (int64_t)row * p.ldq;
+  T* Kt = reinterpret_cast<T*>(const_cast<void*>(p.Kt));
+  T* Vt = reinterpret_cast<T*>(const_cast<void*>(p.Vt));
+
+  // ---- phase 0: queries (+ RoPE) into LDS; new k (+ RoPE) / v appended to the tail cache ----
+  for (int i = tid; i < 16 * HD; i += kThreads) reinterpret_cast<T*>(sq)[i] = from_f32<T>(0.f);
   __syncthreads();
-  auto kv_row = [&](const void* pre, const void* tail, int j) -> const T* {
-    if (j < plen) return reinterpret_cast<const T*>(pre) + (((int64_t)utt * p.n_kv_heads + kvh) * p.max_prefix + j) * HD;
-    int t = j - plen;
-    int src = p.anc ? p.anc[(int64_t)row * p.max_tail + t] : row;
-    return reinterpret_cast<const T*>(tail) + (((int64_t)src * p.n_kv_heads + kvh) * p.max_tail + t) * HD;
+  if (p.inv_freq) {
+    constexpr int half = HD / 2;
+    const float pos = (float)p.pos[row];
+    for (int i = tid; i < (G + 1) * half; i += kThreads) {
+      const int h = i / half, d = i - h * half;
+      float sn, cs;
+      sincosf(pos * p.inv_freq[d], &sn, &cs);
+      const T* src = h < G ? qrow + (int64_t)(kvh * G + h) * HD : qrow + (int64_t)(p.n_heads + kvh) * HD;
+      const float x0 = to_f32(src[d]), x1 = to_f32(src[d + half]);
+      const T r0 = from_f32<T>(x0 * cs - x1 * sn), r1 = from_f32<T>(x1 * cs + x0 * sn);
+      if (h < G) {
+        T* dst = reinterpret_cast<T*>(sq + h * RB);
+        // chunk-swizzled like the K/V tiles are NOT needed here: sq rows are read as B operand with row = lane&15
+        dst[d] = r0; dst[d + half] = r1;
+      } else {
+        T* kd = Kt + (((int64_t)row * p.n_kv_heads + kvh) * p.max_tail + p.cpos[row]) * HD;
+        kd[d] = r0; kd[d + half] = r1;
+      }
+    }
+    const T* vsrc = qrow + (int64_t)(p.n_heads + p.n_kv_heads + kvh) * HD;
+    T* vd = Vt + (((int64_t)row * p.n_kv_heads + kvh) * p.max_tail + p.cpos[row]) * HD;
+    for (int i = tid; i < HD; i += kThreads) vd[i] = vsrc[i];
+  } else {
+    for (int i = tid; i < G * HD; i += kThreads) reinterpret_cast<T*>(sq)[i] = qrow[(int64_t)kvh * G * HD + i];
+  }
+  __syncthreads();
+
+  Chunk16 qf[NBLK];
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b) qf[b] = *reinterpret_cast<const Chunk16*>(sq + qi * RB + (b * 4 + g) * 16);
+
+  auto kv_row = [&](const void* pre, const void* tail, int j) -> const char* {
+    if (j < plen) return reinterpret_cast<const char*>(pre) + (((int64_t)utt * p.n_kv_heads + kvh) * p.max_prefix + j) * RB;
+    const int t = j - plen;
+    const int src = p.anc ? p.anc[(int64_t)row * p.max_tail + t] : row;
+    return reinterpret_cast<const char*>(tail) + (((int64_t)src * p.n_kv_heads + kvh) * p.max_tail + t) * RB;
   };
-  // phase 1: scores
-  for (int j = tid; j < ctx; j += kThreads) {
-    const T* kr = kv_row(p.Kp, p.Kt, j);
-    float acc[MAXG];
+
+  const float sc = p.scale * 1.44269504088896340736f;
+  f32x4 o[NDT];
 #pragma unroll
-    for (int h = 0; h < MAXG; ++h) acc[h] = 0.f;
-#pragma unroll 4
-    for (int c = 0; c < NCH; ++c) {
-      Chunk16 ck = *reinterpret_cast<const Chunk16*>(kr + c * VEC);
-      float kf[VEC];
-      chunk_to_f32<T>(ck, kf);
+  for (int i = 0; i < NDT; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  char* svw = sv + wave * (64 * RB);
+
+  for (int kt0 = wave * 64; kt0 < ctx; kt0 += 4 * 64) {
+    // K fragments straight from the cache: A operand row = key (lane & 15), 16-byte chunk (blk*4 + g)
+    Chunk16 kf[4][NBLK];
 #pragma unroll
-      for (int h = 0; h < MAXG; ++h) {
-        if (h < G) {
+    for (int kt = 0; kt < 4; ++kt) {
+      const int key = kt0 + kt * 16 + qi;
+      const char* kr = key < ctx ? kv_row(p.Kp, p.Kt, key) : nullptr;
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) acc[h] += kf[e] * sq[h * HD + c * VEC + e];
+      for (int b = 0; b < NBLK; ++b) {
+        if (kr) kf[kt][b] = *reinterpret_cast<const Chunk16*>(kr + (b * 4 + g) * 16);
+        else kf[kt][b].v = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+    // V tile -> this wave's LDS image (lane = key row)
+    {
+      const int key = kt0 + lane;
+      const char* vr = key < ctx ? kv_row(p.Vp, p.Vt, key) : nullptr;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        Chunk16 cv;
+        if (vr) cv = *reinterpret_cast<const Chunk16*>(vr + c * 16);
+        else cv.v = u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<Chunk16*>(svw + lane * RB + ((c ^ (lane & SWZ)) << 4)) = cv;
+      }
+    }
+    f32x4 s[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int b = 0; b < NBLK; ++b) MmaT<T>::run(kf[kt][b], qf[b], s[kt]);
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt0 + kt * 16 + 4 * g + r;
+        float v = key < ctx ? s[kt][r] * sc : -INFINITY;
+        s[kt][r] = v;
+        mt = fmaxf(mt, v);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = exp2f(m_run - m_use);
+    float lsum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { float e = exp2f(s[kt][r] - m_use); s[kt][r] = e; lsum += e; }
+    l_run = l_run * alpha + lsum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) o[i] *= alpha;
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's V tile writes have landed before its own reads
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        bf16x8 pf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pf[r] = (bf16_t)s[2 * u][r]; pf[4 + r] = (bf16_t)s[2 * u + 1][r]; }
+        const int qq = qi >> 2, pp = qi & 3;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+          const int c = dt * 2 + (pp >> 1);
+          const int row0 = (2 * u) * 16 + 4 * g + qq, row1 = row0 + 16;
+          auto a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(svw + row0 * RB + ((c ^ (row0 & SWZ)) << 4) + (pp & 1) * 8));
+          auto a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(svw + row1 * RB + ((c ^ (row1 & SWZ)) << 4) + (pp & 1) * 8));
+          bf16x4 v0 = __builtin_bit_cast(bf16x4, a0), v1 = __builtin_bit_cast(bf16x4, a1);
+          bf16x8 vf;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { vf[r] = v0[r]; vf[4 + r] = v1[r]; }
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
         }
       }
-    }
+    } else {
 #pragma unroll
-    for (int h = 0; h < MAXG; ++h)
-      if (h < G) ss[h * ctx_cap + j] = acc[h];
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+          const int c = dt * 4 + (qi >> 2);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int vrow = kt * 16 + 4 * g + r;
+            float vv = *reinterpret_cast<const float*>(svw + vrow * RB + ((c ^ (vrow & SWZ)) << 4) + (qi & 3) * 4);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, s[kt][r], o[dt], 0, 0, 0);
+          }
+        }
+    }
   }
+  // ---- merge the 4 waves: partials (m, l, O^T[d][q]) through LDS (reusing the V-tile region) ----
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
   __syncthreads();
-  // phase 2: softmax per head (one wave per head, strided)
-  for (int h = wave; h < G; h += 4) {
-    float m = -INFINITY;
-    for (int j = lane; j < ctx; j += 64) m = fmaxf(m, ss[h * ctx_cap + j]);
-    m = wave_max(m);
-    float l = 0.f;
-    for (int j = lane; j < ctx; j += 64) { float e = __expf(ss[h * ctx_cap + j] - m); ss[h * ctx_cap + j] = e; l += e; }
-    l = wave_sum(l);
-    float inv = 1.f / l;
-    for (int j = lane; j < ctx; j += 64) ss[h * ctx_cap + j] *= inv;
-  }
-  __syncthreads();
-  // phase 3: out[h][d] = sum_j p[h][j] V[j][d];  thread -> (key group kg, chunk c)
-  constexpr int KG = kThreads / NCH;
-  const int c = tid % NCH, kg = tid / NCH;
-  float acc[MAXG][VEC];
+  float* sm = reinterpret_cast<float*>(sv);            // [4][16] m, [4][16] l, [4][HD][16] O^T
+  float* sl = sm + 64;
+  float* so = sl + 64;
+  if (g == 0) { sm[wave * 16 + qi] = m_run; sl[wave * 16 + qi] = l_run; }
 #pragma unroll
-  for (int h = 0; h < MAXG; ++h)
+  for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) acc[h][e] = 0.f;
-  for (int j = kg; j < ctx; j += KG) {
-    const T* vr = kv_row(p.Vp, p.Vt, j);
-    Chunk16 cv = *reinterpret_cast<const Chunk16*>(vr + c * VEC);
-    float vf[VEC];
-    chunk_to_f32<T>(cv, vf);
-#pragma unroll
-    for (int h = 0; h < MAXG; ++h) {
-      if (h < G) {
-        float pj = ss[h * ctx_cap + j];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) acc[h][e] += pj * vf[e];
-      }
-    }
-  }
-  // reduce over key groups: lanes with equal c inside the wave, then across waves through LDS
-#pragma unroll
-  for (int h = 0; h < MAXG; ++h)
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      float v = acc[h][e];
-      for (int o = NCH; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-      acc[h][e] = v;
-    }
-  if (lane < NCH) {
-#pragma unroll
-    for (int h = 0; h < MAXG; ++h)
-      if (h < G)
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) sred[(wave * MAXG + h) * HD + lane * VEC + e] = acc[h][e];
-  }
+    for (int r = 0; r < 4; ++r) so[(wave * HD + dt * 16 + 4 * g + r) * 16 + qi] = o[dt][r];
   __syncthreads();
   T* O = reinterpret_cast<T*>(p.O) + (int64_t)row * p.ldo + (int64_t)kvh * G * HD;
   for (int i = tid; i < G * HD; i += kThreads) {
-    int h = i / HD, d = i - h * HD;
-    float v = 0.f;
+    const int h = i / HD, d = i - h * HD;
+    float mstar = fmaxf(fmaxf(sm[h], sm[16 + h]), fmaxf(sm[32 + h], sm[48 + h]));
+    if (mstar == -INFINITY) mstar = 0.f;
+    float num = 0.f, den = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) v += sred[(w * MAXG + h) * HD + d];
-    O[i] = from_f32<T>(v);
+    for (int w = 0; w < 4; ++w) {
+      const float f = exp2f(sm[w * 16 + h] - mstar);
+      num += f * so[(w * HD + d) * 16 + h];
+      den += f * sl[w * 16 + h];
+    }
+    O[i] = from_f32<T>(den > 0.f ? num / den : 0.f);
   }
 }
 
@@ -323,13 +412,15 @@ int launch_attn_t(const AttnArgs& a, hipStream_t st) {
 
 template <typename T, int HD>
 int launch_dec_t(const DecodeAttnArgs& a, hipStream_t st) {
-  size_t smem = sizeof(float) * (8 * HD + 8 * (size_t)(a.max_prefix + a.max_tail) + 4 * 8 * HD);
-  OAVSR_REQUIRE(smem <= 160 * 1024, "decode attention: context %d too long for LDS", a.max_prefix + a.max_tail);
+  constexpr int RB = HD * (int)sizeof(T);
+  constexpr size_t tiles = 4 * 64 * RB, merge = (128 + 4 * HD * 16) * 4;
+  constexpr size_t smem = 16 * RB + (tiles > merge ? tiles : merge);
+  static_assert(smem <= 160 * 1024, "LDS");
   auto kern = decode_attn_kernel<T, HD>;
-  static size_t attr = 0;
-  if (smem > attr) {
+  static bool attr = false;
+  if (!attr && smem > 48 * 1024) {
     OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr = smem;
+    attr = true;
   }
   dim3 grid(a.rows, a.n_kv_heads);
   hipLaunchKernelGGL(kern, grid, dim3(kThreads), smem, st, a);

@@ -79,6 +79,9 @@ struct DecodeAttnArgs {
   const int* step = nullptr;         // device scalar: number of tail tokens INCLUDING the current one
   const int* anc = nullptr;          // [rows][max_tail] row that holds tail position t (null: own row)
   float scale = 1.f;
+  // fused RoPE + cache append (inv_freq != nullptr): Q then points at the fused [q|k|v] rows (ldq = row stride); q and the
+  // new k are rotated with pos[row], k/v are written to the tail cache at cpos[row] before the keys are read
+  const float* inv_freq = nullptr; const int* pos = nullptr; const int* cpos = nullptr;
 };
 int launch_decode_attention(const DecodeAttnArgs& a, hipStream_t st);
 

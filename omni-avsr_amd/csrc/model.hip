@@ -590,12 +590,13 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
     if (decode) { g.norm_gain = L.ln1w; g.norm_eps = c.llm_rms_eps; }
     g.C = ws->lqkv; g.ldc = nqkv;
     OAVSR_TRY(run_gemm(g, st, decode));
-    RopeArgs r; r.dtype = dt; r.rows = rows; r.n_heads = H; r.n_kv_heads = KV; r.head_dim = hd; r.qkv = ws->lqkv; r.ld = nqkv;
-    r.inv_freq = m->inv_freq; r.pos = pos; r.slot = ws->slot; r.cpos = cpos;
-    if (decode) { r.kcache = (char*)ws->ktail + li * ws->ktail_layer; r.vcache = (char*)ws->vtail + li * ws->ktail_layer; r.max_ctx = ws->max_new; }
-    else { r.kcache = (char*)ws->kpre + li * ws->kpre_layer; r.vcache = (char*)ws->vpre + li * ws->kpre_layer; r.max_ctx = ws->max_prefix; }
-    { ProfScope ps("rope_kv", 0, 2.0 * rows * nqkv * m->esz, st);
-      OAVSR_TRY(launch_rope_kv(r, st)); }
+    if (!decode) {   // decode: RoPE + cache append are fused into the decode-attention kernel
+      RopeArgs r; r.dtype = dt; r.rows = rows; r.n_heads = H; r.n_kv_heads = KV; r.head_dim = hd; r.qkv = ws->lqkv; r.ld = nqkv;
+      r.inv_freq = m->inv_freq; r.pos = pos; r.slot = ws->slot; r.cpos = cpos;
+      r.kcache = (char*)ws->kpre + li * ws->kpre_layer; r.vcache = (char*)ws->vpre + li * ws->kpre_layer; r.max_ctx = ws->max_prefix;
+      ProfScope ps("rope_kv", 0, 2.0 * rows * nqkv * m->esz, st);
+      OAVSR_TRY(launch_rope_kv(r, st));
+    }
     if (!decode) {
       AttnArgs a; a.dtype = dt; a.head_dim = hd; a.n_heads = H; a.n_kv_heads = KV; a.n_seqs = B;
       a.Q = ws->lqkv; a.K = (const char*)ws->lqkv + (size_t)nq * m->esz; a.V = (const char*)ws->lqkv + (size_t)(nq + KV * hd) * m->esz;
@@ -609,6 +610,7 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
       a.Kp = (char*)ws->kpre + li * ws->kpre_layer; a.Vp = (char*)ws->vpre + li * ws->kpre_layer; a.max_prefix = ws->max_prefix;
       a.Kt = (char*)ws->ktail + li * ws->ktail_layer; a.Vt = (char*)ws->vtail + li * ws->ktail_layer; a.max_tail = ws->max_new;
       a.prefix_len = ws->prefix_len; a.step = ws->gs.step; a.anc = nullptr; a.scale = 1.0f / sqrtf((float)hd);
+      a.inv_freq = m->inv_freq; a.pos = pos; a.cpos = cpos;
       ProfScope ps("decode_attention", 0, 2.0 * rows * max_S * KV * hd * m->esz, st);
       OAVSR_TRY(launch_decode_attention(a, st));
     }
@@ -973,6 +975,7 @@ int oavsr_op_decode_attention(const oavsr_decode_attn_desc* d, oavsr_stream stre
   DecodeAttnArgs a; a.dtype = d->dtype; a.head_dim = d->head_dim; a.n_heads = d->n_heads; a.n_kv_heads = d->n_kv_heads; a.rows = d->rows;
   a.beams = d->beams; a.max_prefix = d->max_prefix; a.max_tail = d->max_tail; a.Q = d->Q; a.Kp = d->Kp; a.Vp = d->Vp; a.Kt = d->Kt; a.Vt = d->Vt;
   a.O = d->O; a.ldq = d->ldq; a.ldo = d->ldo; a.prefix_len = d->prefix_len; a.step = d->step; a.anc = d->anc; a.scale = d->scale;
+  a.inv_freq = d->inv_freq; a.pos = d->pos; a.cpos = d->cpos;
   return launch_decode_attention(a, (hipStream_t)stream);
 }
 

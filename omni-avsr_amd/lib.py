@@ -75,6 +75,7 @@ class DecodeAttnDesc(C.Structure):
         ("Q", C.c_void_p), ("Kp", C.c_void_p), ("Vp", C.c_void_p), ("Kt", C.c_void_p), ("Vt", C.c_void_p), ("O", C.c_void_p),
         ("ldq", C.c_int64), ("ldo", C.c_int64),
         ("prefix_len", C.c_void_p), ("step", C.c_void_p), ("anc", C.c_void_p), ("scale", C.c_float),
+        ("inv_freq", C.c_void_p), ("pos", C.c_void_p), ("cpos", C.c_void_p),
     ]
 
 

@@ -339,6 +339,51 @@ def test_decode_attention(dtype, hd, H, KV):
     close(out, torch.stack(refs), tol(dtype), what="decode attention")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hd,H,KV", [(64, 8, 2), (128, 6, 2)])
+def test_decode_attention_fused_rope_append(dtype, hd, H, KV):
+    """RoPE on q / new k + append of k,v to the tail cache inside the decode-attention kernel, long context (> 4 tiles)."""
+    from omni_avsr_amd.weights import rope_inv_freq
+    utts, maxp, maxt = 2, 320, 8
+    plen, step = [300, 77], 3                      # tail holds 2 old tokens, the kernel appends the 3rd
+    G = H // KV
+    ld = (H + 2 * KV) * hd
+    qkv, qkvr = q(rnd(utts, ld, seed=1), dtype)
+    kp, kpr = q(rnd(utts, KV, maxp, hd, seed=2), dtype)
+    vp, vpr = q(rnd(utts, KV, maxp, hd, seed=3), dtype)
+    kt, ktr = q(rnd(utts, KV, maxt, hd, seed=4), dtype)
+    vt, vtr = q(rnd(utts, KV, maxt, hd, seed=5), dtype)
+    inv = rope_inv_freq(hd, 500000.0, None)
+    pos = torch.tensor([p + step - 1 for p in plen], dtype=torch.int32)
+    invd, posd = inv.to(DEV), pos.to(DEV)
+    cposd = torch.full((utts,), step - 1, dtype=torch.int32, device=DEV)
+    pl = torch.tensor(plen, dtype=torch.int32, device=DEV)
+    st = torch.tensor([step], dtype=torch.int32, device=DEV)
+    out = torch.empty(utts, H * hd, dtype=tdt(dtype), device=DEV)
+    d = L.DecodeAttnDesc()
+    d.dtype, d.head_dim, d.n_heads, d.n_kv_heads, d.rows, d.beams, d.max_prefix, d.max_tail = dcode(dtype), hd, H, KV, utts, 1, maxp, maxt
+    d.Q, d.Kp, d.Vp, d.Kt, d.Vt, d.O = qkv.data_ptr(), kp.data_ptr(), vp.data_ptr(), kt.data_ptr(), vt.data_ptr(), out.data_ptr()
+    d.ldq, d.ldo = ld, H * hd
+    d.prefix_len, d.step, d.anc, d.scale = pl.data_ptr(), st.data_ptr(), None, 1.0 / math.sqrt(hd)
+    d.inv_freq, d.pos, d.cpos = invd.data_ptr(), posd.data_ptr(), cposd.data_ptr()
+    L.check(L.load().oavsr_op_decode_attention(C.byref(d), stream()))
+    ang = pos.float()[:, None] * inv[None]
+    cos, sin = torch.cat([ang, ang], -1).cos()[:, None], torch.cat([ang, ang], -1).sin()[:, None]
+    rot = lambda x: x * cos + torch.cat([-x[..., hd // 2:], x[..., :hd // 2]], -1) * sin
+    qh = rot(qkvr[:, :H * hd].reshape(utts, H, hd)).to(tdt(dtype)).float()
+    kn = rot(qkvr[:, H * hd:(H + KV) * hd].reshape(utts, KV, hd)).to(tdt(dtype)).float()
+    vn = qkvr[:, (H + KV) * hd:].reshape(utts, KV, hd)
+    refs = []
+    for r in range(utts):
+        k = torch.cat([kpr[r, :, :plen[r]], ktr[r, :, :step - 1], kn[r][:, None]], 1).repeat_interleave(G, 0)
+        v = torch.cat([vpr[r, :, :plen[r]], vtr[r, :, :step - 1], vn[r][:, None]], 1).repeat_interleave(G, 0)
+        w = torch.softmax(qh[r][:, None] @ k.transpose(1, 2) / math.sqrt(hd), -1)
+        refs.append((w @ v).reshape(H * hd))
+    close(out, torch.stack(refs), tol(dtype), what="decode attention fused rope")
+    close(kt[:, :, step - 1], kn, tol(dtype), what="appended k")
+    close(vt[:, :, step - 1], vn, 0.0, what="appended v")
+
+
 # ------------------------------------------------------------------------------------------------ norms & elementwise
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("mode", [0, 1, 2])
