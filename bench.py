@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--streams", type=int, default=3, help="batches in flight (one HIP stream + workspace each); 1 = strictly sequential steps")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -104,18 +105,29 @@ def main():
     Tvs, Ts = [Tv] * B, [640 * Tv] * B
     setup_s = time.time() - t0
 
-    def step():
-        return eng.generate("audiovisual", video, Tvs, audio, Ts, 4, 4, beams=1, max_new=args.max_new, force_len=True, video_is_flat=True)
+    # Independent batches are pipelined over `--streams` HIP streams (each with its own workspace): the latency-bound decode
+    # loop of one batch overlaps the MFMA-bound encoders / prefill of the next.  Every step still is one complete pass.
+    nstream = max(1, args.streams)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nstream)]
+    results = [None] * nstream
 
-    for _ in range(args.warmup):
-        ids, lens = step()
+    def step(i=0):
+        s = i % nstream
+        with torch.cuda.stream(streams[s]):
+            results[s] = eng.generate("audiovisual", video, Tvs, audio, Ts, 4, 4, beams=1, max_new=args.max_new, force_len=True,
+                                      video_is_flat=True, slot=s)
+        return results[s]
+
+    torch.cuda.synchronize()
+    for i in range(max(args.warmup, nstream)):
+        ids, lens = step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ids, lens = step()
+    for i in range(args.steps):
+        ids, lens = step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -171,7 +183,7 @@ def main():
             "rtf": round(elapsed / (n_utt * Tv / 25.0), 6),
             "config": {"workload": f"AVSR, AV-HuBERT-Large + Whisper-medium.en + Llama-3.2-1B (Omni-LoRA ST r32/a4), batch={B} x {Tv / 25:.0f}s clips per GPU, "
                                    f"compression (4,4), greedy {args.max_new} new tokens (EOS suppressed), BASELINE.json configs[1]",
-                       "global_batch": world * B, "parallelism": f"utterance-sharded dp{world}", "setup_s": round(setup_s, 1)},
+                       "global_batch": world * B, "parallelism": f"utterance-sharded dp{world}", "streams_per_gpu": nstream, "setup_s": round(setup_s, 1)},
             "roofline": roofline, "cpu_baseline": cpu, "stages": stages,
         }
         print(json.dumps(line), flush=True)

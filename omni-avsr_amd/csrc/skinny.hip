@@ -36,11 +36,11 @@ template <> struct MmaS<float> {
   }
 };
 
-template <typename T, int MT, int NT, bool NORM>
+template <typename T, int MT, int NT, bool NORM, int U>
 __global__ __launch_bounds__(kThreads) void skinny_kernel(const GemmArgs p) {
   constexpr int KBE = 64 / (int)sizeof(T);       // elements per 64-byte k block
   constexpr int VEC = TypeInfo<T>::kVec;
-  constexpr int U = (NT >= 4) ? 4 : 8;            // k blocks in flight per wave
+  // U = k blocks in flight per wave
   constexpr int MR = MT * 16, NC = NT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sred = reinterpret_cast<float*>(smem);   // [8][MR][NC]
@@ -81,7 +81,8 @@ __global__ __launch_bounds__(kThreads) void skinny_kernel(const GemmArgs p) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int n = n0 + j * 16 + r16;
-        bf[u][j] = (in && n < p.N) ? *reinterpret_cast<const Chunk16*>(Wb + (int64_t)n * ldw + k) : zchunk();
+        if (in && n < p.N) bf[u][j].v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Wb + (int64_t)n * ldw + k));   // streamed once
+        else bf[u][j] = zchunk();
       }
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
@@ -189,11 +190,11 @@ __global__ __launch_bounds__(kThreads) void skinny_kernel(const GemmArgs p) {
   }
 }
 
-template <typename T, int MT, int NT, bool NORM>
-int launch_sk(const GemmArgs& a, hipStream_t st) {
+template <typename T, int MT, int NT, bool NORM, int U>
+int launch_sk_u(const GemmArgs& a, hipStream_t st) {
   constexpr int smem = kWaves * MT * 16 * NT * 16 * 4 * (NORM ? 2 : 1) + (NORM ? kWaves * MT * 16 * 4 : 0);
   static_assert(smem <= 160 * 1024, "LDS");
-  auto kern = skinny_kernel<T, MT, NT, NORM>;
+  auto kern = skinny_kernel<T, MT, NT, NORM, U>;
   static bool attr_set = false;
   if (!attr_set && smem > 48 * 1024) {
     OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -202,6 +203,14 @@ int launch_sk(const GemmArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(ceil_div(a.N, NT * 16)), dim3(kThreads), smem, st, a);
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+template <typename T, int MT, int NT, bool NORM>
+int launch_sk(const GemmArgs& a, hipStream_t st) {
+  constexpr int U0 = (NT >= 4) ? 4 : 8;
+  // deep K with few column tiles (down_proj): keep twice as many weight loads in flight per wave
+  if (MT == 1 && NT == 1 && (a.K + a.K2) * (int)sizeof(T) >= 64 * kWaves * 16) return launch_sk_u<T, MT, NT, NORM, 16>(a, st);
+  return launch_sk_u<T, MT, NT, NORM, U0>(a, st);
 }
 
 template <typename T, bool NORM>

@@ -42,6 +42,7 @@ class OmniEngine:
         self._model = C.c_void_p(None)
         self._ws = C.c_void_p(None)
         self._ws_key = None
+        self._slots = {}            # extra workspaces (one per concurrent stream): slot -> (ptr, key)
         self._blob = None
         self._names = None
 
@@ -115,7 +116,28 @@ class OmniEngine:
     def workspace_bytes(self) -> int:
         return int(self.lib.oavsr_workspace_bytes(self._ws)) if self._ws else 0
 
+    def _slot_workspace(self, slot: int, B: int, Tv: int, Ts: int, beams: int, max_new: int):
+        """slot 0 is the default workspace; slots >= 1 are independent workspaces for pipelining batches on other streams
+        (one oavsr_workspace per stream, include/omni_avsr.h)."""
+        if slot == 0:
+            self.ensure_workspace(B, Tv, Ts, beams, max_new)
+            return self._ws
+        ptr, key = self._slots.get(slot, (None, None))
+        if key is not None and key[0] >= B and key[1] >= Tv and key[2] >= Ts and key[3] >= beams and key[4] >= max_new:
+            return ptr
+        if ptr:
+            torch.cuda.synchronize(self.device)
+            self.lib.oavsr_workspace_destroy(ptr)
+        ptr = C.c_void_p(None)
+        L.check(self.lib.oavsr_workspace_create(self._model, B, max(Tv, 1), max(Ts, 1), beams, max_new, C.byref(ptr)))
+        self._slots[slot] = (ptr, (B, Tv, Ts, beams, max_new))
+        return ptr
+
     def close(self):
+        for ptr, _ in self._slots.values():
+            if ptr:
+                self.lib.oavsr_workspace_destroy(ptr)
+        self._slots = {}
         if self._ws:
             self.lib.oavsr_workspace_destroy(self._ws)
             self._ws = C.c_void_p(None)
@@ -205,7 +227,7 @@ class OmniEngine:
 
     def generate(self, task: str, video: Optional[torch.Tensor], Tv: Optional[Sequence[int]], audio: Optional[torch.Tensor],
                  lengths: Optional[Sequence[int]], rate_a: int, rate_v: int, beams: int = 1, max_new: Optional[int] = None,
-                 force_len: bool = False, video_is_flat: bool = False):
+                 force_len: bool = False, video_is_flat: bool = False, slot: int = 0):
         """End-to-end `forward(is_trainval=False)`: returns (ids int32 [B,max_new] pad-filled, lens int32 [B]) on device.
         No host synchronisation happens inside."""
         max_new = max_new or self.spec.max_dec_tokens
@@ -220,17 +242,18 @@ class OmniEngine:
             if a.device != self.device or a.dtype != torch.float32 or not a.is_contiguous():
                 a = a.to(self.device, torch.float32).contiguous()
             keep = [whisper_keep_tokens(int(n)) for n in lengths]
-        self.ensure_workspace(B, max(Tv) if use_v else 1, int(max(lengths)) if use_a else 16000, beams, max_new)
+        ws = self._slot_workspace(slot, B, max(Tv) if use_v else 1, int(max(lengths)) if use_a else 16000, beams, max_new)
         ids = torch.empty(B, max_new, dtype=torch.int32, device=self.device)
         lens = torch.empty(B, dtype=torch.int32, device=self.device)
         L.check(self.lib.oavsr_generate(
-            self._model, self._ws, L.TASK_ID[task],
+            self._model, ws, L.TASK_ID[task],
             C.c_void_p(flat.data_ptr()) if use_v else None, _i32arr(Tv) if use_v else None,
             C.c_void_p(a.data_ptr()) if use_a else None, a.stride(0) if use_a else 0,
             _i32arr(lengths) if use_a else None, _i32arr(keep) if use_a else None,
             B, int(rate_a or 1), int(rate_v or 1), beams, max_new, int(force_len),
             C.c_void_p(ids.data_ptr()), C.c_void_p(lens.data_ptr()), self._stream()))
-        self._keepalive = (flat, a)
+        self._keepalive = getattr(self, "_keepalive", {})
+        self._keepalive[slot] = (flat, a)
         return ids, lens
 
     # ---- profiling (bench.py roofline) ------------------------------------------------------------------
