@@ -10,6 +10,7 @@
 // * optional second K segment (A2,W2) accumulates the LoRA term (x A^T)(s B)^T in the same accumulators
 //   (Llama_LoRA.py:250-259, multihead_attention.py:485-494) -> "fused W + BA".
 // * fused epilogue: per-column scale/shift (BatchNorm eval, bias), residual, GELU / ReLU / PReLU / SiLU.
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace oavsr {
@@ -311,6 +312,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   if (a.amode == A_CONV1D) OAVSR_REQUIRE(a.Cin % vec == 0 && a.rowinfo && a.Kvalid == a.taps * a.Cin && a.Kvalid <= a.K, "gemm/conv1d: bad geometry");
   if (a.amode == A_STEM) OAVSR_REQUIRE(a.frameinfo && a.K == 256 && a.M % 1936 == 0, "gemm/stem: bad geometry");
   OAVSR_REQUIRE(a.act != ACT_PRELU || a.prelu, "gemm: PReLU needs slopes");
+  static const bool use_dma = [] { const char* e = getenv("OAVSR_GEMM_DMA"); return !(e && e[0] == '0'); }();
+  if (use_dma && gemm_dma_eligible(a)) return launch_gemm_dma(a, st);
   return a.dtype == DT_F32 ? launch_mode<float>(a, st) : launch_mode<bf16_t>(a, st);
 }
 

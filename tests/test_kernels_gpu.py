@@ -46,6 +46,67 @@ def test_gemm_dense(dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,K2", [(4096, 2048, 512, 0), (3000, 3072 + 40, 384, 128), (12000, 1024, 256, 0)])
+def test_gemm_dma_pipeline(dtype, M, N, K, K2):
+    """Shapes large enough to take the LDS-DMA 256x128 3-stage kernel (gemm2.hip): ragged M/N edges, 2nd K segment, epilogue."""
+    a, ar = q(rnd(M, K, seed=1), dtype)
+    w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
+    r, rr = q(rnd(M, N, seed=5), dtype)
+    bias = rnd(N, seed=7)
+    kw, ref = {}, ar @ wr.T
+    if K2:
+        a2, a2r = q(rnd(M, K2, seed=3), dtype)
+        w2, w2r = q(rnd(N, K2, seed=4) / math.sqrt(K2), dtype)
+        kw = dict(A2=a2, W2=w2)
+        ref = ref + a2r @ w2r.T
+    out = gemm(dtype, a, w, bias=bias.to(DEV), act=1, residual=r, res_after_act=1, **kw)
+    close(out, F.gelu(ref + bias) + rr, tol(dtype) * 2, what="gemm dma")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_dma_identity_layout(dtype):
+    n = 2048
+    a, _ = q(torch.eye(n), dtype)
+    wv = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 253) / 64.0
+    w, wr = q(wv, dtype)
+    out = gemm(dtype, a, w)
+    close(out, wr.T, 1e-6, what="gemm dma identity")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv2d_dma(dtype):
+    imgs, Cin, Cout, H, stride, ks = 420, 64, 128, 22, 2, 3
+    x = rnd(imgs, Cin, H, H, seed=1)
+    w = rnd(Cout, Cin, ks, ks, seed=2) / math.sqrt(Cin * ks * ks)
+    xd, xr = q(x.permute(0, 2, 3, 1).contiguous(), dtype)
+    wd, wr = q(w.permute(0, 2, 3, 1).reshape(Cout, -1), dtype)
+    OH = (H + 2 - ks) // stride + 1
+    out = gemm(dtype, xd, wd, M=imgs * OH * OH, amode=1, H=H, W_=H, Cin=Cin, OH=OH, OW=OH, stride=stride, pad=1, ksize=ks, lda=0)
+    ref = F.conv2d(xr.permute(0, 3, 1, 2), wr.reshape(Cout, ks, ks, Cin).permute(0, 3, 1, 2), stride=stride, padding=1)
+    close(out.reshape(imgs, OH, OH, Cout), ref.permute(0, 2, 3, 1), tol(dtype), what="conv2d dma")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("stride,Cin", [(1, 80), (2, 128)])
+def test_conv1d_dma(dtype, stride, Cin):
+    B, Tin, D = 4, 16000, 256
+    Tout = Tin // stride
+    x = rnd(B * Tin, Cin, seed=1)
+    w = rnd(D, Cin, 3, seed=2) / math.sqrt(3 * Cin)
+    b = rnd(D, seed=3)
+    xd, xr = q(x, dtype)
+    Kp = 256 if Cin == 80 else 3 * Cin
+    wp = torch.zeros(D, Kp)
+    wp[:, : 3 * Cin] = w.permute(0, 2, 1).reshape(D, -1)
+    wd, wr = q(wp, dtype)
+    ri = _rowinfo([i * Tout for i in range(B + 1)], [i * Tin for i in range(B + 1)], stride)
+    out = gemm(dtype, xd, wd, M=B * Tout, N=D, K=Kp, amode=2, Cin=Cin, taps=3, Kvalid=3 * Cin, pad=1, rowinfo=ri, bias=b.to(DEV), act=1, lda=Cin)
+    wref = wr[:, : 3 * Cin].reshape(D, 3, Cin).permute(0, 2, 1)
+    ref = F.gelu(F.conv1d(xr.reshape(B, Tin, Cin).transpose(1, 2), wref, b, stride=stride, padding=1)).transpose(1, 2).reshape(B * Tout, D)
+    close(out, ref, tol(dtype) * 2, what="conv1d dma")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_asymmetric_identity(dtype):
     """A = I with an asymmetric W catches row/col swaps of the MFMA C layout."""
     n = 128
