@@ -8,18 +8,13 @@
 //   * the DMA writes LDS linearly (wave-uniform base + lane*16), so the XOR swizzle that makes the ds_read_b128 fragment
 //     reads conflict-free is applied to the per-lane SOURCE address (chunk ^ (row & 7)) and again on the read
 //   * out-of-range rows / conv padding read a 16-byte zero page instead of branching
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace oavsr {
 namespace {
 
-constexpr int kThreads = 512;
 constexpr int kRowBytes = 128;
-constexpr int BM = 256, BN = 128;
-constexpr int kStageBytes = (BM + BN) * kRowBytes;      // 48 KiB
-constexpr int kStages = 3;
-constexpr int NLD = (BM + BN) * 8 / kThreads;           // 6 DMA instructions per thread per k-tile
-constexpr int NLA = BM * 8 / kThreads;                  // 4 of them fetch A rows
 
 __device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];
 
@@ -86,15 +81,23 @@ __device__ __forceinline__ void dma16(const void* src, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, int AMODE>
-__global__ __launch_bounds__(kThreads) void gemm_dma_kernel(const GemmArgs p) {
+// BM x BN tile, kStages LDS stages (kStages - 1 k-tiles in flight), 8 waves as WAVES_M x (8 / WAVES_M), wave tile (BM/WAVES_M) x 64:
+//   256 x 128, 3 stages, 4 x 2 waves (wave tile 64 x 64)   -- mid-size grids
+//   256 x 256, 2 stages, 2 x 4 waves (wave tile 128 x 64)  -- large grids: half the L2->LDS bytes and LDS reads per flop
+template <typename T, int AMODE, int BM, int BN, int kStages, int WAVES_M, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p) {
+  constexpr int kThreads = NWAVES * 64;
   constexpr int VEC = TypeInfo<T>::kVec;
   constexpr int BKE = kRowBytes / (int)sizeof(T);
-  constexpr int TM = 4, TN = 4;
+  constexpr int WAVES_N = NWAVES / WAVES_M;
+  constexpr int TM = BM / (WAVES_M * 16), TN = BN / (WAVES_N * 16);
+  constexpr int kStageBytes = (BM + BN) * kRowBytes;
+  constexpr int NLD = (BM + BN) * 8 / kThreads;           // DMA instructions per thread per k-tile
+  constexpr int NLA = BM * 8 / kThreads;                  // ... of which fetch A rows
   extern __shared__ __attribute__((aligned(1024))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int ntn = (p.N + BN - 1) / BN;
   const int bid = blockIdx.x;
   const int mt = bid / ntn, nt_ = bid - mt * ntn;
@@ -107,11 +110,11 @@ __global__ __launch_bounds__(kThreads) void gemm_dma_kernel(const GemmArgs p) {
   const int lchunk = (lane & 7) ^ lrow;
   ARow2 arow[NLA];
 #pragma unroll
-  for (int j = 0; j < NLA; ++j) init_arow2<T, AMODE>(p, m0 + (j * 8 + wave) * 8 + lrow, g, arow[j]);
+  for (int j = 0; j < NLA; ++j) init_arow2<T, AMODE>(p, m0 + (j * NWAVES + wave) * 8 + lrow, g, arow[j]);
   int64_t wbase[NLD - NLA]; int wvalid[NLD - NLA];
 #pragma unroll
   for (int j = 0; j < NLD - NLA; ++j) {
-    int n = n0 + ((j + NLA) * 8 + wave) * 8 + lrow - BM;
+    int n = n0 + ((j + NLA) * NWAVES + wave) * 8 + lrow - BM;
     wvalid[j] = n < p.N;
     wbase[j] = (int64_t)(g * p.N + n);
   }
@@ -125,20 +128,20 @@ __global__ __launch_bounds__(kThreads) void gemm_dma_kernel(const GemmArgs p) {
     if (t < nt1) {
       const int k = t * BKE + lchunk * VEC;
 #pragma unroll
-      for (int j = 0; j < NLA; ++j) dma16(a_src<T, AMODE>(p, arow[j], k, g), st + (j * 8 + wave) * 1024);
+      for (int j = 0; j < NLA; ++j) dma16(a_src<T, AMODE>(p, arow[j], k, g), st + (j * NWAVES + wave) * 1024);
 #pragma unroll
       for (int j = 0; j < NLD - NLA; ++j)
-        dma16(wvalid[j] ? (const void*)(W1 + wbase[j] * p.ldw + k) : (const void*)g_zero_page, st + ((j + NLA) * 8 + wave) * 1024);
+        dma16(wvalid[j] ? (const void*)(W1 + wbase[j] * p.ldw + k) : (const void*)g_zero_page, st + ((j + NLA) * NWAVES + wave) * 1024);
     } else {
       const int k = (t - nt1) * BKE + lchunk * VEC;
 #pragma unroll
       for (int j = 0; j < NLA; ++j) {
-        const int m = m0 + (j * 8 + wave) * 8 + lrow;
-        dma16(m < p.M ? (const void*)(A2 + (int64_t)m * p.lda2 + k) : (const void*)g_zero_page, st + (j * 8 + wave) * 1024);
+        const int m = m0 + (j * NWAVES + wave) * 8 + lrow;
+        dma16(m < p.M ? (const void*)(A2 + (int64_t)m * p.lda2 + k) : (const void*)g_zero_page, st + (j * NWAVES + wave) * 1024);
       }
 #pragma unroll
       for (int j = 0; j < NLD - NLA; ++j)
-        dma16(wvalid[j] ? (const void*)(W2 + wbase[j] * p.ldw2 + k) : (const void*)g_zero_page, st + ((j + NLA) * 8 + wave) * 1024);
+        dma16(wvalid[j] ? (const void*)(W2 + wbase[j] * p.ldw2 + k) : (const void*)g_zero_page, st + ((j + NLA) * NWAVES + wave) * 1024);
     }
   };
 
@@ -148,36 +151,43 @@ __global__ __launch_bounds__(kThreads) void gemm_dma_kernel(const GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  issue(0);
-  if (ntot > 1) issue(1);
+#pragma unroll
+  for (int t = 0; t < kStages - 1; ++t)
+    if (t < ntot) issue(t);
   const int frow = lane & 15, fg = lane >> 4;
   for (int t = 0; t < ntot; ++t) {
-    // tile t has landed once at most one younger tile (NLD loads) is still outstanding
-    if (t + 1 < ntot) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+    // tile t has landed once at most (kStages - 2) younger tiles (NLD loads each) are still outstanding
+    if (kStages >= 3 && t + kStages - 2 < ntot) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kStages - 2) * NLD) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (t + 2 < ntot) issue(t + 2);      // stage (t+2)%3 == (t-1)%3: every wave finished reading it before the barrier
+    // stage (t + kStages - 1) % kStages held tile t-1: every wave finished reading it before the barrier
+    if (t + kStages - 1 < ntot) issue(t + kStages - 1);
     const char* sA = smem + (t % kStages) * kStageBytes;
     const char* sB = sA + BM * kRowBytes;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      Chunk16 af[TM], bf[TN];
+      constexpr int TMH = TM > 4 ? 4 : TM;              // A fragments are consumed in groups of 4 row tiles (register budget)
+      Chunk16 bf[TN];
       const int chunk = kb * 4 + fg;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        int row = wm * 64 + i * 16 + frow;
-        af[i] = *reinterpret_cast<const Chunk16*>(sA + row * kRowBytes + ((chunk ^ (row & 7)) << 4));
-      }
-#pragma unroll
       for (int j = 0; j < TN; ++j) {
-        int row = wn * 64 + j * 16 + frow;
+        int row = wn * (TN * 16) + j * 16 + frow;
         bf[j] = *reinterpret_cast<const Chunk16*>(sB + row * kRowBytes + ((chunk ^ (row & 7)) << 4));
       }
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int ih = 0; ih < TM / TMH; ++ih) {
+        Chunk16 af[TMH];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) Mma2<T>::run(af[i], bf[j], acc[i][j]);
+        for (int i = 0; i < TMH; ++i) {
+          int row = wm * (TM * 16) + (ih * TMH + i) * 16 + frow;
+          af[i] = *reinterpret_cast<const Chunk16*>(sA + row * kRowBytes + ((chunk ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < TMH; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) Mma2<T>::run(af[i], bf[j], acc[ih * TMH + i][j]);
+      }
     }
     asm volatile("" ::: "memory");
   }
@@ -185,7 +195,7 @@ __global__ __launch_bounds__(kThreads) void gemm_dma_kernel(const GemmArgs p) {
   const T* R = reinterpret_cast<const T*>(p.residual);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * 64 + j * 16 + frow;
+    const int n = n0 + wn * (TN * 16) + j * 16 + frow;
     if (n >= p.N) continue;
     const int ng = g * p.N + n;
     const float sc = p.col_scale ? p.col_scale[ng] : 1.f;
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(kThreads) void gemm_dma_kernel(const GemmArgs p) {
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * 64 + i * 16 + fg * 4 + r;
+        const int m = m0 + wm * (TM * 16) + i * 16 + fg * 4 + r;
         if (m >= p.M) continue;
         float y = acc[i][j][r] * sc + bi;
         float res = R ? to_f32(R[(int64_t)m * p.ldr + ng]) : 0.f;
@@ -215,10 +225,10 @@ __global__ __launch_bounds__(kThreads) void gemm_dma_kernel(const GemmArgs p) {
   }
 }
 
-template <typename T, int AMODE>
+template <typename T, int AMODE, int BM, int BN, int kStages, int WAVES_M, int NWAVES>
 int launch_dma(const GemmArgs& a, hipStream_t st) {
-  auto kern = gemm_dma_kernel<T, AMODE>;
-  constexpr int smem = kStages * kStageBytes;
+  auto kern = gemm_dma_kernel<T, AMODE, BM, BN, kStages, WAVES_M, NWAVES>;
+  constexpr int smem = kStages * (BM + BN) * kRowBytes;
   static bool attr_set = false;
   if (!attr_set) {
     OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -226,28 +236,40 @@ int launch_dma(const GemmArgs& a, hipStream_t st) {
   }
   int64_t nblk = (int64_t)ceil_div(a.M, BM) * ceil_div(a.N, BN);
   dim3 grid((unsigned)nblk, 1, a.groups);
-  hipLaunchKernelGGL(kern, grid, dim3(kThreads), smem, st, a);
+  hipLaunchKernelGGL(kern, grid, dim3(NWAVES * 64), smem, st, a);
   OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+static int dma_tile_choice(const GemmArgs& a) {
+  // 0: not eligible, 1: 256x128, 2: 256x256
+  static const int force = [] { const char* e = getenv("OAVSR_GEMM_TILE"); return e ? atoi(e) : -1; }();
+  if (a.amode == A_STEM || a.N < 128) return 0;
+  const int64_t n128 = (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 128) * a.groups;
+  const int64_t n256 = (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 256) * a.groups;
+  if (force == 1) return n128 >= 1 ? 1 : 0;
+  if (force == 2) return (a.N >= 256 && a.amode == A_DENSE) ? 2 : 1;
+  // measured on MI355X (tools/bench_kernels.py): the 256x256 tile wins as soon as ~60 % of the CUs get a tile
+  if (a.amode == A_DENSE && a.N >= 256 && n256 >= 144) return 2;
+  if (n128 >= 144) return 1;
   return 0;
 }
 
 template <typename T>
 int launch_dma_mode(const GemmArgs& a, hipStream_t st) {
+  // 256x256: 16 waves (4 x 4) of 64 x 64, 2 stages; dense only.  256x128: 8 waves (4 x 2) of 64 x 64, 3 stages.
+  if (dma_tile_choice(a) == 2) return launch_dma<T, A_DENSE, 256, 256, 2, 4, 16>(a, st);
   switch (a.amode) {
-    case A_DENSE: return launch_dma<T, A_DENSE>(a, st);
-    case A_CONV2D: return launch_dma<T, A_CONV2D>(a, st);
-    case A_CONV1D: return launch_dma<T, A_CONV1D>(a, st);
+    case A_DENSE: return launch_dma<T, A_DENSE, 256, 128, 3, 4, 8>(a, st);
+    case A_CONV2D: return launch_dma<T, A_CONV2D, 256, 128, 3, 4, 8>(a, st);
+    case A_CONV1D: return launch_dma<T, A_CONV1D, 256, 128, 3, 4, 8>(a, st);
   }
   return -1;
 }
 
 }  // namespace
 
-bool gemm_dma_eligible(const GemmArgs& a) {
-  if (a.amode == A_STEM || a.N < 128) return false;
-  const int64_t nblk = (int64_t)ceil_div(a.M, BM) * ceil_div(a.N, BN) * a.groups;
-  return nblk >= 192;      // enough 256x128 tiles for (nearly) every CU; smaller grids keep the 128x128 kernel at 2 WG/CU
-}
+bool gemm_dma_eligible(const GemmArgs& a) { return dma_tile_choice(a) != 0; }
 
 int launch_gemm_dma(const GemmArgs& a, hipStream_t st) {
   return a.dtype == DT_F32 ? launch_dma_mode<float>(a, st) : launch_dma_mode<bf16_t>(a, st);
