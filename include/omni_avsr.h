@@ -158,6 +158,9 @@ typedef struct oavsr_gemm_desc {
   const float* norm_gain;
   float norm_eps;
   int32_t swiglu_pairs;
+  /* classic kernel only: split-K with fp32 partial slabs [ksplit][M][N] and a deterministic reduce + epilogue pass */
+  int32_t ksplit;
+  float* partial;
 } oavsr_gemm_desc;
 int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream);
 

@@ -190,13 +190,21 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(const GemmArgs p) {
     for (int j = 0; j < NB; ++j) *reinterpret_cast<Chunk16*>(s + b_lds[j]) = rb[j];
   };
 
-  gload(0);
+  // split-K (ksplit > 1): blockIdx.y owns k-tiles [t0, t1) and writes raw fp32 partial sums; splitk_reduce_kernel finishes
+  int t0 = 0, t1 = ntot;
+  if (p.ksplit > 1) {
+    const int per = (ntot + p.ksplit - 1) / p.ksplit;
+    t0 = blockIdx.y * per; t1 = t0 + per < ntot ? t0 + per : ntot;
+  }
+  const int frow = lane & 15, fg = lane >> 4;
+  if (t0 < t1) {
+  gload(t0);
   swrite(0);
   __syncthreads();
-  const int frow = lane & 15, fg = lane >> 4;
-  for (int t = 0; t < ntot; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < ntot) gload(t + 1);
+  }
+  for (int t = t0; t < t1; ++t) {
+    const int cur = (t - t0) & 1;
+    if (t + 1 < t1) gload(t + 1);
     const char* sA = smem + cur * kStage;
     const char* sB = sA + BM * kRowBytes;
 #pragma unroll
@@ -218,11 +226,27 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) Mma<T>::run(af[i], bf[j], acc[i][j]);
     }
-    if (t + 1 < ntot) swrite(cur ^ 1);
+    if (t + 1 < t1) swrite(cur ^ 1);
     __syncthreads();
   }
 
   // ---- epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = 4*(lane>>4) + reg -------------
+  if (p.ksplit > 1) {
+    float* P = p.partial + (int64_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (TN * 16) + j * 16 + frow;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + wm * (TM * 16) + i * 16 + fg * 4 + r;
+          if (m < p.M) P[(int64_t)m * p.N + n] = acc[i][j][r];
+        }
+    }
+    return;
+  }
   const T* R = reinterpret_cast<const T*>(p.residual);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -267,10 +291,35 @@ int launch_one(const GemmArgs& a, hipStream_t st) {
   }
   int64_t nblk = (int64_t)ceil_div(a.M, BM) * ceil_div(a.N, BN);
   OAVSR_REQUIRE(nblk < (1ll << 31), "gemm: grid too large");
-  dim3 grid((unsigned)nblk, 1, a.groups);
+  dim3 grid((unsigned)nblk, a.ksplit > 1 ? a.ksplit : 1, a.groups);
   hipLaunchKernelGGL(kern, grid, dim3(kThreads), smem, st, a);
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
+  const int64_t total = (int64_t)p.M * p.N;
+  const T* R = reinterpret_cast<const T*>(p.residual);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int m = (int)(i / p.N), n = (int)(i - (int64_t)m * p.N);
+    float y = 0.f;
+    for (int s = 0; s < p.ksplit; ++s) y += p.partial[(int64_t)s * total + i];     // fixed order: deterministic
+    if (p.col_scale) y *= p.col_scale[n];
+    if (p.col_bias) y += p.col_bias[n];
+    float res = R ? to_f32(R[(int64_t)m * p.ldr + n]) : 0.f;
+    if (!p.res_after_act) y += res;
+    switch (p.act) {
+      case ACT_GELU: y = gelu_erf(y); break;
+      case ACT_RELU: y = fmaxf(y, 0.f); break;
+      case ACT_PRELU: y = y >= 0.f ? y : p.prelu[n] * y; break;
+      case ACT_SILU: y = silu(y); break;
+      default: break;
+    }
+    if (p.res_after_act) y += res;
+    if (p.out_f32) reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n] = y;
+    else reinterpret_cast<T*>(p.C)[(int64_t)m * p.ldc + n] = from_f32<T>(y);
+  }
 }
 
 template <typename T, int AMODE>
@@ -312,6 +361,16 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   if (a.amode == A_CONV1D) OAVSR_REQUIRE(a.Cin % vec == 0 && a.rowinfo && a.Kvalid == a.taps * a.Cin && a.Kvalid <= a.K, "gemm/conv1d: bad geometry");
   if (a.amode == A_STEM) OAVSR_REQUIRE(a.frameinfo && a.K == 256 && a.M % 1936 == 0, "gemm/stem: bad geometry");
   OAVSR_REQUIRE(a.act != ACT_PRELU || a.prelu, "gemm: PReLU needs slopes");
+  if (a.ksplit > 1) {
+    OAVSR_REQUIRE(a.partial && a.groups == 1 && a.amode == A_DENSE, "gemm: split-K needs a partial buffer, dense A, no groups");
+    OAVSR_TRY(a.dtype == DT_F32 ? launch_mode<float>(a, st) : launch_mode<bf16_t>(a, st));
+    int64_t total = (int64_t)a.M * a.N;
+    int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    if (a.dtype == DT_F32) hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, a);
+    OAVSR_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   static const bool use_dma = [] { const char* e = getenv("OAVSR_GEMM_DMA"); return !(e && e[0] == '0'); }();
   if (use_dma && gemm_dma_eligible(a)) return launch_gemm_dma(a, st);
   return a.dtype == DT_F32 ? launch_mode<float>(a, st) : launch_mode<bf16_t>(a, st);

@@ -38,6 +38,8 @@ struct GemmArgs {
   // skinny kernel only: fused RMSNorm prologue (gain[K], eps) and SwiGLU epilogue on 16-row interleaved gate/up weights
   const float* norm_gain = nullptr; float norm_eps = 0.f;
   int swiglu_pairs = 0;
+  // classic kernel only: split-K over blockIdx.y with fp32 partial slabs [ksplit][M][N] + deterministic reduce/epilogue kernel
+  int ksplit = 1; float* partial = nullptr;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t st);
 // LDS-DMA pipelined 256x128 variant (gemm2.hip); launch_gemm dispatches to it when the grid fills the chip
@@ -149,5 +151,22 @@ struct GreedyState {
   int* cpos;       // [B] cache position of the next token
 };
 int launch_greedy_update(const int* argmax, GreedyState s, int B, int max_new, int eos, int pad, hipStream_t st);
+
+// ---- beam search (beam.hip) ------------------------------------------------------------------------
+struct BeamArgs {
+  int B = 0, K = 0, V = 0, max_new = 0, eos = 0, pad = 0;
+  int* step = nullptr;            // device scalar: tokens generated so far
+  float* beam_scores = nullptr;   // [B*K]
+  int* next_tok = nullptr; int* pos = nullptr; int* cpos = nullptr;   // [B*K] inputs of the next decode step
+  const int* prefix_len = nullptr;   // [B]
+  float* cand_val = nullptr; int* cand_tok = nullptr;   // [rows][2K] per-row top-2K (value = logp + beam score)
+  int* done = nullptr; int* hyp_n = nullptr;            // [B]
+  double* hyp_score = nullptr; int* hyp_len = nullptr; int* hyp_tok = nullptr;   // [B][K], [B][K], [B][K][max_new]
+  int* out_ids = nullptr; int* out_len = nullptr;
+};
+int launch_beam_topk(const float* logits, int64_t ld, int rows, int V, int K, const float* beam_scores, float* cand_val, int* cand_tok,
+                     hipStream_t st);
+int launch_beam_step(const BeamArgs& a, int first, const int* seq_old, const int* anc_old, int* seq_new, int* anc_new, hipStream_t st);
+int launch_beam_finalize(const BeamArgs& a, const int* seqs, hipStream_t st);
 
 }  // namespace oavsr

@@ -156,6 +156,8 @@ struct oavsr_workspace {
   void *kpre, *vpre, *ktail, *vtail; int max_prefix = 0; size_t kpre_layer = 0, ktail_layer = 0;
   int *pos, *slot, *cpos, *cu_s, *prefix_len, *last_rows;
   int *amax; void* amax_scratch; GreedyState gs;
+  // beam search state
+  float *beam_scores, *cand_val, *partial; int *cand_tok, *hyp_n, *hyp_len, *hyp_tok, *seq[2], *anc[2]; double* hyp_score; size_t partial_bytes = 0;
   int max_tok_enc = 0, max_S_total = 0;
   int S_host[1024]; int B_cur = 0;
 
@@ -565,39 +567,53 @@ static int build_prompt_impl(const oavsr_model* m, oavsr_workspace* ws, int task
 // ------------------------------------------------------------------------------------------------
 // LLM layer stack; rows = prompt rows (prefill, big GEMM) or decode rows (skinny GEMM)
 // ------------------------------------------------------------------------------------------------
+// GEMM dispatch of the LLM stack: prefill rows -> tiled MFMA GEMM; decode with <= 32 rows -> weight-streaming skinny kernel
+// (RMSNorm / SwiGLU fused); decode with more rows (beam search: B*K) -> 128-row tiles with split-K so every CU streams weights.
+static int llm_gemm(const oavsr_model* m, oavsr_workspace* ws, GemmArgs& g, int mode /*0 prefill, 1 skinny, 2 split-K*/, hipStream_t st) {
+  if (mode == 0) return run_gemm(g, st, false);
+  if (mode == 1) return run_gemm(g, st, true);
+  const int esz = (int)m->esz;
+  const int ktiles = (g.K + g.K2) / (128 / esz);
+  const int tiles = ceil_div(g.M, 128) * ceil_div(g.N, g.N <= 64 ? 64 : 128);
+  int ks = 256 / std::max(1, tiles);
+  ks = std::min(ks, std::max(1, ktiles / 2));
+  ks = std::min(ks, 16);
+  while (ks > 1 && (size_t)ks * g.M * g.N * 4 > ws->partial_bytes) --ks;
+  if (ks > 1) { g.ksplit = ks; g.partial = ws->partial; }
+  return run_gemm(g, st, false);
+}
+
 static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int rows, bool decode, int B, int beams, int max_S,
-                      const int* pos, const int* cpos, hipStream_t st) {
+                      const int* pos, const int* cpos, const int* anc, const int* step, hipStream_t st) {
   const oavsr_config& c = m->cfg;
   const int dt = m->dtype, d = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, hd = c.llm_head_dim, I = c.llm_mlp;
   const int nq = H * hd, nqkv = (H + 2 * KV) * hd;
   const int tl = c.lora_task_specific ? task : 0;
+  const int mode = !decode ? 0 : (rows <= 32 ? 1 : 2);
+  const bool fused_norm = mode == 1;       // RMSNorm folded into the skinny GEMMs (gain on the A fragments, rstd in the epilogue)
   for (int li = 0; li < c.llm_layers; ++li) {
     const LlmLayer& L = m->llayers[li];
-    // prefill: RMSNorm kernel + big GEMMs.  decode: the norm is fused into the skinny GEMMs (gain on the A fragments,
-    // rstd in the epilogue), so the raw residual stream lx is the A operand.
-    if (!decode) { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
+    if (!fused_norm) { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
       OAVSR_TRY(launch_rmsnorm(dt, ws->lx, d, ws->lh, d, L.ln1w, rows, d, c.llm_rms_eps, st)); }
-    const void* hin = decode ? ws->lx : ws->lh;
+    const void* hin = fused_norm ? ws->lx : ws->lh;
     GemmArgs g;
     if (c.lora_k2 > 0) {
       g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = c.lora_k2; g.K = d; g.A = hin; g.lda = d; g.W = L.lora_dn[tl]; g.ldw = d;
       g.C = ws->llora; g.ldc = c.lora_k2;
-      if (decode) { g.norm_gain = L.ln1w; g.norm_eps = c.llm_rms_eps; }
-      OAVSR_TRY(run_gemm(g, st, decode));
+      if (fused_norm) { g.norm_gain = L.ln1w; g.norm_eps = c.llm_rms_eps; }
+      OAVSR_TRY(llm_gemm(m, ws, g, mode, st));
     }
     g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = nqkv; g.K = d; g.A = hin; g.lda = d; g.W = L.qkvw; g.ldw = d; g.col_bias = L.qkvb;
     if (c.lora_k2 > 0) { g.A2 = ws->llora; g.lda2 = c.lora_k2; g.W2 = L.lora_up[tl]; g.ldw2 = c.lora_k2; g.K2 = c.lora_k2; }
-    if (decode) { g.norm_gain = L.ln1w; g.norm_eps = c.llm_rms_eps; }
+    if (fused_norm) { g.norm_gain = L.ln1w; g.norm_eps = c.llm_rms_eps; }
     g.C = ws->lqkv; g.ldc = nqkv;
-    OAVSR_TRY(run_gemm(g, st, decode));
+    OAVSR_TRY(llm_gemm(m, ws, g, mode, st));
     if (!decode) {   // decode: RoPE + cache append are fused into the decode-attention kernel
       RopeArgs r; r.dtype = dt; r.rows = rows; r.n_heads = H; r.n_kv_heads = KV; r.head_dim = hd; r.qkv = ws->lqkv; r.ld = nqkv;
       r.inv_freq = m->inv_freq; r.pos = pos; r.slot = ws->slot; r.cpos = cpos;
       r.kcache = (char*)ws->kpre + li * ws->kpre_layer; r.vcache = (char*)ws->vpre + li * ws->kpre_layer; r.max_ctx = ws->max_prefix;
-      ProfScope ps("rope_kv", 0, 2.0 * rows * nqkv * m->esz, st);
-      OAVSR_TRY(launch_rope_kv(r, st));
-    }
-    if (!decode) {
+      { ProfScope ps("rope_kv", 0, 2.0 * rows * nqkv * m->esz, st);
+        OAVSR_TRY(launch_rope_kv(r, st)); }
       AttnArgs a; a.dtype = dt; a.head_dim = hd; a.n_heads = H; a.n_kv_heads = KV; a.n_seqs = B;
       a.Q = ws->lqkv; a.K = (const char*)ws->lqkv + (size_t)nq * m->esz; a.V = (const char*)ws->lqkv + (size_t)(nq + KV * hd) * m->esz;
       a.ldq = a.ldk = a.ldv = nqkv; a.O = ws->lattn; a.ldo = nq; a.cu_q = ws->cu_s; a.cu_k = ws->cu_s; a.max_q = max_S;
@@ -609,30 +625,29 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
       a.Q = ws->lqkv; a.ldq = nqkv; a.O = ws->lattn; a.ldo = nq;
       a.Kp = (char*)ws->kpre + li * ws->kpre_layer; a.Vp = (char*)ws->vpre + li * ws->kpre_layer; a.max_prefix = ws->max_prefix;
       a.Kt = (char*)ws->ktail + li * ws->ktail_layer; a.Vt = (char*)ws->vtail + li * ws->ktail_layer; a.max_tail = ws->max_new;
-      a.prefix_len = ws->prefix_len; a.step = ws->gs.step; a.anc = nullptr; a.scale = 1.0f / sqrtf((float)hd);
+      a.prefix_len = ws->prefix_len; a.step = step; a.anc = anc; a.scale = 1.0f / sqrtf((float)hd);
       a.inv_freq = m->inv_freq; a.pos = pos; a.cpos = cpos;
       ProfScope ps("decode_attention", 0, 2.0 * rows * max_S * KV * hd * m->esz, st);
       OAVSR_TRY(launch_decode_attention(a, st));
     }
     g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = d; g.K = nq; g.A = ws->lattn; g.lda = nq; g.W = L.ow; g.ldw = nq;
     g.residual = ws->lx; g.ldr = d; g.C = ws->lx; g.ldc = d;
-    OAVSR_TRY(run_gemm(g, st, decode));
-    if (decode && rows <= 32) {   // RMSNorm + gate/up + SwiGLU in one launch
+    OAVSR_TRY(llm_gemm(m, ws, g, mode, st));
+    if (fused_norm) {   // RMSNorm + gate/up + SwiGLU in one launch
       g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 2 * I; g.K = d; g.A = ws->lx; g.lda = d; g.W = L.guw; g.ldw = d;
       g.norm_gain = L.ln2w; g.norm_eps = c.llm_rms_eps; g.swiglu_pairs = 1; g.C = ws->lact; g.ldc = I;
       OAVSR_TRY(run_gemm(g, st, true));
     } else {
-      if (!decode) { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
+      { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
         OAVSR_TRY(launch_rmsnorm(dt, ws->lx, d, ws->lh, d, L.ln2w, rows, d, c.llm_rms_eps, st)); }
-      g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 2 * I; g.K = d; g.A = decode ? ws->lx : ws->lh; g.lda = d; g.W = L.guw; g.ldw = d; g.C = ws->lgu; g.ldc = 2 * I;
-      if (decode) { g.norm_gain = L.ln2w; g.norm_eps = c.llm_rms_eps; }
-      OAVSR_TRY(run_gemm(g, st, decode));
+      g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 2 * I; g.K = d; g.A = ws->lh; g.lda = d; g.W = L.guw; g.ldw = d; g.C = ws->lgu; g.ldc = 2 * I;
+      OAVSR_TRY(llm_gemm(m, ws, g, mode, st));
       { ProfScope ps("swiglu", 0, 3.0 * rows * I * m->esz, st);
         OAVSR_TRY(launch_swiglu(dt, ws->lgu, 2 * I, ws->lact, I, rows, I, 1, st)); }
     }
     g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = d; g.K = I; g.A = ws->lact; g.lda = I; g.W = L.downw; g.ldw = I;
     g.residual = ws->lx; g.ldr = d; g.C = ws->lx; g.ldc = d;
-    OAVSR_TRY(run_gemm(g, st, decode));
+    OAVSR_TRY(llm_gemm(m, ws, g, mode, st));
   }
   return 0;
 }
@@ -642,7 +657,7 @@ static int lm_head_rows(const oavsr_model* m, oavsr_workspace* ws, const void* x
   const int d = c.llm_hidden;
   GemmArgs g; g.dtype = m->dtype; g.M = rows; g.N = c.llm_vocab; g.K = d; g.W = m->lm_head; g.ldw = d;
   g.C = logits; g.ldc = c.llm_vocab; g.out_f32 = 1;
-  if (rows <= 128) {          // final RMSNorm fused into the weight-streaming kernel
+  if (rows <= 32) {          // final RMSNorm fused into the weight-streaming kernel
     g.A = x; g.lda = d; g.norm_gain = m->norm_w; g.norm_eps = c.llm_rms_eps;
     return run_gemm(g, st, true);
   }
@@ -672,7 +687,7 @@ static int prefill_impl(const oavsr_model* m, oavsr_workspace* ws, int task, int
   OAVSR_TRY(h2d(ws->last_rows, last, sizeof(int) * B, st));
   OAVSR_TRY(h2d(ws->prefix_len, plen, sizeof(int) * B, st));
   if (embeds != ws->lx) OAVSR_CHECK_HIP(hipMemcpyAsync(ws->lx, embeds, (size_t)total * c.llm_hidden * m->esz, hipMemcpyDeviceToDevice, st));
-  OAVSR_TRY(llm_layers(m, ws, task, total, false, B, 1, maxS, ws->pos, ws->cpos, st));
+  OAVSR_TRY(llm_layers(m, ws, task, total, false, B, 1, maxS, ws->pos, ws->cpos, nullptr, nullptr, st));
   // last position of every utterance only (the reference materialises all positions, Llama_LoRA.py:372-373)
   OAVSR_TRY(launch_copy_rows(m->dtype, ws->lx, c.llm_hidden, ws->last_rows, ws->lastx, c.llm_hidden, B, c.llm_hidden, st));
   OAVSR_TRY(lm_head_rows(m, ws, ws->lastx, B, ws->logits, st));
@@ -711,12 +726,52 @@ static int decode_greedy(const oavsr_model* m, oavsr_workspace* ws, int task, in
   OAVSR_TRY(launch_greedy_update(ws->amax, gs, B, max_new, c.id_eos, c.id_pad, st));
   for (int step = 1; step < max_new; ++step) {
     OAVSR_TRY(launch_embed(m->dtype, m->embed, c.llm_hidden, gs.tok, ws->lx, c.llm_hidden, B, c.llm_hidden, st));
-    OAVSR_TRY(llm_layers(m, ws, task, B, true, B, 1, maxS + max_new, gs.pos, gs.cpos, st));
+    OAVSR_TRY(llm_layers(m, ws, task, B, true, B, 1, maxS + max_new, gs.pos, gs.cpos, nullptr, gs.step, st));
     OAVSR_TRY(lm_head_rows(m, ws, ws->lx, B, ws->logits, st));
     OAVSR_TRY(launch_argmax(ws->logits, c.llm_vocab, B, c.llm_vocab, banned, ws->amax, ws->amax_scratch, st));
     OAVSR_TRY(launch_greedy_update(ws->amax, gs, B, max_new, c.id_eos, c.id_pad, st));
   }
   return 0;
+}
+
+// HF beam search (modeling_OmniAVSR.py:313-322 with num_beams > 1): rows = B*K share the utterance's prefix KV, tails are
+// addressed through the ancestry table maintained by beam_step_kernel.  No host synchronisation; all max_new steps are
+// issued (finished utterances keep padding, exactly as BeamSearchScorer.process does for done batches).
+static int decode_beam(const oavsr_model* m, oavsr_workspace* ws, int task, int B, int K, int max_new, int32_t* out_ids, int32_t* out_len,
+                       hipStream_t st) {
+  const oavsr_config& c = m->cfg;
+  OAVSR_REQUIRE(B == ws->B_cur, "decode: call oavsr_prefill for this batch first");
+  OAVSR_REQUIRE(max_new >= 1 && max_new <= ws->max_new, "decode: max_new=%d exceeds workspace (%d)", max_new, ws->max_new);
+  OAVSR_REQUIRE(K <= ws->max_beams && K <= 32, "decode: num_beams=%d exceeds workspace (%d) / kernel limit 32", K, ws->max_beams);
+  OAVSR_REQUIRE(max_new == ws->max_new, "decode: beam search needs max_new == workspace max_new (tail-cache stride)");
+  const int R = B * K;
+  int maxS = 0;
+  for (int b = 0; b < B; ++b) maxS = std::max(maxS, ws->S_host[b]);
+  BeamArgs a;
+  a.B = B; a.K = K; a.V = c.llm_vocab; a.max_new = max_new; a.eos = c.id_eos; a.pad = c.id_pad;
+  a.step = ws->gs.step; a.beam_scores = ws->beam_scores; a.next_tok = ws->gs.tok; a.pos = ws->gs.pos; a.cpos = ws->gs.cpos;
+  a.prefix_len = ws->prefix_len; a.cand_val = ws->cand_val; a.cand_tok = ws->cand_tok; a.done = ws->gs.finished; a.hyp_n = ws->hyp_n;
+  a.hyp_score = ws->hyp_score; a.hyp_len = ws->hyp_len; a.hyp_tok = ws->hyp_tok; a.out_ids = out_ids; a.out_len = out_len;
+  OAVSR_CHECK_HIP(hipMemsetAsync(ws->gs.step, 0, sizeof(int), st));
+  OAVSR_CHECK_HIP(hipMemsetAsync(ws->gs.finished, 0, sizeof(int) * B, st));
+  OAVSR_CHECK_HIP(hipMemsetAsync(ws->hyp_n, 0, sizeof(int) * B, st));
+  int* seq[2] = {ws->seq[0], ws->seq[1]};
+  int* anc[2] = {ws->anc[0], ws->anc[1]};
+  // step 0: candidates from the prefill logits (one row per utterance; beam_scores = [0, -1e9, ...] <=> only beam 0 counts)
+  { ProfScope ps("beam_search", 0, (double)B * c.llm_vocab * 16, st);
+    OAVSR_TRY(launch_beam_topk(ws->logits, c.llm_vocab, B, c.llm_vocab, K, nullptr, ws->cand_val, ws->cand_tok, st));
+    OAVSR_TRY(launch_beam_step(a, 1, seq[0], anc[0], seq[1], anc[1], st)); }
+  int cur = 1;
+  for (int t = 1; t < max_new; ++t) {
+    OAVSR_TRY(launch_embed(m->dtype, m->embed, c.llm_hidden, ws->gs.tok, ws->lx, c.llm_hidden, R, c.llm_hidden, st));
+    OAVSR_TRY(llm_layers(m, ws, task, R, true, B, K, maxS + max_new, ws->gs.pos, ws->gs.cpos, anc[cur], ws->gs.step, st));
+    OAVSR_TRY(lm_head_rows(m, ws, ws->lx, R, ws->logits, st));
+    ProfScope ps("beam_search", 0, (double)R * c.llm_vocab * 16, st);
+    OAVSR_TRY(launch_beam_topk(ws->logits, c.llm_vocab, R, c.llm_vocab, K, ws->beam_scores, ws->cand_val, ws->cand_tok, st));
+    OAVSR_TRY(launch_beam_step(a, 0, seq[cur], anc[cur], seq[cur ^ 1], anc[cur ^ 1], st));
+    cur ^= 1;
+  }
+  return launch_beam_finalize(a, seq[cur], st);
 }
 
 }  // namespace oavsr
@@ -830,6 +885,12 @@ int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, 
   WANT(amax, rows_dec * 4); WANT(amax_scratch, rows_dec * 64 * 8);
   WANT(gs.tok, rows_dec * 4); WANT(gs.finished, rows_dec * 4); WANT(gs.out_ids, rows_dec * (size_t)max_new * 4); WANT(gs.out_len, rows_dec * 4);
   WANT(gs.step, 256); WANT(gs.pos, rows_dec * 4); WANT(gs.cpos, rows_dec * 4);
+  if (rows_dec > 32) { ws->partial_bytes = (size_t)32 << 20; WANT(partial, ws->partial_bytes); }
+  if (max_beams > 1) {
+    WANT(beam_scores, rows_dec * 4); WANT(cand_val, rows_dec * 2 * max_beams * 4); WANT(cand_tok, rows_dec * 2 * max_beams * 4);
+    WANT(hyp_n, max_B * 4); WANT(hyp_len, rows_dec * 4); WANT(hyp_tok, rows_dec * (size_t)max_new * 4); WANT(hyp_score, rows_dec * 8);
+    for (int i = 0; i < 2; ++i) { WANT(seq[i], rows_dec * (size_t)max_new * 4); WANT(anc[i], rows_dec * (size_t)max_new * 4); }
+  }
 #undef WANT
   size_t total = 0;
   for (auto& r : reqs) total = align_up(total, 256) + std::max<size_t>(r.bytes, 256);
@@ -897,8 +958,12 @@ int oavsr_prefill(const oavsr_model* m, oavsr_workspace* ws, int32_t task, int32
 int oavsr_decode(const oavsr_model* m, oavsr_workspace* ws, int32_t task, int32_t B, int32_t beams, int32_t max_new, int32_t force_len,
                  int32_t* out_ids_dev, int32_t* out_len_dev, oavsr_stream stream) {
   OAVSR_REQUIRE(m && ws && out_ids_dev && out_len_dev, "decode: null argument");
-  OAVSR_REQUIRE(beams == 1, "decode: beam search (num_beams=%d) is not built yet; use num_beams=1", beams);
+  OAVSR_REQUIRE(beams >= 1, "decode: num_beams=%d", beams);
   CallScope cs(ws, (hipStream_t)stream);
+  if (beams > 1) {
+    OAVSR_REQUIRE(!force_len, "decode: force_len is a greedy-only benchmark switch");
+    return decode_beam(m, ws, task, B, beams, max_new, out_ids_dev, out_len_dev, (hipStream_t)stream);
+  }
   return decode_greedy(m, ws, task, B, max_new, force_len, out_ids_dev, out_len_dev, (hipStream_t)stream);
 }
 
@@ -906,7 +971,7 @@ int oavsr_generate(const oavsr_model* m, oavsr_workspace* ws, int32_t task, cons
                    int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host, int32_t B, int32_t rate_audio, int32_t rate_video,
                    int32_t beams, int32_t max_new, int32_t force_len, int32_t* out_ids_dev, int32_t* out_len_dev, oavsr_stream stream) {
   OAVSR_REQUIRE(m && ws && out_ids_dev && out_len_dev, "generate: null argument");
-  OAVSR_REQUIRE(beams == 1, "generate: beam search (num_beams=%d) is not built yet; use num_beams=1", beams);
+  OAVSR_REQUIRE(beams >= 1 && !(beams > 1 && force_len), "generate: bad num_beams / force_len");
   OAVSR_REQUIRE(B >= 1 && B <= ws->max_B, "generate: B=%d exceeds workspace (%d)", B, ws->max_B);
   hipStream_t st = (hipStream_t)stream;
   CallScope cs(ws, st);
@@ -929,6 +994,7 @@ int oavsr_generate(const oavsr_model* m, oavsr_workspace* ws, int32_t task, cons
   std::vector<int> S(B);
   OAVSR_TRY(build_prompt_impl(m, ws, task, B, use_a ? na.data() : nullptr, ws->tok_a, use_v ? nv.data() : nullptr, ws->tok_v, ws->lx, S.data(), st));
   OAVSR_TRY(prefill_impl(m, ws, task, B, ws->lx, S.data(), nullptr, st));
+  if (beams > 1) return decode_beam(m, ws, task, B, beams, max_new, out_ids_dev, out_len_dev, st);
   return decode_greedy(m, ws, task, B, max_new, force_len, out_ids_dev, out_len_dev, st);
 }
 
@@ -959,6 +1025,7 @@ int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream) {
   g.H = d->H; g.Wd = d->W_; g.Cin = d->Cin; g.OH = d->OH; g.OW = d->OW; g.stride = d->stride; g.pad = d->pad; g.ksize = d->ksize;
   g.rowinfo = (const int4*)d->rowinfo; g.taps = d->taps; g.Kvalid = d->Kvalid; g.frameinfo = (const int2*)d->frameinfo;
   g.norm_gain = d->norm_gain; g.norm_eps = d->norm_eps; g.swiglu_pairs = d->swiglu_pairs;
+  g.ksplit = d->ksplit < 1 ? 1 : d->ksplit; g.partial = d->partial;
   return d->skinny ? launch_gemm_skinny(g, (hipStream_t)stream) : launch_gemm(g, (hipStream_t)stream);
 }
 

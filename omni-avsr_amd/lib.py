@@ -55,6 +55,7 @@ class GemmDesc(C.Structure):
         ("stride", C.c_int32), ("pad", C.c_int32), ("ksize", C.c_int32),
         ("rowinfo", C.c_void_p), ("taps", C.c_int32), ("Kvalid", C.c_int32), ("frameinfo", C.c_void_p),
         ("skinny", C.c_int32), ("norm_gain", C.c_void_p), ("norm_eps", C.c_float), ("swiglu_pairs", C.c_int32),
+        ("ksplit", C.c_int32), ("partial", C.c_void_p),
     ]
 
 

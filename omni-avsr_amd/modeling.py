@@ -6,8 +6,8 @@ the owner of device memory and of the HIP stream.
 Differences from the reference that are deliberate:
   * batches > 1 are allowed; every utterance is computed exactly as if it were alone (no padded attention), which is
     what the reference's batch-1 evaluation does.  Optional `inputs["video_lengths"]` gives frames per utterance.
-  * `num_beams == 1` runs the hipGraph-free greedy loop with `do_sample=False` (the north-star decode); HF beam search
-    is the next row of SURVEY.md §8(f) and raises NotImplementedError for now.
+  * decoding is deterministic (`do_sample=False`): `num_beams == 1` greedy (the north-star decode) or HF-equivalent beam
+    search on device (`num_beams > 1`, the reference's default 15; csrc/beam.hip).
   * `is_trainval=True` (loss computation) is training and out of scope: NotImplementedError.
 """
 from __future__ import annotations
@@ -104,7 +104,8 @@ class OmniEngine:
     def ensure_workspace(self, B: int, Tv: int, Ts: int, beams: int = 1, max_new: Optional[int] = None):
         max_new = max_new or self.spec.max_dec_tokens
         key = self._ws_key
-        if key is not None and key[0] >= B and key[1] >= Tv and key[2] >= Ts and key[3] >= beams and key[4] >= max_new:
+        # beam search indexes the tail cache / ancestry table with the workspace's max_new stride: needs an exact match
+        if key is not None and key[0] >= B and key[1] >= Tv and key[2] >= Ts and key[3] >= beams and (key[4] == max_new or (beams == 1 and key[4] >= max_new)):
             return
         if self._ws:
             torch.cuda.synchronize(self.device)
@@ -123,7 +124,7 @@ class OmniEngine:
             self.ensure_workspace(B, Tv, Ts, beams, max_new)
             return self._ws
         ptr, key = self._slots.get(slot, (None, None))
-        if key is not None and key[0] >= B and key[1] >= Tv and key[2] >= Ts and key[3] >= beams and key[4] >= max_new:
+        if key is not None and key[0] >= B and key[1] >= Tv and key[2] >= Ts and key[3] >= beams and (key[4] == max_new or (beams == 1 and key[4] >= max_new)):
             return ptr
         if ptr:
             torch.cuda.synchronize(self.device)
@@ -345,8 +346,6 @@ class AVSR_LLMs:
             raise KeyError(ra)        # matry_map_audio[...] modeling_OmniAVSR.py:447,556
         if use_v and rv not in self.spec.rates("video"):
             raise KeyError(rv)
-        if self.num_beams != 1:
-            raise NotImplementedError("HF beam search (num_beams>1) is the next row of SURVEY.md §8(f); use num_beams=1")
         video = inputs.get("video") if use_v else None
         audio = inputs.get("audio") if use_a else None
         Tv = lengths = None

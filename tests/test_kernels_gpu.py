@@ -46,6 +46,24 @@ def test_gemm_dense(dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,K2,S", [(120, 2048, 8192, 0, 16), (120, 3072, 2048, 256, 4), (45, 200, 384, 0, 5), (120, 256, 2048, 0, 8)])
+def test_gemm_splitk(dtype, M, N, K, K2, S):
+    """Split-K (beam-search decode rows): fp32 partial slabs + deterministic reduce with the fused epilogue."""
+    a, ar = q(rnd(M, K, seed=1), dtype)
+    w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
+    r, rr = q(rnd(M, N, seed=5), dtype)
+    kw, ref = {}, ar @ wr.T
+    if K2:
+        a2, a2r = q(rnd(M, K2, seed=3), dtype)
+        w2, w2r = q(rnd(N, K2, seed=4) / math.sqrt(K2), dtype)
+        kw = dict(A2=a2, W2=w2)
+        ref = ref + a2r @ w2r.T
+    part = torch.empty(S * M * N, dtype=torch.float32, device=DEV)
+    out = gemm(dtype, a, w, residual=r, ksplit=S, partial=part, **kw)
+    close(out, ref + rr, tol(dtype) * 2, what="gemm split-K")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K,K2", [(4096, 2048, 512, 0), (3000, 3072 + 40, 384, 128), (12000, 1024, 256, 0)])
 def test_gemm_dma_pipeline(dtype, M, N, K, K2):
     """Shapes large enough to take the LDS-DMA 256x128 3-stage kernel (gemm2.hip): ragged M/N edges, 2nd K segment, epilogue."""

@@ -125,6 +125,43 @@ def test_generate_token_ids_f32(family, task):
             assert all(int(t) == spec.ids["pad"] for t in ids[b, int(lens[b]):])
 
 
+@pytest.mark.parametrize("family,task,K", [("llama", "audiovisual", 3), ("llama", "audiovisual", 15), ("llama", "video", 15), ("qwen2", "audio", 4)])
+def test_generate_beam_search_token_ids_f32(family, task, K):
+    """HF-equivalent beam search on device (the reference's default decode, num_beams=15): token ids vs the oracle's
+    restatement of transformers' BeamSearchScorer (itself pinned to transformers.generate by tests/golden/llm_*.npz)."""
+    spec, sd, eng, orc = make("f32", family=family, task_specific=True, shared=(family == "llama"))
+    Tv, Ts = [12, 9], [7680, 5000]
+    video, audio = inputs(Tv=Tv, Ts=Ts)
+    ids, lens = eng.generate(task, video, Tv, audio, Ts, 4, 2, beams=K, max_new=spec.max_dec_tokens)
+    ids, lens = ids.cpu(), lens.cpu()
+    tokens = torch.full((2, 1), spec.ids["bos"]) if family == "llama" else torch.zeros(2, 0, dtype=torch.long)
+    ref = orc.forward(dict(video=video, audio=audio, lengths=torch.tensor(Ts), video_lens=torch.tensor(Tv), tokens=tokens), task, 4, 2, num_beams=K)
+    for b in range(2):
+        got = ids[b, : int(lens[b])].tolist()
+        assert got == ref[b], f"utt {b} K={K}: got {got} want {ref[b]}"
+
+
+def test_beam_search_eos_paths_f32():
+    """Declare a token the model likes to emit to be EOS so hypotheses finish early (add / is_done / finalize paths)."""
+    spec, sd, eng, orc = make("f32", family="llama", task_specific=True, shared=True)
+    Tv, Ts = [12, 9], [7680, 5000]
+    video, audio = inputs(Tv=Tv, Ts=Ts)
+    tokens = torch.full((2, 1), spec.ids["bos"])
+    batch = dict(video=video, audio=audio, lengths=torch.tensor(Ts), video_lens=torch.tensor(Tv), tokens=tokens)
+    greedy = orc.forward(dict(batch), "audiovisual", 4, 2, num_beams=1, force_len=True)
+    for alt in sorted(set(greedy[0][1:4] + greedy[1][1:4]))[:3]:
+        spec2, sd2, eng2, orc2 = make("f32", family="llama", task_specific=True, shared=True)
+        spec2.ids["eos"] = alt
+        eng2 = OmniEngine(spec2, dtype="f32").load_state_dict(sd2)
+        orc2 = O.OmniOracle(sd2, spec2.oracle_cfg())
+        for K in (3, 15):
+            ids, lens = eng2.generate("audiovisual", video, Tv, audio, Ts, 4, 2, beams=K, max_new=spec2.max_dec_tokens)
+            ids, lens = ids.cpu(), lens.cpu()
+            ref = orc2.forward(dict(batch), "audiovisual", 4, 2, num_beams=K)
+            for b in range(2):
+                assert ids[b, : int(lens[b])].tolist() == ref[b], f"eos={alt} K={K} utt {b}: {ids[b].tolist()} vs {ref[b]}"
+
+
 def test_generate_bf16_close_to_oracle():
     """Throughput mode: token agreement with the fp32 oracle is reported, first token must match."""
     spec, sd, eng, orc = make("bf16", family="llama", task_specific=True, shared=True)
