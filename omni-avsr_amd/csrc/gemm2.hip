@@ -99,7 +99,12 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int ntn = (p.N + BN - 1) / BN;
-  const int bid = blockIdx.x;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2s), so give every XCD a CONTIGUOUS
+  // range of logical tiles (= whole M-tile rows): the A panel of a row is then fetched by one L2 instead of all eight.
+  // Bijective for any grid size; affects speed only, never results.
+  const int nwg = gridDim.x;
+  const int xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
   const int mt = bid / ntn, nt_ = bid - mt * ntn;
   const int m0 = mt * BM, n0 = nt_ * BN;
   const int g = blockIdx.z;
@@ -192,34 +197,82 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
     asm volatile("" ::: "memory");
   }
 
+  // ---- epilogue: each 16-row slab of the wave tile is transposed through a wave-private fp32 LDS patch so that a lane
+  //      owns 16 consecutive columns of one row: residual / bias loads and the C stores are full 16-byte vectors and
+  //      every output row segment is written as whole 128-byte lines (the MFMA C layout alone gives 2-byte stores).
+  static_assert(TN == 4, "wave tile is 64 columns wide");
+  __builtin_amdgcn_s_barrier();                      // every wave is done reading the last k-tile
+  asm volatile("" ::: "memory");
+  constexpr int PW = 68;                             // padded row (floats)
+  float* sw = reinterpret_cast<float*>(smem) + wave * (16 * PW);
   const T* R = reinterpret_cast<const T*>(p.residual);
+  const int rr = lane >> 2, c0 = (lane & 3) * 16;
+  const int nb = n0 + wn * 64 + c0;                  // first of this lane's 16 columns
+  const int ngb = g * p.N + nb;
+  const bool vec_ok = nb + 16 <= p.N && (p.ldc % VEC) == 0 && ((uintptr_t)p.C & 15) == 0 && (ngb % 16) == 0 &&
+                      (!R || ((p.ldr % VEC) == 0 && ((uintptr_t)R & 15) == 0));
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * (TN * 16) + j * 16 + frow;
-    if (n >= p.N) continue;
-    const int ng = g * p.N + n;
-    const float sc = p.col_scale ? p.col_scale[ng] : 1.f;
-    const float bi = p.col_bias ? p.col_bias[ng] : 0.f;
-    const float sl = (p.act == ACT_PRELU) ? p.prelu[ng] : 0.f;
+  for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * (TM * 16) + i * 16 + fg * 4 + r;
-        if (m >= p.M) continue;
-        float y = acc[i][j][r] * sc + bi;
-        float res = R ? to_f32(R[(int64_t)m * p.ldr + ng]) : 0.f;
-        if (!p.res_after_act) y += res;
-        switch (p.act) {
-          case ACT_GELU: y = gelu_erf(y); break;
-          case ACT_RELU: y = fmaxf(y, 0.f); break;
-          case ACT_PRELU: y = y >= 0.f ? y : sl * y; break;
-          case ACT_SILU: y = silu(y); break;
-          default: break;
-        }
-        if (p.res_after_act) y += res;
-        if (p.out_f32) reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + ng] = y;
-        else reinterpret_cast<T*>(p.C)[(int64_t)m * p.ldc + ng] = from_f32<T>(y);
+      for (int r = 0; r < 4; ++r) sw[(fg * 4 + r) * PW + j * 16 + frow] = acc[i][j][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float y[16];
+#pragma unroll
+    for (int e = 0; e < 16; e += 4) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(sw + rr * PW + c0 + e);
+      y[e] = v[0]; y[e + 1] = v[1]; y[e + 2] = v[2]; y[e + 3] = v[3];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int m = m0 + wm * (TM * 16) + i * 16 + rr;
+    if (m >= p.M) continue;
+    float res[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) res[e] = 0.f;
+    if (R) {
+      if (vec_ok) {
+#pragma unroll
+        for (int e = 0; e < 16; e += VEC) chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(R + (int64_t)m * p.ldr + ngb + e), res + e);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) if (nb + e < p.N) res[e] = to_f32(R[(int64_t)m * p.ldr + ngb + e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const bool in = nb + e < p.N;            // per-column parameters are re-read per slab (L1 hits) to keep registers free
+      float v = y[e];
+      if (p.col_scale && in) v *= p.col_scale[ngb + e];
+      if (p.col_bias && in) v += p.col_bias[ngb + e];
+      if (!p.res_after_act) v += res[e];
+      switch (p.act) {
+        case ACT_GELU: v = gelu_erf(v); break;
+        case ACT_RELU: v = fmaxf(v, 0.f); break;
+        case ACT_PRELU: v = v >= 0.f ? v : (in ? p.prelu[ngb + e] : 0.f) * v; break;
+        case ACT_SILU: v = silu(v); break;
+        default: break;
+      }
+      if (p.res_after_act) v += res[e];
+      y[e] = v;
+    }
+    if (p.out_f32) {
+      float* Cf = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + ngb;
+      if (nb + 16 <= p.N && (p.ldc % 4) == 0 && ((uintptr_t)p.C & 15) == 0 && (ngb % 4) == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; e += 4) *reinterpret_cast<f32x4*>(Cf + e) = f32x4{y[e], y[e + 1], y[e + 2], y[e + 3]};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) if (nb + e < p.N) Cf[e] = y[e];
+      }
+    } else {
+      T* Ct = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + ngb;
+      if (vec_ok) {
+#pragma unroll
+        for (int e = 0; e < 16; e += VEC) *reinterpret_cast<Chunk16*>(Ct + e) = chunk_from_f32<T>(y + e);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) if (nb + e < p.N) Ct[e] = from_f32<T>(y[e]);
       }
     }
   }
