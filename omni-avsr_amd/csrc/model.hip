@@ -11,6 +11,7 @@
 //                   last-position logits only
 //   decode        : greedy loop, one skinny-GEMM step per token, no host sync inside the loop
 #include <stdarg.h>
+#include <stdlib.h>
 #include <math.h>
 #include <string>
 #include <unordered_map>
@@ -135,8 +136,14 @@ struct oavsr_model {
   }
 };
 
+struct DecodeGraphKey {
+  int B, task, max_new, banned;
+  bool operator==(const DecodeGraphKey& o) const { return B == o.B && task == o.task && max_new == o.max_new && banned == o.banned; }
+};
+
 struct oavsr_workspace {
   const oavsr_model* m = nullptr;
+  std::vector<std::pair<DecodeGraphKey, hipGraphExec_t>> graphs;   // captured greedy decode steps
   int max_B = 0, max_Tv = 0, max_Ts = 0, max_beams = 1, max_new = 0;
   char* arena = nullptr; size_t arena_bytes = 0, used = 0;
   char* host_base = nullptr; char* host = nullptr; size_t host_bytes = 0, host_used = 0;   // pinned staging (2 halves)
@@ -708,8 +715,12 @@ static int decode_greedy(const oavsr_model* m, oavsr_workspace* ws, int task, in
   for (int b = 0; b < B; ++b) { ipos[b] = ws->S_host[b] - 1; icpos[b] = -1; ifin[b] = 0; ilen[b] = 0; maxS = std::max(maxS, ws->S_host[b]); }
   *istep = 0;
   for (int i = 0; i < B * max_new; ++i) iout[i] = c.id_pad;
+  static const bool graphs_on = [] { const char* e = getenv("OAVSR_DECODE_GRAPH"); return !(e && e[0] == '0'); }();
+  // hipGraph replay needs stable addresses -> results land in workspace buffers and are copied out at the end; the eager
+  // path (profiling, legacy default stream which cannot be captured) writes the caller's buffers directly.
+  const bool use_graph = graphs_on && !g_prof.on && max_new > 3 && st != nullptr;
   GreedyState gs = ws->gs;
-  gs.out_ids = out_ids; gs.out_len = out_len;
+  if (!use_graph) { gs.out_ids = out_ids; gs.out_len = out_len; }
   OAVSR_TRY(h2d(gs.pos, ipos, sizeof(int) * B, st));
   OAVSR_TRY(h2d(gs.cpos, icpos, sizeof(int) * B, st));
   OAVSR_TRY(h2d(gs.finished, ifin, sizeof(int) * B, st));
@@ -724,12 +735,38 @@ static int decode_greedy(const oavsr_model* m, oavsr_workspace* ws, int task, in
   const int banned = force_len ? c.id_eos : -1;
   OAVSR_TRY(launch_argmax(ws->logits, c.llm_vocab, B, c.llm_vocab, banned, ws->amax, ws->amax_scratch, st));
   OAVSR_TRY(launch_greedy_update(ws->amax, gs, B, max_new, c.id_eos, c.id_pad, st));
-  for (int step = 1; step < max_new; ++step) {
+  auto one_step = [&]() -> int {
     OAVSR_TRY(launch_embed(m->dtype, m->embed, c.llm_hidden, gs.tok, ws->lx, c.llm_hidden, B, c.llm_hidden, st));
     OAVSR_TRY(llm_layers(m, ws, task, B, true, B, 1, maxS + max_new, gs.pos, gs.cpos, nullptr, gs.step, st));
     OAVSR_TRY(lm_head_rows(m, ws, ws->lx, B, ws->logits, st));
     OAVSR_TRY(launch_argmax(ws->logits, c.llm_vocab, B, c.llm_vocab, banned, ws->amax, ws->amax_scratch, st));
-    OAVSR_TRY(launch_greedy_update(ws->amax, gs, B, max_new, c.id_eos, c.id_pad, st));
+    return launch_greedy_update(ws->amax, gs, B, max_new, c.id_eos, c.id_pad, st);
+  };
+  // The decode step is identical every iteration (all step-dependent values live in device memory), so it is captured
+  // once per (B, task, max_new, force_len) into a hipGraph and replayed: one graph launch instead of ~110 kernel launches.
+  int step = 1;
+  if (use_graph) {
+    const DecodeGraphKey key{B, task, max_new, banned};
+    hipGraphExec_t exec = nullptr;
+    for (auto& e : ws->graphs) if (e.first == key) exec = e.second;
+    if (!exec) {
+      OAVSR_TRY(one_step());            // eager once: sets the per-kernel attributes outside of the capture
+      step = 2;
+      hipGraph_t graph = nullptr;
+      OAVSR_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+      int rc = one_step();
+      hipError_t ce = hipStreamEndCapture(st, &graph);
+      OAVSR_REQUIRE(rc == 0 && ce == hipSuccess && graph, "decode: hipGraph capture failed (%d / %d)", rc, (int)ce);
+      OAVSR_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      hipGraphDestroy(graph);
+      ws->graphs.push_back({key, exec});
+    }
+    for (; step < max_new; ++step) OAVSR_CHECK_HIP(hipGraphLaunch(exec, st));
+  }
+  for (; step < max_new; ++step) OAVSR_TRY(one_step());
+  if (use_graph) {
+    OAVSR_CHECK_HIP(hipMemcpyAsync(out_ids, gs.out_ids, sizeof(int) * B * max_new, hipMemcpyDeviceToDevice, st));
+    OAVSR_CHECK_HIP(hipMemcpyAsync(out_len, gs.out_len, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
   }
   return 0;
 }
@@ -914,6 +951,7 @@ int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, 
 
 void oavsr_workspace_destroy(oavsr_workspace* ws) {
   if (!ws) return;
+  for (auto& e : ws->graphs) hipGraphExecDestroy(e.second);
   if (ws->arena) hipFree(ws->arena);
   if (ws->host_base) hipHostFree(ws->host_base);
   for (int i = 0; i < 2; ++i) if (ws->host_ev[i]) hipEventDestroy(ws->host_ev[i]);

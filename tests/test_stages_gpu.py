@@ -162,6 +162,25 @@ def test_beam_search_eos_paths_f32():
                 assert ids[b, : int(lens[b])].tolist() == ref[b], f"eos={alt} K={K} utt {b}: {ids[b].tolist()} vs {ref[b]}"
 
 
+def test_greedy_hipgraph_replay_matches_eager():
+    """On a non-default stream the decode step is captured into a hipGraph and replayed; ids must equal the eager path
+    (default stream, where capture is not allowed) and a second call must reuse the instantiated graph."""
+    spec, sd, eng, orc = make("f32", family="llama", task_specific=True, shared=True)
+    Tv, Ts = [12, 9], [7680, 5000]
+    video, audio = inputs(Tv=Tv, Ts=Ts)
+    ids0, lens0 = eng.generate("audiovisual", video, Tv, audio, Ts, 4, 2, beams=1, max_new=spec.max_dec_tokens)
+    side = torch.cuda.Stream()
+    outs = []
+    for _ in range(2):
+        with torch.cuda.stream(side):
+            ids1, lens1 = eng.generate("audiovisual", video, Tv, audio, Ts, 4, 2, beams=1, max_new=spec.max_dec_tokens, slot=1)
+        side.synchronize()
+        outs.append((ids1.cpu(), lens1.cpu()))
+    torch.cuda.synchronize()
+    for ids1, lens1 in outs:
+        assert torch.equal(ids0.cpu(), ids1) and torch.equal(lens0.cpu(), lens1)
+
+
 def test_generate_bf16_close_to_oracle():
     """Throughput mode: token agreement with the fp32 oracle is reported, first token must match."""
     spec, sd, eng, orc = make("bf16", family="llama", task_specific=True, shared=True)

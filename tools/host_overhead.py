@@ -18,10 +18,14 @@ Tvs, Ts = [400] * 8, [256000] * 8
 for _ in range(2):
     eng.generate("audiovisual", video, Tvs, audio, Ts, 4, 4, max_new=32, force_len=True, video_is_flat=True)
 torch.cuda.synchronize()
-for _ in range(3):
-    t0 = time.perf_counter()
-    eng.generate("audiovisual", video, Tvs, audio, Ts, 4, 4, max_new=32, force_len=True, video_is_flat=True)
-    t1 = time.perf_counter()
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    print(f"host issue {1e3 * (t1 - t0):.1f} ms, until GPU done {1e3 * (t2 - t0):.1f} ms")
+side = torch.cuda.Stream()
+for name, stream in (("default stream (eager decode)", torch.cuda.current_stream()), ("side stream (hipGraph decode)", side)):
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(stream):
+            eng.generate("audiovisual", video, Tvs, audio, Ts, 4, 4, max_new=32, force_len=True, video_is_flat=True)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print(f"{name}: host issue {1e3 * (t1 - t0):.1f} ms, until GPU done {1e3 * (t2 - t0):.1f} ms")
