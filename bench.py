@@ -68,8 +68,8 @@ def cpu_baseline(spec, sd_cpu, Tv, max_new):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--frames", type=int, default=400, help="video frames per utterance (400 = 16 s)")
     ap.add_argument("--max-new", type=int, default=32)
@@ -156,7 +156,7 @@ def main():
                                    tflops=round(e["flops"] / e["ms"] / 1e9, 1) if e["ms"] > 0 and e["flops"] > 0 else None,
                                    gbs=round(e["bytes"] / e["ms"] / 1e6, 1) if e["ms"] > 0 else None) for e in sorted(ents, key=lambda e: -e["ms"])}
         dom = max(ents, key=lambda e: e["ms"])
-        is_mfma = dom["flops"] > 0 and (("gemm" in dom["name"] and "skinny" not in dom["name"]) or dom["name"].startswith("attention_"))
+        is_mfma = dom["flops"] > 0 and (("gemm" in dom["name"] and "skinny" not in dom["name"] and "splitk" not in dom["name"]) or dom["name"].startswith("attention_"))
         if is_mfma:
             ach = dom["flops"] / dom["ms"] / 1e9
             peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3

@@ -323,6 +323,7 @@ int launch_dma_mode(const GemmArgs& a, hipStream_t st) {
 }  // namespace
 
 bool gemm_dma_eligible(const GemmArgs& a) { return dma_tile_choice(a) != 0; }
+const char* gemm_dma_variant(const GemmArgs& a) { return dma_tile_choice(a) == 2 ? "dma_256x256" : "dma_256x128"; }
 
 int launch_gemm_dma(const GemmArgs& a, hipStream_t st) {
   return a.dtype == DT_F32 ? launch_dma_mode<float>(a, st) : launch_dma_mode<bf16_t>(a, st);

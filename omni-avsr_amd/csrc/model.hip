@@ -68,14 +68,22 @@ struct ProfScope {
   ~ProfScope() { if (idx >= 0) hipEventRecord(g_prof.recs[idx].e1, st); }
 };
 
+// Profiling families are named after the kernel instantiation that will actually run, so that the HIP-event averages
+// bench.py reports line up 1:1 with the rows of a `rocprofv3 --kernel-trace --stats` summary.
 static const char* gemm_family(const GemmArgs& a, bool skinny) {
-  if (skinny) return a.dtype == DT_F32 ? "skinny_gemm_f32" : "skinny_gemm_bf16";
-  switch (a.amode) {
-    case A_DENSE: return a.dtype == DT_F32 ? "gemm_f32" : "gemm_bf16";
-    case A_CONV2D: return a.dtype == DT_F32 ? "conv2d_gemm_f32" : "conv2d_gemm_bf16";
-    case A_CONV1D: return a.dtype == DT_F32 ? "conv1d_gemm_f32" : "conv1d_gemm_bf16";
-    default: return a.dtype == DT_F32 ? "stem_gemm_f32" : "stem_gemm_bf16";
+  static thread_local char buf[64];
+  const char* dt = a.dtype == DT_F32 ? "f32" : "bf16";
+  if (skinny) {
+    const int mt = ceil_div(a.M, 16) <= 1 ? 1 : ceil_div(a.M, 16) <= 2 ? 2 : ceil_div(a.M, 16) <= 4 ? 4 : 8;
+    const bool wide = a.N >= 8192;
+    const int nt = a.swiglu_pairs ? (wide ? 4 : 2) : (mt <= 2 && wide ? 4 : 1);
+    snprintf(buf, sizeof(buf), "skinny_mt%d_nt%d%s%s_%s", mt, nt, a.norm_gain ? "_norm" : "", a.swiglu_pairs ? "_swiglu" : "", dt);
+    return buf;
   }
+  const char* mode = a.amode == A_DENSE ? "gemm" : a.amode == A_CONV2D ? "conv2d_gemm" : a.amode == A_CONV1D ? "conv1d_gemm" : "stem_gemm";
+  const char* tile = a.ksplit > 1 ? "splitk_128x128" : gemm_dma_eligible(a) ? gemm_dma_variant(a) : (a.N <= 64 ? "128x64" : "128x128");
+  snprintf(buf, sizeof(buf), "%s_%s_%s", mode, tile, dt);
+  return buf;
 }
 
 static int run_gemm(const GemmArgs& a, hipStream_t st, bool skinny = false) {

@@ -1,0 +1,160 @@
+"""Host-side counterparts of the reference's L4 glue: manifest, test-time transforms, text decoding and
+WER, plus a sharded evaluation loop.  Pure host code (torch CPU ops only); torchvision / torchaudio / Lightning are not
+needed.  Every function restates the reference lines it cites; media decoding (mp4 / wav) stays with the caller.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+
+
+# ---- datamodule/av_dataset.py -------------------------------------------------------------------------------------
+def load_manifest(label_path: str) -> List[Tuple[str, str, int, str]]:
+    """`dataset,rel_path,frames,_,text` CSV (av_dataset.py:78-83) -> [(dataset, rel_path, frames, text)]"""
+    out = []
+    for line in open(label_path, encoding="utf8").read().splitlines():
+        dataset_name, rel_path, input_length, _, text = line.split(",")
+        out.append((dataset_name, rel_path, int(input_length), text))
+    return out
+
+
+def cut_or_pad(data: torch.Tensor, size: int) -> torch.Tensor:
+    """av_dataset.py:14-25: pad the time axis (dim 0) with zeros or trim to `size`."""
+    if data.size(0) < size:
+        data = torch.nn.functional.pad(data, (0, 0, 0, size - data.size(0)), "constant")
+    elif data.size(0) > size:
+        data = data[:size]
+    return data
+
+
+# ---- datamodule/transforms.py -------------------------------------------------------------------------------------
+def video_test_transform(frames: torch.Tensor) -> torch.Tensor:
+    """transforms.py:93-99 (subset val/test): x/255 -> CenterCrop(88) -> Grayscale -> Normalize(0.421, 0.165).
+    frames: [T, C, H, W] uint8 / float (C = 1 or 3) -> float32 [T, 1, 88, 88]."""
+    x = frames.float() / 255.0
+    T, C, H, W = x.shape
+    top, left = int(round((H - 88) / 2.0)), int(round((W - 88) / 2.0))        # torchvision CenterCrop
+    x = x[:, :, top:top + 88, left:left + 88]
+    if C == 3:                                                               # torchvision rgb_to_grayscale (ITU-R 601-2)
+        x = (0.2989 * x[:, 0] + 0.587 * x[:, 1] + 0.114 * x[:, 2]).unsqueeze(1)
+    elif C != 1:
+        raise ValueError(f"video frames must have 1 or 3 channels, got {C}")
+    return (x - 0.421) / 0.165
+
+
+def add_noise(speech: torch.Tensor, noise: torch.Tensor, snr_db: float) -> torch.Tensor:
+    """torchaudio.functional.add_noise as used by transforms.py:61-80: scale the noise to the requested SNR.
+    speech, noise: [1, T]."""
+    es = torch.linalg.vector_norm(speech, ord=2, dim=-1) ** 2
+    en = torch.linalg.vector_norm(noise, ord=2, dim=-1) ** 2
+    original_snr_db = 10 * (torch.log10(es) - torch.log10(en))
+    scale = 10 ** ((original_snr_db - snr_db) / 20.0)
+    return speech + scale.unsqueeze(-1) * noise
+
+
+def audio_test_transform(wave: torch.Tensor, snr_target: Optional[float] = None, noise: Optional[torch.Tensor] = None,
+                         noise_start: int = 0) -> torch.Tensor:
+    """transforms.py:118-126 (subset val/test): optional babble noise at `snr_target`, then layer_norm over the WHOLE utterance
+    (eps 1e-8).  wave: [T, 1] -> [T, 1].  The reference draws the noise offset at random (:73); here it is an argument."""
+    x = wave.float()
+    if snr_target is not None and noise is not None:
+        seg = noise[:, noise_start:noise_start + x.shape[0]]
+        x = add_noise(x.t(), seg, float(snr_target)).t()
+    return torch.nn.functional.layer_norm(x, x.shape, eps=1e-8)
+
+
+def make_sample(frames: Optional[torch.Tensor], wave: Optional[torch.Tensor], modality: str, rate_ratio: int = 640,
+                snr_target: Optional[float] = None, noise: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """AVDataset_LLM.__getitem__ (av_dataset.py:85-114) on already decoded media."""
+    out: Dict[str, torch.Tensor] = {}
+    if modality in ("video", "audiovisual"):
+        out["video"] = video_test_transform(frames)
+    if modality in ("audio", "audiovisual"):
+        if modality == "audiovisual":
+            wave = cut_or_pad(wave, frames.shape[0] * rate_ratio)               # :107
+        out["audio"] = audio_test_transform(wave, snr_target, noise)
+    return out
+
+
+def collate_test(samples: Sequence[Dict[str, torch.Tensor]], modality: str, bos_id: Optional[int]) -> Dict[str, torch.Tensor]:
+    """collate_LLM for inference (data_module.py:19-79) generalised to B >= 1: right-pads to the longest utterance and records
+    the true lengths (`lengths` in samples as the reference does, plus `video_lengths` in frames for var-len batches)."""
+    B = len(samples)
+    batch: Dict[str, torch.Tensor] = {}
+    batch["tokens"] = torch.full((B, 1), bos_id, dtype=torch.long) if bos_id is not None and bos_id >= 0 else torch.zeros(B, 0, dtype=torch.long)
+    if modality in ("audio", "audiovisual"):
+        batch["lengths"] = torch.tensor([s["audio"].shape[0] for s in samples])
+        batch["audio"] = torch.nn.utils.rnn.pad_sequence([s["audio"] for s in samples], batch_first=True, padding_value=0)
+    if modality in ("video", "audiovisual"):
+        batch["video_lengths"] = torch.tensor([s["video"].shape[0] for s in samples])
+        batch["video"] = torch.nn.utils.rnn.pad_sequence([s["video"] for s in samples], batch_first=True, padding_value=0)
+    return batch
+
+
+# ---- lightning_OmniAVSR.py:40-42,201-219 ---------------------------------------------------------------------------
+def edit_distance(a: Sequence, b: Sequence) -> int:
+    """torchaudio.functional.edit_distance: Levenshtein distance with unit costs."""
+    prev = list(range(len(b) + 1))
+    for i, x in enumerate(a, 1):
+        cur = [i] + [0] * len(b)
+        for j, y in enumerate(b, 1):
+            cur[j] = min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y))
+        prev = cur
+    return prev[-1]
+
+
+def compute_word_level_distance(seq1: str, seq2: str) -> int:
+    """lightning_OmniAVSR.py:40-42"""
+    return edit_distance(seq1.lower().split(), seq2.lower().split())
+
+
+def decode_text(tokenizer, ids: torch.Tensor) -> List[str]:
+    """lightning_OmniAVSR.py:201: tokenizer.batch_decode(ids, skip_special_tokens=True, clean_up_tokenization_spaces=False)"""
+    return tokenizer.batch_decode(ids, skip_special_tokens=True, clean_up_tokenization_spaces=False)
+
+
+def strip_special(ids: Sequence[int], special_ids: Iterable[int]) -> List[int]:
+    """Tokenizer-free equivalent of `skip_special_tokens=True` for tests / synthetic vocabularies."""
+    sp = set(int(s) for s in special_ids)
+    return [int(t) for t in ids if int(t) not in sp]
+
+
+@dataclass
+class WerMeter:
+    """test_step / on_test_epoch_end accumulation (lightning_OmniAVSR.py:206-219): wer = sum(edits) / sum(words)."""
+    total_edit_distance: int = 0
+    total_length: int = 0
+    per_utt: List[Tuple[str, str, int, int]] = field(default_factory=list)
+
+    def update(self, gold_text: str, generated_text: str):
+        e = compute_word_level_distance(gold_text, generated_text)
+        n = len(gold_text.split())
+        self.total_edit_distance += e
+        self.total_length += n
+        self.per_utt.append((gold_text, generated_text, e, n))
+
+    @property
+    def wer(self) -> float:
+        return self.total_edit_distance / max(self.total_length, 1)
+
+
+def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], modality: str, to_text: Callable[[torch.Tensor], List[str]],
+             batch_size: int = 8, bos_id: Optional[int] = None, rank: int = 0, world: int = 1, **forward_kw) -> WerMeter:
+    """Evaluation loop of eval_OmniAVSR.py:273-357 for one (task, rates) cell, utterance-sharded over `world` ranks
+     and batched (the reference runs batch 1).  `samples`: [(transformed sample dict, gold text)].
+    Returns this rank's WerMeter; combine with dist.reduce_wer_counters."""
+    from .dist import make_batches, shard_utterances
+    dur = [float((s.get("video") if "video" in s else s["audio"]).shape[0]) / (1.0 if "video" in s else 640.0) for s, _ in samples]
+    owned = shard_utterances(dur, world, rank)
+    meter = WerMeter()
+    model.modality = modality
+    for idxs in make_batches(owned, batch_size):
+        batch = collate_test([samples[i][0] for i in idxs], modality, bos_id)
+        ids = model(batch, is_trainval=False, modality=modality if getattr(model, "is_task_specific", False) else None, **forward_kw)
+        texts = to_text(ids)
+        for i, t in zip(idxs, texts):
+            meter.update(samples[i][1], t)
+    return meter

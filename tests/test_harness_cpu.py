@@ -1,0 +1,57 @@
+"""CPU: host-side L4 counterparts (manifest, transforms, WER) against hand-computed expectations."""
+import torch
+
+from omni_avsr_amd import harness as H
+
+
+def test_manifest_and_cut_or_pad(tmp_path):
+    p = tmp_path / "m.csv"
+    p.write_text("lrs3,test/a/0001.mp4,57,12,HELLO WORLD\nlrs3,test/b/0002.mp4,400,30,IT IS\n")
+    assert H.load_manifest(str(p)) == [("lrs3", "test/a/0001.mp4", 57, "HELLO WORLD"), ("lrs3", "test/b/0002.mp4", 400, "IT IS")]
+    a = torch.arange(10.0).reshape(5, 2)
+    assert H.cut_or_pad(a, 3).shape == (3, 2) and torch.equal(H.cut_or_pad(a, 3), a[:3])
+    pd = H.cut_or_pad(a, 7)
+    assert pd.shape == (7, 2) and torch.equal(pd[:5], a) and float(pd[5:].abs().sum()) == 0
+
+
+def test_video_transform_matches_formula():
+    g = torch.Generator().manual_seed(0)
+    fr = torch.randint(0, 256, (4, 3, 96, 96), generator=g, dtype=torch.uint8)
+    out = H.video_test_transform(fr)
+    assert out.shape == (4, 1, 88, 88) and out.dtype == torch.float32
+    x = fr.float()[:, :, 4:92, 4:92] / 255
+    ref = ((0.2989 * x[:, 0] + 0.587 * x[:, 1] + 0.114 * x[:, 2]) - 0.421) / 0.165
+    assert torch.allclose(out[:, 0], ref, atol=1e-6)
+    mono = H.video_test_transform(fr[:, :1])
+    assert torch.allclose(mono[:, 0], (fr[:, 0, 4:92, 4:92].float() / 255 - 0.421) / 0.165, atol=1e-6)
+
+
+def test_audio_transform_and_noise():
+    g = torch.Generator().manual_seed(1)
+    w = torch.randn(16000, 1, generator=g) * 0.3 + 0.1
+    out = H.audio_test_transform(w)
+    assert abs(float(out.mean())) < 1e-5 and abs(float(out.var(unbiased=False)) - 1) < 1e-4
+    noise = torch.randn(1, 40000, generator=g)
+    for snr in (-5.0, 0.0, 15.0):
+        noisy = H.add_noise(w.t(), noise[:, :16000], snr)
+        resid = noisy - w.t()
+        got = 10 * torch.log10((w.t() ** 2).sum() / (resid ** 2).sum())
+        assert abs(float(got) - snr) < 1e-3
+    s = H.make_sample(torch.zeros(10, 1, 96, 96, dtype=torch.uint8), torch.randn(5000, 1, generator=g), "audiovisual")
+    assert s["video"].shape == (10, 1, 88, 88) and s["audio"].shape == (6400, 1)      # cut_or_pad to 640 * frames
+
+
+def test_wer_and_collate():
+    assert H.edit_distance("kitten", "sitting") == 3
+    assert H.compute_word_level_distance("The cat sat", "the cat sat") == 0
+    assert H.compute_word_level_distance("a b c d", "a x c") == 2
+    m = H.WerMeter()
+    m.update("hello big world", "hello world")
+    m.update("one two", "one two three")
+    assert m.total_edit_distance == 2 and m.total_length == 5 and abs(m.wer - 0.4) < 1e-9
+    assert H.strip_special([5, 1, 7, 2, 2], [1, 2]) == [5, 7]
+    b = H.collate_test([{"video": torch.ones(3, 1, 88, 88), "audio": torch.ones(1920, 1)}, {"video": torch.ones(5, 1, 88, 88), "audio": torch.ones(3200, 1)}],
+                       "audiovisual", 128000)
+    assert b["video"].shape == (2, 5, 1, 88, 88) and b["audio"].shape == (2, 3200, 1)
+    assert b["lengths"].tolist() == [1920, 3200] and b["video_lengths"].tolist() == [3, 5] and b["tokens"].tolist() == [[128000], [128000]]
+    assert H.collate_test([{"audio": torch.ones(10, 1)}], "audio", -1)["tokens"].shape == (1, 0)      # Qwen: no BOS
