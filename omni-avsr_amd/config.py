@@ -180,7 +180,7 @@ class OmniSpec:
 
 def tiny_spec(family: str = "llama", *, head_dim: int = 64, task_specific: bool = False, shared: bool = False,
               use_lora_avhubert: bool = True, matryoshka: bool = False, compression_mode: str = "avg-pooling",
-              vocab: int = 512) -> OmniSpec:
+              vocab: int = 512, lora_rank: int = 4, single_projector: bool = False, remove_layernorm: bool = False) -> OmniSpec:
     """Small but structurally faithful configuration for parity tests (GQA 4:1, LoRA on, 2-layer encoders)."""
     if family == "llama":
         llm = LLMSpec("llama", 4 * head_dim, 2, 4, 1, head_dim, 512, vocab, 1e-5, 500000.0, _L3, False, True)
@@ -193,7 +193,8 @@ def tiny_spec(family: str = "llama", *, head_dim: int = 64, task_specific: bool 
         avhubert=AVHubertSpec(128, 2, 2, 256, conv_pos=16, conv_pos_groups=4, use_lora=use_lora_avhubert),
         intermediate_size=192, compression_mode=compression_mode,
         downsample_ratio_audio=[2, 4] if matryoshka else 4, downsample_ratio_video=[1, 2] if matryoshka else 2,
-        is_matryoshka=matryoshka, lora_rank=4, lora_alpha=2, is_task_specific=task_specific, shared_lora=shared,
+        is_matryoshka=matryoshka, is_single_matry_projector=single_projector, remove_layernorm_from_projector=remove_layernorm,
+        lora_rank=lora_rank, lora_alpha=2, is_task_specific=task_specific, shared_lora=shared,
         prompt_len={"audio": 5, "video": 6, "audiovisual": 7}, max_dec_tokens=8, num_beams=1)
 
 

@@ -162,6 +162,30 @@ def test_beam_search_eos_paths_f32():
                 assert ids[b, : int(lens[b])].tolist() == ref[b], f"eos={alt} K={K} utt {b}: {ids[b].tolist()} vs {ref[b]}"
 
 
+@pytest.mark.parametrize("kw,ra,rv", [
+    (dict(compression_mode="stack"), 4, 2),                                             # frame stacking, projector in = D*rate (:507-514)
+    (dict(compression_mode="stack", matryoshka=True), 2, 1),                            # per-rate stack projectors, audio LN polarity quirk (:74-77)
+    (dict(matryoshka=True, single_projector=True), 4, 2),                               # one projector + LayerNorm for every rate (:102,:186)
+    (dict(matryoshka=True), 2, 1),                                                      # per-rate projectors, LayerNorm swallowed (:104,:188), rate 1
+    (dict(remove_layernorm=True), 4, 2),                                                # --no-layernorm-projector
+    (dict(lora_rank=0, use_lora_avhubert=False), 4, 2),                                 # plain LLM / plain AV-HuBERT (PETF_LLM_name=None)
+    (dict(family="qwen2", head_dim=128), 4, 2),                                         # head_dim 128, qkv bias, no BOS, non-task-specific LoRA
+])
+def test_generate_config_variants_f32(kw, ra, rv):
+    """Every constructor variant of AVSR_LLMs that changes the arithmetic, end to end, token ids vs the oracle."""
+    spec, sd, eng, orc = make("f32", **kw)
+    Tv, Ts = [11, 8], [7040, 5120]
+    video, audio = inputs(Tv=Tv, Ts=Ts)
+    fam = spec.llm.family
+    tokens = torch.full((2, 1), spec.ids["bos"]) if fam == "llama" else torch.zeros(2, 0, dtype=torch.long)
+    ids, lens = eng.generate("audiovisual", video, Tv, audio, Ts, ra, rv, beams=1, max_new=spec.max_dec_tokens, force_len=True)
+    ref = orc.forward(dict(video=video, audio=audio, lengths=torch.tensor(Ts), video_lens=torch.tensor(Tv), tokens=tokens), "audiovisual", ra, rv,
+                      num_beams=1, force_len=True)
+    ids = ids.cpu()
+    for b in range(2):
+        assert ids[b].tolist() == ref[b], f"{kw}: utt {b}: {ids[b].tolist()} vs {ref[b]}"
+
+
 def test_greedy_hipgraph_replay_matches_eager():
     """On a non-default stream the decode step is captured into a hipGraph and replayed; ids must equal the eager path
     (default stream, where capture is not allowed) and a second call must reuse the instantiated graph."""
