@@ -262,7 +262,7 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(const GemmArgs p) {
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm * (TM * 16) + i * 16 + fg * 4 + r;
         if (m >= p.M) continue;
-        float y = acc[i][j][r] * sc + bi;
+        float y = fmaf(acc[i][j][r], sc, bi);
         float res = R ? to_f32(R[(int64_t)m * p.ldr + ng]) : 0.f;
         if (!p.res_after_act) y += res;
         switch (p.act) {
@@ -305,8 +305,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     const int m = (int)(i / p.N), n = (int)(i - (int64_t)m * p.N);
     float y = 0.f;
     for (int s = 0; s < p.ksplit; ++s) y += p.partial[(int64_t)s * total + i];     // fixed order: deterministic
-    if (p.col_scale) y *= p.col_scale[n];
-    if (p.col_bias) y += p.col_bias[n];
+    y = fmaf(y, p.col_scale ? p.col_scale[n] : 1.f, p.col_bias ? p.col_bias[n] : 0.f);
     float res = R ? to_f32(R[(int64_t)m * p.ldr + n]) : 0.f;
     if (!p.res_after_act) y += res;
     switch (p.act) {

@@ -242,9 +242,8 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const bool in = nb + e < p.N;            // per-column parameters are re-read per slab (L1 hits) to keep registers free
-      float v = y[e];
-      if (p.col_scale && in) v *= p.col_scale[ngb + e];
-      if (p.col_bias && in) v += p.col_bias[ngb + e];
+      // one explicit FMA, identical in every GEMM variant, so an element has the same bits whichever tile shape computed it
+      float v = fmaf(y[e], (p.col_scale && in) ? p.col_scale[ngb + e] : 1.f, (p.col_bias && in) ? p.col_bias[ngb + e] : 0.f);
       if (!p.res_after_act) v += res[e];
       switch (p.act) {
         case ACT_GELU: v = gelu_erf(v); break;

@@ -153,9 +153,7 @@ __global__ __launch_bounds__(kThreads) void skinny_kernel(const GemmArgs p) {
       y = y * rsqrtf(s / (float)p.K + p.norm_eps) + y2;
     }
     const int n = n0 + nn;
-    if (p.col_scale) y *= p.col_scale[n];
-    if (p.col_bias) y += p.col_bias[n];
-    return y;
+    return fmaf(y, p.col_scale ? p.col_scale[n] : 1.f, p.col_bias ? p.col_bias[n] : 0.f);
   };
   if (p.swiglu_pairs) {
     // weight rows interleaved [gate block b | up block b] in 16-row blocks; out column = (n0/32 + pblk)*16 + i

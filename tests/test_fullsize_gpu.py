@@ -1,0 +1,81 @@
+"""-m gpu: parity at BASELINE.json's full model sizes (AV-HuBERT-Large + Whisper-medium + Llama-3.2-1B, Omni-LoRA ST).
+ * f32 parity mode against the CPU oracle on a 4 s clip: encoder activations within the north-star 1e-3 (relative to the
+   activation scale) and the 32 greedy token ids bit-exact;
+ * size-independent properties at 16 s / batch sizes the oracle cannot afford: an utterance decodes to the same ids and the
+   same encoder activations (bit for bit) alone and inside a ragged batch (no cross-utterance leakage, the reference's
+   batch-1 semantics), and repeated runs are deterministic."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from omni_avsr_amd.config import spec_from_names  # noqa: E402
+from omni_avsr_amd.modeling import OmniEngine  # noqa: E402
+from omni_avsr_amd.synth import synth_state_dict  # noqa: E402
+from oracle import torch_oracle as O  # noqa: E402
+
+
+def full_spec():
+    return spec_from_names("meta-llama/Llama-3.2-1B", "openai/whisper-medium.en", "large_vox_iter5", use_lora_avhubert=True,
+                           intermediate_size=2048, compression_mode="avg-pooling", downsample_ratio_audio=[4, 16], downsample_ratio_video=[2, 4, 5],
+                           is_matryoshka=True, lora_rank=32, lora_alpha=4, is_task_specific=True, shared_lora=True,
+                           prompt_len={"audio": 8, "video": 8, "audiovisual": 8}, max_dec_tokens=32, num_beams=1)
+
+
+def clips(Tv, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    B = len(Tv)
+    video = torch.randn(B, max(Tv), 1, 88, 88, generator=g)
+    audio = torch.zeros(B, 640 * max(Tv), 1)
+    for b, t in enumerate(Tv):
+        video[b, t:] = 0
+        audio[b, : 640 * t, 0] = torch.nn.functional.layer_norm(torch.randn(640 * t, generator=g), (640 * t,))
+    return video, audio, [640 * t for t in Tv]
+
+
+def test_fullsize_f32_matches_oracle():
+    spec = full_spec()
+    sd = synth_state_dict(spec, seed=1234, device="cuda:0")
+    eng = OmniEngine(spec, dtype="f32").load_state_dict(sd)
+    sd_cpu = {k: v.cpu() for k, v in sd.items()}
+    del sd
+    torch.cuda.empty_cache()
+    Tv = [100]
+    video, audio, Ts = clips(Tv, seed=5)
+    _, venc, _ = eng.encode_video(video, Tv, 4, return_enc=True)
+    _, aenc, _, _ = eng.encode_audio(audio, Ts, 4, return_enc=True)
+    ids, lens = eng.generate("audiovisual", video, Tv, audio, Ts, 4, 4, beams=1, max_new=32, force_len=True)
+    orc = O.OmniOracle(sd_cpu, spec.oracle_cfg())
+    with torch.no_grad():
+        _, vs = orc.encode_video(video, 4, return_stages=True)
+        _, as_ = orc.encode_audio(audio[:, : Ts[0]], Ts[0], 4, return_stages=True)
+        ref = orc.forward(dict(video=video, audio=audio, lengths=torch.tensor(Ts), tokens=torch.full((1, 1), spec.ids["bos"])), "audiovisual", 4, 4,
+                          num_beams=1, force_len=True)
+    ev = (venc.float().cpu() - vs["enc"][0]).abs().max().item() / vs["enc"][0].abs().max().item()
+    ea = (aenc[0].float().cpu() - as_["enc"][0]).abs().max().item() / as_["enc"][0].abs().max().item()
+    print(f"full-size f32: video encoder rel err {ev:.2e}, whisper encoder rel err {ea:.2e}")
+    assert ev < 1e-3 and ea < 1e-3
+    assert ids[0].cpu().tolist() == ref[0]
+
+
+@pytest.mark.parametrize("dtype", ["bf16"])
+def test_fullsize_batch_invariance_and_determinism(dtype):
+    spec = full_spec()
+    sd = synth_state_dict(spec, seed=1234, device="cuda:0", dtype=torch.bfloat16)
+    eng = OmniEngine(spec, dtype=dtype).load_state_dict(sd)
+    del sd
+    torch.cuda.empty_cache()
+    Tv = [400, 250, 100, 61]
+    video, audio, Ts = clips(Tv, seed=9)
+    ids_b, lens_b = eng.generate("audiovisual", video, Tv, audio, Ts, 4, 4, beams=1, max_new=32, force_len=True)
+    ids_b2, _ = eng.generate("audiovisual", video, Tv, audio, Ts, 4, 4, beams=1, max_new=32, force_len=True)
+    assert torch.equal(ids_b, ids_b2), "two runs of the same batch differ"
+    _, venc_b, _ = eng.encode_video(video, Tv, 4, return_enc=True)
+    off = 0
+    for b, t in enumerate(Tv):
+        v1, a1 = video[b:b + 1, :t], audio[b:b + 1, : 640 * t]
+        ids1, _ = eng.generate("audiovisual", v1, [t], a1, [640 * t], 4, 4, beams=1, max_new=32, force_len=True)
+        assert ids1[0].tolist() == ids_b[b].tolist(), f"utterance {b} (T_v={t}) decodes differently alone vs in the ragged batch"
+        _, venc1, _ = eng.encode_video(v1, [t], 4, return_enc=True)
+        assert torch.equal(venc1, venc_b[off:off + t]), f"utterance {b}: video encoder output depends on its batch mates"
+        off += t
