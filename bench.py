@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--beams", type=int, default=1, help="1 = greedy (north-star decode); 15 = the reference's default HF beam search")
+    ap.add_argument("--no-stagger", action="store_true", help="let the encoder phases of in-flight batches share the chip (default: chained)")
     ap.add_argument("--streams", type=int, default=3, help="batches in flight (one HIP stream + workspace each); 1 = strictly sequential steps")
     args = ap.parse_args()
 
@@ -110,6 +111,8 @@ def main():
     # loop of one batch overlaps the MFMA-bound encoders / prefill of the next.  Every step still is one complete pass.
     nstream = max(1, args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstream)]
+    if nstream > 1 and not args.no_stagger:
+        eng.serialize_encoders(True)
     results = [None] * nstream
 
     def step(i=0):

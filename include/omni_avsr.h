@@ -73,6 +73,10 @@ const char* oavsr_last_error(void);
 int oavsr_model_create(const oavsr_config* cfg, const void* blob_dev, uint64_t blob_bytes, const oavsr_tensor* tensors,
                        int32_t n_tensors, oavsr_model** out);
 void oavsr_model_destroy(oavsr_model* m);
+/* Scheduling hint for callers that keep several oavsr_generate() calls in flight (one workspace + stream each): when on,
+ * the encoder + prefill phase of a call starts only after the prefill of the previously issued call has finished, so the
+ * MFMA-bound phases run back to back and only the decode loops overlap them.  Results are unaffected. */
+int oavsr_model_serialize_encoders(oavsr_model* m, int32_t on);
 
 /* scratch + KV caches for batches of up to max_B utterances, max_Tv video frames / max_Ts samples each */
 int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, int32_t max_Ts, int32_t max_beams,
@@ -190,6 +194,11 @@ int oavsr_op_decode_attention(const oavsr_decode_attn_desc* d, oavsr_stream stre
 /* mode: 0 LayerNorm, 1 RMSNorm, 2 LayerNorm over [zeros(D), x] */
 int oavsr_op_norm(int32_t mode, int32_t dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, const float* b,
                   int32_t rows, int32_t D, float eps, oavsr_stream stream);
+/* Fused visual stem: Conv3d(1->64, k (5,7,7), s (1,2,2), p (2,3,3)) + folded BN + PReLU + MaxPool3d((1,3,3), s (1,2,2), p (0,1,1))
+ * (reference resnet.py:137-141).  video f32 [F][88][88]; frameinfo int32 pairs {t, len} per frame; w [64][256] in the model
+ * dtype with k = dt*49 + ky*7 + kx (245 valid); wp_scratch: 64*288 elements of the model dtype; out [F][22][22][64]. */
+int oavsr_op_stem_pool(int32_t dtype, const float* video, const int32_t* frameinfo_dev, int32_t F, const void* w, void* wp_scratch,
+                       const float* scale, const float* shift, const float* slope, void* out, oavsr_stream stream);
 int oavsr_op_maxpool3x3s2(int32_t dtype, const void* x, void* y, int32_t imgs, int32_t H, int32_t W, int32_t C, oavsr_stream stream);
 int oavsr_op_avgpool_hw(int32_t dtype, const void* x, void* y, int32_t imgs, int32_t HW, int32_t C, oavsr_stream stream);
 int oavsr_op_time_compress(int32_t dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const int32_t* seg_dev, int32_t n_seqs,

@@ -99,6 +99,11 @@ int launch_layernorm_zero_prefix(int dtype, const void* x, int64_t ldx, void* y,
                                  const float* b, int rows, int D, float eps, hipStream_t st);
 int launch_rmsnorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, int rows, int D,
                    float eps, hipStream_t st);
+// Fused visual stem (stem.hip): Conv3d(1->64, 5x7x7, s (1,2,2)) + BN + PReLU + MaxPool(3x3, s2) on f32 video [F][88][88];
+// frameinfo[f] = {t, len}; wp = weights repacked by launch_stem_repack ([64][256] -> [64][288]); out [F][22][22][64].
+int launch_stem_repack(int dtype, const void* w, void* wp, hipStream_t st);
+int launch_stem_pool(int dtype, const float* video, const int2* frameinfo, int F, const void* wp, const float* scale, const float* shift,
+                     const float* slope, void* out, hipStream_t st);
 // 3x3 stride-2 pad-1 max pool, NHWC
 int launch_maxpool3x3s2(int dtype, const void* x, void* y, int imgs, int H, int W, int C, hipStream_t st);
 // global average pool over HW, NHWC -> [imgs][C]

@@ -136,6 +136,12 @@ struct oavsr_model {
   const void* prompt[3];
   // constants built at create
   double* twiddle = nullptr; float* melfb = nullptr;
+  void* stem_wp = nullptr;                     // stem weights in the (dt, ky, kx8) order of stem.hip
+  // cross-stream scheduling of concurrent generate() calls (oavsr_model_serialize_encoders)
+  mutable bool serialize_enc = false;
+  mutable hipEvent_t enc_done = nullptr;       // recorded after the prefill of the most recent generate()
+  mutable hipStream_t enc_last = nullptr;
+  mutable bool enc_recorded = false;
 
   const void* ptr(const std::string& n, bool required = true) const {
     auto it = t.find(n);
@@ -159,7 +165,7 @@ struct oavsr_workspace {
   // encoder scratch (shared by both encoders)
   void *enc_x, *enc_h, *enc_qkv, *enc_attn, *enc_ffn, *enc_lora, *enc_out_v, *enc_out_a;
   // video front
-  void *stem_out, *pool_out, *trunk[2], *feat512, *featproj, *ln2d;
+  void *pool_out, *trunk[2], *feat512, *featproj, *ln2d;
   int2* frameinfo; int4* rowinfo; int4* rowinfo2; int* cu_a; int* cu_b; int4* seg;
   // audio front
   void *mel, *conv1_out, *pos_rep; float *mel_ws, *max_ws; int* lens_dev;
@@ -408,13 +414,10 @@ static int encode_video_impl(const oavsr_model* m, oavsr_workspace* ws, const fl
     for (int b = 0; b < B; ++b) { for (int t = 0; t < Tv[b]; ++t) fi[f++] = make_int2(t, Tv[b]); cu[b + 1] = f; } }
   OAVSR_TRY(h2d(ws->frameinfo, fi, sizeof(int2) * F, st));
   OAVSR_TRY(h2d(ws->cu_a, cu, sizeof(int) * (B + 1), st));
-  // K1: stem conv3d + BN + PReLU (resnet.py:137-140) as implicit GEMM, then MaxPool3d (:141)
-  GemmArgs g; g.dtype = dt; g.amode = A_STEM; g.M = F * 1936; g.N = 64; g.K = 256; g.A = video; g.frameinfo = ws->frameinfo;
-  g.W = m->stem.w; g.ldw = 256; g.col_scale = m->stem.scale; g.col_bias = m->stem.shift; g.act = ACT_PRELU; g.prelu = m->stem.slope;
-  g.C = ws->stem_out; g.ldc = 64;
-  OAVSR_TRY(run_gemm(g, st));
-  { ProfScope ps("maxpool", 0, (double)F * (1936 + 484) * 64 * m->esz, st);
-    OAVSR_TRY(launch_maxpool3x3s2(dt, ws->stem_out, ws->pool_out, F, 44, 44, 64, st)); }
+  // K1: stem conv3d + BN + PReLU + MaxPool3d (resnet.py:137-141), one fused kernel (stem.hip)
+  { ProfScope ps(dt == DT_F32 ? "stem_conv_pool_f32" : "stem_conv_pool_bf16", 2.0 * F * 1936 * 245 * 64, (double)F * (7744 * 4 + 484 * 64 * m->esz), st);
+    OAVSR_TRY(launch_stem_pool(dt, video, ws->frameinfo, F, m->stem_wp, m->stem.scale, m->stem.shift, m->stem.slope, ws->pool_out, st)); }
+  GemmArgs g;
   // K2: ResNet-18 trunk (resnet.py:61-74, 121-126)
   // x lives in pool_out and is updated in place: conv2's epilogue reads residual[m][n] and writes C[m][n] from the
   // same thread, and conv1 / downsample (the only readers of x as a GEMM operand) precede it in stream order.
@@ -853,6 +856,12 @@ int oavsr_model_create(const oavsr_config* cfg, const void* blob_dev, uint64_t b
   }
   hipMemcpy(m->twiddle, tw.data(), 800 * sizeof(double), hipMemcpyHostToDevice);
   hipMemcpy(m->melfb, fb.data(), fb.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (m->has_video) {
+    if (hipMalloc(&m->stem_wp, 64 * 288 * m->esz) != hipSuccess) { set_last_error("model_create: hipMalloc failed"); oavsr_model_destroy(m); return -2; }
+    if (launch_stem_repack(m->dtype, m->stem.w, m->stem_wp, nullptr) != 0 || hipDeviceSynchronize() != hipSuccess) {
+      set_last_error("model_create: stem repack failed"); oavsr_model_destroy(m); return -2;
+    }
+  }
   *out = m;
   return 0;
 }
@@ -861,7 +870,17 @@ void oavsr_model_destroy(oavsr_model* m) {
   if (!m) return;
   if (m->twiddle) hipFree(m->twiddle);
   if (m->melfb) hipFree(m->melfb);
+  if (m->stem_wp) hipFree(m->stem_wp);
+  if (m->enc_done) hipEventDestroy(m->enc_done);
   delete m;
+}
+
+int oavsr_model_serialize_encoders(oavsr_model* m, int32_t on) {
+  OAVSR_REQUIRE(m, "serialize_encoders: null model");
+  if (on && !m->enc_done) OAVSR_CHECK_HIP(hipEventCreateWithFlags(&m->enc_done, hipEventDisableTiming));
+  m->serialize_enc = on != 0;
+  m->enc_recorded = false;
+  return 0;
 }
 
 int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, int32_t max_Ts, int32_t max_beams, int32_t max_new,
@@ -904,7 +923,7 @@ int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, 
   WANT(enc_ffn, NT * Fe * e); WANT(enc_lora, NT * (size_t)std::max(64, c.av_lora_k2) * e);
   WANT(enc_out_v, F * Dv * e); WANT(enc_out_a, TA * Da * e);
   if (m->has_video) {
-    WANT(stem_out, F * 1936 * 64 * e); WANT(pool_out, F * 484 * 64 * e);
+    WANT(pool_out, F * 484 * 64 * e);
     for (int i = 0; i < 2; ++i) WANT(trunk[i], F * 484 * 64 * e);
     WANT(feat512, F * 512 * e); WANT(featproj, F * Dv * e); WANT(ln2d, F * 2 * Dv * e);
     WANT(frameinfo, F * sizeof(int2));
@@ -1021,6 +1040,10 @@ int oavsr_generate(const oavsr_model* m, oavsr_workspace* ws, int32_t task, cons
   OAVSR_REQUIRE(B >= 1 && B <= ws->max_B, "generate: B=%d exceeds workspace (%d)", B, ws->max_B);
   hipStream_t st = (hipStream_t)stream;
   CallScope cs(ws, st);
+  // Concurrent generate() calls on different streams: the MFMA-bound encoder + prefill phases gain nothing from sharing
+  // the chip with each other, so they are chained one after another; only the latency-bound decode loop of one call
+  // overlaps the encoders of the next.
+  if (m->serialize_enc && m->enc_recorded && m->enc_last != st) OAVSR_CHECK_HIP(hipStreamWaitEvent(st, m->enc_done, 0));
   const bool use_a = task == OAVSR_TASK_AUDIO || task == OAVSR_TASK_AUDIOVISUAL;
   const bool use_v = task == OAVSR_TASK_VIDEO || task == OAVSR_TASK_AUDIOVISUAL;
   std::vector<int> na(B), nv(B);
@@ -1040,6 +1063,10 @@ int oavsr_generate(const oavsr_model* m, oavsr_workspace* ws, int32_t task, cons
   std::vector<int> S(B);
   OAVSR_TRY(build_prompt_impl(m, ws, task, B, use_a ? na.data() : nullptr, ws->tok_a, use_v ? nv.data() : nullptr, ws->tok_v, ws->lx, S.data(), st));
   OAVSR_TRY(prefill_impl(m, ws, task, B, ws->lx, S.data(), nullptr, st));
+  if (m->serialize_enc) {
+    OAVSR_CHECK_HIP(hipEventRecord(m->enc_done, st));
+    m->enc_last = st; m->enc_recorded = true;
+  }
   if (beams > 1) return decode_beam(m, ws, task, B, beams, max_new, out_ids_dev, out_len_dev, st);
   return decode_greedy(m, ws, task, B, max_new, force_len, out_ids_dev, out_len_dev, st);
 }
@@ -1073,6 +1100,13 @@ int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream) {
   g.norm_gain = d->norm_gain; g.norm_eps = d->norm_eps; g.swiglu_pairs = d->swiglu_pairs;
   g.ksplit = d->ksplit < 1 ? 1 : d->ksplit; g.partial = d->partial;
   return d->skinny ? launch_gemm_skinny(g, (hipStream_t)stream) : launch_gemm(g, (hipStream_t)stream);
+}
+
+int oavsr_op_stem_pool(int32_t dtype, const float* video, const int32_t* frameinfo_dev, int32_t F, const void* w, void* wp_scratch,
+                       const float* scale, const float* shift, const float* slope, void* out, oavsr_stream stream) {
+  OAVSR_REQUIRE(w && wp_scratch, "op_stem_pool: null weights");
+  OAVSR_TRY(launch_stem_repack(dtype, w, wp_scratch, (hipStream_t)stream));
+  return launch_stem_pool(dtype, video, (const int2*)frameinfo_dev, F, wp_scratch, scale, shift, slope, out, (hipStream_t)stream);
 }
 
 int oavsr_op_attention(const oavsr_attn_desc* d, oavsr_stream stream) {

@@ -12,6 +12,13 @@
 //     same fragments, and rstd scales the segment-1 accumulator in the epilogue:  y = rstd * ((x*g) W^T) + t B^T
 //     (LlamaRMSNorm -> q/k/v_proj, Llama_LoRA.py:624-645 via transformers)
 //   * SwiGLU epilogue on a gate/up weight whose rows are interleaved in blocks of 16: out = silu(gate) * up
+//
+// HALF mode (M <= 8 rows, few column tiles: o_proj / down_proj / qkv of a B=8 greedy step): a workgroup owns 8 columns
+// instead of 16, so N/8 workgroups cover the chip where N/16 would leave half the CUs idle.  The 16x16 MFMA is fed
+// [8 columns x even k-blocks | the same 8 columns x odd k-blocks] on the weight side and [8 rows x even | 8 rows x odd] on
+// the activation side; the two diagonal 8x8 blocks of the result are the even / odd partial sums (the off-diagonal blocks
+// are discarded).  One wave load then covers 8 weight rows x one whole 128-byte line.
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace oavsr {
@@ -36,8 +43,9 @@ template <> struct MmaS<float> {
   }
 };
 
-template <typename T, int MT, int NT, bool NORM, int U>
+template <typename T, int MT, int NT, bool NORM, int U, bool HALF>
 __global__ __launch_bounds__(kThreads) void skinny_kernel(const GemmArgs p) {
+  static_assert(!HALF || MT == 1, "HALF mode: at most 8 rows");
   constexpr int KBE = 64 / (int)sizeof(T);       // elements per 64-byte k block
   constexpr int VEC = TypeInfo<T>::kVec;
   // U = k blocks in flight per wave
@@ -48,7 +56,9 @@ __global__ __launch_bounds__(kThreads) void skinny_kernel(const GemmArgs p) {
   float* sssq = sred2 + (NORM ? kWaves * MR * NC : 0);   // [8][MR]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * NC;
+  const int hi = HALF ? (r16 >> 3) : 0, rw = HALF ? (r16 & 7) : r16;   // k-block parity, row within the operand tile
+  constexpr int TW = HALF ? 8 : 16;                                    // output columns per MFMA tile
+  const int n0 = blockIdx.x * (NT * TW);
   const T* A1 = reinterpret_cast<const T*>(p.A);
   const T* A2 = reinterpret_cast<const T*>(p.A2);
   const T* W1 = reinterpret_cast<const T*>(p.W);
@@ -67,11 +77,26 @@ __global__ __launch_bounds__(kThreads) void skinny_kernel(const GemmArgs p) {
     }
   }
 
-  for (int kb0 = wave; kb0 < nkb; kb0 += kWaves * U) {
+  // epilogue operands of this thread's first output element are fetched now, under the weight stream
+  constexpr int OR = HALF ? 8 : MR, OC = NT * TW;         // output tile of the workgroup
+  const T* R = reinterpret_cast<const T*>(p.residual);
+  float pre_res = 0.f, pre_scale = 1.f, pre_bias = 0.f;
+  if (!p.swiglu_pairs && tid < OR * OC) {
+    const int m = tid / OC, n = n0 + (tid - m * OC);
+    if (m < p.M && n < p.N) {
+      if (R) pre_res = to_f32(R[(int64_t)m * p.ldr + n]);
+      if (p.col_scale) pre_scale = p.col_scale[n];
+      if (p.col_bias) pre_bias = p.col_bias[n];
+    }
+  }
+  // HALF: the loop walks PAIRS of k blocks (nkb1 is even there, so a pair never straddles the two K segments)
+  const int nsteps = HALF ? (nkb + 1) / 2 : nkb;
+  for (int kb0 = wave; kb0 < nsteps; kb0 += kWaves * U) {
     Chunk16 bf[U][NT], af[U][MT];
+    f32x4 gn4[NORM ? U : 1][VEC / 4];               // norm gain of the k block, fetched with the operands (not after them)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int kb = kb0 + kWaves * u;
+      const int kb = HALF ? 2 * (kb0 + kWaves * u) + hi : kb0 + kWaves * u;
       const bool in = kb < nkb;
       const bool s1 = kb < nkb1;
       const T* Ab = s1 ? A1 : A2;
@@ -80,26 +105,30 @@ __global__ __launch_bounds__(kThreads) void skinny_kernel(const GemmArgs p) {
       const int k = (s1 ? kb : kb - nkb1) * KBE + g * VEC;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const int n = n0 + j * 16 + r16;
+        const int n = n0 + j * TW + rw;
         if (in && n < p.N) bf[u][j].v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Wb + (int64_t)n * ldw + k));   // streamed once
         else bf[u][j] = zchunk();
       }
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        const int m = i * 16 + r16;
+        const int m = i * 16 + rw;
         af[u][i] = (in && m < p.M) ? *reinterpret_cast<const Chunk16*>(Ab + (int64_t)m * lda + k) : zchunk();
+      }
+      if (NORM) {
+#pragma unroll
+        for (int e = 0; e < VEC / 4; ++e)
+          gn4[u][e] = (in && s1) ? *reinterpret_cast<const f32x4*>(p.norm_gain + k + e * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int kb = kb0 + kWaves * u;
-      const bool s1 = kb < nkb1;
+      const int kb = HALF ? 2 * (kb0 + kWaves * u) + hi : kb0 + kWaves * u;
+      const bool s1 = (HALF ? 2 * (kb0 + kWaves * u) : kb) < nkb1;      // wave-uniform
       if (NORM && s1 && kb < nkb) {
-        const int k = kb * KBE + g * VEC;
         float gn[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; e += 4) {
-          f32x4 t = *reinterpret_cast<const f32x4*>(p.norm_gain + k + e);
+          f32x4 t = gn4[u][e / 4];
           gn[e] = t[0]; gn[e + 1] = t[1]; gn[e + 2] = t[2]; gn[e + 3] = t[3];
         }
 #pragma unroll
@@ -141,24 +170,33 @@ __global__ __launch_bounds__(kThreads) void skinny_kernel(const GemmArgs p) {
     }
   }
   __syncthreads();
-  const T* R = reinterpret_cast<const T*>(p.residual);
-  auto value = [&](int m, int nn) -> float {
+  auto raw = [&](int m, int nn) -> float {
     float y = 0.f;
+    const int lc = HALF ? ((nn >> 3) * 16 + (nn & 7)) : nn;      // column inside the LDS image (16 per MFMA tile)
 #pragma unroll
-    for (int w = 0; w < kWaves; ++w) y += sred[(w * MR + m) * NC + nn];
+    for (int w = 0; w < kWaves; ++w) {
+      y += sred[(w * MR + m) * NC + lc];
+      if (HALF) y += sred[(w * MR + m + 8) * NC + lc + 8];
+    }
     if (NORM) {
       float s = 0.f, y2 = 0.f;
 #pragma unroll
-      for (int w = 0; w < kWaves; ++w) { s += sssq[w * MR + m]; y2 += sred2[(w * MR + m) * NC + nn]; }
+      for (int w = 0; w < kWaves; ++w) {
+        s += sssq[w * MR + m]; y2 += sred2[(w * MR + m) * NC + lc];
+        if (HALF) { s += sssq[w * MR + m + 8]; y2 += sred2[(w * MR + m + 8) * NC + lc + 8]; }
+      }
       y = y * rsqrtf(s / (float)p.K + p.norm_eps) + y2;
     }
+    return y;
+  };
+  auto value = [&](int m, int nn) -> float {
     const int n = n0 + nn;
-    return fmaf(y, p.col_scale ? p.col_scale[n] : 1.f, p.col_bias ? p.col_bias[n] : 0.f);
+    return fmaf(raw(m, nn), p.col_scale ? p.col_scale[n] : 1.f, p.col_bias ? p.col_bias[n] : 0.f);
   };
   if (p.swiglu_pairs) {
     // weight rows interleaved [gate block b | up block b] in 16-row blocks; out column = (n0/32 + pblk)*16 + i
-    for (int idx = tid; idx < MR * (NC / 2); idx += kThreads) {
-      const int m = idx / (NC / 2), q = idx - m * (NC / 2);
+    for (int idx = tid; idx < OR * (OC / 2); idx += kThreads) {
+      const int m = idx / (OC / 2), q = idx - m * (OC / 2);
       const int pblk = q >> 4, i = q & 15;
       const int ncol = (n0 >> 1) + q;
       if (m >= p.M || n0 + pblk * 32 + i >= p.N) continue;
@@ -168,12 +206,13 @@ __global__ __launch_bounds__(kThreads) void skinny_kernel(const GemmArgs p) {
     }
     return;
   }
-  for (int idx = tid; idx < MR * NC; idx += kThreads) {
-    const int m = idx / NC, nn = idx - m * NC;
+  for (int idx = tid; idx < OR * OC; idx += kThreads) {
+    const int m = idx / OC, nn = idx - m * OC;
     const int n = n0 + nn;
     if (m >= p.M || n >= p.N) continue;
-    float y = value(m, nn);
-    float res = R ? to_f32(R[(int64_t)m * p.ldr + n]) : 0.f;
+    const bool first = idx == tid;                 // prefetched operands
+    float y = first ? fmaf(raw(m, nn), pre_scale, pre_bias) : value(m, nn);
+    float res = first ? pre_res : (R ? to_f32(R[(int64_t)m * p.ldr + n]) : 0.f);
     if (!p.res_after_act) y += res;
     switch (p.act) {
       case ACT_GELU: y = gelu_erf(y); break;
@@ -188,24 +227,39 @@ __global__ __launch_bounds__(kThreads) void skinny_kernel(const GemmArgs p) {
   }
 }
 
-template <typename T, int MT, int NT, bool NORM, int U>
+template <typename T, int MT, int NT, bool NORM, int U, bool HALF = false>
 int launch_sk_u(const GemmArgs& a, hipStream_t st) {
   constexpr int smem = kWaves * MT * 16 * NT * 16 * 4 * (NORM ? 2 : 1) + (NORM ? kWaves * MT * 16 * 4 : 0);
   static_assert(smem <= 160 * 1024, "LDS");
-  auto kern = skinny_kernel<T, MT, NT, NORM, U>;
+  auto kern = skinny_kernel<T, MT, NT, NORM, U, HALF>;
   static bool attr_set = false;
   if (!attr_set && smem > 48 * 1024) {
     OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(ceil_div(a.N, NT * 16)), dim3(kThreads), smem, st, a);
+  hipLaunchKernelGGL(kern, dim3(ceil_div(a.N, NT * (HALF ? 8 : 16))), dim3(kThreads), smem, st, a);
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+static bool half_enabled() {
+  static const int on = [] { const char* e = getenv("OAVSR_SKINNY_HALF"); return e ? atoi(e) : 1; }();
+  return on != 0;
 }
 
 template <typename T, int MT, int NT, bool NORM>
 int launch_sk(const GemmArgs& a, hipStream_t st) {
   constexpr int U0 = (NT >= 4) ? 4 : 8;
+  constexpr int kbe = 64 / (int)sizeof(T);
+  if constexpr (MT == 1 && (NT == 1 || NT == 4)) {
+    // B <= 8 rows: 8-column MFMA tiles (HALF mode).  NT = 1: doubles the grid where 16-column tiles leave CUs idle;
+    // NT = 4 (gate/up, lm_head): same 256+ workgroups x 32 columns, but every wave load is 8 rows x one whole 128-B line.
+    const bool want = NT == 1 ? (a.N >= 64 && a.N / 16 < 384) : true;
+    if (half_enabled() && want && a.M <= 8 && a.N % (NT == 1 ? 8 : 32) == 0 && (a.K / kbe) % 2 == 0) {
+      if (NT == 1 && (a.K + a.K2) * (int)sizeof(T) >= 128 * kWaves * 16) return launch_sk_u<T, 1, NT, NORM, 16, true>(a, st);
+      return launch_sk_u<T, 1, NT, NORM, U0, true>(a, st);
+    }
+  }
   // deep K with few column tiles (down_proj): keep twice as many weight loads in flight per wave
   if (MT == 1 && NT == 1 && (a.K + a.K2) * (int)sizeof(T) >= 64 * kWaves * 16) return launch_sk_u<T, MT, NT, NORM, 16>(a, st);
   return launch_sk_u<T, MT, NT, NORM, U0>(a, st);

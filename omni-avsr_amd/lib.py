@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libomniavsr_hip.so")
+# OAVSR_LIB points the binding at another build of the same library (A/B timing of kernel variants on one box)
+LIB_PATH = os.environ.get("OAVSR_LIB") or os.path.join(_HERE, "libomniavsr_hip.so")
 
 MAX_RATES = 8
 DT_F32, DT_BF16 = 0, 1
@@ -87,6 +88,7 @@ SYMBOLS = {
     "oavsr_last_error": (C.c_char_p, []),
     "oavsr_model_create": (C.c_int, [C.POINTER(OavsrConfig), _P, C.c_uint64, C.POINTER(OavsrTensor), _I, C.POINTER(_P)]),
     "oavsr_model_destroy": (None, [_P]),
+    "oavsr_model_serialize_encoders": (C.c_int, [_P, C.c_int32]),
     "oavsr_workspace_create": (C.c_int, [_P, _I, _I, _I, _I, _I, C.POINTER(_P)]),
     "oavsr_workspace_destroy": (None, [_P]),
     "oavsr_workspace_bytes": (C.c_uint64, [_P]),
@@ -104,6 +106,7 @@ SYMBOLS = {
     "oavsr_op_attention": (C.c_int, [C.POINTER(AttnDesc), _P]),
     "oavsr_op_decode_attention": (C.c_int, [C.POINTER(DecodeAttnDesc), _P]),
     "oavsr_op_norm": (C.c_int, [_I, _I, _P, _L, _P, _L, _P, _P, _I, _I, _F, _P]),
+    "oavsr_op_stem_pool": (C.c_int, [_I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "oavsr_op_maxpool3x3s2": (C.c_int, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "oavsr_op_avgpool_hw": (C.c_int, [_I, _P, _P, _I, _I, _I, _P]),
     "oavsr_op_time_compress": (C.c_int, [_I, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _P]),

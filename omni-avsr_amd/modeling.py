@@ -114,6 +114,11 @@ class OmniEngine:
         L.check(self.lib.oavsr_workspace_create(self._model, B, max(Tv, 1), max(Ts, 1), beams, max_new, C.byref(self._ws)))
         self._ws_key = (B, Tv, Ts, beams, max_new)
 
+    def serialize_encoders(self, on: bool = True):
+        """Several generate() calls in flight (slots): run their encoder + prefill phases back to back, overlap only decode."""
+        L.check(self.lib.oavsr_model_serialize_encoders(self._model, int(on)))
+        return self
+
     def workspace_bytes(self) -> int:
         return int(self.lib.oavsr_workspace_bytes(self._ws)) if self._ws else 0
 
