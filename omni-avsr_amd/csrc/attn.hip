@@ -12,6 +12,7 @@
 //     f32 : exact-f32 MFMA 16x16x4, V read with ds_read_b32.
 // (2) decode_attn_kernel: one new token per row against a KV cache (shared utterance prefix + per-row tail
 //     addressed through a beam ancestry table).  HBM-bound, VALU only.
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace oavsr {
@@ -196,6 +197,197 @@ __global__ __launch_bounds__(kThreads) void attn_varlen_kernel(const AttnArgs p)
       } else {
         f32x4 w = o[dt] * inv;
         *reinterpret_cast<f32x4*>(O + dt * 16 + 4 * g) = w;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// (1b) attn_dma_kernel: the bf16 / head_dim 64 fast path of (1).  Same math and fragment layouts; what changes is the data
+//      movement: K/V tiles (64 keys x 128 B each) go HBM -> LDS by LDS-DMA through a 3-stage ring, two tiles ahead of their
+//      use, with ONE barrier per tile (counted vmcnt, never a drain); a wave owns QT query tiles of 16 rows so every K / V^T
+//      fragment read from LDS feeds QT MFMAs; masking is skipped on tiles that are fully visible; exp2 is the bare
+//      v_exp_f32 with the softmax scale folded into one fma.
+__device__ __attribute__((aligned(256))) unsigned int g_attn_zero_page[64];
+
+template <int QT>
+__global__ __launch_bounds__(kThreads) void attn_dma_kernel(const AttnArgs p) {
+  constexpr int HD = 64, RB = 128, NDT = 4, NSTAGE = 3;
+  constexpr int kStage = 2 * KT * RB;                  // K image then V image
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+  const int seq = blockIdx.z, head = blockIdx.y;
+  const int q0 = p.cu_q[seq], qlen = p.cu_q[seq + 1] - q0;
+  const int k0 = p.cu_k[seq], klen = p.cu_k[seq + 1] - k0;
+  const int qt0 = blockIdx.x * (64 * QT);
+  if (qt0 >= qlen) return;
+  const int kvh = head / (p.n_heads / p.n_kv_heads);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qi = lane & 15, g = lane >> 4;
+  const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.Q);
+  const bf16_t* K = reinterpret_cast<const bf16_t*>(p.K) + (int64_t)kvh * HD;
+  const bf16_t* V = reinterpret_cast<const bf16_t*>(p.V) + (int64_t)kvh * HD;
+
+  const int shift = klen - qlen;                         // causal: key j visible iff j <= qrow + shift
+  int kend = klen;
+  if (p.causal) {
+    int last = qt0 + 64 * QT - 1 < qlen ? qt0 + 64 * QT - 1 : qlen - 1;
+    kend = last + shift + 1;
+    if (kend > klen) kend = klen;
+    if (kend < 0) kend = 0;
+  }
+  const int ntile = (kend + KT - 1) / KT;
+
+  // DMA: wave w fills 1-KiB segments w and w+4 (8 key rows each) of the K and of the V image; lane i lands at physical
+  // chunk i&7 of row seg*8 + (i>>3) and therefore fetches logical chunk (i&7) ^ (i>>3)   [chunk ^ (row & 7) swizzle]
+  const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
+  auto issue = [&](int t) {
+    char* st = smem + (t % NSTAGE) * kStage;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int sg = wave + 4 * h;
+      const int key = t * KT + sg * 8 + lrow;
+      const bool in = key < klen;
+      const void* ks = in ? (const void*)(K + (int64_t)(k0 + key) * p.ldk + lchunk * 8) : (const void*)g_attn_zero_page;
+      const void* vs = in ? (const void*)(V + (int64_t)(k0 + key) * p.ldv + lchunk * 8) : (const void*)g_attn_zero_page;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks,
+                                       (__attribute__((address_space(3))) void*)(st + sg * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vs,
+                                       (__attribute__((address_space(3))) void*)(st + KT * RB + sg * 1024), 16, 0, 0);
+    }
+  };
+
+  Chunk16 qf[QT][2];
+  int qrow[QT];
+#pragma unroll
+  for (int j = 0; j < QT; ++j) {
+    qrow[j] = qt0 + (wave * QT + j) * 16 + qi;           // query index inside the sequence (may be >= qlen)
+    const int qc = qrow[j] < qlen ? qrow[j] : qlen - 1;
+    const char* qp = reinterpret_cast<const char*>(Q + (int64_t)(q0 + qc) * p.ldq + (int64_t)head * HD);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) qf[j][b] = *reinterpret_cast<const Chunk16*>(qp + b * 64 + g * 16);
+  }
+  if (ntile > 0) issue(0);
+  if (ntile > 1) issue(1);
+
+  const float sc = p.scale * 1.44269504088896340736f;    // softmax in base 2
+  f32x4 o[QT][NDT];
+  float m_run[QT], l_run[QT];
+#pragma unroll
+  for (int j = 0; j < QT; ++j) {
+    m_run[j] = -INFINITY; l_run[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) o[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  for (int t = 0; t < ntile; ++t) {
+    // tile t has landed once only tile t+1's 4 DMA instructions of this wave are still outstanding
+    if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 2 < ntile) issue(t + 2);                     // its stage held tile t-1: every wave is past it
+    const char* sK = smem + (t % NSTAGE) * kStage;
+    const char* sV = sK + KT * RB;
+    const int kt0 = t * KT;
+
+    // ---- S^T[key][q] for 4 sub-tiles of 16 keys; a K fragment feeds all QT query tiles ----
+    f32x4 s[QT][4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int row = kt * 16 + qi;                       // A-operand row = key (lane & 15)
+      Chunk16 kf[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) kf[b] = *reinterpret_cast<const Chunk16*>(sK + row * RB + (((b * 4 + g) ^ (row & 7)) << 4));
+#pragma unroll
+      for (int j = 0; j < QT; ++j) {
+        s[j][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 2; ++b) MmaT<bf16_t>::run(kf[b], qf[j][b], s[j][kt]);
+      }
+    }
+    // ---- online softmax (lane owns query qi of each tile; its keys: kt*16 + 4g + r) ----
+    bf16x8 pf[QT][2];
+#pragma unroll
+    for (int j = 0; j < QT; ++j) {
+      const int qmin = qt0 + (wave * QT + j) * 16;
+      const bool need_mask = kt0 + KT > klen || (p.causal && kt0 + KT - 1 > qmin + shift);     // wave-uniform
+      if (need_mask) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kt0 + kt * 16 + 4 * g + r;
+            const bool vis = key < klen && (!p.causal || key <= qrow[j] + shift);
+            if (!vis) s[j][kt][r] = -INFINITY;
+          }
+      }
+      float mt = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[j][kt][r]);
+      mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      mt *= sc;                                           // sc > 0: max(s) * sc == max(s * sc)
+      const float m_new = fmaxf(m_run[j], mt);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_use);
+      float lsum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(fmaf(s[j][kt][r], sc, -m_use));
+          s[j][kt][r] = e;
+          lsum += e;
+        }
+      l_run[j] = l_run[j] * alpha + lsum;
+      m_run[j] = m_new;
+#pragma unroll
+      for (int i = 0; i < NDT; ++i) o[j][i] *= alpha;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pf[j][u][r] = (bf16_t)s[j][2 * u][r]; pf[j][u][4 + r] = (bf16_t)s[j][2 * u + 1][r]; }
+    }
+    // ---- O^T[d][q] += V^T[d][key] . P^T[key][q]; a V^T fragment feeds all QT query tiles ----
+    const int qq = qi >> 2, pp = qi & 3;                 // tr-read: lane 4q+p addresses row q, cols 4p..4p+3
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                         // 32 keys per MFMA: sub-tiles 2u, 2u+1
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const int c = dt * 2 + (pp >> 1);
+        const int row0 = (2 * u) * 16 + 4 * g + qq, row1 = row0 + 16;
+        auto a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(sV + row0 * RB + ((c ^ (row0 & 7)) << 4) + (pp & 1) * 8));
+        auto a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(sV + row1 * RB + ((c ^ (row1 & 7)) << 4) + (pp & 1) * 8));
+        bf16x4 v0 = __builtin_bit_cast(bf16x4, a0), v1 = __builtin_bit_cast(bf16x4, a1);
+        bf16x8 vf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { vf[r] = v0[r]; vf[4 + r] = v1[r]; }
+#pragma unroll
+        for (int j = 0; j < QT; ++j) o[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[j][u], o[j][dt], 0, 0, 0);
+      }
+    }
+    asm volatile("" ::: "memory");
+  }
+  // ---- finalize: l over the 4 lane groups, write O[q][d = dt*16 + 4g + r] ----
+#pragma unroll
+  for (int j = 0; j < QT; ++j) {
+    float l = l_run[j];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (qrow[j] < qlen) {
+      const float inv = l > 0.f ? 1.f / l : 0.f;
+      bf16_t* O = reinterpret_cast<bf16_t*>(p.O) + (int64_t)(q0 + qrow[j]) * p.ldo + (int64_t)head * HD;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        bf16x4 w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = (bf16_t)(o[j][dt][r] * inv);
+        *reinterpret_cast<bf16x4*>(O + dt * 16 + 4 * g) = w;
       }
     }
   }
@@ -410,6 +602,21 @@ int launch_attn_t(const AttnArgs& a, hipStream_t st) {
   return 0;
 }
 
+template <int QT>
+int launch_attn_dma(const AttnArgs& a, hipStream_t st) {
+  constexpr int smem = 3 * 2 * KT * 128;
+  auto kern = attn_dma_kernel<QT>;
+  static bool attr = false;
+  if (!attr) {
+    OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr = true;
+  }
+  dim3 grid(ceil_div(a.max_q, 64 * QT), a.n_heads, a.n_seqs);
+  hipLaunchKernelGGL(kern, grid, dim3(kThreads), smem, st, a);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 template <typename T, int HD>
 int launch_dec_t(const DecodeAttnArgs& a, hipStream_t st) {
   constexpr int RB = HD * (int)sizeof(T);
@@ -438,6 +645,12 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
   OAVSR_REQUIRE(a.ldq % vec == 0 && a.ldk % vec == 0 && a.ldv % vec == 0 && a.ldo % vec == 0, "attention: rows must be 16-byte aligned");
   OAVSR_REQUIRE((((uintptr_t)a.Q | (uintptr_t)a.K | (uintptr_t)a.V | (uintptr_t)a.O) & 15) == 0, "attention: pointers must be 16-byte aligned");
   if (a.dtype == DT_F32) return a.head_dim == 64 ? launch_attn_t<float, 64>(a, st) : launch_attn_t<float, 128>(a, st);
+  static const int dma = [] { const char* e = getenv("OAVSR_ATTN_DMA"); return e ? atoi(e) : 1; }();
+  if (dma && a.head_dim == 64) {
+    // two query tiles per wave (128-row workgroups) once the sequences are long enough that the ragged last workgroup is cheap
+    if (dma == 2 || (dma == 1 && a.max_q >= 1024)) return launch_attn_dma<2>(a, st);
+    return launch_attn_dma<1>(a, st);
+  }
   return a.head_dim == 64 ? launch_attn_t<bf16_t, 64>(a, st) : launch_attn_t<bf16_t, 128>(a, st);
 }
 
