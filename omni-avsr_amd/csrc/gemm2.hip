@@ -126,10 +126,16 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
   const T* W1 = reinterpret_cast<const T*>(p.W);
   const T* W2 = reinterpret_cast<const T*>(p.W2);
   const T* A2 = reinterpret_cast<const T*>(p.A2);
-  const int nt1 = p.K / BKE, ntot = nt1 + p.K2 / BKE;
+  const int nt1 = p.K / BKE, nall = nt1 + p.K2 / BKE;
+  // split-K (gridDim.y > 1): this workgroup owns k-tiles [tbeg, tbeg + ntot) and stores raw fp32 partial sums
+  const bool split = gridDim.y > 1;
+  const int per = (nall + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int tbeg = split ? (int)blockIdx.y * per : 0;
+  const int ntot = split ? (tbeg + per < nall ? per : (nall - tbeg > 0 ? nall - tbeg : 0)) : nall;
 
-  auto issue = [&](int t) {
-    char* st = smem + (t % kStages) * kStageBytes;
+  auto issue = [&](int tl) {
+    char* st = smem + (tl % kStages) * kStageBytes;
+    const int t = tbeg + tl;
     if (t < nt1) {
       const int k = t * BKE + lchunk * VEC;
 #pragma unroll
@@ -205,11 +211,17 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
   asm volatile("" ::: "memory");
   constexpr int PW = 68;                             // padded row (floats)
   float* sw = reinterpret_cast<float*>(smem) + wave * (16 * PW);
-  const T* R = reinterpret_cast<const T*>(p.residual);
+  const T* R = split ? nullptr : reinterpret_cast<const T*>(p.residual);
+  const float* e_scale = split ? nullptr : p.col_scale;
+  const float* e_bias = split ? nullptr : p.col_bias;
+  const int e_act = split ? (int)ACT_NONE : p.act;
+  const bool e_f32 = split || p.out_f32;
+  void* e_C = split ? (void*)(p.partial + (int64_t)blockIdx.y * p.M * p.N) : p.C;
+  const int64_t e_ldc = split ? (int64_t)p.N : p.ldc;
   const int rr = lane >> 2, c0 = (lane & 3) * 16;
   const int nb = n0 + wn * 64 + c0;                  // first of this lane's 16 columns
   const int ngb = g * p.N + nb;
-  const bool vec_ok = nb + 16 <= p.N && (p.ldc % VEC) == 0 && ((uintptr_t)p.C & 15) == 0 && (ngb % 16) == 0 &&
+  const bool vec_ok = nb + 16 <= p.N && (e_ldc % VEC) == 0 && ((uintptr_t)e_C & 15) == 0 && (ngb % 16) == 0 &&
                       (!R || ((p.ldr % VEC) == 0 && ((uintptr_t)R & 15) == 0));
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -243,9 +255,9 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
     for (int e = 0; e < 16; ++e) {
       const bool in = nb + e < p.N;            // per-column parameters are re-read per slab (L1 hits) to keep registers free
       // one explicit FMA, identical in every GEMM variant, so an element has the same bits whichever tile shape computed it
-      float v = fmaf(y[e], (p.col_scale && in) ? p.col_scale[ngb + e] : 1.f, (p.col_bias && in) ? p.col_bias[ngb + e] : 0.f);
+      float v = fmaf(y[e], (e_scale && in) ? e_scale[ngb + e] : 1.f, (e_bias && in) ? e_bias[ngb + e] : 0.f);
       if (!p.res_after_act) v += res[e];
-      switch (p.act) {
+      switch (e_act) {
         case ACT_GELU: v = gelu_erf(v); break;
         case ACT_RELU: v = fmaxf(v, 0.f); break;
         case ACT_PRELU: v = v >= 0.f ? v : (in ? p.prelu[ngb + e] : 0.f) * v; break;
@@ -255,9 +267,9 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
       if (p.res_after_act) v += res[e];
       y[e] = v;
     }
-    if (p.out_f32) {
-      float* Cf = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + ngb;
-      if (nb + 16 <= p.N && (p.ldc % 4) == 0 && ((uintptr_t)p.C & 15) == 0 && (ngb % 4) == 0) {
+    if (e_f32) {
+      float* Cf = reinterpret_cast<float*>(e_C) + (int64_t)m * e_ldc + ngb;
+      if (nb + 16 <= p.N && (e_ldc % 4) == 0 && ((uintptr_t)e_C & 15) == 0 && (ngb % 4) == 0) {
 #pragma unroll
         for (int e = 0; e < 16; e += 4) *reinterpret_cast<f32x4*>(Cf + e) = f32x4{y[e], y[e + 1], y[e + 2], y[e + 3]};
       } else {
@@ -265,7 +277,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
         for (int e = 0; e < 16; ++e) if (nb + e < p.N) Cf[e] = y[e];
       }
     } else {
-      T* Ct = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + ngb;
+      T* Ct = reinterpret_cast<T*>(e_C) + (int64_t)m * e_ldc + ngb;
       if (vec_ok) {
 #pragma unroll
         for (int e = 0; e < 16; e += VEC) *reinterpret_cast<Chunk16*>(Ct + e) = chunk_from_f32<T>(y + e);
@@ -287,7 +299,7 @@ int launch_dma(const GemmArgs& a, hipStream_t st) {
     attr_set = true;
   }
   int64_t nblk = (int64_t)ceil_div(a.M, BM) * ceil_div(a.N, BN);
-  dim3 grid((unsigned)nblk, 1, a.groups);
+  dim3 grid((unsigned)nblk, a.ksplit > 1 ? a.ksplit : 1, a.groups);
   hipLaunchKernelGGL(kern, grid, dim3(NWAVES * 64), smem, st, a);
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;
@@ -296,6 +308,7 @@ int launch_dma(const GemmArgs& a, hipStream_t st) {
 static int dma_tile_choice(const GemmArgs& a) {
   // 0: not eligible, 1: 256x128, 2: 256x256
   static const int force = [] { const char* e = getenv("OAVSR_GEMM_TILE"); return e ? atoi(e) : -1; }();
+  if (a.ksplit > 1) return (a.amode == A_DENSE && a.groups == 1 && a.N >= 64) ? 1 : 0;   // independent of M on purpose
   if (a.amode == A_STEM || a.N < 128) return 0;
   const int64_t n128 = (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 128) * a.groups;
   const int64_t n256 = (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 256) * a.groups;
@@ -322,7 +335,7 @@ int launch_dma_mode(const GemmArgs& a, hipStream_t st) {
 }  // namespace
 
 bool gemm_dma_eligible(const GemmArgs& a) { return dma_tile_choice(a) != 0; }
-const char* gemm_dma_variant(const GemmArgs& a) { return dma_tile_choice(a) == 2 ? "dma_256x256" : "dma_256x128"; }
+const char* gemm_dma_variant(const GemmArgs& a) { return a.ksplit > 1 ? "dma_splitk_256x128" : dma_tile_choice(a) == 2 ? "dma_256x256" : "dma_256x128"; }
 
 int launch_gemm_dma(const GemmArgs& a, hipStream_t st) {
   return a.dtype == DT_F32 ? launch_dma_mode<float>(a, st) : launch_dma_mode<bf16_t>(a, st);

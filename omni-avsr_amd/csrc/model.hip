@@ -81,10 +81,23 @@ static const char* gemm_family(const GemmArgs& a, bool skinny) {
     return buf;
   }
   const char* mode = a.amode == A_DENSE ? "gemm" : a.amode == A_CONV2D ? "conv2d_gemm" : a.amode == A_CONV1D ? "conv1d_gemm" : "stem_gemm";
-  const char* tile = a.ksplit > 1 ? "splitk_128x128" : gemm_dma_eligible(a) ? gemm_dma_variant(a) : (a.N <= 64 ? "128x64" : "128x128");
+  const char* tile = (a.ksplit > 1 && !(a.M > 128 && gemm_dma_eligible(a))) ? "splitk_128x128" : gemm_dma_eligible(a) ? gemm_dma_variant(a) : (a.N <= 64 ? "128x64" : "128x128");
+  static const bool shapes = getenv("OAVSR_PROF_SHAPES") != nullptr;      // developer aid: one family per GEMM shape
+  if (shapes) { snprintf(buf, sizeof(buf), "%c%s %dx%dx%d", mode[0], tile, a.M, a.N, a.K + a.K2); buf[31] = 0; return buf; }
   snprintf(buf, sizeof(buf), "%s_%s_%s", mode, tile, dt);
   return buf;
 }
+
+// Split-K factors are STATIC per call site (functions of the layer's N and K, never of the row count), so that an utterance
+// gets the same bits whether it runs alone or inside a batch: the k-slices are summed in a fixed order by the reduce kernel.
+constexpr int kVideoNarrowSplit = 2;   // AV-HuBERT out-proj / fc2: N = D leaves ~100 tiles for a batch of 8 x 400 frames
+constexpr int kLoraDnSplitMax = 8;     // LoRA down projections: N = k*r is one or two column tiles
+static int lora_dn_split(int K, int esz) {
+  const int ktiles = K / (128 / esz);
+  int ks = ktiles / 4;                 // at least 4 k-tiles per slice
+  return ks < 1 ? 1 : ks > kLoraDnSplitMax ? kLoraDnSplitMax : ks;
+}
+static void set_split(GemmArgs& g, const oavsr_workspace* ws, int ks);
 
 static int run_gemm(const GemmArgs& a, hipStream_t st, bool skinny = false) {
   const double esz = a.dtype == DT_F32 ? 4 : 2;
@@ -330,8 +343,12 @@ static int resolve_model(oavsr_model* m) {
 // ------------------------------------------------------------------------------------------------
 // shared transformer-encoder layer stack (AV-HuBERT wav2vec2.py:977-1006 / WhisperEncoderLayer), pre-LN
 // ------------------------------------------------------------------------------------------------
+static void set_split(GemmArgs& g, const oavsr_workspace* ws, int ks) {
+  if (ks > 1 && ws->partial && (size_t)ks * g.M * g.N * 4 <= ws->partial_bytes) { g.ksplit = ks; g.partial = ws->partial; }
+}
+
 static int run_encoder_layers(const oavsr_model* m, oavsr_workspace* ws, const std::vector<EncLayer>& layers, int rows, int D,
-                              int heads, int ffn, int lora_k2, const int* cu_dev, int n_seqs, int max_len, hipStream_t st) {
+                              int heads, int ffn, int lora_k2, const int* cu_dev, int n_seqs, int max_len, int narrow_split, hipStream_t st) {
   const int dt = m->dtype;
   const int hd = D / heads;
   for (const EncLayer& L : layers) {
@@ -341,6 +358,7 @@ static int run_encoder_layers(const oavsr_model* m, oavsr_workspace* ws, const s
     if (lora_k2 > 0) {   // t = h . [A_q; A_v]^T
       g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = lora_k2; g.K = D; g.A = ws->enc_h; g.lda = D; g.W = L.lora_dn; g.ldw = D;
       g.C = ws->enc_lora; g.ldc = lora_k2;
+      set_split(g, ws, lora_dn_split(D, (int)m->esz));
       OAVSR_TRY(run_gemm(g, st));
     }
     g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 3 * D; g.K = D; g.A = ws->enc_h; g.lda = D; g.W = L.qkvw; g.ldw = D;
@@ -356,6 +374,7 @@ static int run_encoder_layers(const oavsr_model* m, oavsr_workspace* ws, const s
       OAVSR_TRY(launch_attention(a, st)); }
     g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = D; g.K = D; g.A = ws->enc_attn; g.lda = D; g.W = L.ow; g.ldw = D; g.col_bias = L.ob;
     g.residual = ws->enc_x; g.ldr = D; g.C = ws->enc_x; g.ldc = D;
+    set_split(g, ws, narrow_split);
     OAVSR_TRY(run_gemm(g, st));
     { ProfScope ps("layernorm", 0, 2.0 * rows * D * m->esz, st);
       OAVSR_TRY(launch_layernorm(dt, ws->enc_x, D, ws->enc_h, D, L.ln2w, L.ln2b, rows, D, 1e-5f, st)); }
@@ -364,6 +383,7 @@ static int run_encoder_layers(const oavsr_model* m, oavsr_workspace* ws, const s
     OAVSR_TRY(run_gemm(g, st));
     g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = D; g.K = ffn; g.A = ws->enc_ffn; g.lda = ffn; g.W = L.fc2w; g.ldw = ffn; g.col_bias = L.fc2b;
     g.residual = ws->enc_x; g.ldr = D; g.C = ws->enc_x; g.ldc = D;
+    set_split(g, ws, narrow_split);
     OAVSR_TRY(run_gemm(g, st));
   }
   return 0;
@@ -451,7 +471,7 @@ static int encode_video_impl(const oavsr_model* m, oavsr_workspace* ws, const fl
   g.Cin = Cg; g.A = ws->enc_h; g.lda = D; g.groups = G; g.a_goff = Cg; g.rowinfo = ws->rowinfo; g.W = m->vpos_w; g.ldw = g.K;
   g.col_bias = m->vpos_b; g.act = ACT_GELU; g.residual = ws->enc_h; g.ldr = D; g.res_after_act = 1; g.C = ws->enc_x; g.ldc = D;
   OAVSR_TRY(run_gemm(g, st));
-  OAVSR_TRY(run_encoder_layers(m, ws, m->vlayers, F, D, c.av_heads, c.av_ffn, c.av_lora_k2, ws->cu_a, B, maxT, st));
+  OAVSR_TRY(run_encoder_layers(m, ws, m->vlayers, F, D, c.av_heads, c.av_ffn, c.av_lora_k2, ws->cu_a, B, maxT, kVideoNarrowSplit, st));
   void* enc = ws->enc_out_v;
   { ProfScope ps("layernorm", 0, 2.0 * F * D * m->esz, st);
     OAVSR_TRY(launch_layernorm(dt, ws->enc_x, D, enc, D, m->vlnf_w, m->vlnf_b, F, D, 1e-5f, st)); }
@@ -500,7 +520,7 @@ static int encode_audio_impl(const oavsr_model* m, oavsr_workspace* ws, const fl
   g.A = ws->conv1_out; g.lda = D; g.rowinfo = ws->rowinfo2; g.W = m->aconv2_w; g.ldw = 3 * D; g.col_bias = m->aconv2_b; g.act = ACT_GELU;
   g.residual = ws->pos_rep; g.ldr = D; g.res_after_act = 1; g.C = ws->enc_x; g.ldc = D;
   OAVSR_TRY(run_gemm(g, st));
-  OAVSR_TRY(run_encoder_layers(m, ws, m->alayers, B * 1500, D, c.wh_heads, c.wh_ffn, 0, ws->cu_b, B, 1500, st));
+  OAVSR_TRY(run_encoder_layers(m, ws, m->alayers, B * 1500, D, c.wh_heads, c.wh_ffn, 0, ws->cu_b, B, 1500, 1, st));
   void* enc = ws->enc_out_a;
   { ProfScope ps("layernorm", 0, 2.0 * B * 1500 * D * m->esz, st);
     OAVSR_TRY(launch_layernorm(dt, ws->enc_x, D, enc, D, m->alnf_w, m->alnf_b, B * 1500, D, 1e-5f, st)); }
@@ -619,6 +639,7 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
       g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = c.lora_k2; g.K = d; g.A = hin; g.lda = d; g.W = L.lora_dn[tl]; g.ldw = d;
       g.C = ws->llora; g.ldc = c.lora_k2;
       if (fused_norm) { g.norm_gain = L.ln1w; g.norm_eps = c.llm_rms_eps; }
+      if (mode == 0) set_split(g, ws, lora_dn_split(d, (int)m->esz));
       OAVSR_TRY(llm_gemm(m, ws, g, mode, st));
     }
     g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = nqkv; g.K = d; g.A = hin; g.lda = d; g.W = L.qkvw; g.ldw = d; g.col_bias = L.qkvb;
@@ -949,7 +970,14 @@ int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, 
   WANT(amax, rows_dec * 4); WANT(amax_scratch, rows_dec * 64 * 8);
   WANT(gs.tok, rows_dec * 4); WANT(gs.finished, rows_dec * 4); WANT(gs.out_ids, rows_dec * (size_t)max_new * 4); WANT(gs.out_len, rows_dec * 4);
   WANT(gs.step, 256); WANT(gs.pos, rows_dec * 4); WANT(gs.cpos, rows_dec * 4);
-  if (rows_dec > 32) { ws->partial_bytes = (size_t)32 << 20; WANT(partial, ws->partial_bytes); }
+  {   // split-K partial slabs: decode GEMMs with > 32 rows, the narrow video-encoder projections, the LoRA down projections
+    size_t pb = rows_dec > 32 ? (size_t)32 << 20 : 0;
+    if (m->has_video) pb = std::max(pb, (size_t)kVideoNarrowSplit * F * Dv * 4);
+    if (m->has_video && c.av_lora_k2 > 0) pb = std::max(pb, (size_t)kLoraDnSplitMax * F * c.av_lora_k2 * 4);
+    if (c.lora_k2 > 0) pb = std::max(pb, (size_t)kLoraDnSplitMax * ST * c.lora_k2 * 4);
+    ws->partial_bytes = pb;
+    if (pb) WANT(partial, pb);
+  }
   if (max_beams > 1) {
     WANT(beam_scores, rows_dec * 4); WANT(cand_val, rows_dec * 2 * max_beams * 4); WANT(cand_tok, rows_dec * 2 * max_beams * 4);
     WANT(hyp_n, max_B * 4); WANT(hyp_len, rows_dec * 4); WANT(hyp_tok, rows_dec * (size_t)max_new * 4); WANT(hyp_score, rows_dec * 8);

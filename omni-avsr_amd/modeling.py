@@ -268,8 +268,8 @@ class OmniEngine:
         self.lib.oavsr_profile_reset()
 
     def profile_read(self) -> List[dict]:
-        arr = (L.OavsrProfEntry * 64)()
-        n = self.lib.oavsr_profile_read(arr, 64)
+        arr = (L.OavsrProfEntry * 256)()
+        n = self.lib.oavsr_profile_read(arr, 256)
         return [dict(name=arr[i].name.decode(), launches=int(arr[i].launches), ms=float(arr[i].ms), flops=float(arr[i].flops),
                      bytes=float(arr[i].bytes)) for i in range(max(n, 0))]
 

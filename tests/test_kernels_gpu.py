@@ -46,9 +46,11 @@ def test_gemm_dense(dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K,K2,S", [(120, 2048, 8192, 0, 16), (120, 3072, 2048, 256, 4), (45, 200, 384, 0, 5), (120, 256, 2048, 0, 8)])
+@pytest.mark.parametrize("M,N,K,K2,S", [(120, 2048, 8192, 0, 16), (120, 3072, 2048, 256, 4), (45, 200, 384, 0, 5), (120, 256, 2048, 0, 8),
+                                        (3200, 1024, 4096, 0, 2), (700, 96, 2048, 0, 8), (1000, 1024 + 24, 1024, 128, 3), (300, 128, 512, 0, 5)])
 def test_gemm_splitk(dtype, M, N, K, K2, S):
-    """Split-K (beam-search decode rows): fp32 partial slabs + deterministic reduce with the fused epilogue."""
+    """Split-K: fp32 partial slabs + deterministic reduce with the fused epilogue.  M <= 128 (beam-search decode rows) runs the
+    classic kernel, larger M (narrow encoder projections, LoRA down projections) the LDS-DMA kernel with the same k order."""
     a, ar = q(rnd(M, K, seed=1), dtype)
     w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
     r, rr = q(rnd(M, N, seed=5), dtype)
