@@ -400,8 +400,9 @@ __global__ __launch_bounds__(kThreads) void attn_dma_kernel(const AttnArgs p) {
 //     is written to the tail cache first and then read back like any other key (workgroup-scope visibility via the barrier)
 //   * the 4 waves split the 64-key tiles; K fragments go HBM -> VGPR directly (A operand), V tiles go through a per-wave
 //     LDS image for the transposed reads; per-wave (m, l, O^T) partials are merged through LDS at the end.
-template <typename T, int HD>
-__global__ __launch_bounds__(kThreads) void decode_attn_kernel(const DecodeAttnArgs p) {
+template <typename T, int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnArgs p) {
+  constexpr int kDecThreads = NW * 64;
   constexpr int RB = HD * (int)sizeof(T);
   constexpr int NCH = RB / 16;
   constexpr int SWZ = (RB == 128) ? 7 : 15;
@@ -410,7 +411,9 @@ __global__ __launch_bounds__(kThreads) void decode_attn_kernel(const DecodeAttnA
   constexpr int VEC = TypeInfo<T>::kVec;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sq = smem;                                   // [16][RB]  rotated queries (rows >= G are zero)
-  char* sv = smem + 16 * RB;                         // [4 waves][64][RB]  V tiles; reused for the merge
+  char* sknew = smem + 16 * RB;                      // [RB] rotated new key, [RB] new value (fused append only)
+  char* svnew = sknew + RB;
+  char* sv = svnew + RB;                             // [NW waves][64][RB]  V tiles; reused for the merge
   const int row = blockIdx.x, kvh = blockIdx.y;
   const int G = p.n_heads / p.n_kv_heads;
   const int utt = row / p.beams;
@@ -422,40 +425,8 @@ __global__ __launch_bounds__(kThreads) void decode_attn_kernel(const DecodeAttnA
   const T* qrow = reinterpret_cast<const T*>(p.Q) + (int64_t)row * p.ldq;
   T* Kt = reinterpret_cast<T*>(const_cast<void*>(p.Kt));
   T* Vt = reinterpret_cast<T*>(const_cast<void*>(p.Vt));
-
-  // ---- phase 0: queries (+ RoPE) into LDS; new k (+ RoPE) / v appended to the tail cache ----
-  for (int i = tid; i < 16 * HD; i += kThreads) reinterpret_cast<T*>(sq)[i] = from_f32<T>(0.f);
-  __syncthreads();
-  if (p.inv_freq) {
-    constexpr int half = HD / 2;
-    const float pos = (float)p.pos[row];
-    for (int i = tid; i < (G + 1) * half; i += kThreads) {
-      const int h = i / half, d = i - h * half;
-      float sn, cs;
-      sincosf(pos * p.inv_freq[d], &sn, &cs);
-      const T* src = h < G ? qrow + (int64_t)(kvh * G + h) * HD : qrow + (int64_t)(p.n_heads + kvh) * HD;
-      const float x0 = to_f32(src[d]), x1 = to_f32(src[d + half]);
-      const T r0 = from_f32<T>(x0 * cs - x1 * sn), r1 = from_f32<T>(x1 * cs + x0 * sn);
-      if (h < G) {
-        T* dst = reinterpret_cast<T*>(sq + h * RB);
-        // chunk-swizzled like the K/V tiles are NOT needed here: sq rows are read as B operand with row = lane&15
-        dst[d] = r0; dst[d + half] = r1;
-      } else {
-        T* kd = Kt + (((int64_t)row * p.n_kv_heads + kvh) * p.max_tail + p.cpos[row]) * HD;
-        kd[d] = r0; kd[d + half] = r1;
-      }
-    }
-    const T* vsrc = qrow + (int64_t)(p.n_heads + p.n_kv_heads + kvh) * HD;
-    T* vd = Vt + (((int64_t)row * p.n_kv_heads + kvh) * p.max_tail + p.cpos[row]) * HD;
-    for (int i = tid; i < HD; i += kThreads) vd[i] = vsrc[i];
-  } else {
-    for (int i = tid; i < G * HD; i += kThreads) reinterpret_cast<T*>(sq)[i] = qrow[(int64_t)kvh * G * HD + i];
-  }
-  __syncthreads();
-
-  Chunk16 qf[NBLK];
-#pragma unroll
-  for (int b = 0; b < NBLK; ++b) qf[b] = *reinterpret_cast<const Chunk16*>(sq + qi * RB + (b * 4 + g) * 16);
+  // fused append: the new token's key index; its K/V come from LDS (sknew/svnew), never from the just-written cache row
+  const int newkey = p.inv_freq ? plen + p.cpos[row] : -1;
 
   auto kv_row = [&](const void* pre, const void* tail, int j) -> const char* {
     if (j < plen) return reinterpret_cast<const char*>(pre) + (((int64_t)utt * p.n_kv_heads + kvh) * p.max_prefix + j) * RB;
@@ -463,6 +434,64 @@ __global__ __launch_bounds__(kThreads) void decode_attn_kernel(const DecodeAttnA
     const int src = p.anc ? p.anc[(int64_t)row * p.max_tail + t] : row;
     return reinterpret_cast<const char*>(tail) + (((int64_t)src * p.n_kv_heads + kvh) * p.max_tail + t) * RB;
   };
+  // K fragments straight from the cache (A operand row = key (lane & 15), 16-byte chunk blk*4 + g); V row of key kt0 + lane
+  auto load_tile = [&](int kt0, Chunk16 (&kf)[4][NBLK], Chunk16 (&vr)[NCH]) {
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int key = kt0 + kt * 16 + qi;
+      const char* kr = (key < ctx && key != newkey) ? kv_row(p.Kp, p.Kt, key) : nullptr;
+#pragma unroll
+      for (int b = 0; b < NBLK; ++b) {
+        if (kr) kf[kt][b] = *reinterpret_cast<const Chunk16*>(kr + (b * 4 + g) * 16);
+        else kf[kt][b].v = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+    const int key = kt0 + lane;
+    const char* vp = (key < ctx && key != newkey) ? kv_row(p.Vp, p.Vt, key) : nullptr;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if (vp) vr[c] = *reinterpret_cast<const Chunk16*>(vp + c * 16);
+      else vr[c].v = u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+
+  // ---- the first K/V tile of every wave is requested before anything else: its latency hides the RoPE phase ----
+  Chunk16 kf[4][NBLK], vr[NCH];
+  int kt0 = wave * 64;
+  if (kt0 < ctx) load_tile(kt0, kf, vr);
+
+  // ---- phase 0: queries (+ RoPE) into LDS; new k (+ RoPE) / v appended to the tail cache and kept in LDS ----
+  for (int i = tid + G * HD; i < 16 * HD; i += kDecThreads) reinterpret_cast<T*>(sq)[i] = from_f32<T>(0.f);   // rows >= G
+  if (p.inv_freq) {
+    constexpr int half = HD / 2;
+    const float pos = (float)p.pos[row];
+    for (int i = tid; i < (G + 1) * half; i += kDecThreads) {
+      const int h = i / half, d = i - h * half;
+      float sn, cs;
+      sincosf(pos * p.inv_freq[d], &sn, &cs);
+      const T* src = h < G ? qrow + (int64_t)(kvh * G + h) * HD : qrow + (int64_t)(p.n_heads + kvh) * HD;
+      const float x0 = to_f32(src[d]), x1 = to_f32(src[d + half]);
+      const T r0 = from_f32<T>(x0 * cs - x1 * sn), r1 = from_f32<T>(x1 * cs + x0 * sn);
+      if (h < G) {
+        T* dst = reinterpret_cast<T*>(sq + h * RB);     // sq rows are read as B operand with row = lane & 15: no swizzle
+        dst[d] = r0; dst[d + half] = r1;
+      } else {
+        T* kd = Kt + (((int64_t)row * p.n_kv_heads + kvh) * p.max_tail + p.cpos[row]) * HD;
+        kd[d] = r0; kd[d + half] = r1;
+        reinterpret_cast<T*>(sknew)[d] = r0; reinterpret_cast<T*>(sknew)[d + half] = r1;
+      }
+    }
+    const T* vsrc = qrow + (int64_t)(p.n_heads + p.n_kv_heads + kvh) * HD;
+    T* vd = Vt + (((int64_t)row * p.n_kv_heads + kvh) * p.max_tail + p.cpos[row]) * HD;
+    for (int i = tid; i < HD; i += kDecThreads) { const T v = vsrc[i]; vd[i] = v; reinterpret_cast<T*>(svnew)[i] = v; }
+  } else {
+    for (int i = tid; i < G * HD; i += kDecThreads) reinterpret_cast<T*>(sq)[i] = qrow[(int64_t)kvh * G * HD + i];
+  }
+  __syncthreads();
+
+  Chunk16 qf[NBLK];
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b) qf[b] = *reinterpret_cast<const Chunk16*>(sq + qi * RB + (b * 4 + g) * 16);
 
   const float sc = p.scale * 1.44269504088896340736f;
   f32x4 o[NDT];
@@ -471,31 +500,23 @@ __global__ __launch_bounds__(kThreads) void decode_attn_kernel(const DecodeAttnA
   float m_run = -INFINITY, l_run = 0.f;
   char* svw = sv + wave * (64 * RB);
 
-  for (int kt0 = wave * 64; kt0 < ctx; kt0 += 4 * 64) {
-    // K fragments straight from the cache: A operand row = key (lane & 15), 16-byte chunk (blk*4 + g)
-    Chunk16 kf[4][NBLK];
+  for (; kt0 < ctx; kt0 += NW * 64) {
+    if (kt0 != wave * 64) load_tile(kt0, kf, vr);         // later tiles (contexts longer than NW * 64 keys)
+    if (newkey >= kt0 && newkey < kt0 + 64) {             // wave-uniform: this tile holds the token being appended
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      const int key = kt0 + kt * 16 + qi;
-      const char* kr = key < ctx ? kv_row(p.Kp, p.Kt, key) : nullptr;
+      for (int kt = 0; kt < 4; ++kt)
+        if (kt0 + kt * 16 + qi == newkey) {
 #pragma unroll
-      for (int b = 0; b < NBLK; ++b) {
-        if (kr) kf[kt][b] = *reinterpret_cast<const Chunk16*>(kr + (b * 4 + g) * 16);
-        else kf[kt][b].v = u32x4{0u, 0u, 0u, 0u};
+          for (int b = 0; b < NBLK; ++b) kf[kt][b] = *reinterpret_cast<const Chunk16*>(sknew + (b * 4 + g) * 16);
+        }
+      if (kt0 + lane == newkey) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) vr[c] = *reinterpret_cast<const Chunk16*>(svnew + c * 16);
       }
     }
     // V tile -> this wave's LDS image (lane = key row)
-    {
-      const int key = kt0 + lane;
-      const char* vr = key < ctx ? kv_row(p.Vp, p.Vt, key) : nullptr;
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        Chunk16 cv;
-        if (vr) cv = *reinterpret_cast<const Chunk16*>(vr + c * 16);
-        else cv.v = u32x4{0u, 0u, 0u, 0u};
-        *reinterpret_cast<Chunk16*>(svw + lane * RB + ((c ^ (lane & SWZ)) << 4)) = cv;
-      }
-    }
+    for (int c = 0; c < NCH; ++c) *reinterpret_cast<Chunk16*>(svw + lane * RB + ((c ^ (lane & SWZ)) << 4)) = vr[c];
     f32x4 s[4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -565,13 +586,13 @@ __global__ __launch_bounds__(kThreads) void decode_attn_kernel(const DecodeAttnA
         }
     }
   }
-  // ---- merge the 4 waves: partials (m, l, O^T[d][q]) through LDS (reusing the V-tile region) ----
+  // ---- merge the NW waves: partials (m, l, O^T[d][q]) through LDS (reusing the V-tile region) ----
   l_run += __shfl_xor(l_run, 16, 64);
   l_run += __shfl_xor(l_run, 32, 64);
   __syncthreads();
-  float* sm = reinterpret_cast<float*>(sv);            // [4][16] m, [4][16] l, [4][HD][16] O^T
-  float* sl = sm + 64;
-  float* so = sl + 64;
+  float* sm = reinterpret_cast<float*>(sv);            // [NW][16] m, [NW][16] l, [NW][HD][16] O^T
+  float* sl = sm + NW * 16;
+  float* so = sl + NW * 16;
   if (g == 0) { sm[wave * 16 + qi] = m_run; sl[wave * 16 + qi] = l_run; }
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt)
@@ -579,13 +600,15 @@ __global__ __launch_bounds__(kThreads) void decode_attn_kernel(const DecodeAttnA
     for (int r = 0; r < 4; ++r) so[(wave * HD + dt * 16 + 4 * g + r) * 16 + qi] = o[dt][r];
   __syncthreads();
   T* O = reinterpret_cast<T*>(p.O) + (int64_t)row * p.ldo + (int64_t)kvh * G * HD;
-  for (int i = tid; i < G * HD; i += kThreads) {
+  for (int i = tid; i < G * HD; i += kDecThreads) {
     const int h = i / HD, d = i - h * HD;
-    float mstar = fmaxf(fmaxf(sm[h], sm[16 + h]), fmaxf(sm[32 + h], sm[48 + h]));
+    float mstar = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) mstar = fmaxf(mstar, sm[w * 16 + h]);
     if (mstar == -INFINITY) mstar = 0.f;
     float num = 0.f, den = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
       const float f = exp2f(sm[w * 16 + h] - mstar);
       num += f * so[(w * HD + d) * 16 + h];
       den += f * sl[w * 16 + h];
@@ -620,17 +643,18 @@ int launch_attn_dma(const AttnArgs& a, hipStream_t st) {
 template <typename T, int HD>
 int launch_dec_t(const DecodeAttnArgs& a, hipStream_t st) {
   constexpr int RB = HD * (int)sizeof(T);
-  constexpr size_t tiles = 4 * 64 * RB, merge = (128 + 4 * HD * 16) * 4;
-  constexpr size_t smem = 16 * RB + (tiles > merge ? tiles : merge);
+  constexpr int NW = (8 * 64 * RB <= 128 * 1024) ? 8 : 4;      // waves per workgroup: 8 x 64 keys in one pass when the V tiles fit
+  constexpr size_t tiles = (size_t)NW * 64 * RB, merge = (size_t)(2 * NW * 16 + NW * HD * 16) * 4;
+  constexpr size_t smem = 18 * RB + (tiles > merge ? tiles : merge);
   static_assert(smem <= 160 * 1024, "LDS");
-  auto kern = decode_attn_kernel<T, HD>;
+  auto kern = decode_attn_kernel<T, HD, NW>;
   static bool attr = false;
   if (!attr && smem > 48 * 1024) {
     OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr = true;
   }
   dim3 grid(a.rows, a.n_kv_heads);
-  hipLaunchKernelGGL(kern, grid, dim3(kThreads), smem, st, a);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, st, a);
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;
 }
