@@ -199,6 +199,11 @@ int oavsr_op_norm(int32_t mode, int32_t dtype, const void* x, int64_t ldx, void*
  * dtype with k = dt*49 + ky*7 + kx (245 valid); wp_scratch: 64*288 elements of the model dtype; out [F][22][22][64]. */
 int oavsr_op_stem_pool(int32_t dtype, const float* video, const int32_t* frameinfo_dev, int32_t F, const void* w, void* wp_scratch,
                        const float* scale, const float* shift, const float* slope, void* out, oavsr_stream stream);
+/* Image-resident 3x3 / stride 1 / pad 1 convolution, 64 -> 64 channels, NHWC bf16, H*W <= 512 (ResNet trunk layer1,
+ * resnet.py:61-74): out = prelu(scale * conv(x, w) + shift + residual); w [64][3*3*64] tap-major; slope NULL = no activation;
+ * residual may alias out. */
+int oavsr_op_conv3x3_c64(const void* x, int32_t imgs, int32_t H, int32_t W, const void* w, const float* scale, const float* shift,
+                         const float* slope, const void* residual, void* out, oavsr_stream stream);
 int oavsr_op_maxpool3x3s2(int32_t dtype, const void* x, void* y, int32_t imgs, int32_t H, int32_t W, int32_t C, oavsr_stream stream);
 int oavsr_op_avgpool_hw(int32_t dtype, const void* x, void* y, int32_t imgs, int32_t HW, int32_t C, oavsr_stream stream);
 int oavsr_op_time_compress(int32_t dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const int32_t* seg_dev, int32_t n_seqs,

@@ -55,6 +55,24 @@ template <> __device__ __forceinline__ Chunk16 chunk_from_f32<bf16_t>(const floa
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// GELU (erf form, torch.nn.functional.gelu default) of a value that will be rounded to T.
+//   f32 : libm erff (parity mode).
+//   bf16: erf by Abramowitz-Stegun 7.1.26 (|err| < 6.1e-7, 2^-9 of a bf16 ulp at |y| >= 2^-12): one rcp, one exp, six fma --
+//         a third of erff's instructions in every fc1 epilogue.  Every GEMM variant calls this one function, so an element
+//         has the same bits whichever kernel produced it.
+template <typename T> __device__ __forceinline__ float gelu_act(float x);
+template <> __device__ __forceinline__ float gelu_act<float>(float x) { return gelu_erf(x); }
+template <> __device__ __forceinline__ float gelu_act<bf16_t>(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float pl = fmaf(1.061405429f, t, -1.453152027f);
+  pl = fmaf(pl, t, 1.421413741f);
+  pl = fmaf(pl, t, -0.284496736f);
+  pl = fmaf(pl, t, 0.254829592f);
+  pl *= t;
+  const float e = 1.0f - pl * __expf(-z * z);                 // erf(|x| / sqrt 2)
+  return 0.5f * x * (1.0f + copysignf(e, x));
+}
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -1,0 +1,171 @@
+// Image-resident 3x3 convolution for the 64-channel stage of the visual ResNet trunk (layer1: four 64 -> 64 convs on
+// 22 x 22 maps; reference resnet.py:61-74 BasicBlock), gfx950, bf16.
+//
+// The implicit-GEMM path gathers every input pixel nine times (once per tap) through L2 -> LDS; here a whole NHWC image
+// (484 pixels x 128 B = 61 KB) plus the complete weight matrix (64 x 576 = 72 KB) live in LDS, so HBM/L2 see each input
+// byte once and the MFMA fragments are plain 16-byte LDS reads:
+//   * persistent workgroups (one per CU, 8 waves) load the weights once and walk images b, b + G, b + 2G, ...;
+//     the next image is prefetched into registers while the current one is computed;
+//   * a wave owns 4 pixel tiles (64 output pixels) and shares every weight fragment among them;
+//   * K runs tap-major then channels -- the same order as the implicit GEMM -- and the epilogue is the same
+//     fmaf(acc, scale, shift) (+ residual) -> PReLU, so the result is bit-identical to that path;
+//   * operands are swapped (weights = A, pixels = B) so a lane ends up with 4 consecutive channels of one pixel and
+//     residual / output move as 8-byte vectors.
+// LDS rows (128 B per pixel / per 64 weights) are XOR-swizzled by (row & 7) on their 16-byte chunks.
+#include "kernels.h"
+
+namespace oavsr {
+namespace {
+
+constexpr int kConvThreads = 512, kConvWaves = 8;
+constexpr int kC = 64;                         // channels in == channels out
+constexpr int kKW = 9 * kC;                    // 576
+
+__global__ __launch_bounds__(kConvThreads) void conv3x3_c64_kernel(const bf16_t* __restrict__ x, int imgs, int H, int W,
+                                                                   const bf16_t* __restrict__ w, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, const float* __restrict__ slope,
+                                                                   const bf16_t* residual, bf16_t* out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int HW = H * W;
+  char* simg = smem;                                          // [HW + 1][128 B]; pixel HW is all zero (padding taps)
+  char* sw = smem + (size_t)(HW + 1) * 128;                   // [64][1152 B]
+  float* spar = reinterpret_cast<float*>(sw + kC * kKW * 2);  // scale[64] shift[64] slope[64]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int nchunk = HW * 8;                                  // 16-byte chunks per image
+  constexpr int kPre = 8;                                     // prefetch registers: up to 8 chunks per thread (HW <= 512)
+
+  // ---- once per workgroup: weights, parameters, the zero pixel ----
+  for (int i = tid; i < kC * (kKW / 8); i += kConvThreads) {
+    const int n = i / (kKW / 8), c = i - n * (kKW / 8);
+    const Chunk16 v = *reinterpret_cast<const Chunk16*>(w + (size_t)n * kKW + c * 8);
+    *reinterpret_cast<Chunk16*>(sw + n * (kKW * 2) + (((c & ~7) | ((c ^ n) & 7)) << 4)) = v;
+  }
+  if (tid < 64) { spar[tid] = scale[tid]; spar[64 + tid] = shift[tid]; spar[128 + tid] = slope ? slope[tid] : 1.f; }
+  if (tid < 8) { Chunk16 z; z.v = u32x4{0u, 0u, 0u, 0u}; *reinterpret_cast<Chunk16*>(simg + (size_t)HW * 128 + tid * 16) = z; }
+
+  Chunk16 pre[kPre];
+  auto prefetch = [&](int img) {
+    const bf16_t* src = x + (size_t)img * HW * kC;
+#pragma unroll
+    for (int j = 0; j < kPre; ++j) {
+      const int i = tid + j * kConvThreads;
+      if (i < nchunk) pre[j] = *reinterpret_cast<const Chunk16*>(src + (size_t)i * 8);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < kPre; ++j) {
+      const int i = tid + j * kConvThreads;
+      if (i < nchunk) { const int p = i >> 3, c = i & 7; *reinterpret_cast<Chunk16*>(simg + p * 128 + ((c ^ (p & 7)) << 4)) = pre[j]; }
+    }
+  };
+
+  // the 4 pixel tiles of this wave: output pixel q = (wave*4 + i)*16 + r16
+  int qy[4], qx[4], qv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = (wave * 4 + i) * 16 + r16;
+    qv[i] = q < HW;
+    const int qq = qv[i] ? q : 0;
+    qy[i] = qq / W; qx[i] = qq - qy[i] * W;
+  }
+
+  int img = blockIdx.x;
+  if (img < imgs) prefetch(img);
+  for (; img < imgs; img += gridDim.x) {
+    __syncthreads();                                          // every wave is done with the previous image
+    commit();
+    __syncthreads();
+    if (img + (int)gridDim.x < imgs) prefetch(img + gridDim.x);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3 - 1, kx = tap % 3 - 1;
+      int pin[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int iy = qy[i] + ky, ix = qx[i] + kx;
+        pin[i] = (qv[i] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? iy * W + ix : HW;
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int c = kb * 4 + g;                             // 16-byte chunk of the 64 channels
+        Chunk16 wf[4], pf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = j * 16 + r16, wc = tap * 8 + c;
+          wf[j] = *reinterpret_cast<const Chunk16*>(sw + n * (kKW * 2) + (((wc & ~7) | ((wc ^ n) & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pf[i] = *reinterpret_cast<const Chunk16*>(simg + pin[i] * 128 + ((c ^ (pin[i] & 7)) << 4));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j].v), __builtin_bit_cast(bf16x8, pf[i].v),
+                                                                acc[i][j], 0, 0, 0);
+      }
+    }
+    // D[channel = 16j + 4g + r][pixel = r16]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (!qv[i]) continue;
+      const size_t o = ((size_t)img * HW + (size_t)(wave * 4 + i) * 16 + r16) * kC;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c0 = j * 16 + 4 * g;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(spar + c0);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(spar + 64 + c0);
+        const f32x4 sl = *reinterpret_cast<const f32x4*>(spar + 128 + c0);
+        float res[4] = {0.f, 0.f, 0.f, 0.f};
+        if (residual) {
+          const bf16x4 rv = *reinterpret_cast<const bf16x4*>(residual + o + c0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) res[r] = (float)rv[r];
+        }
+        bf16x4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = fmaf(acc[i][j][r], sc[r], sh[r]);
+          v += res[r];
+          if (slope) v = v >= 0.f ? v : sl[r] * v;
+          h[r] = (bf16_t)v;
+        }
+        *reinterpret_cast<bf16x4*>(out + o + c0) = h;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+bool conv3x3_c64_eligible(int dtype, int H, int W, int Cin, int Cout, int ks, int stride) {
+  return dtype == DT_BF16 && Cin == kC && Cout == kC && ks == 3 && stride == 1 && H * W <= 512 &&
+         (size_t)(H * W + 1) * 128 + kC * kKW * 2 + 768 <= 160 * 1024;
+}
+
+int launch_conv3x3_c64(const void* x, int imgs, int H, int W, const void* w, const float* scale, const float* shift, const float* slope,
+                       const void* residual, void* out, hipStream_t st) {
+  if (imgs <= 0) return 0;
+  const size_t smem = (size_t)(H * W + 1) * 128 + kC * kKW * 2 + 768;
+  static bool attr = false;
+  if (!attr) {
+    OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  static const int ncu = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
+  const int grid = imgs < ncu ? imgs : ncu;
+  hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(kConvThreads), smem, st, (const bf16_t*)x, imgs, H, W, (const bf16_t*)w, scale, shift,
+                     slope, (const bf16_t*)residual, (bf16_t*)out);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace oavsr

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
       float v = fmaf(y[e], (e_scale && in) ? e_scale[ngb + e] : 1.f, (e_bias && in) ? e_bias[ngb + e] : 0.f);
       if (!p.res_after_act) v += res[e];
       switch (e_act) {
-        case ACT_GELU: v = gelu_erf(v); break;
+        case ACT_GELU: v = gelu_act<T>(v); break;
         case ACT_RELU: v = fmaxf(v, 0.f); break;
         case ACT_PRELU: v = v >= 0.f ? v : (in ? p.prelu[ngb + e] : 0.f) * v; break;
         case ACT_SILU: v = silu(v); break;

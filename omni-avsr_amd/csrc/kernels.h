@@ -104,6 +104,11 @@ int launch_rmsnorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, 
 int launch_stem_repack(int dtype, const void* w, void* wp, hipStream_t st);
 int launch_stem_pool(int dtype, const float* video, const int2* frameinfo, int F, const void* wp, const float* scale, const float* shift,
                      const float* slope, void* out, hipStream_t st);
+// Image-resident 3x3 / stride 1 / pad 1 convolution, 64 -> 64 channels, NHWC bf16 (conv.hip): folded BN + residual + PReLU
+// (slope == nullptr: no activation).  Bit-identical to the implicit-GEMM path.
+bool conv3x3_c64_eligible(int dtype, int H, int W, int Cin, int Cout, int ks, int stride);
+int launch_conv3x3_c64(const void* x, int imgs, int H, int W, const void* w, const float* scale, const float* shift, const float* slope,
+                       const void* residual, void* out, hipStream_t st);
 // 3x3 stride-2 pad-1 max pool, NHWC
 int launch_maxpool3x3s2(int dtype, const void* x, void* y, int imgs, int H, int W, int C, hipStream_t st);
 // global average pool over HW, NHWC -> [imgs][C]

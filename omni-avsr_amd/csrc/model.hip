@@ -391,6 +391,11 @@ static int run_encoder_layers(const oavsr_model* m, oavsr_workspace* ws, const s
 
 static int conv2d_gemm(const oavsr_model* m, const void* x, int imgs, int H, int W, int Cin, int Cout, int ks, int stride, const ConvBN& c,
                        const void* residual, bool prelu, void* out, hipStream_t st) {
+  static const bool direct = [] { const char* e = getenv("OAVSR_CONV_DIRECT"); return !(e && e[0] == '0'); }();
+  if (direct && conv3x3_c64_eligible(m->dtype, H, W, Cin, Cout, ks, stride)) {
+    ProfScope ps("conv3x3_c64_bf16", 2.0 * imgs * H * W * 9.0 * Cin * Cout, 2.0 * imgs * H * W * (Cin + Cout * (residual ? 2 : 1)), st);
+    return launch_conv3x3_c64(x, imgs, H, W, c.w, c.scale, c.shift, prelu ? c.slope : nullptr, residual, out, st);
+  }
   GemmArgs g; g.dtype = m->dtype; g.amode = A_CONV2D; g.H = H; g.Wd = W; g.Cin = Cin; g.ksize = ks; g.stride = stride; g.pad = ks / 2;
   g.OH = (H + 2 * g.pad - ks) / stride + 1; g.OW = (W + 2 * g.pad - ks) / stride + 1;
   g.M = imgs * g.OH * g.OW; g.N = Cout; g.K = ks * ks * Cin; g.A = x; g.W = c.w; g.ldw = g.K;
@@ -1135,6 +1140,13 @@ int oavsr_op_stem_pool(int32_t dtype, const float* video, const int32_t* framein
   OAVSR_REQUIRE(w && wp_scratch, "op_stem_pool: null weights");
   OAVSR_TRY(launch_stem_repack(dtype, w, wp_scratch, (hipStream_t)stream));
   return launch_stem_pool(dtype, video, (const int2*)frameinfo_dev, F, wp_scratch, scale, shift, slope, out, (hipStream_t)stream);
+}
+
+int oavsr_op_conv3x3_c64(const void* x, int32_t imgs, int32_t H, int32_t W, const void* w, const float* scale, const float* shift,
+                         const float* slope, const void* residual, void* out, oavsr_stream stream) {
+  OAVSR_REQUIRE(x && w && scale && shift && out, "op_conv3x3_c64: null argument");
+  OAVSR_REQUIRE(conv3x3_c64_eligible(DT_BF16, H, W, 64, 64, 3, 1), "op_conv3x3_c64: %dx%d image does not fit", H, W);
+  return launch_conv3x3_c64(x, imgs, H, W, w, scale, shift, slope, residual, out, (hipStream_t)stream);
 }
 
 int oavsr_op_attention(const oavsr_attn_desc* d, oavsr_stream stream) {

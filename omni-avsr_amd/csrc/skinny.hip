@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kThreads) void skinny_kernel(const GemmArgs p) {
     float res = first ? pre_res : (R ? to_f32(R[(int64_t)m * p.ldr + n]) : 0.f);
     if (!p.res_after_act) y += res;
     switch (p.act) {
-      case ACT_GELU: y = gelu_erf(y); break;
+      case ACT_GELU: y = gelu_act<T>(y); break;
       case ACT_RELU: y = fmaxf(y, 0.f); break;
       case ACT_PRELU: y = y >= 0.f ? y : p.prelu[n] * y; break;
       case ACT_SILU: y = silu(y); break;

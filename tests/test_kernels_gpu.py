@@ -254,6 +254,38 @@ def test_conv2d_implicit_gemm(dtype, Cin, Cout, H, stride, ks):
     close(out.reshape(imgs, OH, OH, Cout), ref.permute(0, 2, 3, 1), tol(dtype), what="conv2d")
 
 
+@pytest.mark.parametrize("imgs,H,with_res,with_prelu", [(7, 22, True, True), (300, 22, False, True), (3, 13, True, False), (1, 22, False, False)])
+def test_conv3x3_c64_image_resident(imgs, H, with_res, with_prelu):
+    """conv.hip: image + weights resident in LDS; must equal the implicit-GEMM path bit for bit (same k order, same epilogue)
+    and match torch conv2d + BN + residual + PReLU; residual aliasing the output is the trunk's in-place update."""
+    dtype = "bf16"
+    x = rnd(imgs, 64, H, H, seed=1)
+    w = rnd(64, 64, 3, 3, seed=2) / math.sqrt(576)
+    xd, xr = q(x.permute(0, 2, 3, 1).contiguous(), dtype)
+    wd, wr = q(w.permute(0, 2, 3, 1).reshape(64, -1), dtype)
+    scale, shift, slope = rnd(64, seed=3) * 0.1 + 1, rnd(64, seed=4) * 0.1, rnd(64, seed=5) * 0.05 + 0.25
+    res, resr = q(rnd(imgs * H * H, 64, seed=6), dtype)
+    sc, sh, sl = scale.to(DEV), shift.to(DEV), slope.to(DEV)
+    kw = dict(scale=sc, bias=sh)
+    if with_prelu:
+        kw.update(prelu=sl, act=3)
+    if with_res:
+        kw.update(residual=res)
+    want = gemm(dtype, xd, wd, M=imgs * H * H, amode=1, H=H, W_=H, Cin=64, OH=H, OW=H, stride=1, pad=1, ksize=3, lda=0, **kw)
+    out = res.clone() if with_res else torch.empty(imgs * H * H, 64, dtype=tdt(dtype), device=DEV)      # residual aliases the output
+    L.check(L.load().oavsr_op_conv3x3_c64(P(xd), imgs, H, H, P(wd), P(sc), P(sh), P(sl) if with_prelu else None,
+                                          P(out) if with_res else None, P(out), stream()))
+    assert torch.equal(out, want), f"direct conv differs from implicit GEMM: max {(out.float() - want.float()).abs().max().item():.3e}"
+    y = F.conv2d(xr.permute(0, 3, 1, 2), wr.reshape(64, 3, 3, 64).permute(0, 3, 1, 2), padding=1)
+    y = y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    y = y.permute(0, 2, 3, 1).reshape(imgs * H * H, 64)
+    if with_res:
+        y = y + resr
+    if with_prelu:
+        y = torch.where(y >= 0, y, slope.view(1, -1) * y)
+    close(out, y, tol(dtype) * 2, what="direct conv")
+
+
 def _rowinfo(cu_out, cu_in, stride):
     lib = L.load()
     n = len(cu_out) - 1
