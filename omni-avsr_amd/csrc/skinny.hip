@@ -44,7 +44,7 @@ template <> struct MmaS<float> {
 };
 
 template <typename T, int MT, int NT, bool NORM, int U, bool HALF>
-__global__ __launch_bounds__(kThreads) void skinny_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(kThreads, (MT == 1 && U * NT <= 8) ? 4 : 2) void skinny_kernel(const GemmArgs p) {
   static_assert(!HALF || MT == 1, "HALF mode: at most 8 rows");
   constexpr int KBE = 64 / (int)sizeof(T);       // elements per 64-byte k block
   constexpr int VEC = TypeInfo<T>::kVec;
@@ -93,7 +93,6 @@ __global__ __launch_bounds__(kThreads) void skinny_kernel(const GemmArgs p) {
   const int nsteps = HALF ? (nkb + 1) / 2 : nkb;
   for (int kb0 = wave; kb0 < nsteps; kb0 += kWaves * U) {
     Chunk16 bf[U][NT], af[U][MT];
-    f32x4 gn4[NORM ? U : 1][VEC / 4];               // norm gain of the k block, fetched with the operands (not after them)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int kb = HALF ? 2 * (kb0 + kWaves * u) + hi : kb0 + kWaves * u;
@@ -114,21 +113,17 @@ __global__ __launch_bounds__(kThreads) void skinny_kernel(const GemmArgs p) {
         const int m = i * 16 + rw;
         af[u][i] = (in && m < p.M) ? *reinterpret_cast<const Chunk16*>(Ab + (int64_t)m * lda + k) : zchunk();
       }
-      if (NORM) {
-#pragma unroll
-        for (int e = 0; e < VEC / 4; ++e)
-          gn4[u][e] = (in && s1) ? *reinterpret_cast<const f32x4*>(p.norm_gain + k + e * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int kb = HALF ? 2 * (kb0 + kWaves * u) + hi : kb0 + kWaves * u;
       const bool s1 = (HALF ? 2 * (kb0 + kWaves * u) : kb) < nkb1;      // wave-uniform
       if (NORM && s1 && kb < nkb) {
+        const int k = kb * KBE + g * VEC;
         float gn[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; e += 4) {
-          f32x4 t = gn4[u][e / 4];
+          f32x4 t = *reinterpret_cast<const f32x4*>(p.norm_gain + k + e);
           gn[e] = t[0]; gn[e + 1] = t[1]; gn[e + 2] = t[2]; gn[e + 3] = t[3];
         }
 #pragma unroll
@@ -249,19 +244,20 @@ static bool half_enabled() {
 
 template <typename T, int MT, int NT, bool NORM>
 int launch_sk(const GemmArgs& a, hipStream_t st) {
-  constexpr int U0 = (NT >= 4) ? 4 : 8;
+  constexpr int U0 = MT >= 8 ? 2 : MT >= 4 ? 4 : 8 / NT;                // weight loads in flight per wave: U0 * NT KiB; sized for <= 128 VGPRs (2 workgroups per CU)
   constexpr int kbe = 64 / (int)sizeof(T);
   if constexpr (MT == 1 && (NT == 1 || NT == 4)) {
     // B <= 8 rows: 8-column MFMA tiles (HALF mode).  NT = 1: doubles the grid where 16-column tiles leave CUs idle;
     // NT = 4 (gate/up, lm_head): same 256+ workgroups x 32 columns, but every wave load is 8 rows x one whole 128-B line.
     const bool want = NT == 1 ? (a.N >= 64 && a.N / 16 < 384) : true;
     if (half_enabled() && want && a.M <= 8 && a.N % (NT == 1 ? 8 : 32) == 0 && (a.K / kbe) % 2 == 0) {
-      if (NT == 1 && (a.K + a.K2) * (int)sizeof(T) >= 128 * kWaves * 16) return launch_sk_u<T, 1, NT, NORM, 16, true>(a, st);
       return launch_sk_u<T, 1, NT, NORM, U0, true>(a, st);
     }
   }
   // deep K with few column tiles (down_proj): keep twice as many weight loads in flight per wave
-  if (MT == 1 && NT == 1 && (a.K + a.K2) * (int)sizeof(T) >= 64 * kWaves * 16) return launch_sk_u<T, MT, NT, NORM, 16>(a, st);
+  if constexpr (MT == 1 && NT == 1) {
+    if ((a.K + a.K2) * (int)sizeof(T) >= 64 * kWaves * 16) return launch_sk_u<T, MT, NT, NORM, 16>(a, st);
+  }
   return launch_sk_u<T, MT, NT, NORM, U0>(a, st);
 }
 
