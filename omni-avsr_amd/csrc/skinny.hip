@@ -54,6 +54,8 @@ __global__ __launch_bounds__(kThreads, (MT == 1 && U * NT <= 8) ? 4 : 2) void sk
   float* sred = reinterpret_cast<float*>(smem);   // [8][MR][NC]
   float* sred2 = sred + kWaves * MR * NC;         // [8][MR][NC]   (NORM && K2)
   float* sssq = sred2 + (NORM ? kWaves * MR * NC : 0);   // [8][MR]
+  float* sgain = sssq + (NORM ? kWaves * MR : 0);        // [K]  norm gain, staged once per workgroup (small tiles only)
+  constexpr bool GAIN_LDS = NORM && (kWaves * MR * NC * 8 + kWaves * MR * 4) <= 96 * 1024;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, g = lane >> 4;
   const int hi = HALF ? (r16 >> 3) : 0, rw = HALF ? (r16 & 7) : r16;   // k-block parity, row within the operand tile
@@ -77,6 +79,11 @@ __global__ __launch_bounds__(kThreads, (MT == 1 && U * NT <= 8) ? 4 : 2) void sk
     }
   }
 
+  if (GAIN_LDS) {                                        // K floats, 16 B per thread and trip; read back after the first barrier-free
+    for (int i = tid * 4; i < p.K; i += kThreads * 4)   // use is safe: every wave waits on its own operands, then on this barrier
+      *reinterpret_cast<f32x4*>(sgain + i) = *reinterpret_cast<const f32x4*>(p.norm_gain + i);
+    __syncthreads();
+  }
   // epilogue operands of this thread's first output element are fetched now, under the weight stream
   constexpr int OR = HALF ? 8 : MR, OC = NT * TW;         // output tile of the workgroup
   const T* R = reinterpret_cast<const T*>(p.residual);
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(kThreads, (MT == 1 && U * NT <= 8) ? 4 : 2) void sk
         float gn[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; e += 4) {
-          f32x4 t = *reinterpret_cast<const f32x4*>(p.norm_gain + k + e);
+          f32x4 t = *reinterpret_cast<const f32x4*>((GAIN_LDS ? sgain : p.norm_gain) + k + e);
           gn[e] = t[0]; gn[e + 1] = t[1]; gn[e + 2] = t[2]; gn[e + 3] = t[3];
         }
 #pragma unroll
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(kThreads, (MT == 1 && U * NT <= 8) ? 4 : 2) void sk
       for (int r = 0; r < 4; ++r) {
         const int o = (wave * MR + i * 16 + g * 4 + r) * NC + j * 16 + r16;
         sred[o] = acc[i][j][r];
-        if (NORM) sred2[o] = acc2[i][j][r];
+        if (NORM && p.K2) sred2[o] = acc2[i][j][r];
       }
   if (NORM) {
 #pragma unroll
@@ -177,8 +184,15 @@ __global__ __launch_bounds__(kThreads, (MT == 1 && U * NT <= 8) ? 4 : 2) void sk
       float s = 0.f, y2 = 0.f;
 #pragma unroll
       for (int w = 0; w < kWaves; ++w) {
-        s += sssq[w * MR + m]; y2 += sred2[(w * MR + m) * NC + lc];
-        if (HALF) { s += sssq[w * MR + m + 8]; y2 += sred2[(w * MR + m + 8) * NC + lc + 8]; }
+        s += sssq[w * MR + m];
+        if (HALF) s += sssq[w * MR + m + 8];
+      }
+      if (p.K2) {
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+          y2 += sred2[(w * MR + m) * NC + lc];
+          if (HALF) y2 += sred2[(w * MR + m + 8) * NC + lc + 8];
+        }
       }
       y = y * rsqrtf(s / (float)p.K + p.norm_eps) + y2;
     }
@@ -224,12 +238,15 @@ __global__ __launch_bounds__(kThreads, (MT == 1 && U * NT <= 8) ? 4 : 2) void sk
 
 template <typename T, int MT, int NT, bool NORM, int U, bool HALF = false>
 int launch_sk_u(const GemmArgs& a, hipStream_t st) {
-  constexpr int smem = kWaves * MT * 16 * NT * 16 * 4 * (NORM ? 2 : 1) + (NORM ? kWaves * MT * 16 * 4 : 0);
-  static_assert(smem <= 160 * 1024, "LDS");
+  constexpr int smem0 = kWaves * MT * 16 * NT * 16 * 4 * (NORM ? 2 : 1) + (NORM ? kWaves * MT * 16 * 4 : 0);
+  static_assert(smem0 <= 160 * 1024, "LDS");
+  constexpr bool gain_lds = NORM && smem0 <= 96 * 1024;
+  const int smem = smem0 + (gain_lds ? a.K * 4 : 0);   // + the staged norm gain
+  OAVSR_REQUIRE(smem <= 160 * 1024, "skinny gemm: K=%d too deep for the fused RMSNorm prologue", a.K);
   auto kern = skinny_kernel<T, MT, NT, NORM, U, HALF>;
   static bool attr_set = false;
-  if (!attr_set && smem > 48 * 1024) {
-    OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  if (!attr_set) {
+    OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(ceil_div(a.N, NT * (HALF ? 8 : 16))), dim3(kThreads), smem, st, a);

@@ -107,6 +107,15 @@ int main() {
     const int Kb = 4096;   // K = 2048 bf16
     auto rep2 = [&](const char* name, int rows_per_wg, float ms) { int grid = (int)(total / Kb / rows_per_wg); printf("%-44s grid %5d: %8.1f us  %7.0f GB/s\n", name, grid, ms * 1e3, (double)grid * rows_per_wg * Kb / ms / 1e6); };
 #define SK(NTT, U, NTF, H) rep2("skinny-pattern NT=" #NTT " U=" #U " nt=" #NTF " half=" #H, NTT * (H ? 8 : 16), timeit([&] { int grid = (int)(total / Kb / (NTT * (H ? 8 : 16))); hipLaunchKernelGGL((skinny_pattern<NTT, U, NTF, H>), dim3(grid), dim3(512), 0, 0, buf, Kb, sink); }, 5));
+    // single-round launches of one gate/up-sized matrix (67 MB), as the decode step issues them
+    { const size_t one = (size_t)16384 * Kb;
+      auto rep3 = [&](const char* name, float ms) { printf("%-44s one 67 MB matrix: %8.1f us  %7.0f GB/s\n", name, ms * 1e3, one / ms / 1e6); };
+      int it = 0;
+      rep3("single round NT=4 U=2 half (512 WGs)", timeit([&] { hipLaunchKernelGGL((skinny_pattern<4, 2, true, true>), dim3(512), dim3(512), 0, 0, buf + (size_t)(it++ % 24) * one, Kb, sink); }, 48));
+      rep3("single round NT=4 U=4 half (512 WGs)", timeit([&] { hipLaunchKernelGGL((skinny_pattern<4, 4, true, true>), dim3(512), dim3(512), 0, 0, buf + (size_t)(it++ % 24) * one, Kb, sink); }, 48));
+      rep3("single round NT=2 U=4 half (1024 WGs)", timeit([&] { hipLaunchKernelGGL((skinny_pattern<2, 4, true, true>), dim3(1024), dim3(512), 0, 0, buf + (size_t)(it++ % 24) * one, Kb, sink); }, 48));
+      rep3("single round NT=4 U=4 (256 WGs)", timeit([&] { hipLaunchKernelGGL((skinny_pattern<4, 4, true, false>), dim3(256), dim3(512), 0, 0, buf + (size_t)(it++ % 24) * one, Kb, sink); }, 48));
+    }
     SK(4, 4, true, false) SK(4, 4, false, false) SK(4, 8, true, false) SK(1, 8, true, false) SK(4, 4, true, true) SK(1, 8, true, true) SK(8, 4, true, false)
   }
   return 0;
