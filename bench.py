@@ -65,6 +65,20 @@ def cpu_baseline(spec, sd_cpu, Tv, max_new):
                 sample=f"1 utterance of the same workload (16 s clip, greedy, {max_new} tokens) in {dt:.1f} s, torch CPU fp32")
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic_*.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate runs, gfx950 read-side correction applied; counters cannot be read from inside this process)."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic_*.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("kernel") == kernel:
+            return d.get("traffic_bytes_per_launch")
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,17 +173,18 @@ def main():
                                    tflops=round(e["flops"] / e["ms"] / 1e9, 1) if e["ms"] > 0 and e["flops"] > 0 else None,
                                    gbs=round(e["bytes"] / e["ms"] / 1e6, 1) if e["ms"] > 0 else None) for e in sorted(ents, key=lambda e: -e["ms"])}
         dom = max(ents, key=lambda e: e["ms"])
+        traffic = pmc_traffic(dom["name"])
         is_mfma = dom["flops"] > 0 and (("gemm" in dom["name"] and "skinny" not in dom["name"] and "splitk" not in dom["name"]) or dom["name"].startswith("attention_"))
         if is_mfma:
             ach = dom["flops"] / dom["ms"] / 1e9
             peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
             roofline = dict(bound="mfma", kernel=dom["name"], achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
-                            traffic=None, avg_launch_ms=round(dom["ms"] / dom["launches"], 4), launches=dom["launches"],
+                            traffic=traffic, avg_launch_ms=round(dom["ms"] / dom["launches"], 4), launches=dom["launches"],
                             share_of_step=round(dom["ms"] / tot_ms, 3))
         else:
             ach = dom["bytes"] / dom["ms"] / 1e6
             roofline = dict(bound="hbm", kernel=dom["name"], achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                            traffic=None, avg_launch_ms=round(dom["ms"] / dom["launches"], 4), launches=dom["launches"],
+                            traffic=traffic, avg_launch_ms=round(dom["ms"] / dom["launches"], 4), launches=dom["launches"],
                             share_of_step=round(dom["ms"] / tot_ms, 3))
 
     cpu = None

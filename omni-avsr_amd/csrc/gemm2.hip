@@ -105,7 +105,11 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
   const int nwg = gridDim.x;
   const int xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-  const int mt = bid / ntn, nt_ = bid - mt * ntn;
+  // An XCD's contiguous range covers whole M-tile rows (A panel read once, W by every XCD) or, when M < N, whole N-tile
+  // columns (W slice read once, A by every XCD): memory-side reads are A + 8 W vs 8 A + W bytes.
+  const int ntm = (p.M + BM - 1) / BM;
+  const bool nmajor = p.M < p.N;
+  const int mt = nmajor ? bid % ntm : bid / ntn, nt_ = nmajor ? bid / ntm : bid - (bid / ntn) * ntn;
   const int m0 = mt * BM, n0 = nt_ * BN;
   const int g = blockIdx.z;
 
