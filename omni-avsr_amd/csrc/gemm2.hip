@@ -76,6 +76,23 @@ __device__ __forceinline__ const void* a_src(const GemmArgs& p, const ARow2& r, 
   return A + (r.base + d) * p.lda + (int64_t)g * p.a_goff + c;
 }
 
+// conv2d / conv1d with C_in a multiple of the k-tile: the whole k-tile lies inside ONE tap, so (ky, kx) / the time offset are
+// wave-uniform scalars computed once per k-tile (kt0 = first element of the k-tile, kc = this lane's offset inside it)
+template <typename T, int AMODE>
+__device__ __forceinline__ const void* a_src_tap(const GemmArgs& p, const ARow2& r, int tap, int c, int g) {
+  const T* A = reinterpret_cast<const T*>(p.A);
+  if (!r.valid) return g_zero_page;
+  if (AMODE == A_CONV2D) {
+    const int ky = tap / p.ksize, kx = tap - ky * p.ksize;           // scalar
+    const int iy = r.a + ky, ix = r.b + kx;
+    if ((unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.Wd) return g_zero_page;
+    return A + r.base + ((int64_t)iy * p.Wd + ix) * p.Cin + c;
+  }
+  const int d = tap - p.pad, tt = r.a + d;
+  if (tap >= p.taps || (unsigned)tt >= (unsigned)r.b) return g_zero_page;
+  return A + (r.base + d) * p.lda + (int64_t)g * p.a_goff + c;
+}
+
 __device__ __forceinline__ void dma16(const void* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -137,13 +154,20 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
   const int tbeg = split ? (int)blockIdx.y * per : 0;
   const int ntot = split ? (tbeg + per < nall ? per : (nall - tbeg > 0 ? nall - tbeg : 0)) : nall;
 
+  const bool tap_uniform = AMODE != A_DENSE && p.Cin % BKE == 0;
   auto issue = [&](int tl) {
     char* st = smem + (tl % kStages) * kStageBytes;
     const int t = tbeg + tl;
     if (t < nt1) {
       const int k = t * BKE + lchunk * VEC;
+      if ((AMODE == A_CONV2D || AMODE == A_CONV1D) && tap_uniform) {
+        const int kt0 = t * BKE, tap = kt0 / p.Cin, c = kt0 - tap * p.Cin + lchunk * VEC;   // tap: scalar division, once per k-tile
 #pragma unroll
-      for (int j = 0; j < NLA; ++j) dma16(a_src<T, AMODE>(p, arow[j], k, g), st + (j * NWAVES + wave) * 1024);
+        for (int j = 0; j < NLA; ++j) dma16(a_src_tap<T, AMODE>(p, arow[j], tap, c, g), st + (j * NWAVES + wave) * 1024);
+      } else {
+#pragma unroll
+        for (int j = 0; j < NLA; ++j) dma16(a_src<T, AMODE>(p, arow[j], k, g), st + (j * NWAVES + wave) * 1024);
+      }
 #pragma unroll
       for (int j = 0; j < NLD - NLA; ++j)
         dma16(wvalid[j] ? (const void*)(W1 + wbase[j] * p.ldw + k) : (const void*)g_zero_page, st + ((j + NLA) * NWAVES + wave) * 1024);
