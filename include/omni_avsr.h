@@ -204,6 +204,11 @@ int oavsr_op_stem_pool(int32_t dtype, const float* video, const int32_t* framein
  * residual may alias out. */
 int oavsr_op_conv3x3_c64(const void* x, int32_t imgs, int32_t H, int32_t W, const void* w, const float* scale, const float* shift,
                          const float* slope, const void* residual, void* out, oavsr_stream stream);
+/* Row-wise candidates of one HF beam-search step (`_beam_search`: log_softmax + beam score, top 2K per row, ties by lower
+ * token id): cand_val / cand_tok [rows][2K], sorted.  need_exact: rows int32 of scratch for the certified fast path
+ * (NULL = exact radix-select kernel only). */
+int oavsr_op_beam_topk(const float* logits, int64_t ld, int32_t rows, int32_t V, int32_t K, const float* beam_scores, float* cand_val,
+                       int32_t* cand_tok, int32_t* need_exact, oavsr_stream stream);
 int oavsr_op_maxpool3x3s2(int32_t dtype, const void* x, void* y, int32_t imgs, int32_t H, int32_t W, int32_t C, oavsr_stream stream);
 int oavsr_op_avgpool_hw(int32_t dtype, const void* x, void* y, int32_t imgs, int32_t HW, int32_t C, oavsr_stream stream);
 int oavsr_op_time_compress(int32_t dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const int32_t* seg_dev, int32_t n_seqs,

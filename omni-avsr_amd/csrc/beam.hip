@@ -11,6 +11,7 @@
 //                      KV ancestry table (beam b's tail position t lives in row anc[b][t]; no KV bytes are moved)
 //   beam_finalize_kernel  open beams are added, best hypothesis per utterance is written (EOS appended when there is room)
 // Hypothesis scores are kept in fp64 exactly like the Python floats of the reference implementation.
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace oavsr {
@@ -48,9 +49,10 @@ __device__ int pick_bin(const int* hist, int nbins, int& need, int* s_scratch) {
   return d;
 }
 
-__global__ __launch_bounds__(kTopkThreads) void beam_topk_kernel(const float* __restrict__ logits, int64_t ld, int V, int twoK,
-                                                                  const float* __restrict__ beam_scores, float* __restrict__ cand_val,
-                                                                  int* __restrict__ cand_tok) {
+__global__ __launch_bounds__(kTopkThreads) void beam_topk_exact_kernel(const float* __restrict__ logits, int64_t ld, int V, int twoK,
+                                                                        const float* __restrict__ beam_scores, float* __restrict__ cand_val,
+                                                                        int* __restrict__ cand_tok, const int* __restrict__ need_exact) {
+  if (need_exact && !need_exact[blockIdx.x]) return;     // fallback of beam_topk_fast_kernel: only rows it could not certify
   __shared__ int hist[2048];
   __shared__ float red[kTopkThreads / 64 * 2];
   __shared__ int scratch[4];
@@ -138,6 +140,131 @@ __global__ __launch_bounds__(kTopkThreads) void beam_topk_kernel(const float* __
     for (int j = 0; j < n; ++j) rank += (sel_key[j] > k) || (sel_key[j] == k && sel_idx[j] < idx);
     cand_val[(int64_t)row * twoK + rank] = ((val_of(k) - m) - logz) + bs;
     cand_tok[(int64_t)row * twoK + rank] = idx;
+  }
+}
+
+// ---- fast path of the row top-2K (same outputs, bit for bit): no histogram atomics ----
+// Sweep 1 keeps, per thread, the kTopT best of its strided elements in registers plus the best element it had to drop; sweep 2 is
+// the same sum of exp as the exact kernel (same element -> thread mapping, same reduction order => identical logZ bits).  The
+// 1024 x kTopT survivors are reduced to the top 2K by max-extraction (per wave, then one wave over the 16 x 2K finalists), with
+// the tie rule (value desc, index asc).  A row is CERTIFIED exact when no thread dropped an element that beats the 2K-th
+// survivor; otherwise need_exact[row] is set and beam_topk_exact_kernel redoes the row (probability ~ C(2K, T+1) / 1024^T).
+constexpr int kTopT = 6;
+
+struct Cand { float v; int i; };
+__device__ __forceinline__ bool beats(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
+
+__global__ __launch_bounds__(kTopkThreads) void beam_topk_fast_kernel(const float* __restrict__ logits, int64_t ld, int V, int twoK,
+                                                                       const float* __restrict__ beam_scores, float* __restrict__ cand_val,
+                                                                       int* __restrict__ cand_tok, int* __restrict__ need_exact) {
+  constexpr int NW = kTopkThreads / 64;
+  __shared__ float red[NW];
+  __shared__ float fin_v[NW * kMax2K];
+  __shared__ int fin_i[NW * kMax2K];
+  __shared__ float sel_v[kMax2K];
+  __shared__ int sel_i[kMax2K];
+  __shared__ int s_bad;
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* x = logits + (int64_t)row * ld;
+  if (tid == 0) s_bad = 0;
+  // ---- sweep 1: max + local top-T (sorted descending) + best dropped element ----
+  float tv[kTopT]; int tix[kTopT];
+#pragma unroll
+  for (int k = 0; k < kTopT; ++k) { tv[k] = -INFINITY; tix[k] = 0x7fffffff; }
+  float dv = -INFINITY; int di = 0x7fffffff;     // best dropped
+  float m = -INFINITY;
+  auto consider = [&](float v, int i) {
+    m = fmaxf(m, v);
+    if (beats(v, i, tv[kTopT - 1], tix[kTopT - 1])) {
+      // the current last is dropped (if it was a real element)
+      if (tix[kTopT - 1] != 0x7fffffff && beats(tv[kTopT - 1], tix[kTopT - 1], dv, di)) { dv = tv[kTopT - 1]; di = tix[kTopT - 1]; }
+      tv[kTopT - 1] = v; tix[kTopT - 1] = i;
+#pragma unroll
+      for (int k = kTopT - 1; k > 0; --k) {
+        if (beats(tv[k], tix[k], tv[k - 1], tix[k - 1])) {
+          const float fv = tv[k]; tv[k] = tv[k - 1]; tv[k - 1] = fv;
+          const int fi = tix[k]; tix[k] = tix[k - 1]; tix[k - 1] = fi;
+        }
+      }
+    } else if (beats(v, i, dv, di)) { dv = v; di = i; }
+  };
+  constexpr int UL = 16;                          // loads in flight per thread (the row is streamed from HBM / L2)
+  for (int i0 = tid; i0 < V; i0 += kTopkThreads * UL) {
+    float buf[UL];
+#pragma unroll
+    for (int u = 0; u < UL; ++u) { const int i = i0 + u * kTopkThreads; buf[u] = i < V ? x[i] : -INFINITY; }
+#pragma unroll
+    for (int u = 0; u < UL; ++u) { const int i = i0 + u * kTopkThreads; if (i < V) consider(buf[u], i); }
+  }
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = red[0];
+  for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w]);
+  __syncthreads();
+  // ---- sweep 2: sum of exp, identical order to the exact kernel ----
+  float s = 0.f;
+  for (int i0 = tid; i0 < V; i0 += kTopkThreads * UL) {    // same element order per thread as the exact kernel
+    float buf[UL];
+#pragma unroll
+    for (int u = 0; u < UL; ++u) { const int i = i0 + u * kTopkThreads; buf[u] = i < V ? x[i] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < UL; ++u) { const int i = i0 + u * kTopkThreads; if (i < V) s += expf(buf[u] - m); }
+  }
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  s = 0.f;
+  for (int w = 0; w < NW; ++w) s += red[w];
+  const float logz = logf(s);
+  // ---- per wave: extract the best `twoK` of its 64 x T survivors (each lane's list is sorted: only its head competes) ----
+  const int need = twoK < V ? twoK : V;
+  int head = 0;
+  for (int r = 0; r < need; ++r) {
+    float bv = head < kTopT ? tv[0] : -INFINITY; int bi = head < kTopT ? tix[0] : 0x7fffffff;
+    float wv = bv; int wi = bi;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(wv, o, 64); const int oi = __shfl_xor(wi, o, 64);
+      if (beats(ov, oi, wv, wi)) { wv = ov; wi = oi; }
+    }
+    if (lane == 0) { fin_v[wave * kMax2K + r] = wv; fin_i[wave * kMax2K + r] = wi; }
+    if (bi == wi && wi != 0x7fffffff) {            // this lane's head won: pop it
+#pragma unroll
+      for (int k = 0; k < kTopT - 1; ++k) { tv[k] = tv[k + 1]; tix[k] = tix[k + 1]; }
+      tv[kTopT - 1] = -INFINITY; tix[kTopT - 1] = 0x7fffffff;
+      ++head;
+    }
+  }
+  __syncthreads();
+  // ---- wave 0: merge the NW sorted lists of finalists (lane w < NW walks list w) ----
+  if (wave == 0) {
+    int pos = 0;
+    for (int r = 0; r < need; ++r) {
+      float bv = (lane < NW && pos < need) ? fin_v[lane * kMax2K + pos] : -INFINITY;
+      int bi = (lane < NW && pos < need) ? fin_i[lane * kMax2K + pos] : 0x7fffffff;
+      float wv = bv; int wi = bi;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(wv, o, 64); const int oi = __shfl_xor(wi, o, 64);
+        if (beats(ov, oi, wv, wi)) { wv = ov; wi = oi; }
+      }
+      if (lane == 0) { sel_v[r] = wv; sel_i[r] = wi; }
+      if (bi == wi && wi != 0x7fffffff) ++pos;
+    }
+  }
+  __syncthreads();
+  // ---- certify: nothing that was dropped beats the last selected element; a popped-out list (head == T) must not either ----
+  const float lv = sel_v[need - 1]; const int li = sel_i[need - 1];
+  bool bad = beats(dv, di, lv, li) && di != 0x7fffffff;
+  if (bad) s_bad = 1;
+  __syncthreads();
+  if (tid == 0) need_exact[row] = s_bad;
+  if (s_bad) return;
+  const float bs = beam_scores ? beam_scores[row] : 0.f;
+  if (tid < need) {
+    cand_val[(int64_t)row * twoK + tid] = ((sel_v[tid] - m) - logz) + bs;
+    cand_tok[(int64_t)row * twoK + tid] = sel_i[tid];
   }
 }
 
@@ -293,10 +420,14 @@ __global__ __launch_bounds__(64) void beam_finalize_kernel(BeamArgs a, const int
 }  // namespace
 
 int launch_beam_topk(const float* logits, int64_t ld, int rows, int V, int K, const float* beam_scores, float* cand_val, int* cand_tok,
-                     hipStream_t st) {
+                     int* need_exact, hipStream_t st) {
   OAVSR_REQUIRE(K >= 1 && K <= kMaxK, "beam search: num_beams=%d unsupported (max %d)", K, kMaxK);
   if (rows <= 0) return 0;
-  hipLaunchKernelGGL(beam_topk_kernel, dim3(rows), dim3(kTopkThreads), 0, st, logits, ld, V, 2 * K, beam_scores, cand_val, cand_tok);
+  static const bool fast = [] { const char* e = getenv("OAVSR_BEAM_TOPK_FAST"); return !(e && e[0] == '0'); }();
+  if (fast && need_exact)
+    hipLaunchKernelGGL(beam_topk_fast_kernel, dim3(rows), dim3(kTopkThreads), 0, st, logits, ld, V, 2 * K, beam_scores, cand_val, cand_tok, need_exact);
+  hipLaunchKernelGGL(beam_topk_exact_kernel, dim3(rows), dim3(kTopkThreads), 0, st, logits, ld, V, 2 * K, beam_scores, cand_val, cand_tok,
+                     (fast && need_exact) ? need_exact : nullptr);
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;
 }

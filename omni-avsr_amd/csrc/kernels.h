@@ -175,8 +175,9 @@ struct BeamArgs {
   double* hyp_score = nullptr; int* hyp_len = nullptr; int* hyp_tok = nullptr;   // [B][K], [B][K], [B][K][max_new]
   int* out_ids = nullptr; int* out_len = nullptr;
 };
+// need_exact: rows ints of scratch (nullptr = always run the exact radix-select kernel)
 int launch_beam_topk(const float* logits, int64_t ld, int rows, int V, int K, const float* beam_scores, float* cand_val, int* cand_tok,
-                     hipStream_t st);
+                     int* need_exact, hipStream_t st);
 int launch_beam_step(const BeamArgs& a, int first, const int* seq_old, const int* anc_old, int* seq_new, int* anc_new, hipStream_t st);
 int launch_beam_finalize(const BeamArgs& a, const int* seqs, hipStream_t st);
 

@@ -191,7 +191,7 @@ struct oavsr_workspace {
   int *pos, *slot, *cpos, *cu_s, *prefix_len, *last_rows;
   int *amax; void* amax_scratch; GreedyState gs;
   // beam search state
-  float *beam_scores, *cand_val, *partial; int *cand_tok, *hyp_n, *hyp_len, *hyp_tok, *seq[2], *anc[2]; double* hyp_score; size_t partial_bytes = 0;
+  float *beam_scores, *cand_val, *partial; int *cand_tok, *topk_flag, *hyp_n, *hyp_len, *hyp_tok, *seq[2], *anc[2]; double* hyp_score; size_t partial_bytes = 0;
   int max_tok_enc = 0, max_S_total = 0;
   int S_host[1024]; int B_cur = 0;
 
@@ -833,7 +833,7 @@ static int decode_beam(const oavsr_model* m, oavsr_workspace* ws, int task, int 
   int* anc[2] = {ws->anc[0], ws->anc[1]};
   // step 0: candidates from the prefill logits (one row per utterance; beam_scores = [0, -1e9, ...] <=> only beam 0 counts)
   { ProfScope ps("beam_search", 0, (double)B * c.llm_vocab * 16, st);
-    OAVSR_TRY(launch_beam_topk(ws->logits, c.llm_vocab, B, c.llm_vocab, K, nullptr, ws->cand_val, ws->cand_tok, st));
+    OAVSR_TRY(launch_beam_topk(ws->logits, c.llm_vocab, B, c.llm_vocab, K, nullptr, ws->cand_val, ws->cand_tok, ws->topk_flag, st));
     OAVSR_TRY(launch_beam_step(a, 1, seq[0], anc[0], seq[1], anc[1], st)); }
   int cur = 1;
   for (int t = 1; t < max_new; ++t) {
@@ -841,7 +841,7 @@ static int decode_beam(const oavsr_model* m, oavsr_workspace* ws, int task, int 
     OAVSR_TRY(llm_layers(m, ws, task, R, true, B, K, maxS + max_new, ws->gs.pos, ws->gs.cpos, anc[cur], ws->gs.step, st));
     OAVSR_TRY(lm_head_rows(m, ws, ws->lx, R, ws->logits, st));
     ProfScope ps("beam_search", 0, (double)R * c.llm_vocab * 16, st);
-    OAVSR_TRY(launch_beam_topk(ws->logits, c.llm_vocab, R, c.llm_vocab, K, ws->beam_scores, ws->cand_val, ws->cand_tok, st));
+    OAVSR_TRY(launch_beam_topk(ws->logits, c.llm_vocab, R, c.llm_vocab, K, ws->beam_scores, ws->cand_val, ws->cand_tok, ws->topk_flag, st));
     OAVSR_TRY(launch_beam_step(a, 0, seq[cur], anc[cur], seq[cur ^ 1], anc[cur ^ 1], st));
     cur ^= 1;
   }
@@ -984,7 +984,7 @@ int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, 
     if (pb) WANT(partial, pb);
   }
   if (max_beams > 1) {
-    WANT(beam_scores, rows_dec * 4); WANT(cand_val, rows_dec * 2 * max_beams * 4); WANT(cand_tok, rows_dec * 2 * max_beams * 4);
+    WANT(beam_scores, rows_dec * 4); WANT(cand_val, rows_dec * 2 * max_beams * 4); WANT(cand_tok, rows_dec * 2 * max_beams * 4); WANT(topk_flag, rows_dec * 4);
     WANT(hyp_n, max_B * 4); WANT(hyp_len, rows_dec * 4); WANT(hyp_tok, rows_dec * (size_t)max_new * 4); WANT(hyp_score, rows_dec * 8);
     for (int i = 0; i < 2; ++i) { WANT(seq[i], rows_dec * (size_t)max_new * 4); WANT(anc[i], rows_dec * (size_t)max_new * 4); }
   }
@@ -1147,6 +1147,12 @@ int oavsr_op_conv3x3_c64(const void* x, int32_t imgs, int32_t H, int32_t W, cons
   OAVSR_REQUIRE(x && w && scale && shift && out, "op_conv3x3_c64: null argument");
   OAVSR_REQUIRE(conv3x3_c64_eligible(DT_BF16, H, W, 64, 64, 3, 1), "op_conv3x3_c64: %dx%d image does not fit", H, W);
   return launch_conv3x3_c64(x, imgs, H, W, w, scale, shift, slope, residual, out, (hipStream_t)stream);
+}
+
+int oavsr_op_beam_topk(const float* logits, int64_t ld, int32_t rows, int32_t V, int32_t K, const float* beam_scores, float* cand_val,
+                       int32_t* cand_tok, int32_t* need_exact, oavsr_stream stream) {
+  OAVSR_REQUIRE(logits && cand_val && cand_tok, "op_beam_topk: null argument");
+  return launch_beam_topk(logits, ld, rows, V, K, beam_scores, cand_val, cand_tok, need_exact, (hipStream_t)stream);
 }
 
 int oavsr_op_attention(const oavsr_attn_desc* d, oavsr_stream stream) {

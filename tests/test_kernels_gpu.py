@@ -666,3 +666,38 @@ def test_rope_kv(dtype, hd):
         vref[slot[r], :, cpos[r]] = refq[r, (H + KV) * hd:].reshape(KV, hd)
     close(kc, kref, tol(dtype), what="k cache")
     close(vc, vref, tol(dtype), what="v cache")
+
+
+# ------------------------------------------------------------------------------------------------ beam-search candidates
+@pytest.mark.parametrize("rows,V,K,mode", [(120, 128256, 15, "random"), (7, 128256, 15, "clustered"), (5, 151936, 4, "ties"), (3, 1000, 32, "random"),
+                                           (2, 40, 15, "random")])
+def test_beam_topk_fast_and_fallback(rows, V, K, mode):
+    """Top-2K of log_softmax(logits) + beam score per row.  "clustered" puts the whole top-2K on indices that one thread of the
+    fast kernel owns (stride 1024), which it cannot certify -> exact fallback; "ties" checks the lower-index-first rule."""
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(rows, V, generator=g) * 3
+    if mode == "clustered":
+        for r in range(rows):
+            x[r, (torch.arange(40) * 1024 + 5 + r) % V] = 20.0 + torch.arange(40).float()
+    if mode == "ties":
+        x = torch.round(x * 2) / 2               # many exact ties
+    bs = torch.randn(rows, generator=g)
+    xd, bsd = x.to(DEV), bs.to(DEV)
+    twoK = min(2 * K, V)
+    outs = []
+    for use_fast in (True, False):
+        val = torch.full((rows, 2 * K), float("nan"), device=DEV)
+        tok = torch.full((rows, 2 * K), -1, dtype=torch.int32, device=DEV)
+        flag = torch.zeros(rows, dtype=torch.int32, device=DEV)
+        L.check(L.load().oavsr_op_beam_topk(P(xd), V, rows, V, K, P(bsd), P(val), P(tok), P(flag) if use_fast else None, stream()))
+        outs.append((val.cpu(), tok.cpu(), flag.cpu()))
+    (vf, tf, ff), (ve, te, _) = outs
+    assert torch.equal(tf[:, :twoK], te[:, :twoK]) and torch.equal(vf[:, :twoK], ve[:, :twoK]), "fast path differs from the exact kernel"
+    if mode == "clustered":
+        assert int(ff.sum()) == rows, "the clustered rows must have taken the fallback"
+    if mode == "random" and V > 100000:
+        assert int(ff.sum()) == 0, "random rows should be certified by the fast path"
+    lp = torch.log_softmax(x, -1) + bs[:, None]
+    order = torch.argsort(torch.stack([-x, torch.arange(V).expand(rows, V).float()], -1)[..., 0], dim=-1, stable=True)[:, :twoK]
+    assert torch.equal(te[:, :twoK].long(), order), "candidate tokens differ from a stable descending sort"
+    close(ve[:, :twoK], torch.gather(lp, 1, order), 1e-4, what="candidate scores")
