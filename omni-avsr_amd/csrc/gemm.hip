@@ -363,7 +363,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   if (a.ksplit > 1) {
     OAVSR_REQUIRE(a.partial && a.groups == 1 && a.amode == A_DENSE, "gemm: split-K needs a partial buffer, dense A, no groups");
     static const bool dma_sk = [] { const char* e = getenv("OAVSR_GEMM_DMA"); return !(e && e[0] == '0'); }();
-    if (dma_sk && a.M > 128 && gemm_dma_eligible(a)) OAVSR_TRY(launch_gemm_dma(a, st));   // same k order as the classic kernel
+    if (dma_sk && gemm_dma_eligible(a)) OAVSR_TRY(launch_gemm_dma(a, st));   // same k order as the classic kernel
     else OAVSR_TRY(a.dtype == DT_F32 ? launch_mode<float>(a, st) : launch_mode<bf16_t>(a, st));
     int64_t total = (int64_t)a.M * a.N;
     int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);

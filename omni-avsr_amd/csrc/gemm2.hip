@@ -336,6 +336,8 @@ int launch_dma(const GemmArgs& a, hipStream_t st) {
 static int dma_tile_choice(const GemmArgs& a) {
   // 0: not eligible, 1: 256x128, 2: 256x256
   static const int force = [] { const char* e = getenv("OAVSR_GEMM_TILE"); return e ? atoi(e) : -1; }();
+  // <= 128 rows (beam-search decode, tiny prefills): 128 x 64 tiles stream the weights with 4 x more workgroups per N
+  if (a.amode == A_DENSE && a.groups == 1 && a.M <= 128 && a.M > 32 && a.N >= 64 && force < 0) return 4;
   if (a.ksplit > 1) return (a.amode == A_DENSE && a.groups == 1 && a.N >= 64) ? 1 : 0;   // independent of M on purpose
   if (a.amode == A_STEM || a.N < 128) return 0;
   const int64_t n128 = (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 128) * a.groups;
@@ -352,6 +354,7 @@ template <typename T>
 int launch_dma_mode(const GemmArgs& a, hipStream_t st) {
   // 256x256: 16 waves (4 x 4) of 64 x 64, 2 stages; dense only.  256x128: 8 waves (4 x 2) of 64 x 64, 3 stages.
   if (dma_tile_choice(a) == 2) return launch_dma<T, A_DENSE, 256, 256, 2, 4, 16>(a, st);
+  if (dma_tile_choice(a) == 4) return launch_dma<T, A_DENSE, 128, 64, 4, 4, 4>(a, st);     // 4 waves (4 x 1) of 32 x 64, 4 stages of 24 KiB
   switch (a.amode) {
     case A_DENSE: return launch_dma<T, A_DENSE, 256, 128, 3, 4, 8>(a, st);
     case A_CONV2D: return launch_dma<T, A_CONV2D, 256, 128, 3, 4, 8>(a, st);
@@ -363,7 +366,11 @@ int launch_dma_mode(const GemmArgs& a, hipStream_t st) {
 }  // namespace
 
 bool gemm_dma_eligible(const GemmArgs& a) { return dma_tile_choice(a) != 0; }
-const char* gemm_dma_variant(const GemmArgs& a) { return a.ksplit > 1 ? "dma_splitk_256x128" : dma_tile_choice(a) == 2 ? "dma_256x256" : "dma_256x128"; }
+const char* gemm_dma_variant(const GemmArgs& a) {
+  const int c = dma_tile_choice(a);
+  if (c == 4) return a.ksplit > 1 ? "dma_splitk_128x64" : "dma_128x64";
+  return a.ksplit > 1 ? "dma_splitk_256x128" : c == 2 ? "dma_256x256" : "dma_256x128";
+}
 
 int launch_gemm_dma(const GemmArgs& a, hipStream_t st) {
   return a.dtype == DT_F32 ? launch_dma_mode<float>(a, st) : launch_dma_mode<bf16_t>(a, st);

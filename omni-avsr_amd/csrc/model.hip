@@ -81,7 +81,7 @@ static const char* gemm_family(const GemmArgs& a, bool skinny) {
     return buf;
   }
   const char* mode = a.amode == A_DENSE ? "gemm" : a.amode == A_CONV2D ? "conv2d_gemm" : a.amode == A_CONV1D ? "conv1d_gemm" : "stem_gemm";
-  const char* tile = (a.ksplit > 1 && !(a.M > 128 && gemm_dma_eligible(a))) ? "splitk_128x128" : gemm_dma_eligible(a) ? gemm_dma_variant(a) : (a.N <= 64 ? "128x64" : "128x128");
+  const char* tile = (a.ksplit > 1 && !gemm_dma_eligible(a)) ? "splitk_128x128" : gemm_dma_eligible(a) ? gemm_dma_variant(a) : (a.N <= 64 ? "128x64" : "128x128");
   static const bool shapes = getenv("OAVSR_PROF_SHAPES") != nullptr;      // developer aid: one family per GEMM shape
   if (shapes) { snprintf(buf, sizeof(buf), "%c%s %dx%dx%d", mode[0], tile, a.M, a.N, a.K + a.K2); buf[31] = 0; return buf; }
   snprintf(buf, sizeof(buf), "%s_%s_%s", mode, tile, dt);
@@ -617,7 +617,7 @@ static int llm_gemm(const oavsr_model* m, oavsr_workspace* ws, GemmArgs& g, int 
   if (mode == 1) return run_gemm(g, st, true);
   const int esz = (int)m->esz;
   const int ktiles = (g.K + g.K2) / (128 / esz);
-  const int tiles = ceil_div(g.M, 128) * ceil_div(g.N, g.N <= 64 ? 64 : 128);
+  const int tiles = ceil_div(g.M, 128) * ceil_div(g.N, 64);      // 128 x 64 weight-streaming tiles (gemm2.hip)
   int ks = 256 / std::max(1, tiles);
   ks = std::min(ks, std::max(1, ktiles / 2));
   ks = std::min(ks, 16);
