@@ -468,7 +468,8 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnAr
     for (int i = tid; i < (G + 1) * half; i += kDecThreads) {
       const int h = i / half, d = i - h * half;
       float sn, cs;
-      sincosf(pos * p.inv_freq[d], &sn, &cs);
+      if (p.rope_cs) { const float2 t = p.rope_cs[(int64_t)row * half + d]; cs = t.x; sn = t.y; }
+      else sincosf(pos * p.inv_freq[d], &sn, &cs);
       const T* src = h < G ? qrow + (int64_t)(kvh * G + h) * HD : qrow + (int64_t)(p.n_heads + kvh) * HD;
       const float x0 = to_f32(src[d]), x1 = to_f32(src[d + half]);
       const T r0 = from_f32<T>(x0 * cs - x1 * sn), r1 = from_f32<T>(x1 * cs + x0 * sn);

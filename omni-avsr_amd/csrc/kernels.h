@@ -84,6 +84,7 @@ struct DecodeAttnArgs {
   const int* prefix_len = nullptr;   // [utts] device
   const int* step = nullptr;         // device scalar: number of tail tokens INCLUDING the current one
   const int* anc = nullptr;          // [rows][max_tail] row that holds tail position t (null: own row)
+  const float2* rope_cs = nullptr;   // [rows][hd/2] {cos, sin} of pos[row] (optional; else sincosf(pos * inv_freq) in the kernel)
   float scale = 1.f;
   // fused RoPE + cache append (inv_freq != nullptr): Q then points at the fused [q|k|v] rows (ldq = row stride); q and the
   // new k are rotated with pos[row], k/v are written to the tail cache at cpos[row] before the keys are read
@@ -160,6 +161,9 @@ struct GreedyState {
   int* step;       // scalar: number of generated tokens so far
   int* pos;        // [B] absolute position of the next token
   int* cpos;       // [B] cache position of the next token
+  // optional: RoPE table of the NEXT position, refreshed by greedy_update so the 16 decode-attention launches of a step read
+  // (cos, sin) instead of each running sincosf:  rope_cs[b][d] = {cos, sin}(pos[b] * inv_freq[d]), d < rope_half
+  float2* rope_cs = nullptr; const float* inv_freq = nullptr; int rope_half = 0;
 };
 int launch_greedy_update(const int* argmax, GreedyState s, int B, int max_new, int eos, int pad, hipStream_t st);
 

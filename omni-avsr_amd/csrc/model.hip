@@ -627,7 +627,7 @@ static int llm_gemm(const oavsr_model* m, oavsr_workspace* ws, GemmArgs& g, int 
 }
 
 static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int rows, bool decode, int B, int beams, int max_S,
-                      const int* pos, const int* cpos, const int* anc, const int* step, hipStream_t st) {
+                      const int* pos, const int* cpos, const int* anc, const int* step, hipStream_t st, const float2* rope_cs = nullptr) {
   const oavsr_config& c = m->cfg;
   const int dt = m->dtype, d = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, hd = c.llm_head_dim, I = c.llm_mlp;
   const int nq = H * hd, nqkv = (H + 2 * KV) * hd;
@@ -670,7 +670,7 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
       a.Kp = (char*)ws->kpre + li * ws->kpre_layer; a.Vp = (char*)ws->vpre + li * ws->kpre_layer; a.max_prefix = ws->max_prefix;
       a.Kt = (char*)ws->ktail + li * ws->ktail_layer; a.Vt = (char*)ws->vtail + li * ws->ktail_layer; a.max_tail = ws->max_new;
       a.prefix_len = ws->prefix_len; a.step = step; a.anc = anc; a.scale = 1.0f / sqrtf((float)hd);
-      a.inv_freq = m->inv_freq; a.pos = pos; a.cpos = cpos;
+      a.inv_freq = m->inv_freq; a.pos = pos; a.cpos = cpos; a.rope_cs = rope_cs;
       ProfScope ps("decode_attention", 0, 2.0 * rows * max_S * KV * hd * m->esz, st);
       OAVSR_TRY(launch_decode_attention(a, st));
     }
@@ -757,6 +757,7 @@ static int decode_greedy(const oavsr_model* m, oavsr_workspace* ws, int task, in
   // path (profiling, legacy default stream which cannot be captured) writes the caller's buffers directly.
   const bool use_graph = graphs_on && !g_prof.on && max_new > 3 && st != nullptr;
   GreedyState gs = ws->gs;
+  gs.inv_freq = m->inv_freq; gs.rope_half = c.llm_head_dim / 2;
   if (!use_graph) { gs.out_ids = out_ids; gs.out_len = out_len; }
   OAVSR_TRY(h2d(gs.pos, ipos, sizeof(int) * B, st));
   OAVSR_TRY(h2d(gs.cpos, icpos, sizeof(int) * B, st));
@@ -774,7 +775,7 @@ static int decode_greedy(const oavsr_model* m, oavsr_workspace* ws, int task, in
   OAVSR_TRY(launch_greedy_update(ws->amax, gs, B, max_new, c.id_eos, c.id_pad, st));
   auto one_step = [&]() -> int {
     OAVSR_TRY(launch_embed(m->dtype, m->embed, c.llm_hidden, gs.tok, ws->lx, c.llm_hidden, B, c.llm_hidden, st));
-    OAVSR_TRY(llm_layers(m, ws, task, B, true, B, 1, maxS + max_new, gs.pos, gs.cpos, nullptr, gs.step, st));
+    OAVSR_TRY(llm_layers(m, ws, task, B, true, B, 1, maxS + max_new, gs.pos, gs.cpos, nullptr, gs.step, st, gs.rope_cs));
     OAVSR_TRY(lm_head_rows(m, ws, ws->lx, B, ws->logits, st));
     OAVSR_TRY(launch_argmax(ws->logits, c.llm_vocab, B, c.llm_vocab, banned, ws->amax, ws->amax_scratch, st));
     return launch_greedy_update(ws->amax, gs, B, max_new, c.id_eos, c.id_pad, st);
@@ -974,7 +975,7 @@ int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, 
   WANT(pos, Rl * 4); WANT(slot, Rl * 4); WANT(cpos, Rl * 4); WANT(cu_s, (max_B + 1) * 4); WANT(prefix_len, max_B * 4); WANT(last_rows, max_B * 4);
   WANT(amax, rows_dec * 4); WANT(amax_scratch, rows_dec * 64 * 8);
   WANT(gs.tok, rows_dec * 4); WANT(gs.finished, rows_dec * 4); WANT(gs.out_ids, rows_dec * (size_t)max_new * 4); WANT(gs.out_len, rows_dec * 4);
-  WANT(gs.step, 256); WANT(gs.pos, rows_dec * 4); WANT(gs.cpos, rows_dec * 4);
+  WANT(gs.step, 256); WANT(gs.pos, rows_dec * 4); WANT(gs.cpos, rows_dec * 4); WANT(gs.rope_cs, rows_dec * (size_t)(hd / 2) * sizeof(float2));
   {   // split-K partial slabs: decode GEMMs with > 32 rows, the narrow video-encoder projections, the LoRA down projections
     size_t pb = rows_dec > 32 ? (size_t)32 << 20 : 0;
     if (m->has_video) pb = std::max(pb, (size_t)kVideoNarrowSplit * F * Dv * 4);

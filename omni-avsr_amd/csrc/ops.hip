@@ -328,6 +328,14 @@ __global__ void greedy_update_kernel(const int* __restrict__ amax, GreedyState s
   // all rows read `step` before anyone bumps it: single block launch guarantees this via the barrier below
   __syncthreads();
   if (b == 0) *s.step = step + 1;
+  if (s.rope_cs) {                                   // same expression as the attention kernel's inline path => same bits
+    for (int i = threadIdx.x; i < B * s.rope_half; i += blockDim.x) {
+      const int r = i / s.rope_half, d = i - r * s.rope_half;
+      float sn, cs;
+      sincosf((float)s.pos[r] * s.inv_freq[d], &sn, &cs);
+      s.rope_cs[i] = make_float2(cs, sn);
+    }
+  }
 }
 
 __global__ void rowinfo_kernel(const int* __restrict__ cu_out, const int* __restrict__ cu_in, int n_seqs, int stride, int4* __restrict__ ri, int rows) {
@@ -446,6 +454,7 @@ int launch_argmax(const float* logits, int64_t ld, int rows, int V, int banned, 
 int launch_greedy_update(const int* amax, GreedyState s, int B, int max_new, int eos, int pad, hipStream_t st) {
   OAVSR_REQUIRE(B <= 1024, "greedy_update: B=%d > 1024", B);
   int threads = ((B + 63) / 64) * 64;
+  if (s.rope_cs && threads < 256) threads = 256;
   hipLaunchKernelGGL(greedy_update_kernel, dim3(1), dim3(threads), 0, st, amax, s, B, max_new, eos, pad);
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;
