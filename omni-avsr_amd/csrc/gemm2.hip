@@ -354,7 +354,12 @@ template <typename T>
 int launch_dma_mode(const GemmArgs& a, hipStream_t st) {
   // 256x256: 16 waves (4 x 4) of 64 x 64, 2 stages; dense only.  256x128: 8 waves (4 x 2) of 64 x 64, 3 stages.
   if (dma_tile_choice(a) == 2) return launch_dma<T, A_DENSE, 256, 256, 2, 4, 16>(a, st);
-  if (dma_tile_choice(a) == 4) return launch_dma<T, A_DENSE, 128, 64, 4, 4, 4>(a, st);     // 4 waves (4 x 1) of 32 x 64, 4 stages of 24 KiB
+  if (dma_tile_choice(a) == 4) {
+    // every workgroup re-reads the A rows of its k range: 64-column tiles move 2 B of A per byte of W, 128-column tiles 1 B --
+    // worth it as soon as N / 128 still gives every CU several workgroups (lm_head)
+    if (a.N >= 256 * 128 && a.ksplit <= 1) return launch_dma<T, A_DENSE, 128, 128, 3, 2, 4>(a, st);   // 4 waves (2 x 2) of 64 x 64
+    return launch_dma<T, A_DENSE, 128, 64, 4, 4, 4>(a, st);     // 4 waves (4 x 1) of 32 x 64, 4 stages of 24 KiB
+  }
   switch (a.amode) {
     case A_DENSE: return launch_dma<T, A_DENSE, 256, 128, 3, 4, 8>(a, st);
     case A_CONV2D: return launch_dma<T, A_CONV2D, 256, 128, 3, 4, 8>(a, st);
