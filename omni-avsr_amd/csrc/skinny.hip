@@ -267,7 +267,7 @@ int launch_sk(const GemmArgs& a, hipStream_t st) {
     // B <= 8 rows: 8-column MFMA tiles (HALF mode).  NT = 1: doubles the grid where 16-column tiles leave CUs idle;
     // NT = 4 (gate/up, lm_head): same 256+ workgroups x 32 columns, but every wave load is 8 rows x one whole 128-B line.
     const bool want = NT == 1 ? (a.N >= 64 && a.N / 16 < 384) : true;
-    if (half_enabled() && want && a.M <= 8 && a.N % (NT == 1 ? 8 : 32) == 0 && (a.K / kbe) % 2 == 0) {
+    if (half_enabled() && want && a.M <= 8 && (!a.swiglu_pairs || a.N % 32 == 0) && (a.K / kbe) % 2 == 0) {   // ragged N: loads and stores are guarded
       return launch_sk_u<T, 1, NT, NORM, U0, true>(a, st);
     }
   }

@@ -183,7 +183,7 @@ def test_gemm_skinny(dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K,K2", [(8, 2048, 8192, 96), (8, 2048, 2048, 96), (7, 136, 8192 + 64, 32), (3, 64, 128, 0)])
+@pytest.mark.parametrize("M,N,K,K2", [(8, 2048, 8192, 96), (8, 2048, 2048, 96), (7, 136, 8192 + 64, 32), (3, 64, 128, 0), (8, 16384 + 37, 256, 0), (5, 203, 512, 64)])
 def test_gemm_skinny_half_tiles(dtype, M, N, K, K2):
     """M <= 8 rows: 8-column workgroups (even / odd k blocks in the two diagonal 8x8 blocks of the MFMA tile), incl. an odd
     number of LoRA k blocks and the deep-K (down_proj) unroll; residual epilogue."""
