@@ -125,6 +125,14 @@ int oavsr_generate(const oavsr_model* m, oavsr_workspace* ws, int32_t task, cons
                    const float* wav_dev, int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host, int32_t B,
                    int32_t rate_audio, int32_t rate_video, int32_t beams, int32_t max_new, int32_t force_len,
                    int32_t* out_ids_dev, int32_t* out_len_dev, oavsr_stream stream);
+/* Same result as oavsr_generate on the B utterances, scheduled for throughput: encoders / projector / prompt / prefill run in
+ * chunks of chunk_B utterances (the launch shapes of a batch-of-chunk_B request), every chunk's prefix KV and last-token logits
+ * land in their own slots, and ONE decode loop then serves all B rows, so the LLM weights are streamed once per step for the
+ * whole group (continuous batching of the decode phase).  chunk_B == B is oavsr_generate. */
+int oavsr_generate_chunked(const oavsr_model* m, oavsr_workspace* ws, int32_t task, const float* video_dev, const int32_t* Tv_host,
+                           const float* wav_dev, int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host, int32_t B, int32_t chunk_B,
+                           int32_t rate_audio, int32_t rate_video, int32_t beams, int32_t max_new, int32_t force_len, int32_t* out_ids_dev,
+                           int32_t* out_len_dev, oavsr_stream stream);
 
 /* ---- profiling hook (bench.py roofline): per-kernel-family HIP-event timing of every launch ---------------- */
 typedef struct oavsr_prof_entry {

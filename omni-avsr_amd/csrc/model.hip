@@ -711,10 +711,12 @@ static int lm_head_rows(const oavsr_model* m, oavsr_workspace* ws, const void* x
   return run_gemm(g, st, false);
 }
 
+// utt0: first utterance slot of this call (prefix-cache index, logits row); > 0 only for the chunked generate, whose chunks are
+// prefilled one after another into consecutive slots and then decoded together.
 static int prefill_impl(const oavsr_model* m, oavsr_workspace* ws, int task, int B, const void* embeds, const int32_t* S, float* logits_out,
-                        hipStream_t st) {
+                        hipStream_t st, int utt0 = 0) {
   const oavsr_config& c = m->cfg;
-  OAVSR_REQUIRE(B >= 1 && B <= ws->max_B, "prefill: B=%d exceeds workspace (%d)", B, ws->max_B);
+  OAVSR_REQUIRE(B >= 1 && utt0 >= 0 && utt0 + B <= ws->max_B, "prefill: B=%d (+%d) exceeds workspace (%d)", B, utt0, ws->max_B);
   int total = 0, maxS = 0;
   for (int b = 0; b < B; ++b) { OAVSR_REQUIRE(S[b] >= 1 && S[b] <= ws->max_prefix, "prefill: S[%d]=%d exceeds prefix cache (%d)", b, S[b], ws->max_prefix); total += S[b]; maxS = std::max(maxS, S[b]); }
   OAVSR_REQUIRE(total <= ws->max_S_total, "prefill: too many prompt rows");
@@ -722,20 +724,21 @@ static int prefill_impl(const oavsr_model* m, oavsr_workspace* ws, int task, int
   int* plen = ws->stage<int>(B);
   OAVSR_REQUIRE(pos && slot && cu && last && plen, "host staging exhausted");
   int r = 0; cu[0] = 0;
-  for (int b = 0; b < B; ++b) { for (int i = 0; i < S[b]; ++i) { pos[r] = i; slot[r] = b; ++r; } cu[b + 1] = r; last[b] = r - 1; plen[b] = S[b]; ws->S_host[b] = S[b]; }
-  ws->B_cur = B;
+  for (int b = 0; b < B; ++b) { for (int i = 0; i < S[b]; ++i) { pos[r] = i; slot[r] = utt0 + b; ++r; } cu[b + 1] = r; last[b] = r - 1; plen[b] = S[b]; ws->S_host[utt0 + b] = S[b]; }
+  ws->B_cur = utt0 + B;
   OAVSR_TRY(h2d(ws->pos, pos, sizeof(int) * total, st));
   OAVSR_TRY(h2d(ws->cpos, pos, sizeof(int) * total, st));
   OAVSR_TRY(h2d(ws->slot, slot, sizeof(int) * total, st));
   OAVSR_TRY(h2d(ws->cu_s, cu, sizeof(int) * (B + 1), st));
   OAVSR_TRY(h2d(ws->last_rows, last, sizeof(int) * B, st));
-  OAVSR_TRY(h2d(ws->prefix_len, plen, sizeof(int) * B, st));
+  OAVSR_TRY(h2d(ws->prefix_len + utt0, plen, sizeof(int) * B, st));
   if (embeds != ws->lx) OAVSR_CHECK_HIP(hipMemcpyAsync(ws->lx, embeds, (size_t)total * c.llm_hidden * m->esz, hipMemcpyDeviceToDevice, st));
   OAVSR_TRY(llm_layers(m, ws, task, total, false, B, 1, maxS, ws->pos, ws->cpos, nullptr, nullptr, st));
   // last position of every utterance only (the reference materialises all positions, Llama_LoRA.py:372-373)
   OAVSR_TRY(launch_copy_rows(m->dtype, ws->lx, c.llm_hidden, ws->last_rows, ws->lastx, c.llm_hidden, B, c.llm_hidden, st));
-  OAVSR_TRY(lm_head_rows(m, ws, ws->lastx, B, ws->logits, st));
-  if (logits_out) OAVSR_CHECK_HIP(hipMemcpyAsync(logits_out, ws->logits, (size_t)B * c.llm_vocab * 4, hipMemcpyDeviceToDevice, st));
+  float* lg = ws->logits + (size_t)utt0 * c.llm_vocab;
+  OAVSR_TRY(lm_head_rows(m, ws, ws->lastx, B, lg, st));
+  if (logits_out) OAVSR_CHECK_HIP(hipMemcpyAsync(logits_out, lg, (size_t)B * c.llm_vocab * 4, hipMemcpyDeviceToDevice, st));
   return 0;
 }
 
@@ -1066,13 +1069,14 @@ int oavsr_decode(const oavsr_model* m, oavsr_workspace* ws, int32_t task, int32_
   return decode_greedy(m, ws, task, B, max_new, force_len, out_ids_dev, out_len_dev, (hipStream_t)stream);
 }
 
-int oavsr_generate(const oavsr_model* m, oavsr_workspace* ws, int32_t task, const float* video_dev, const int32_t* Tv_host, const float* wav_dev,
-                   int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host, int32_t B, int32_t rate_audio, int32_t rate_video,
-                   int32_t beams, int32_t max_new, int32_t force_len, int32_t* out_ids_dev, int32_t* out_len_dev, oavsr_stream stream) {
+static int generate_impl(const oavsr_model* m, oavsr_workspace* ws, int32_t task, const float* video_dev, const int32_t* Tv_host, const float* wav_dev,
+                         int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host, int32_t B, int32_t chunk_B, int32_t rate_audio,
+                         int32_t rate_video, int32_t beams, int32_t max_new, int32_t force_len, int32_t* out_ids_dev, int32_t* out_len_dev,
+                         hipStream_t st) {
   OAVSR_REQUIRE(m && ws && out_ids_dev && out_len_dev, "generate: null argument");
   OAVSR_REQUIRE(beams >= 1 && !(beams > 1 && force_len), "generate: bad num_beams / force_len");
   OAVSR_REQUIRE(B >= 1 && B <= ws->max_B, "generate: B=%d exceeds workspace (%d)", B, ws->max_B);
-  hipStream_t st = (hipStream_t)stream;
+  OAVSR_REQUIRE(chunk_B >= 1, "generate: chunk_B must be >= 1");
   CallScope cs(ws, st);
   // Concurrent generate() calls on different streams: the MFMA-bound encoder + prefill phases gain nothing from sharing
   // the chip with each other, so they are chained one after another; only the latency-bound decode loop of one call
@@ -1080,29 +1084,52 @@ int oavsr_generate(const oavsr_model* m, oavsr_workspace* ws, int32_t task, cons
   if (m->serialize_enc && m->enc_recorded && m->enc_last != st) OAVSR_CHECK_HIP(hipStreamWaitEvent(st, m->enc_done, 0));
   const bool use_a = task == OAVSR_TASK_AUDIO || task == OAVSR_TASK_AUDIOVISUAL;
   const bool use_v = task == OAVSR_TASK_VIDEO || task == OAVSR_TASK_AUDIOVISUAL;
-  std::vector<int> na(B), nv(B);
-  int tot_a = 0, tot_v = 0;
-  if (use_a) {
-    OAVSR_REQUIRE(wav_dev && Ts_host && keep_host, "generate: audio inputs missing");
-    OAVSR_TRY(encode_audio_impl(m, ws, wav_dev, wav_ld, Ts_host, keep_host, B, rate_audio, nullptr, nullptr, nullptr, na.data(), st));
-    for (int b = 0; b < B; ++b) tot_a += na[b];
-    OAVSR_TRY(project_impl(m, ws, 0, rate_audio, ws->comp_a, tot_a, ws->tok_a, st));
+  if (use_a) OAVSR_REQUIRE(wav_dev && Ts_host && keep_host, "generate: audio inputs missing");
+  if (use_v) OAVSR_REQUIRE(video_dev && Tv_host, "generate: video inputs missing");
+  // encoders + projector + prompt + prefill run per chunk of chunk_B utterances (the shapes of a batch-of-chunk_B request);
+  // each chunk's prefix KV / last-token logits land in its own slots, then ONE decode loop serves all B rows: the LLM weights
+  // are streamed once per step for the whole group instead of once per chunk.
+  int64_t frames_before = 0;
+  for (int b0 = 0; b0 < B; b0 += chunk_B) {
+    const int Bc = std::min<int>(chunk_B, B - b0);
+    std::vector<int> na(Bc), nv(Bc);
+    int tot_a = 0, tot_v = 0;
+    if (use_a) {
+      OAVSR_TRY(encode_audio_impl(m, ws, wav_dev + (int64_t)b0 * wav_ld, wav_ld, Ts_host + b0, keep_host + b0, Bc, rate_audio, nullptr, nullptr, nullptr,
+                                  na.data(), st));
+      for (int b = 0; b < Bc; ++b) tot_a += na[b];
+      OAVSR_TRY(project_impl(m, ws, 0, rate_audio, ws->comp_a, tot_a, ws->tok_a, st));
+    }
+    if (use_v) {
+      OAVSR_TRY(encode_video_impl(m, ws, video_dev + frames_before * 7744, Tv_host + b0, Bc, rate_video, nullptr, nullptr, nv.data(), st));
+      for (int b = 0; b < Bc; ++b) { tot_v += nv[b]; frames_before += Tv_host[b0 + b]; }
+      OAVSR_TRY(project_impl(m, ws, 1, rate_video, ws->comp_v, tot_v, ws->tok_v, st));
+    }
+    std::vector<int> S(Bc);
+    OAVSR_TRY(build_prompt_impl(m, ws, task, Bc, use_a ? na.data() : nullptr, ws->tok_a, use_v ? nv.data() : nullptr, ws->tok_v, ws->lx, S.data(), st));
+    OAVSR_TRY(prefill_impl(m, ws, task, Bc, ws->lx, S.data(), nullptr, st, b0));
   }
-  if (use_v) {
-    OAVSR_REQUIRE(video_dev && Tv_host, "generate: video inputs missing");
-    OAVSR_TRY(encode_video_impl(m, ws, video_dev, Tv_host, B, rate_video, nullptr, nullptr, nv.data(), st));
-    for (int b = 0; b < B; ++b) tot_v += nv[b];
-    OAVSR_TRY(project_impl(m, ws, 1, rate_video, ws->comp_v, tot_v, ws->tok_v, st));
-  }
-  std::vector<int> S(B);
-  OAVSR_TRY(build_prompt_impl(m, ws, task, B, use_a ? na.data() : nullptr, ws->tok_a, use_v ? nv.data() : nullptr, ws->tok_v, ws->lx, S.data(), st));
-  OAVSR_TRY(prefill_impl(m, ws, task, B, ws->lx, S.data(), nullptr, st));
   if (m->serialize_enc) {
     OAVSR_CHECK_HIP(hipEventRecord(m->enc_done, st));
     m->enc_last = st; m->enc_recorded = true;
   }
   if (beams > 1) return decode_beam(m, ws, task, B, beams, max_new, out_ids_dev, out_len_dev, st);
   return decode_greedy(m, ws, task, B, max_new, force_len, out_ids_dev, out_len_dev, st);
+}
+
+int oavsr_generate(const oavsr_model* m, oavsr_workspace* ws, int32_t task, const float* video_dev, const int32_t* Tv_host, const float* wav_dev,
+                   int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host, int32_t B, int32_t rate_audio, int32_t rate_video,
+                   int32_t beams, int32_t max_new, int32_t force_len, int32_t* out_ids_dev, int32_t* out_len_dev, oavsr_stream stream) {
+  return generate_impl(m, ws, task, video_dev, Tv_host, wav_dev, wav_ld, Ts_host, keep_host, B, B, rate_audio, rate_video, beams, max_new, force_len,
+                       out_ids_dev, out_len_dev, (hipStream_t)stream);
+}
+
+int oavsr_generate_chunked(const oavsr_model* m, oavsr_workspace* ws, int32_t task, const float* video_dev, const int32_t* Tv_host,
+                           const float* wav_dev, int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host, int32_t B, int32_t chunk_B,
+                           int32_t rate_audio, int32_t rate_video, int32_t beams, int32_t max_new, int32_t force_len, int32_t* out_ids_dev,
+                           int32_t* out_len_dev, oavsr_stream stream) {
+  return generate_impl(m, ws, task, video_dev, Tv_host, wav_dev, wav_ld, Ts_host, keep_host, B, chunk_B, rate_audio, rate_video, beams, max_new,
+                       force_len, out_ids_dev, out_len_dev, (hipStream_t)stream);
 }
 
 int oavsr_profile_enable(int32_t on) { g_prof.on = on != 0; return 0; }

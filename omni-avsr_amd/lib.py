@@ -99,6 +99,7 @@ SYMBOLS = {
     "oavsr_prefill": (C.c_int, [_P, _P, _I, _I, _P, C.POINTER(_I), _P, _P]),
     "oavsr_decode": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "oavsr_generate": (C.c_int, [_P, _P, _I, _P, C.POINTER(_I), _P, _L, C.POINTER(_I), C.POINTER(_I), _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "oavsr_generate_chunked": (C.c_int, [_P, _P, _I, _P, C.POINTER(_I), _P, _L, C.POINTER(_I), C.POINTER(_I), _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "oavsr_profile_enable": (C.c_int, [_I]),
     "oavsr_profile_reset": (C.c_int, []),
     "oavsr_profile_read": (C.c_int, [C.POINTER(OavsrProfEntry), _I]),

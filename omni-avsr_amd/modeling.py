@@ -233,9 +233,10 @@ class OmniEngine:
 
     def generate(self, task: str, video: Optional[torch.Tensor], Tv: Optional[Sequence[int]], audio: Optional[torch.Tensor],
                  lengths: Optional[Sequence[int]], rate_a: int, rate_v: int, beams: int = 1, max_new: Optional[int] = None,
-                 force_len: bool = False, video_is_flat: bool = False, slot: int = 0):
+                 force_len: bool = False, video_is_flat: bool = False, slot: int = 0, chunk: Optional[int] = None):
         """End-to-end `forward(is_trainval=False)`: returns (ids int32 [B,max_new] pad-filled, lens int32 [B]) on device.
-        No host synchronisation happens inside."""
+        No host synchronisation happens inside.  `chunk`: run encoders / prefill in chunks of that many utterances and decode all B
+        rows together (oavsr_generate_chunked: same results, the LLM weights are streamed once per step for the whole group)."""
         max_new = max_new or self.spec.max_dec_tokens
         use_a, use_v = task in ("audio", "audiovisual"), task in ("video", "audiovisual")
         B = len(Tv) if use_v else len(lengths)
@@ -251,12 +252,12 @@ class OmniEngine:
         ws = self._slot_workspace(slot, B, max(Tv) if use_v else 1, int(max(lengths)) if use_a else 16000, beams, max_new)
         ids = torch.empty(B, max_new, dtype=torch.int32, device=self.device)
         lens = torch.empty(B, dtype=torch.int32, device=self.device)
-        L.check(self.lib.oavsr_generate(
+        L.check(self.lib.oavsr_generate_chunked(
             self._model, ws, L.TASK_ID[task],
             C.c_void_p(flat.data_ptr()) if use_v else None, _i32arr(Tv) if use_v else None,
             C.c_void_p(a.data_ptr()) if use_a else None, a.stride(0) if use_a else 0,
             _i32arr(lengths) if use_a else None, _i32arr(keep) if use_a else None,
-            B, int(rate_a or 1), int(rate_v or 1), beams, max_new, int(force_len),
+            B, int(chunk or B), int(rate_a or 1), int(rate_v or 1), beams, max_new, int(force_len),
             C.c_void_p(ids.data_ptr()), C.c_void_p(lens.data_ptr()), self._stream()))
         self._keepalive = getattr(self, "_keepalive", {})
         self._keepalive[slot] = (flat, a)

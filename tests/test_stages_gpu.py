@@ -106,6 +106,25 @@ def test_prompt_prefill_logits(dtype, family):
         off += S[b]
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("task,chunk", [("audiovisual", 2), ("audiovisual", 3), ("video", 1), ("audio", 2)])
+def test_generate_chunked_equals_plain(dtype, task, chunk):
+    """oavsr_generate_chunked (encoders / prefill per chunk, one decode loop for all rows) returns exactly what generate does on the
+    whole batch and what per-chunk generate calls do: ragged lengths, a ragged last chunk, natural EOS and forced length."""
+    spec, sd, eng, orc = make(dtype, family="llama", task_specific=True, shared=True)
+    Tv, Ts = [12, 9, 7, 12, 5], [7680, 5000, 4480, 7000, 3200]
+    video, audio = inputs(B=5, Tv=Tv, Ts=Ts, seed=3)
+    for force in (False, True):
+        kw = dict(beams=1, max_new=spec.max_dec_tokens, force_len=force)
+        ids0, len0 = eng.generate(task, video, Tv, audio, Ts, 4, 2, **kw)
+        ids1, len1 = eng.generate(task, video, Tv, audio, Ts, 4, 2, chunk=chunk, **kw)
+        assert torch.equal(ids0.cpu(), ids1.cpu()) and torch.equal(len0.cpu(), len1.cpu()), f"chunk={chunk} force={force}"
+        for b0 in range(0, 5, chunk):
+            sl = slice(b0, min(5, b0 + chunk))
+            ids2, len2 = eng.generate(task, video[sl], Tv[sl], audio[sl], Ts[sl], 4, 2, **kw)
+            assert torch.equal(ids2.cpu(), ids0[sl].cpu()) and torch.equal(len2.cpu(), len0[sl].cpu()), f"separate calls differ at {b0}"
+
+
 @pytest.mark.parametrize("family,task", [("llama", "audiovisual"), ("llama", "audio"), ("llama", "video"), ("qwen2", "audiovisual")])
 def test_generate_token_ids_f32(family, task):
     """Integer token ids bit-exact against the oracle's greedy decode (parity mode), natural EOS and forced length."""
