@@ -373,6 +373,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     return 0;
   }
   static const bool use_dma = [] { const char* e = getenv("OAVSR_GEMM_DMA"); return !(e && e[0] == '0'); }();
+  if (a.swiglu_pairs) OAVSR_REQUIRE(use_dma && gemm_dma_swiglu_ok(a), "gemm: fused SwiGLU epilogue unavailable for this shape (check gemm_dma_swiglu_ok)");
   if (use_dma && gemm_dma_eligible(a)) return launch_gemm_dma(a, st);
   return a.dtype == DT_F32 ? launch_mode<float>(a, st) : launch_mode<bf16_t>(a, st);
 }

@@ -295,6 +295,30 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
       if (p.res_after_act) v += res[e];
       y[e] = v;
     }
+    if (p.swiglu_pairs && !split) {
+      // gate / up weight rows are interleaved in blocks of 16: the lanes with an even (lane & 3) hold a gate block, their right
+      // neighbour the matching up block of the same row.  Both are rounded to T first (what the unfused GEMM -> swiglu_kernel
+      // sequence reads back), so the fused and the two-launch path give the same bits.
+      float o[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float up = __shfl_down(y[e], 1, 64);
+        o[e] = silu(to_f32(from_f32<T>(y[e]))) * to_f32(from_f32<T>(up));
+      }
+      if ((lane & 1) == 0 && nb + 32 <= p.N) {
+        const int64_t oc = (int64_t)m * p.ldc + (ngb >> 5) * 16;
+        if (p.out_f32) {
+          float* Cf = reinterpret_cast<float*>(p.C) + oc;
+#pragma unroll
+          for (int e = 0; e < 16; e += 4) *reinterpret_cast<f32x4*>(Cf + e) = f32x4{o[e], o[e + 1], o[e + 2], o[e + 3]};
+        } else {
+          T* Ct = reinterpret_cast<T*>(p.C) + oc;
+#pragma unroll
+          for (int e = 0; e < 16; e += VEC) *reinterpret_cast<Chunk16*>(Ct + e) = chunk_from_f32<T>(o + e);
+        }
+      }
+      continue;
+    }
     if (e_f32) {
       float* Cf = reinterpret_cast<float*>(e_C) + (int64_t)m * e_ldc + ngb;
       if (nb + 16 <= p.N && (e_ldc % 4) == 0 && ((uintptr_t)e_C & 15) == 0 && (ngb % 4) == 0) {
@@ -371,6 +395,12 @@ int launch_dma_mode(const GemmArgs& a, hipStream_t st) {
 }  // namespace
 
 bool gemm_dma_eligible(const GemmArgs& a) { return dma_tile_choice(a) != 0; }
+// fused SwiGLU epilogue (gate / up rows interleaved by 16): LDS-DMA kernels only, whole 32-row blocks, plain epilogue, 16-byte rows
+bool gemm_dma_swiglu_ok(const GemmArgs& a) {
+  const int vec = a.dtype == DT_F32 ? 4 : 8;
+  return dma_tile_choice(a) != 0 && a.ksplit <= 1 && a.groups == 1 && a.N % 32 == 0 && !a.residual && a.act == ACT_NONE &&
+         a.ldc % vec == 0 && ((uintptr_t)a.C & 15) == 0;
+}
 const char* gemm_dma_variant(const GemmArgs& a) {
   const int c = dma_tile_choice(a);
   if (c == 4) return a.ksplit > 1 ? "dma_splitk_128x64" : "dma_128x64";

@@ -44,6 +44,7 @@ struct GemmArgs {
 int launch_gemm(const GemmArgs& a, hipStream_t st);
 // LDS-DMA pipelined 256x128 variant (gemm2.hip); launch_gemm dispatches to it when the grid fills the chip
 bool gemm_dma_eligible(const GemmArgs& a);
+bool gemm_dma_swiglu_ok(const GemmArgs& a);
 const char* gemm_dma_variant(const GemmArgs& a);
 int launch_gemm_dma(const GemmArgs& a, hipStream_t st);
 

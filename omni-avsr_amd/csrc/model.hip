@@ -685,9 +685,15 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
       { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
         OAVSR_TRY(launch_rmsnorm(dt, ws->lx, d, ws->lh, d, L.ln2w, rows, d, c.llm_rms_eps, st)); }
       g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 2 * I; g.K = d; g.A = ws->lh; g.lda = d; g.W = L.guw; g.ldw = d; g.C = ws->lgu; g.ldc = 2 * I;
-      OAVSR_TRY(llm_gemm(m, ws, g, mode, st));
-      { ProfScope ps("swiglu", 0, 3.0 * rows * I * m->esz, st);
-        OAVSR_TRY(launch_swiglu(dt, ws->lgu, 2 * I, ws->lact, I, rows, I, 1, st)); }
+      static const bool fuse_swiglu = [] { const char* e = getenv("OAVSR_FUSE_SWIGLU"); return !(e && e[0] == '0'); }();
+      GemmArgs gf = g; gf.swiglu_pairs = 1; gf.C = ws->lact; gf.ldc = I;
+      if (fuse_swiglu && mode == 0 && gemm_dma_swiglu_ok(gf)) {   // prefill: SwiGLU in the GEMM epilogue, the [rows][2I] tensor never exists
+        OAVSR_TRY(run_gemm(gf, st, false));
+      } else {
+        OAVSR_TRY(llm_gemm(m, ws, g, mode, st));
+        ProfScope ps("swiglu", 0, 3.0 * rows * I * m->esz, st);
+        OAVSR_TRY(launch_swiglu(dt, ws->lgu, 2 * I, ws->lact, I, rows, I, 1, st));
+      }
     }
     g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = d; g.K = I; g.A = ws->lact; g.lda = I; g.W = L.downw; g.ldw = I;
     g.residual = ws->lx; g.ldr = d; g.C = ws->lx; g.ldc = d;

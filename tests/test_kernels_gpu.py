@@ -668,6 +668,26 @@ def test_rope_kv(dtype, hd):
     close(vc, vref, tol(dtype), what="v cache")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,I,K", [(2504, 8192, 256), (1000, 4096, 128), (4100, 1024 + 32, 192)])
+def test_gemm_dma_fused_swiglu_prefill(dtype, M, I, K):
+    """SwiGLU in the LDS-DMA GEMM epilogue (prefill): gate / up rows interleaved by 16; must equal GEMM -> swiglu kernel bit for
+    bit (both operands are rounded to the storage type first) and match the fp32 reference."""
+    x, xr = q(rnd(M, K, seed=1), dtype)
+    wg, wgr = q(rnd(I, K, seed=2) / math.sqrt(K), dtype)
+    wu, wur = q(rnd(I, K, seed=3) / math.sqrt(K), dtype)
+    inter = torch.stack([wg.reshape(-1, 16, K), wu.reshape(-1, 16, K)], 1).reshape(2 * I, K).contiguous()
+    fused = gemm(dtype, x, inter, swiglu_pairs=1)
+    assert fused.shape == (M, I)
+    gu = gemm(dtype, x, inter)
+    two = torch.empty(M, I, dtype=tdt(dtype), device=DEV)
+    L.check(L.load().oavsr_op_swiglu(dcode(dtype), P(gu), 2 * I, P(two), I, M, I, 1, stream()))
+    assert torch.equal(fused, two), f"fused epilogue differs from gemm + swiglu: {(fused.float() - two.float()).abs().max().item():.3e}"
+    g_ = (xr @ wgr.T).to(tdt(dtype)).float()
+    u_ = (xr @ wur.T).to(tdt(dtype)).float()
+    close(fused, F.silu(g_) * u_, tol(dtype) * 2, rtol=(8e-3 if dtype == "bf16" else 0.0), what="fused swiglu (prefill)")
+
+
 # ------------------------------------------------------------------------------------------------ beam-search candidates
 @pytest.mark.parametrize("rows,V,K,mode", [(120, 128256, 15, "random"), (7, 128256, 15, "clustered"), (5, 151936, 4, "ties"), (3, 1000, 32, "random"),
                                            (2, 40, 15, "random")])
