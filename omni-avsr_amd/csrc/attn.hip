@@ -344,8 +344,10 @@ __global__ __launch_bounds__(kThreads) void attn_dma_kernel(const AttnArgs p) {
         }
       l_run[j] = l_run[j] * alpha + lsum;
       m_run[j] = m_new;
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {   // the running max moved for some query of this tile (rare after the first tiles)
 #pragma unroll
-      for (int i = 0; i < NDT; ++i) o[j][i] *= alpha;
+        for (int i = 0; i < NDT; ++i) o[j][i] *= alpha;
+      }
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
