@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0
 def build_spec(args):
     from omni_avsr_amd.config import spec_from_names
     return spec_from_names(
-        "meta-llama/Llama-3.2-1B", "openai/whisper-medium.en", "large_vox_iter5", use_lora_avhubert=True,
+        args.llm, "openai/whisper-medium.en", "large_vox_iter5", use_lora_avhubert=True,
         intermediate_size=2048, compression_mode="avg-pooling", downsample_ratio_audio=[4, 16], downsample_ratio_video=[2, 4, 5],
         is_matryoshka=True, is_single_matry_projector=False, lora_rank=32, lora_alpha=4, is_task_specific=True, shared_lora=True,
         prompt_len={"audio": 8, "video": 8, "audiovisual": 8}, max_dec_tokens=args.max_new, num_beams=1)
@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--beams", type=int, default=1, help="1 = greedy (north-star decode); 15 = the reference's default HF beam search")
+    ap.add_argument("--llm", default="meta-llama/Llama-3.2-1B",
+                    help="LLM architecture (random-init); the headline number is quoted on Llama-3.2-1B.  E.g. meta-llama/Meta-Llama-3.1-8B, Qwen/Qwen2.5-7B")
     ap.add_argument("--decode-group", type=int, default=1,
                     help="G > 1: G consecutive steps (batches) share ONE decode loop (encoders / prefill still run per batch of --batch; "
                          "continuous batching of the decode phase).  Opt-in: not the configuration the headline number is quoted on")
@@ -205,8 +207,8 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "rtf": round(elapsed / (n_utt * Tv / 25.0), 6),
-            "config": {"workload": f"AVSR, AV-HuBERT-Large + Whisper-medium.en + Llama-3.2-1B (Omni-LoRA ST r32/a4), batch={B} x {Tv / 25:.0f}s clips per GPU, "
-                                   f"compression (4,4), " + (f"greedy {args.max_new} new tokens (EOS suppressed)" if args.beams == 1 else f"HF beam search K={args.beams}, {args.max_new} steps") + ", BASELINE.json configs[1]",
+            "config": {"workload": f"AVSR, AV-HuBERT-Large + Whisper-medium.en + {args.llm.split('/')[-1]} (Omni-LoRA ST r32/a4), batch={B} x {Tv / 25:.0f}s clips per GPU, "
+                                   f"compression (4,4), " + (f"greedy {args.max_new} new tokens (EOS suppressed)" if args.beams == 1 else f"HF beam search K={args.beams}, {args.max_new} steps") + (", BASELINE.json configs[1]" if args.llm.endswith("Llama-3.2-1B") else ", NOT the headline configuration (other LLM)"),
                        "global_batch": world * B, "parallelism": f"utterance-sharded dp{world}", "streams_per_gpu": nstream, "decode_group": G, "setup_s": round(setup_s, 1)},
             "roofline": roofline, "cpu_baseline": cpu, "stages": stages,
         }
