@@ -75,6 +75,52 @@ __global__ __launch_bounds__(512) void skinny_pattern(const char* __restrict__ s
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[blockIdx.x & 1023] = 1;
 }
 
+// skinny pattern + what the real kernel adds: MODE 1 = also load the activation fragment of every k step from a small L2-resident
+// buffer (global loads in the same queue), MODE 2 = activation fragments from LDS instead, MODE 3 = MODE 1 + one MFMA per fragment
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+template <int NT, int U, int MODE>
+__global__ __launch_bounds__(512) void skinny_plus(const char* __restrict__ src, const char* __restrict__ act, int K_bytes, unsigned* sink) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const char* base = src + (size_t)blockIdx.x * NT * 8 * K_bytes;
+  const int nkb = K_bytes / 128;
+  if (MODE == 2) {
+    for (int i = threadIdx.x * 16; i < 8 * K_bytes; i += 512 * 16) *reinterpret_cast<u32x4*>(lds + i) = *reinterpret_cast<const u32x4*>(act + i);
+    __syncthreads();
+  }
+  u32x4 acc = {0, 0, 0, 0};
+  f32x4_t facc[NT];
+  for (int j = 0; j < NT; ++j) facc[j] = f32x4_t{0, 0, 0, 0};
+  for (int kb0 = wave; kb0 < nkb; kb0 += 8 * U) {
+    u32x4 v[U][NT], a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kb = kb0 + 8 * u;
+      const size_t ko = (size_t)kb * 128 + (r16 >> 3) * 64 + g * 16;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const char* p = base + (size_t)(j * 8 + (r16 & 7)) * K_bytes + ko;
+        v[u][j] = kb < nkb ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)) : u32x4{0, 0, 0, 0};
+      }
+      if (MODE == 1 || MODE == 3) a[u] = kb < nkb ? *reinterpret_cast<const u32x4*>(act + (size_t)(r16 & 7) * K_bytes + ko) : u32x4{0, 0, 0, 0};
+      else if (MODE == 2) a[u] = *reinterpret_cast<const u32x4*>(lds + (size_t)(r16 & 7) * K_bytes + (kb < nkb ? ko : 0));
+      else a[u] = u32x4{1, 2, 3, 4};
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (MODE == 3) facc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[u]), __builtin_bit_cast(bf16x8_t, v[u][j]), facc[j], 0, 0, 0);
+        else acc ^= v[u][j] ^ a[u];
+      }
+  }
+  float fs = 0;
+  for (int j = 0; j < NT; ++j) fs += facc[j][0] + facc[j][1] + facc[j][2] + facc[j][3];
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u || fs == 1.2345f) sink[blockIdx.x & 1023] = 1;
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 template <typename F> float timeit(F f, int iters) {
@@ -115,6 +161,11 @@ int main() {
       rep3("single round NT=4 U=4 half (512 WGs)", timeit([&] { hipLaunchKernelGGL((skinny_pattern<4, 4, true, true>), dim3(512), dim3(512), 0, 0, buf + (size_t)(it++ % 24) * one, Kb, sink); }, 48));
       rep3("single round NT=2 U=4 half (1024 WGs)", timeit([&] { hipLaunchKernelGGL((skinny_pattern<2, 4, true, true>), dim3(1024), dim3(512), 0, 0, buf + (size_t)(it++ % 24) * one, Kb, sink); }, 48));
       rep3("single round NT=4 U=4 (256 WGs)", timeit([&] { hipLaunchKernelGGL((skinny_pattern<4, 4, true, false>), dim3(256), dim3(512), 0, 0, buf + (size_t)(it++ % 24) * one, Kb, sink); }, 48));
+    }
+    { char* act; CK(hipMalloc(&act, 8 * Kb)); CK(hipMemset(act, 0, 8 * Kb));
+      auto rep4 = [&](const char* name, float ms) { int grid = (int)(total / Kb / 32); printf("%-44s grid %5d: %8.1f us  %7.0f GB/s\n", name, grid, ms * 1e3, (double)grid * 32 * Kb / ms / 1e6); };
+#define SP(MODE, LDSB) rep4("skinny+ NT=4 U=2 half mode=" #MODE, timeit([&] { int grid = (int)(total / Kb / 32); hipLaunchKernelGGL((skinny_plus<4, 2, MODE>), dim3(grid), dim3(512), LDSB, 0, buf, act, Kb, sink); }, 5));
+      SP(0, 0) SP(1, 0) SP(2, 8 * Kb) SP(3, 0)
     }
     SK(4, 4, true, false) SK(4, 4, false, false) SK(4, 8, true, false) SK(1, 8, true, false) SK(4, 4, true, true) SK(1, 8, true, true) SK(8, 4, true, false)
   }
