@@ -363,7 +363,10 @@ class AVSR_LLMs:
                 lengths = [int(max(inputs["lengths"]))]                                   # modeling_OmniAVSR.py:399
             else:
                 lengths = [int(x) for x in inputs["lengths"]]
-        ids, lens = self.engine.generate(task, video, Tv, audio, lengths, ra, rv, self.num_beams, self.max_dec_tokens, force_len)
+        # `model.encoder_chunk = 8` (not a reference attribute): large evaluation batches run their encoders / prefill in chunks of
+        # that many utterances and share one decode loop (oavsr_generate_chunked; identical ids)
+        ids, lens = self.engine.generate(task, video, Tv, audio, lengths, ra, rv, self.num_beams, self.max_dec_tokens, force_len,
+                                         chunk=getattr(self, "encoder_chunk", None))
         lens_h = lens.cpu()
         n = int(lens_h.max())
         return ids[:, :n].to(torch.long)
