@@ -115,6 +115,7 @@ class OmniSpec:
     is_matryoshka: bool = False
     is_single_matry_projector: bool = False
     remove_layernorm_from_projector: bool = False
+    projector_layernorm_plain: bool = False     # modeling_LlamaAVSR.py variant: LayerNorm present iff not removed (no Omni quirks)
     lora_rank: int = 0                          # reduction factor RANK (0: no LoRA)
     lora_alpha: int = 1
     is_task_specific: bool = False
@@ -137,6 +138,8 @@ class OmniSpec:
         (:104,:162,:188) so it is never applied; the audio *stack* matryoshka branch has the polarity
         inverted (:74-77)."""
         rm = self.remove_layernorm_from_projector
+        if self.projector_layernorm_plain:
+            return not rm              # modeling_LlamaAVSR.py:60-108,150-196: Sequential(..., LayerNorm) unless removed
         if self.compression_mode == "stack":
             if self.is_matryoshka:
                 return bool(rm) if which == "audio" else False

@@ -135,3 +135,43 @@ def test_synth_is_deterministic_and_complete():
     assert all(torch.equal(a[k], b[k]) for k in a)
     assert "llm.model.layers.0.self_attn.lora_up_V.audiovisual.weight" in a and "prompt_audiovisual" in a
     assert a["video_encoder.encoder.layers.0.self_attn.lora_down_Q.weight"].shape == (8, 128)
+
+
+@pytest.mark.parametrize("mode", ["avg-pooling", "stack"])
+@pytest.mark.parametrize("matry", [False, True])
+@pytest.mark.parametrize("rm", [False, True])
+def test_llamaavsr_projector_layernorm_is_plain(mode, matry, rm):
+    """modeling_LlamaAVSR.py:60-108,150-196: Sequential(..., nn.LayerNorm) unless remove_layernorm_from_projector -- none of the
+    Omni variant's quirks (LayerNorm swallowed as a Linear bias, inverted polarity)."""
+    import dataclasses
+    spec = dataclasses.replace(tiny_spec(matryoshka=matry, compression_mode=mode, remove_layernorm=rm), projector_layernorm_plain=True)
+    assert spec.proj_has_layernorm("audio") == (not rm) and spec.proj_has_layernorm("video") == (not rm)
+
+
+def test_llamaavsr_shim_prompt_ids_follow_reference_slicing():
+    """prompt ids = tokenizer(prompt).input_ids[:, start:-1], start = 1 for Llama (drop BOS), 0 for Qwen (modeling_LlamaAVSR.py:283-285);
+    test_ratio_matry for audiovisual is (video rate, audio rate) (:334,339)."""
+    from omni_avsr_amd.modeling_llamaavsr import AVSR_LLMs
+
+    class Tok:
+        vocab = {"<audio>": 501, "</audio>": 502, "<video>": 503, "</video>": 504}
+
+        def __call__(self, text, return_tensors=None):
+            class R:
+                input_ids = torch.tensor([[7, 11, 12, 13, 9]])
+            return R()
+
+    spec = tiny_spec("llama", matryoshka=True)
+    for name, want in (("meta-llama/Llama-3.2-1B", [11, 12, 13]), ("Qwen/Qwen2.5-7B", [7, 11, 12, 13])):
+        m = AVSR_LLMs("audiovisual", "large", False, name, spec.llm.hidden, 192, Tok(), "Transcribe.", 0, [2, 4], [2, 4], "w", "avg-pooling", [], 8, 1,
+                      is_matryoshka=True, spec=spec, dtype="f32")
+        assert m.prompt_ids == want
+    seen = {}
+    import omni_avsr_amd.modeling as M
+    orig = M.AVSR_LLMs.forward
+    try:
+        M.AVSR_LLMs.forward = lambda self, inputs, **kw: seen.update(kw)
+        m({}, is_trainval=False, test_ratio_matry=(4, 2))
+    finally:
+        M.AVSR_LLMs.forward = orig
+    assert seen["test_ratio_matry_video"] == 4 and seen["test_ratio_matry_audio"] == 2 and seen["modality"] is None
