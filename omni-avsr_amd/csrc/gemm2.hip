@@ -101,7 +101,8 @@ __device__ __forceinline__ void dma16(const void* src, char* lds_wave_base) {
 // BM x BN tile, kStages LDS stages (kStages - 1 k-tiles in flight), 8 waves as WAVES_M x (8 / WAVES_M), wave tile (BM/WAVES_M) x 64:
 //   256 x 128, 3 stages, 4 x 2 waves (wave tile 64 x 64)   -- mid-size grids
 //   256 x 256, 2 stages, 2 x 4 waves (wave tile 128 x 64)  -- large grids: half the L2->LDS bytes and LDS reads per flop
-template <typename T, int AMODE, int BM, int BN, int kStages, int WAVES_M, int NWAVES>
+// DW: waves that issue the LDS-DMA loads (segments are dealt over them); the rest only compute (12-wave 256 x 192 tile: 56 segments = 8 x 7)
+template <typename T, int AMODE, int BM, int BN, int kStages, int WAVES_M, int NWAVES, int DW = NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p) {
   constexpr int kThreads = NWAVES * 64;
   constexpr int VEC = TypeInfo<T>::kVec;
@@ -109,8 +110,9 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
   constexpr int WAVES_N = NWAVES / WAVES_M;
   constexpr int TM = BM / (WAVES_M * 16), TN = BN / (WAVES_N * 16);
   constexpr int kStageBytes = (BM + BN) * kRowBytes;
-  constexpr int NLD = (BM + BN) * 8 / kThreads;           // DMA instructions per thread per k-tile
-  constexpr int NLA = BM * 8 / kThreads;                  // ... of which fetch A rows
+  static_assert((BM + BN) * 8 % (DW * 64) == 0 && BM * 8 % (DW * 64) == 0, "segments must deal evenly over the DMA waves");
+  constexpr int NLD = (BM + BN) * 8 / (DW * 64);          // DMA instructions per issuing thread per k-tile
+  constexpr int NLA = BM * 8 / (DW * 64);                 // ... of which fetch A rows
   extern __shared__ __attribute__((aligned(1024))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -136,11 +138,11 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
   const int lchunk = (lane & 7) ^ lrow;
   ARow2 arow[NLA];
 #pragma unroll
-  for (int j = 0; j < NLA; ++j) init_arow2<T, AMODE>(p, m0 + (j * NWAVES + wave) * 8 + lrow, g, arow[j]);
+  for (int j = 0; j < NLA; ++j) init_arow2<T, AMODE>(p, m0 + (j * DW + wave) * 8 + lrow, g, arow[j]);
   int64_t wbase[NLD - NLA]; int wvalid[NLD - NLA];
 #pragma unroll
   for (int j = 0; j < NLD - NLA; ++j) {
-    int n = n0 + ((j + NLA) * NWAVES + wave) * 8 + lrow - BM;
+    int n = n0 + ((j + NLA) * DW + wave) * 8 + lrow - BM;
     wvalid[j] = n < p.N;
     wbase[j] = (int64_t)(g * p.N + n);
   }
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
 
   const bool tap_uniform = AMODE != A_DENSE && p.Cin % BKE == 0;
   auto issue = [&](int tl) {
+    if (DW < NWAVES && wave >= DW) return;            // compute-only waves
     char* st = smem + (tl % kStages) * kStageBytes;
     const int t = tbeg + tl;
     if (t < nt1) {
@@ -163,24 +166,24 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
       if ((AMODE == A_CONV2D || AMODE == A_CONV1D) && tap_uniform) {
         const int kt0 = t * BKE, tap = kt0 / p.Cin, c = kt0 - tap * p.Cin + lchunk * VEC;   // tap: scalar division, once per k-tile
 #pragma unroll
-        for (int j = 0; j < NLA; ++j) dma16(a_src_tap<T, AMODE>(p, arow[j], tap, c, g), st + (j * NWAVES + wave) * 1024);
+        for (int j = 0; j < NLA; ++j) dma16(a_src_tap<T, AMODE>(p, arow[j], tap, c, g), st + (j * DW + wave) * 1024);
       } else {
 #pragma unroll
-        for (int j = 0; j < NLA; ++j) dma16(a_src<T, AMODE>(p, arow[j], k, g), st + (j * NWAVES + wave) * 1024);
+        for (int j = 0; j < NLA; ++j) dma16(a_src<T, AMODE>(p, arow[j], k, g), st + (j * DW + wave) * 1024);
       }
 #pragma unroll
       for (int j = 0; j < NLD - NLA; ++j)
-        dma16(wvalid[j] ? (const void*)(W1 + wbase[j] * p.ldw + k) : (const void*)g_zero_page, st + ((j + NLA) * NWAVES + wave) * 1024);
+        dma16(wvalid[j] ? (const void*)(W1 + wbase[j] * p.ldw + k) : (const void*)g_zero_page, st + ((j + NLA) * DW + wave) * 1024);
     } else {
       const int k = (t - nt1) * BKE + lchunk * VEC;
 #pragma unroll
       for (int j = 0; j < NLA; ++j) {
-        const int m = m0 + (j * NWAVES + wave) * 8 + lrow;
-        dma16(m < p.M ? (const void*)(A2 + (int64_t)m * p.lda2 + k) : (const void*)g_zero_page, st + (j * NWAVES + wave) * 1024);
+        const int m = m0 + (j * DW + wave) * 8 + lrow;
+        dma16(m < p.M ? (const void*)(A2 + (int64_t)m * p.lda2 + k) : (const void*)g_zero_page, st + (j * DW + wave) * 1024);
       }
 #pragma unroll
       for (int j = 0; j < NLD - NLA; ++j)
-        dma16(wvalid[j] ? (const void*)(W2 + wbase[j] * p.ldw2 + k) : (const void*)g_zero_page, st + ((j + NLA) * NWAVES + wave) * 1024);
+        dma16(wvalid[j] ? (const void*)(W2 + wbase[j] * p.ldw2 + k) : (const void*)g_zero_page, st + ((j + NLA) * DW + wave) * 1024);
     }
   };
 
@@ -341,9 +344,9 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
   }
 }
 
-template <typename T, int AMODE, int BM, int BN, int kStages, int WAVES_M, int NWAVES>
+template <typename T, int AMODE, int BM, int BN, int kStages, int WAVES_M, int NWAVES, int DW = NWAVES>
 int launch_dma(const GemmArgs& a, hipStream_t st) {
-  auto kern = gemm_dma_kernel<T, AMODE, BM, BN, kStages, WAVES_M, NWAVES>;
+  auto kern = gemm_dma_kernel<T, AMODE, BM, BN, kStages, WAVES_M, NWAVES, DW>;
   constexpr int smem = kStages * (BM + BN) * kRowBytes;
   static bool attr_set = false;
   if (!attr_set) {
@@ -368,8 +371,33 @@ static int dma_tile_choice(const GemmArgs& a) {
   const int64_t n256 = (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 256) * a.groups;
   if (force == 1) return n128 >= 1 ? 1 : 0;
   if (force == 2) return (a.N >= 256 && a.amode == A_DENSE) ? 2 : 1;
+  if (force == 5) return (a.N >= 192 && a.amode == A_DENSE) ? 5 : 1;
+  if (force == 6) return (a.N >= 256 && a.amode == A_DENSE) ? 6 : 1;
   // measured on MI355X (tools/bench_kernels.py): the 256x256 tile wins as soon as ~60 % of the CUs get a tile
-  if (a.amode == A_DENSE && a.N >= 256 && n256 >= 144) return 2;
+  if (a.amode == A_DENSE && a.N >= 256 && n256 >= 144) {
+    // one workgroup per CU: time ~ rounds x tile size.  N = 3072 (QKV): 12 tiles of 256 columns leave a ragged last round
+    // (M = 12000: 564 tiles = 2.2 rounds); 16 tiles of 192 columns give 752 tiles = 2.94 rounds of 3/4 the work each
+    static const int ncu = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
+    // Off by default: alone on the chip the 3/4-size tiles win (Whisper QKV 112 -> 99 us, fc2 125 -> 106 us, +1.2 % per
+    // sequential batch), but with three batches in flight the mostly empty last round of the 256 x 256 grid is filled by the
+    // other streams' decode kernels anyway and the 12-wave tiles cost 2 % of throughput.  OAVSR_GEMM_BN192=1 for latency mode.
+    static const int t192 = [] { const char* e = getenv("OAVSR_GEMM_BN192"); return e ? atoi(e) : 0; }();
+    if (t192 && a.groups == 1) {
+      // candidates: 256 x 256 (cost 1), 256 x 192 (N % 192 == 0) and 192 x 256, both 3/4 of the work at ~4 % lower efficiency
+      const double c256 = (double)ceil_div((int)n256, ncu);
+      double best = c256; int pick = 2;
+      if (a.N % 192 == 0) {
+        const double c = (double)ceil_div((int)((int64_t)ceil_div(a.M, 256) * (a.N / 192)), ncu) * 0.75 * 1.04;
+        if (c < best) { best = c; pick = 5; }
+      }
+      {
+        const double c = (double)ceil_div((int)((int64_t)ceil_div(a.M, 192) * ceil_div(a.N, 256)), ncu) * 0.75 * 1.04;
+        if (c < best * 0.97) { best = c; pick = 6; }
+      }
+      return pick;
+    }
+    return 2;
+  }
   if (n128 >= 144) return 1;
   return 0;
 }
@@ -378,6 +406,8 @@ template <typename T>
 int launch_dma_mode(const GemmArgs& a, hipStream_t st) {
   // 256x256: 16 waves (4 x 4) of 64 x 64, 2 stages; dense only.  256x128: 8 waves (4 x 2) of 64 x 64, 3 stages.
   if (dma_tile_choice(a) == 2) return launch_dma<T, A_DENSE, 256, 256, 2, 4, 16>(a, st);
+  if (dma_tile_choice(a) == 5) return launch_dma<T, A_DENSE, 256, 192, 2, 4, 12, 8>(a, st);   // 12 waves (4 x 3) of 64 x 64; 8 of them issue the DMA
+  if (dma_tile_choice(a) == 6) return launch_dma<T, A_DENSE, 192, 256, 2, 3, 12, 8>(a, st);   // 12 waves (3 x 4) of 64 x 64
   if (dma_tile_choice(a) == 4) {
     // every workgroup re-reads the A rows of its k range: 64-column tiles move 2 B of A per byte of W, 128-column tiles 1 B --
     // worth it as soon as N / 128 still gives every CU several workgroups (lm_head)
@@ -404,7 +434,7 @@ bool gemm_dma_swiglu_ok(const GemmArgs& a) {
 const char* gemm_dma_variant(const GemmArgs& a) {
   const int c = dma_tile_choice(a);
   if (c == 4) return a.ksplit > 1 ? "dma_splitk_128x64" : "dma_128x64";
-  return a.ksplit > 1 ? "dma_splitk_256x128" : c == 2 ? "dma_256x256" : "dma_256x128";
+  return a.ksplit > 1 ? "dma_splitk_256x128" : c == 2 ? "dma_256x256" : c == 5 ? "dma_256x192" : c == 6 ? "dma_192x256" : "dma_256x128";
 }
 
 int launch_gemm_dma(const GemmArgs& a, hipStream_t st) {
