@@ -1,10 +1,10 @@
 // Pipelined MFMA GEMM for gfx950 (the encoder / prefill workhorse):  C[M,N] = epi(A1.W1^T + A2.W2^T).
 //
 // Same math, operand layouts, gather functors (dense / NHWC conv2d / token-major conv1d) and fused epilogue as gemm.hip,
-// but built around LDS-DMA (`global_load_lds_dwordx4`): tiles go HBM -> LDS without touching VGPRs, so three 48-KiB
-// stages fit (144 of the CU's 160 KiB) and TWO k-tiles stay in flight across the single barrier per k-tile
-// (counted `s_waitcnt vmcnt(N)`, raw `s_barrier`; never vmcnt(0) inside the loop).
-//   * workgroup = 512 threads = 8 waves (4 x 2), tile 256 x 128 x 128 B of K, wave tile 64 x 64 (4 x 4 MFMA 16x16)
+// but built around LDS-DMA (`global_load_lds_dwordx4`): tiles go HBM -> LDS without touching VGPRs, one raw `s_barrier` per
+// k-tile, counted `s_waitcnt vmcnt(N)` where more than one k-tile is in flight.  Wave tile 64 x 64 (4 x 4 MFMA 16x16) throughout;
+// tile shapes (launch_dma_mode): 256 x 256 / 16 waves / 2 stages (the workhorse), 256 x 128 / 8 waves / 3 stages (mid-size grids,
+// conv gathers, split-K), 128 x 64 and 128 x 128 / 4 waves (<= 128 rows: beam-search decode), 256 x 192 and 192 x 256 / 12 waves (opt-in).
 //   * the DMA writes LDS linearly (wave-uniform base + lane*16), so the XOR swizzle that makes the ds_read_b128 fragment
 //     reads conflict-free is applied to the per-lane SOURCE address (chunk ^ (row & 7)) and again on the read
 //   * out-of-range rows / conv padding read a 16-byte zero page instead of branching
@@ -98,9 +98,7 @@ __device__ __forceinline__ void dma16(const void* src, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// BM x BN tile, kStages LDS stages (kStages - 1 k-tiles in flight), 8 waves as WAVES_M x (8 / WAVES_M), wave tile (BM/WAVES_M) x 64:
-//   256 x 128, 3 stages, 4 x 2 waves (wave tile 64 x 64)   -- mid-size grids
-//   256 x 256, 2 stages, 2 x 4 waves (wave tile 128 x 64)  -- large grids: half the L2->LDS bytes and LDS reads per flop
+// BM x BN tile, kStages LDS stages (kStages - 1 k-tiles in flight), NWAVES waves as WAVES_M x (NWAVES / WAVES_M).
 // DW: waves that issue the LDS-DMA loads (segments are dealt over them); the rest only compute (12-wave 256 x 192 tile: 56 segments = 8 x 7)
 template <typename T, int AMODE, int BM, int BN, int kStages, int WAVES_M, int NWAVES, int DW = NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p) {
