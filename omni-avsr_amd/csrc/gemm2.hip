@@ -280,21 +280,37 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
         for (int e = 0; e < 16; ++e) if (nb + e < p.N) res[e] = to_f32(R[(int64_t)m * p.ldr + ngb + e]);
       }
     }
+    // per-column parameters are re-read per slab (L1 hits), four columns at a time to keep registers free: one 16-byte vector per
+    // array when the lane's 16 columns are all inside N and the array is 16-byte aligned there, scalar loads on the ragged edge
+    const bool pfull = nb + 16 <= p.N;
+    auto load4 = [&](const float* arr, int e, float dflt) -> f32x4 {
+      if (!arr) return f32x4{dflt, dflt, dflt, dflt};
+      if (pfull && (((uintptr_t)(arr + ngb)) & 15) == 0) return *reinterpret_cast<const f32x4*>(arr + ngb + e);
+      f32x4 t;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const bool in = nb + e < p.N;            // per-column parameters are re-read per slab (L1 hits) to keep registers free
-      // one explicit FMA, identical in every GEMM variant, so an element has the same bits whichever tile shape computed it
-      float v = fmaf(y[e], (e_scale && in) ? e_scale[ngb + e] : 1.f, (e_bias && in) ? e_bias[ngb + e] : 0.f);
-      if (!p.res_after_act) v += res[e];
-      switch (e_act) {
-        case ACT_GELU: v = gelu_act<T>(v); break;
-        case ACT_RELU: v = fmaxf(v, 0.f); break;
-        case ACT_PRELU: v = v >= 0.f ? v : (in ? p.prelu[ngb + e] : 0.f) * v; break;
-        case ACT_SILU: v = silu(v); break;
-        default: break;
+      for (int q = 0; q < 4; ++q) t[q] = nb + e + q < p.N ? arr[ngb + e + q] : dflt;
+      return t;
+    };
+#pragma unroll
+    for (int e4 = 0; e4 < 16; e4 += 4) {
+      const f32x4 csc = load4(e_scale, e4, 1.f), cbi = load4(e_bias, e4, 0.f);
+      const f32x4 csl = load4(e_act == ACT_PRELU ? p.prelu : nullptr, e4, 0.f);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = e4 + q;
+        // one explicit FMA, identical in every GEMM variant, so an element has the same bits whichever tile shape computed it
+        float v = fmaf(y[e], csc[q], cbi[q]);
+        if (!p.res_after_act) v += res[e];
+        switch (e_act) {
+          case ACT_GELU: v = gelu_act<T>(v); break;
+          case ACT_RELU: v = fmaxf(v, 0.f); break;
+          case ACT_PRELU: v = v >= 0.f ? v : csl[q] * v; break;
+          case ACT_SILU: v = silu(v); break;
+          default: break;
+        }
+        if (p.res_after_act) v += res[e];
+        y[e] = v;
       }
-      if (p.res_after_act) v += res[e];
-      y[e] = v;
     }
     if (p.swiglu_pairs && !split) {
       // gate / up weight rows are interleaved in blocks of 16: the lanes with an even (lane & 3) hold a gate block, their right
