@@ -294,23 +294,36 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
 #pragma unroll
     for (int e4 = 0; e4 < 16; e4 += 4) {
       const f32x4 csc = load4(e_scale, e4, 1.f), cbi = load4(e_bias, e4, 0.f);
-      const f32x4 csl = load4(e_act == ACT_PRELU ? p.prelu : nullptr, e4, 0.f);
+      float v[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int e = e4 + q;
         // one explicit FMA, identical in every GEMM variant, so an element has the same bits whichever tile shape computed it
-        float v = fmaf(y[e], csc[q], cbi[q]);
-        if (!p.res_after_act) v += res[e];
-        switch (e_act) {
-          case ACT_GELU: v = gelu_act<T>(v); break;
-          case ACT_RELU: v = fmaxf(v, 0.f); break;
-          case ACT_PRELU: v = v >= 0.f ? v : csl[q] * v; break;
-          case ACT_SILU: v = silu(v); break;
-          default: break;
-        }
-        if (p.res_after_act) v += res[e];
-        y[e] = v;
+        v[q] = fmaf(y[e4 + q], csc[q], cbi[q]);
+        if (!p.res_after_act) v[q] += res[e4 + q];
       }
+      switch (e_act) {                            // one uniform branch per four columns
+        case ACT_GELU:
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = gelu_act<T>(v[q]);
+          break;
+        case ACT_RELU:
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+          break;
+        case ACT_PRELU: {
+          const f32x4 csl = load4(p.prelu, e4, 0.f);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = v[q] >= 0.f ? v[q] : csl[q] * v[q];
+          break;
+        }
+        case ACT_SILU:
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
+          break;
+        default: break;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) y[e4 + q] = p.res_after_act ? v[q] + res[e4 + q] : v[q];
     }
     if (p.swiglu_pairs && !split) {
       // gate / up weight rows are interleaved in blocks of 16: the lanes with an even (lane & 3) hold a gate block, their right
