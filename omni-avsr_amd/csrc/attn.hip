@@ -13,6 +13,7 @@
 // (2) decode_attn_kernel: one new token per row against a KV cache (shared utterance prefix + per-row tail
 //     addressed through a beam ancestry table).  HBM-bound, VALU only.
 #include <stdlib.h>
+#include <type_traits>
 #include "kernels.h"
 
 namespace oavsr {
@@ -20,6 +21,21 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int KT = 64;   // keys per LDS tile
+
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+// 8-byte transposing LDS read with an immediate offset; the caller orders it with an explicit s_waitcnt lgkmcnt
+template <int OFF>
+__device__ __forceinline__ u32x2 lds_tr16_b64(unsigned addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
 
 template <typename T> struct MmaT;
 template <> struct MmaT<bf16_t> {
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(kThreads) void attn_varlen_kernel(const AttnArgs p)
 __device__ __attribute__((aligned(256))) unsigned int g_attn_zero_page[64];
 
 template <int QT>
-__global__ __launch_bounds__(kThreads) void attn_dma_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(kThreads, 2) void attn_dma_kernel(const AttnArgs p) {
   constexpr int HD = 64, RB = 128, NDT = 4, NSTAGE = 3;
   constexpr int kStage = 2 * KT * RB;                  // K image then V image
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -270,6 +286,18 @@ __global__ __launch_bounds__(kThreads) void attn_dma_kernel(const AttnArgs p) {
   if (ntile > 0) issue(0);
   if (ntile > 1) issue(1);
 
+  // LDS byte offsets of this lane's fragments inside a stage.  K (A operand): row kt*16 + qi, 16-B chunk (b*4 + g) ^ (qi & 7);
+  // V^T (tr-read: lane 4q+p addresses row q, cols 4p..4p+3): row 32u + 4g + qq (+16), chunk (2dt + (pp>>1)) ^ (row & 7).
+  // kt / u / +16 rows never touch row & 7, so they are plain immediates on top of 2 + 4 per-lane bases.
+  unsigned kbase[2], vbase[NDT];
+  {
+    const int qq = qi >> 2, pp = qi & 3, vrow = 4 * g + qq;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) kbase[b] = qi * RB + (((b * 4 + g) ^ (qi & 7)) << 4);
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) vbase[dt] = vrow * RB + (((dt * 2 + (pp >> 1)) ^ (vrow & 7)) << 4) + (pp & 1) * 8;
+  }
+
   const float sc = p.scale * 1.44269504088896340736f;    // softmax in base 2
   f32x4 o[QT][NDT];
   float m_run[QT], l_run[QT];
@@ -287,18 +315,21 @@ __global__ __launch_bounds__(kThreads) void attn_dma_kernel(const AttnArgs p) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (t + 2 < ntile) issue(t + 2);                     // its stage held tile t-1: every wave is past it
-    const char* sK = smem + (t % NSTAGE) * kStage;
-    const char* sV = sK + KT * RB;
+    const unsigned so = (unsigned)(t % NSTAGE) * kStage;
+    unsigned kaddr[2], vaddr[NDT];                        // lane bases inside this stage; everything else is an immediate offset
+#pragma unroll
+    for (int b = 0; b < 2; ++b) kaddr[b] = so + kbase[b];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) vaddr[dt] = so + KT * RB + vbase[dt];
     const int kt0 = t * KT;
 
     // ---- S^T[key][q] for 4 sub-tiles of 16 keys; a K fragment feeds all QT query tiles ----
     f32x4 s[QT][4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      const int row = kt * 16 + qi;                       // A-operand row = key (lane & 15)
-      Chunk16 kf[2];
+      Chunk16 kf[2];                                      // A-operand row = key kt*16 + (lane & 15)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) kf[b] = *reinterpret_cast<const Chunk16*>(sK + row * RB + (((b * 4 + g) ^ (row & 7)) << 4));
+      for (int b = 0; b < 2; ++b) kf[b] = *reinterpret_cast<const Chunk16*>(smem + (kaddr[b] + kt * 16 * RB));
 #pragma unroll
       for (int j = 0; j < QT; ++j) {
         s[j][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -333,15 +364,19 @@ __global__ __launch_bounds__(kThreads) void attn_dma_kernel(const AttnArgs p) {
       const float m_new = fmaxf(m_run[j], mt);
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
       const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_use);
-      float lsum = 0.f;
+      // exponent argument and row sum as 2-wide packed fp32 (v_pk_fma_f32 / v_pk_add_f32): half the VALU issue slots
+      f32x2 lsum2 = f32x2{0.f, 0.f};
+      const f32x2 sc2 = f32x2{sc, sc}, nm2 = f32x2{-m_use, -m_use};
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(fmaf(s[j][kt][r], sc, -m_use));
-          s[j][kt][r] = e;
-          lsum += e;
+        for (int h = 0; h < 2; ++h) {
+          const f32x2 x = __builtin_elementwise_fma(f32x2{s[j][kt][2 * h], s[j][kt][2 * h + 1]}, sc2, nm2);
+          const f32x2 e = f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+          s[j][kt][2 * h] = e[0]; s[j][kt][2 * h + 1] = e[1];
+          lsum2 += e;
         }
+      const float lsum = lsum2[0] + lsum2[1];
       l_run[j] = l_run[j] * alpha + lsum;
       m_run[j] = m_new;
       if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {   // the running max moved for some query of this tile (rare after the first tiles)
@@ -354,21 +389,23 @@ __global__ __launch_bounds__(kThreads) void attn_dma_kernel(const AttnArgs p) {
         for (int r = 0; r < 4; ++r) { pf[j][u][r] = (bf16_t)s[j][2 * u][r]; pf[j][u][4 + r] = (bf16_t)s[j][2 * u + 1][r]; }
     }
     // ---- O^T[d][q] += V^T[d][key] . P^T[key][q]; a V^T fragment feeds all QT query tiles ----
-    const int qq = qi >> 2, pp = qi & 3;                 // tr-read: lane 4q+p addresses row q, cols 4p..4p+3
+    // (ds_read_b64_tr_b16 issued as inline asm: the builtin never folds the sub-tile offsets into the instruction's offset field
+    //  and would spend 16 address adds per tile; the loads are tied to the s_waitcnt below through its operands)
+    u32x2 vt[2 * NDT][2];
+    static_for<0, 2 * NDT>([&](auto I) {
+      constexpr int u = decltype(I)::value / NDT, dt = decltype(I)::value % NDT;
+      vt[u * NDT + dt][0] = lds_tr16_b64<u * 32 * RB>(vaddr[dt]);
+      vt[u * NDT + dt][1] = lds_tr16_b64<u * 32 * RB + 16 * RB>(vaddr[dt]);
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(vt[0][0]), "+v"(vt[0][1]), "+v"(vt[1][0]), "+v"(vt[1][1]), "+v"(vt[2][0]), "+v"(vt[2][1]), "+v"(vt[3][0]), "+v"(vt[3][1]),
+                   "+v"(vt[4][0]), "+v"(vt[4][1]), "+v"(vt[5][0]), "+v"(vt[5][1]), "+v"(vt[6][0]), "+v"(vt[6][1]), "+v"(vt[7][0]), "+v"(vt[7][1]));
 #pragma unroll
     for (int u = 0; u < 2; ++u) {                         // 32 keys per MFMA: sub-tiles 2u, 2u+1
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
-        const int c = dt * 2 + (pp >> 1);
-        const int row0 = (2 * u) * 16 + 4 * g + qq, row1 = row0 + 16;
-        auto a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(sV + row0 * RB + ((c ^ (row0 & 7)) << 4) + (pp & 1) * 8));
-        auto a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(sV + row1 * RB + ((c ^ (row1 & 7)) << 4) + (pp & 1) * 8));
-        bf16x4 v0 = __builtin_bit_cast(bf16x4, a0), v1 = __builtin_bit_cast(bf16x4, a1);
-        bf16x8 vf;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { vf[r] = v0[r]; vf[4 + r] = v1[r]; }
+        const u32x4 vv = u32x4{vt[u * NDT + dt][0][0], vt[u * NDT + dt][0][1], vt[u * NDT + dt][1][0], vt[u * NDT + dt][1][1]};
+        const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
 #pragma unroll
         for (int j = 0; j < QT; ++j) o[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[j][u], o[j][dt], 0, 0, 0);
       }

@@ -95,7 +95,12 @@ constexpr int kLoraDnSplitMax = 8;     // LoRA down projections: N = k*r is one 
 static int lora_dn_split(int K, int esz) {
   const int ktiles = K / (128 / esz);
   int ks = ktiles / 4;                 // at least 4 k-tiles per slice
-  return ks < 1 ? 1 : ks > kLoraDnSplitMax ? kLoraDnSplitMax : ks;
+  static const int cap = [] { const char* e = getenv("OAVSR_LORA_SPLIT_MAX"); int v = e ? atoi(e) : kLoraDnSplitMax; return v < 1 ? 1 : v > kLoraDnSplitMax ? kLoraDnSplitMax : v; }();
+  return ks < 1 ? 1 : ks > cap ? cap : ks;
+}
+static int video_narrow_split() {
+  static const int v = [] { const char* e = getenv("OAVSR_NARROW_SPLIT"); int x = e ? atoi(e) : kVideoNarrowSplit; return x < 1 ? 1 : x > kVideoNarrowSplit ? kVideoNarrowSplit : x; }();
+  return v;
 }
 static void set_split(GemmArgs& g, const oavsr_workspace* ws, int ks);
 
@@ -476,7 +481,7 @@ static int encode_video_impl(const oavsr_model* m, oavsr_workspace* ws, const fl
   g.Cin = Cg; g.A = ws->enc_h; g.lda = D; g.groups = G; g.a_goff = Cg; g.rowinfo = ws->rowinfo; g.W = m->vpos_w; g.ldw = g.K;
   g.col_bias = m->vpos_b; g.act = ACT_GELU; g.residual = ws->enc_h; g.ldr = D; g.res_after_act = 1; g.C = ws->enc_x; g.ldc = D;
   OAVSR_TRY(run_gemm(g, st));
-  OAVSR_TRY(run_encoder_layers(m, ws, m->vlayers, F, D, c.av_heads, c.av_ffn, c.av_lora_k2, ws->cu_a, B, maxT, kVideoNarrowSplit, st));
+  OAVSR_TRY(run_encoder_layers(m, ws, m->vlayers, F, D, c.av_heads, c.av_ffn, c.av_lora_k2, ws->cu_a, B, maxT, video_narrow_split(), st));
   void* enc = ws->enc_out_v;
   { ProfScope ps("layernorm", 0, 2.0 * F * D * m->esz, st);
     OAVSR_TRY(launch_layernorm(dt, ws->enc_x, D, enc, D, m->vlnf_w, m->vlnf_b, F, D, 1e-5f, st)); }
