@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_dma_kernel(const AttnArgs p)
   const int qt0 = blockIdx.x * (64 * QT);
   if (qt0 >= qlen) return;
   const int kvh = head / (p.n_heads / p.n_kv_heads);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qi = lane & 15, g = lane >> 4;
   const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.Q);
   const bf16_t* K = reinterpret_cast<const bf16_t*>(p.K) + (int64_t)kvh * HD;
@@ -255,24 +255,43 @@ __global__ __launch_bounds__(kThreads, 2) void attn_dma_kernel(const AttnArgs p)
   const int ntile = (kend + KT - 1) / KT;
 
   // DMA: wave w fills 1-KiB segments w and w+4 (8 key rows each) of the K and of the V image; lane i lands at physical
-  // chunk i&7 of row seg*8 + (i>>3) and therefore fetches logical chunk (i&7) ^ (i>>3)   [chunk ^ (row & 7) swizzle]
+  // chunk i&7 of row seg*8 + (i>>3) and therefore fetches logical chunk (i&7) ^ (i>>3)   [chunk ^ (row & 7) swizzle].
+  // issue() is called for tiles 0, 1, 2, ... in order, so the source pointers / key indices / ring slot are running state
+  // (a 64-bit add per pointer instead of re-deriving the address); rows past klen read the zero page.
   const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
-  auto issue = [&](int t) {
-    char* st = smem + (t % NSTAGE) * kStage;
+  const char* zp = reinterpret_cast<const char*>(g_attn_zero_page);
+  asm volatile("" : "+s"(zp));                           // opaque: keeps the address in SGPRs instead of a GOT load per tile
+  const char* kp[2];
+  const char* vp[2];
+  int dkey[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    dkey[h] = (wave + 4 * h) * 8 + lrow;
+    kp[h] = reinterpret_cast<const char*>(K + (int64_t)(k0 + dkey[h]) * p.ldk + lchunk * 8);
+    vp[h] = reinterpret_cast<const char*>(V + (int64_t)(k0 + dkey[h]) * p.ldv + lchunk * 8);
+  }
+  const int64_t kstep = (int64_t)KT * p.ldk * 2, vstep = (int64_t)KT * p.ldv * 2;
+  unsigned dslot = 0;                                    // LDS byte offset of the ring slot the next issue() fills
+  auto issue = [&]() {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int sg = wave + 4 * h;
-      const int key = t * KT + sg * 8 + lrow;
-      const bool in = key < klen;
-      const void* ks = in ? (const void*)(K + (int64_t)(k0 + key) * p.ldk + lchunk * 8) : (const void*)g_attn_zero_page;
-      const void* vs = in ? (const void*)(V + (int64_t)(k0 + key) * p.ldv + lchunk * 8) : (const void*)g_attn_zero_page;
+      const bool in = dkey[h] < klen;
+      const char* ks = in ? kp[h] : zp;
+      const char* vs = in ? vp[h] : zp;
+      char* dst = smem + (dslot + (wave + 4 * h) * 1024);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks,
-                                       (__attribute__((address_space(3))) void*)(st + sg * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vs,
-                                       (__attribute__((address_space(3))) void*)(st + KT * RB + sg * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(dst + KT * RB), 16, 0, 0);
+      kp[h] += kstep; vp[h] += vstep; dkey[h] += KT;
     }
+    dslot = dslot == (NSTAGE - 1) * kStage ? 0u : dslot + kStage;
   };
 
+  // Q fragments are fetched between the first two tile DMAs and then pinned behind an explicit counted wait: the compiler
+  // must not see them as "maybe still in flight" inside the loop, or it drains vmcnt -- and with it the K/V prefetch -- at
+  // their first use in every iteration.
+  if (ntile > 0) issue();
   Chunk16 qf[QT][2];
   int qrow[QT];
 #pragma unroll
@@ -283,8 +302,14 @@ __global__ __launch_bounds__(kThreads, 2) void attn_dma_kernel(const AttnArgs p)
 #pragma unroll
     for (int b = 0; b < 2; ++b) qf[j][b] = *reinterpret_cast<const Chunk16*>(qp + b * 64 + g * 16);
   }
-  if (ntile > 0) issue(0);
-  if (ntile > 1) issue(1);
+  if (ntile > 1) {
+    issue();
+    if constexpr (QT == 2) asm volatile("s_waitcnt vmcnt(4)" : "+v"(qf[0][0].v), "+v"(qf[0][1].v), "+v"(qf[1][0].v), "+v"(qf[1][1].v)::"memory");
+    else asm volatile("s_waitcnt vmcnt(4)" : "+v"(qf[0][0].v), "+v"(qf[0][1].v)::"memory");
+  } else {
+    if constexpr (QT == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0][0].v), "+v"(qf[0][1].v), "+v"(qf[1][0].v), "+v"(qf[1][1].v)::"memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0][0].v), "+v"(qf[0][1].v)::"memory");
+  }
 
   // LDS byte offsets of this lane's fragments inside a stage.  K (A operand): row kt*16 + qi, 16-B chunk (b*4 + g) ^ (qi & 7);
   // V^T (tr-read: lane 4q+p addresses row q, cols 4p..4p+3): row 32u + 4g + qq (+16), chunk (2dt + (pp>>1)) ^ (row & 7).
@@ -308,14 +333,16 @@ __global__ __launch_bounds__(kThreads, 2) void attn_dma_kernel(const AttnArgs p)
     for (int i = 0; i < NDT; ++i) o[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
+  unsigned cslot = 0;                                    // ring slot of the tile being consumed
   for (int t = 0; t < ntile; ++t) {
     // tile t has landed once only tile t+1's 4 DMA instructions of this wave are still outstanding
     if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (t + 2 < ntile) issue(t + 2);                     // its stage held tile t-1: every wave is past it
-    const unsigned so = (unsigned)(t % NSTAGE) * kStage;
+    if (t + 2 < ntile) issue();                          // tile t+2; its stage held tile t-1: every wave is past it
+    const unsigned so = cslot;
+    cslot = cslot == (NSTAGE - 1) * kStage ? 0u : cslot + kStage;
     unsigned kaddr[2], vaddr[NDT];                        // lane bases inside this stage; everything else is an immediate offset
 #pragma unroll
     for (int b = 0; b < 2; ++b) kaddr[b] = so + kbase[b];
@@ -344,11 +371,13 @@ __global__ __launch_bounds__(kThreads, 2) void attn_dma_kernel(const AttnArgs p)
       const int qmin = qt0 + (wave * QT + j) * 16;
       const bool need_mask = kt0 + KT > klen || (p.causal && kt0 + KT - 1 > qmin + shift);     // wave-uniform
       if (need_mask) {
+        int key0 = kt0 + 4 * g;
+        asm volatile("" : "+v"(key0));                    // pins the index / compare chain inside this rarely taken branch
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int key = kt0 + kt * 16 + 4 * g + r;
+            const int key = key0 + kt * 16 + r;
             const bool vis = key < klen && (!p.causal || key <= qrow[j] + shift);
             if (!vis) s[j][kt][r] = -INFINITY;
           }
