@@ -58,7 +58,7 @@ __device__ __forceinline__ void init_arow2(const GemmArgs& p, int m, int g, ARow
 
 // address of the 16-byte chunk that holds K elements [k, k + VEC) of gathered row r (or the zero page)
 template <typename T, int AMODE>
-__device__ __forceinline__ const void* a_src(const GemmArgs& p, const ARow2& r, int k, int g) {
+__device__ __forceinline__ const void* a_src(const GemmArgs& p, const ARow2& r, int k, int g, const void* g_zero_page) {
   const T* A = reinterpret_cast<const T*>(p.A);
   if (!r.valid) return g_zero_page;
   if (AMODE == A_DENSE) return A + r.base + k;
@@ -79,7 +79,7 @@ __device__ __forceinline__ const void* a_src(const GemmArgs& p, const ARow2& r, 
 // conv2d / conv1d with C_in a multiple of the k-tile: the whole k-tile lies inside ONE tap, so (ky, kx) / the time offset are
 // wave-uniform scalars computed once per k-tile (kt0 = first element of the k-tile, kc = this lane's offset inside it)
 template <typename T, int AMODE>
-__device__ __forceinline__ const void* a_src_tap(const GemmArgs& p, const ARow2& r, int tap, int c, int g) {
+__device__ __forceinline__ const void* a_src_tap(const GemmArgs& p, const ARow2& r, int tap, int c, int g, const void* g_zero_page) {
   const T* A = reinterpret_cast<const T*>(p.A);
   if (!r.valid) return g_zero_page;
   if (AMODE == A_CONV2D) {
@@ -113,8 +113,10 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
   constexpr int NLA = BM * 8 / (DW * 64);                 // ... of which fetch A rows
   extern __shared__ __attribute__((aligned(1024))) char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA destinations go to M0 without a VGPR detour
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const void* zp = g_zero_page;                          // source of out-of-range rows
+  asm volatile("" : "+s"(zp));                           // opaque: held in SGPRs, not re-fetched from the GOT (s_load + s_waitcnt) for every DMA group
   const int ntn = (p.N + BN - 1) / BN;
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2s), so give every XCD a CONTIGUOUS
   // range of logical tiles (= whole M-tile rows): the A panel of a row is then fetched by one L2 instead of all eight.
@@ -164,24 +166,24 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
       if ((AMODE == A_CONV2D || AMODE == A_CONV1D) && tap_uniform) {
         const int kt0 = t * BKE, tap = kt0 / p.Cin, c = kt0 - tap * p.Cin + lchunk * VEC;   // tap: scalar division, once per k-tile
 #pragma unroll
-        for (int j = 0; j < NLA; ++j) dma16(a_src_tap<T, AMODE>(p, arow[j], tap, c, g), st + (j * DW + wave) * 1024);
+        for (int j = 0; j < NLA; ++j) dma16(a_src_tap<T, AMODE>(p, arow[j], tap, c, g, zp), st + (j * DW + wave) * 1024);
       } else {
 #pragma unroll
-        for (int j = 0; j < NLA; ++j) dma16(a_src<T, AMODE>(p, arow[j], k, g), st + (j * DW + wave) * 1024);
+        for (int j = 0; j < NLA; ++j) dma16(a_src<T, AMODE>(p, arow[j], k, g, zp), st + (j * DW + wave) * 1024);
       }
 #pragma unroll
       for (int j = 0; j < NLD - NLA; ++j)
-        dma16(wvalid[j] ? (const void*)(W1 + wbase[j] * p.ldw + k) : (const void*)g_zero_page, st + ((j + NLA) * DW + wave) * 1024);
+        dma16(wvalid[j] ? (const void*)(W1 + wbase[j] * p.ldw + k) : zp, st + ((j + NLA) * DW + wave) * 1024);
     } else {
       const int k = (t - nt1) * BKE + lchunk * VEC;
 #pragma unroll
       for (int j = 0; j < NLA; ++j) {
         const int m = m0 + (j * DW + wave) * 8 + lrow;
-        dma16(m < p.M ? (const void*)(A2 + (int64_t)m * p.lda2 + k) : (const void*)g_zero_page, st + (j * DW + wave) * 1024);
+        dma16(m < p.M ? (const void*)(A2 + (int64_t)m * p.lda2 + k) : zp, st + (j * DW + wave) * 1024);
       }
 #pragma unroll
       for (int j = 0; j < NLD - NLA; ++j)
-        dma16(wvalid[j] ? (const void*)(W2 + wbase[j] * p.ldw2 + k) : (const void*)g_zero_page, st + ((j + NLA) * DW + wave) * 1024);
+        dma16(wvalid[j] ? (const void*)(W2 + wbase[j] * p.ldw2 + k) : zp, st + ((j + NLA) * DW + wave) * 1024);
     }
   };
 
