@@ -82,8 +82,8 @@ def pmc_traffic(kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--frames", type=int, default=400, help="video frames per utterance (400 = 16 s)")
     ap.add_argument("--max-new", type=int, default=32)
