@@ -631,16 +631,25 @@ static int llm_gemm(const oavsr_model* m, oavsr_workspace* ws, GemmArgs& g, int 
   return run_gemm(g, st, false);
 }
 
+// last_rows / cu_last (prefill only): row index of every utterance's final prompt token and the device array 0..B.  Only those rows
+// feed lm_head (the reference materialises all positions, Llama_LoRA.py:372-373), so in the LAST layer everything after the KV
+// append -- attention queries, o_proj, the MLP -- runs on the B gathered rows (compact residual stream ws->lastx) through the
+// decode-shaped kernels; *pruned tells the caller that ws->lastx already holds the final hidden rows.
 static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int rows, bool decode, int B, int beams, int max_S,
-                      const int* pos, const int* cpos, const int* anc, const int* step, hipStream_t st, const float2* rope_cs = nullptr) {
+                      const int* pos, const int* cpos, const int* anc, const int* step, hipStream_t st, const float2* rope_cs = nullptr,
+                      const int* last_rows = nullptr, const int* cu_last = nullptr, bool* pruned = nullptr) {
   const oavsr_config& c = m->cfg;
   const int dt = m->dtype, d = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, hd = c.llm_head_dim, I = c.llm_mlp;
   const int nq = H * hd, nqkv = (H + 2 * KV) * hd;
   const int tl = c.lora_task_specific ? task : 0;
   const int mode = !decode ? 0 : (rows <= 32 ? 1 : 2);
   const bool fused_norm = mode == 1;       // RMSNorm folded into the skinny GEMMs (gain on the A fragments, rstd in the epilogue)
+  static const bool prune_on = [] { const char* e = getenv("OAVSR_PREFILL_PRUNE"); return !(e && e[0] == '0'); }();
+  const bool can_prune = prune_on && !decode && last_rows && cu_last && B <= 32;
+  if (pruned) *pruned = false;
   for (int li = 0; li < c.llm_layers; ++li) {
     const LlmLayer& L = m->llayers[li];
+    const bool prune = can_prune && li == c.llm_layers - 1;
     if (!fused_norm) { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
       OAVSR_TRY(launch_rmsnorm(dt, ws->lx, d, ws->lh, d, L.ln1w, rows, d, c.llm_rms_eps, st)); }
     const void* hin = fused_norm ? ws->lx : ws->lh;
@@ -667,7 +676,12 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
       a.Q = ws->lqkv; a.K = (const char*)ws->lqkv + (size_t)nq * m->esz; a.V = (const char*)ws->lqkv + (size_t)(nq + KV * hd) * m->esz;
       a.ldq = a.ldk = a.ldv = nqkv; a.O = ws->lattn; a.ldo = nq; a.cu_q = ws->cu_s; a.cu_k = ws->cu_s; a.max_q = max_S;
       a.scale = 1.0f / sqrtf((float)hd); a.causal = 1;
-      ProfScope ps(dt == DT_F32 ? "attention_f32" : "attention_bf16", 2.0 * rows * max_S * nq, 4.0 * rows * nq * m->esz, st);
+      if (prune) {   // one query row per utterance: gathered q rows (ws->lh is free after the QKV GEMM) against the full K / V
+        OAVSR_TRY(launch_copy_rows(dt, ws->lqkv, nqkv, last_rows, ws->lh, nqkv, B, nqkv, st));
+        OAVSR_TRY(launch_copy_rows(dt, ws->lx, d, last_rows, ws->lastx, d, B, d, st));
+        a.Q = ws->lh; a.cu_q = cu_last; a.max_q = 1;
+      }
+      ProfScope ps(dt == DT_F32 ? "attention_f32" : "attention_bf16", 2.0 * (prune ? B : rows) * max_S * nq, 4.0 * (prune ? B : rows) * nq * m->esz, st);
       OAVSR_TRY(launch_attention(a, st));
     } else {
       DecodeAttnArgs a; a.dtype = dt; a.head_dim = hd; a.n_heads = H; a.n_kv_heads = KV; a.rows = rows; a.beams = beams;
@@ -679,11 +693,15 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
       ProfScope ps("decode_attention", 0, 2.0 * rows * max_S * KV * hd * m->esz, st);
       OAVSR_TRY(launch_decode_attention(a, st));
     }
-    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = d; g.K = nq; g.A = ws->lattn; g.lda = nq; g.W = L.ow; g.ldw = nq;
-    g.residual = ws->lx; g.ldr = d; g.C = ws->lx; g.ldc = d;
-    OAVSR_TRY(llm_gemm(m, ws, g, mode, st));
-    if (fused_norm) {   // RMSNorm + gate/up + SwiGLU in one launch
-      g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 2 * I; g.K = d; g.A = ws->lx; g.lda = d; g.W = L.guw; g.ldw = d;
+    // tail of the layer: on all rows, or (pruned last prefill layer) on the B gathered rows with the decode-shaped kernels
+    const int trows = prune ? B : rows, tmode = prune ? 1 : mode;
+    const bool tfused = tmode == 1;
+    void* xres = prune ? ws->lastx : ws->lx;
+    g = GemmArgs(); g.dtype = dt; g.M = trows; g.N = d; g.K = nq; g.A = ws->lattn; g.lda = nq; g.W = L.ow; g.ldw = nq;
+    g.residual = xres; g.ldr = d; g.C = xres; g.ldc = d;
+    OAVSR_TRY(llm_gemm(m, ws, g, tmode, st));
+    if (tfused) {   // RMSNorm + gate/up + SwiGLU in one launch
+      g = GemmArgs(); g.dtype = dt; g.M = trows; g.N = 2 * I; g.K = d; g.A = xres; g.lda = d; g.W = L.guw; g.ldw = d;
       g.norm_gain = L.ln2w; g.norm_eps = c.llm_rms_eps; g.swiglu_pairs = 1; g.C = ws->lact; g.ldc = I;
       OAVSR_TRY(run_gemm(g, st, true));
     } else {
@@ -700,9 +718,10 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
         OAVSR_TRY(launch_swiglu(dt, ws->lgu, 2 * I, ws->lact, I, rows, I, 1, st));
       }
     }
-    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = d; g.K = I; g.A = ws->lact; g.lda = I; g.W = L.downw; g.ldw = I;
-    g.residual = ws->lx; g.ldr = d; g.C = ws->lx; g.ldc = d;
-    OAVSR_TRY(llm_gemm(m, ws, g, mode, st));
+    g = GemmArgs(); g.dtype = dt; g.M = trows; g.N = d; g.K = I; g.A = ws->lact; g.lda = I; g.W = L.downw; g.ldw = I;
+    g.residual = xres; g.ldr = d; g.C = xres; g.ldc = d;
+    OAVSR_TRY(llm_gemm(m, ws, g, tmode, st));
+    if (prune && pruned) *pruned = true;
   }
   return 0;
 }
@@ -744,9 +763,14 @@ static int prefill_impl(const oavsr_model* m, oavsr_workspace* ws, int task, int
   OAVSR_TRY(h2d(ws->last_rows, last, sizeof(int) * B, st));
   OAVSR_TRY(h2d(ws->prefix_len + utt0, plen, sizeof(int) * B, st));
   if (embeds != ws->lx) OAVSR_CHECK_HIP(hipMemcpyAsync(ws->lx, embeds, (size_t)total * c.llm_hidden * m->esz, hipMemcpyDeviceToDevice, st));
-  OAVSR_TRY(llm_layers(m, ws, task, total, false, B, 1, maxS, ws->pos, ws->cpos, nullptr, nullptr, st));
+  int* cul = ws->stage<int>(B + 1);
+  OAVSR_REQUIRE(cul, "host staging exhausted");
+  for (int b = 0; b <= B; ++b) cul[b] = b;
+  OAVSR_TRY(h2d(ws->cu_b, cul, sizeof(int) * (B + 1), st));   // cu_b: encoder scratch, idle during prefill
+  bool pruned = false;
+  OAVSR_TRY(llm_layers(m, ws, task, total, false, B, 1, maxS, ws->pos, ws->cpos, nullptr, nullptr, st, nullptr, ws->last_rows, ws->cu_b, &pruned));
   // last position of every utterance only (the reference materialises all positions, Llama_LoRA.py:372-373)
-  OAVSR_TRY(launch_copy_rows(m->dtype, ws->lx, c.llm_hidden, ws->last_rows, ws->lastx, c.llm_hidden, B, c.llm_hidden, st));
+  if (!pruned) OAVSR_TRY(launch_copy_rows(m->dtype, ws->lx, c.llm_hidden, ws->last_rows, ws->lastx, c.llm_hidden, B, c.llm_hidden, st));
   float* lg = ws->logits + (size_t)utt0 * c.llm_vocab;
   OAVSR_TRY(lm_head_rows(m, ws, ws->lastx, B, lg, st));
   if (logits_out) OAVSR_CHECK_HIP(hipMemcpyAsync(logits_out, lg, (size_t)B * c.llm_vocab * 4, hipMemcpyDeviceToDevice, st));
