@@ -157,6 +157,14 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
   const int ntot = split ? (tbeg + per < nall ? per : (nall - tbeg > 0 ? nall - tbeg : 0)) : nall;
 
   const bool tap_uniform = AMODE != A_DENSE && p.Cin % BKE == 0;
+  const char* tap_ptr[NLA];
+#pragma unroll
+  for (int j = 0; j < NLA; ++j) {
+    const T* A = reinterpret_cast<const T*>(p.A);
+    if (AMODE == A_CONV2D) tap_ptr[j] = reinterpret_cast<const char*>(A + arow[j].base + ((int64_t)arow[j].a * p.Wd + arow[j].b) * p.Cin + lchunk * VEC);
+    else if (AMODE == A_CONV1D) tap_ptr[j] = reinterpret_cast<const char*>(A + arow[j].base * p.lda + (int64_t)g * p.a_goff + lchunk * VEC);
+    else tap_ptr[j] = nullptr;
+  }
   auto issue = [&](int tl) {
     if (DW < NWAVES && wave >= DW) return;            // compute-only waves
     char* st = smem + (tl % kStages) * kStageBytes;
@@ -164,9 +172,28 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
     if (t < nt1) {
       const int k = t * BKE + lchunk * VEC;
       if ((AMODE == A_CONV2D || AMODE == A_CONV1D) && tap_uniform) {
-        const int kt0 = t * BKE, tap = kt0 / p.Cin, c = kt0 - tap * p.Cin + lchunk * VEC;   // tap: scalar division, once per k-tile
+        // the whole k-tile lies inside ONE tap: (ky, kx) / the time offset and the tap's address delta are wave-uniform
+        // scalars, computed once per k-tile; per row only the bounds test and one 64-bit add remain (tap_ptr: the row's
+        // address at tap (0, 0) / time offset 0, hoisted out of the loop)
+        const int kt0 = t * BKE, tap = kt0 / p.Cin, c0 = kt0 - tap * p.Cin;
+        if (AMODE == A_CONV2D) {
+          const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
+          const int64_t soff = ((int64_t)(ky * p.Wd + kx) * p.Cin + c0) * (int64_t)sizeof(T);
 #pragma unroll
-        for (int j = 0; j < NLA; ++j) dma16(a_src_tap<T, AMODE>(p, arow[j], tap, c, g, zp), st + (j * DW + wave) * 1024);
+          for (int j = 0; j < NLA; ++j) {
+            const bool ok = arow[j].valid && (unsigned)(arow[j].a + ky) < (unsigned)p.H && (unsigned)(arow[j].b + kx) < (unsigned)p.Wd;
+            dma16(ok ? (const void*)(tap_ptr[j] + soff) : zp, st + (j * DW + wave) * 1024);
+          }
+        } else {
+          const int dlt = tap - p.pad;
+          const int64_t soff = ((int64_t)dlt * p.lda + c0) * (int64_t)sizeof(T);
+          const bool tap_ok = tap < p.taps;
+#pragma unroll
+          for (int j = 0; j < NLA; ++j) {
+            const bool ok = arow[j].valid && tap_ok && (unsigned)(arow[j].a + dlt) < (unsigned)arow[j].b;
+            dma16(ok ? (const void*)(tap_ptr[j] + soff) : zp, st + (j * DW + wave) * 1024);
+          }
+        }
       } else {
 #pragma unroll
         for (int j = 0; j < NLA; ++j) dma16(a_src<T, AMODE>(p, arow[j], k, g, zp), st + (j * DW + wave) * 1024);
