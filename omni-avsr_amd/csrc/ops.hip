@@ -70,12 +70,95 @@ __global__ __launch_bounds__(kThreads) void norm_kernel(const T* __restrict__ x,
   }
 }
 
+// Same arithmetic, row held in registers: D == NCH * 64 * VEC, all NCH chunks of the row are requested at once and the three
+// passes (sums, centred variance, normalise) run from registers -- one memory round trip per row instead of three dependent ones.
+// Bit-identical to norm_kernel (same accumulation order).
+template <typename T, int MODE, int NCH>
+__global__ __launch_bounds__(kThreads) void norm_reg_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy,
+                                                             const float* __restrict__ w, const float* __restrict__ b, int rows, int D,
+                                                             float eps) {
+  constexpr int VEC = TypeInfo<T>::kVec;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * kWavesPerBlock + wave;
+  if (row >= rows) return;
+  const T* xr = x + (int64_t)row * ldx;
+  Chunk16 raw[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) raw[i] = *reinterpret_cast<const Chunk16*>(xr + (lane + i * 64) * VEC);
+  float f[NCH][VEC];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    chunk_to_f32<T>(raw[i], f[i]);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { s1 += f[i][e]; s2 += f[i][e] * f[i][e]; }
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  const float n = (MODE == 2) ? 2.f * D : (float)D;
+  float mean = (MODE == 1) ? 0.f : s1 / n;
+  float var = s2 / n - mean * mean;
+  if (MODE != 1) {
+    float v2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { float d = f[i][e] - mean; v2 += d * d; }
+    v2 = wave_sum(v2);
+    if (MODE == 2) v2 += (float)D * mean * mean;   // the D zero inputs
+    var = v2 / n;
+  }
+  const float rstd = rsqrtf(var + eps);
+  T* yr = y + (int64_t)row * ldy;
+  if (MODE == 2) {
+    const float z = -mean * rstd;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (lane + i * 64) * VEC;
+      float o[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = z * w[c + e] + b[c + e];
+      *reinterpret_cast<Chunk16*>(yr + c) = chunk_from_f32<T>(o);
+    }
+    yr += D; w += D; b += D;
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + i * 64) * VEC;
+    float o[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      if (MODE == 1) o[e] = w[c + e] * (f[i][e] * rstd);
+      else o[e] = (f[i][e] - mean) * rstd * w[c + e] + b[c + e];
+    }
+    *reinterpret_cast<Chunk16*>(yr + c) = chunk_from_f32<T>(o);
+  }
+}
+
+template <typename T, int MODE>
+static bool launch_norm_reg(const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, const float* b, int rows, int D, float eps,
+                            hipStream_t st) {
+  constexpr int VEC = TypeInfo<T>::kVec;
+  dim3 grid(ceil_div(rows, kWavesPerBlock));
+  const int nch = D % (64 * VEC) == 0 ? D / (64 * VEC) : 0;
+  if (nch == 1) hipLaunchKernelGGL((norm_reg_kernel<T, MODE, 1>), grid, dim3(kThreads), 0, st, (const T*)x, ldx, (T*)y, ldy, w, b, rows, D, eps);
+  else if (nch == 2) hipLaunchKernelGGL((norm_reg_kernel<T, MODE, 2>), grid, dim3(kThreads), 0, st, (const T*)x, ldx, (T*)y, ldy, w, b, rows, D, eps);
+  else if (nch == 4) hipLaunchKernelGGL((norm_reg_kernel<T, MODE, 4>), grid, dim3(kThreads), 0, st, (const T*)x, ldx, (T*)y, ldy, w, b, rows, D, eps);
+  else return false;
+  return true;
+}
+
 template <int MODE>
 int launch_norm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, const float* b, int rows, int D,
                 float eps, hipStream_t st) {
   if (rows <= 0) return 0;
   const int vec = dtype == DT_F32 ? 4 : 8;
   OAVSR_REQUIRE(D % vec == 0 && ldx % vec == 0 && ldy % vec == 0, "norm: D=%d and strides must be multiples of %d", D, vec);
+  if (dtype == DT_F32 ? launch_norm_reg<float, MODE>(x, ldx, y, ldy, w, b, rows, D, eps, st)
+                      : launch_norm_reg<bf16_t, MODE>(x, ldx, y, ldy, w, b, rows, D, eps, st)) {
+    OAVSR_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   dim3 grid(ceil_div(rows, kWavesPerBlock));
   if (dtype == DT_F32)
     hipLaunchKernelGGL((norm_kernel<float, MODE>), grid, dim3(kThreads), 0, st, (const float*)x, ldx, (float*)y, ldy, w, b, rows, D, eps);
