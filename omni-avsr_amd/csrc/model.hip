@@ -874,16 +874,40 @@ static int decode_beam(const oavsr_model* m, oavsr_workspace* ws, int task, int 
   { ProfScope ps("beam_search", 0, (double)B * c.llm_vocab * 16, st);
     OAVSR_TRY(launch_beam_topk(ws->logits, c.llm_vocab, B, c.llm_vocab, K, nullptr, ws->cand_val, ws->cand_tok, ws->topk_flag, st));
     OAVSR_TRY(launch_beam_step(a, 1, seq[0], anc[0], seq[1], anc[1], st)); }
-  int cur = 1;
-  for (int t = 1; t < max_new; ++t) {
+  // one step reads ping-pong side `cur` of the sequence / ancestry tables and writes the other one
+  auto one_step = [&](int cur) -> int {
     OAVSR_TRY(launch_embed(m->dtype, m->embed, c.llm_hidden, ws->gs.tok, ws->lx, c.llm_hidden, R, c.llm_hidden, st));
     OAVSR_TRY(llm_layers(m, ws, task, R, true, B, K, maxS + max_new, ws->gs.pos, ws->gs.cpos, anc[cur], ws->gs.step, st));
     OAVSR_TRY(lm_head_rows(m, ws, ws->lx, R, ws->logits, st));
     ProfScope ps("beam_search", 0, (double)R * c.llm_vocab * 16, st);
     OAVSR_TRY(launch_beam_topk(ws->logits, c.llm_vocab, R, c.llm_vocab, K, ws->beam_scores, ws->cand_val, ws->cand_tok, ws->topk_flag, st));
-    OAVSR_TRY(launch_beam_step(a, 0, seq[cur], anc[cur], seq[cur ^ 1], anc[cur ^ 1], st));
-    cur ^= 1;
+    return launch_beam_step(a, 0, seq[cur], anc[cur], seq[cur ^ 1], anc[cur ^ 1], st);
+  };
+  // Every step-dependent value lives in device memory, so a PAIR of steps (side 0 -> 1 -> 0) is one hipGraph, captured once per
+  // (B, K, task, max_new) and replayed: one graph launch instead of ~450 kernel launches.  Step 1 always runs eagerly (it also
+  // sets the kernels' attributes before the first capture) and leaves the tables on side 0.
+  static const bool graphs_on = [] { const char* e = getenv("OAVSR_DECODE_GRAPH"); return !(e && e[0] == '0'); }();
+  const bool use_graph = graphs_on && !g_prof.on && max_new > 4 && st != nullptr;
+  int t = 1, cur = 1;
+  if (t < max_new) { OAVSR_TRY(one_step(cur)); cur ^= 1; ++t; }
+  if (use_graph && t + 1 < max_new) {
+    const DecodeGraphKey key{B, task, max_new, -1000 - K};
+    hipGraphExec_t exec = nullptr;
+    for (auto& e : ws->graphs) if (e.first == key) exec = e.second;
+    if (!exec) {
+      hipGraph_t graph = nullptr;
+      OAVSR_CHECK_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+      int rc = one_step(0);
+      if (rc == 0) rc = one_step(1);
+      hipError_t ce = hipStreamEndCapture(st, &graph);
+      OAVSR_REQUIRE(rc == 0 && ce == hipSuccess && graph, "decode: hipGraph capture of the beam step failed (%d / %d)", rc, (int)ce);
+      OAVSR_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      hipGraphDestroy(graph);
+      ws->graphs.push_back({key, exec});
+    }
+    for (; t + 1 < max_new; t += 2) OAVSR_CHECK_HIP(hipGraphLaunch(exec, st));
   }
+  for (; t < max_new; ++t) { OAVSR_TRY(one_step(cur)); cur ^= 1; }
   return launch_beam_finalize(a, seq[cur], st);
 }
 
