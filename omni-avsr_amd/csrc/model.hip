@@ -710,7 +710,10 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
       g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 2 * I; g.K = d; g.A = ws->lh; g.lda = d; g.W = L.guw; g.ldw = d; g.C = ws->lgu; g.ldc = 2 * I;
       static const bool fuse_swiglu = [] { const char* e = getenv("OAVSR_FUSE_SWIGLU"); return !(e && e[0] == '0'); }();
       GemmArgs gf = g; gf.swiglu_pairs = 1; gf.C = ws->lact; gf.ldc = I;
-      if (fuse_swiglu && mode == 0 && gemm_dma_swiglu_ok(gf)) {   // prefill: SwiGLU in the GEMM epilogue, the [rows][2I] tensor never exists
+      // prefill, and beam-search decode (33..128 rows) when the 128 x 64 tiles already fill the chip without split-K:
+      // SwiGLU in the GEMM epilogue, the [rows][2I] tensor never exists
+      const bool dec_fill = mode == 2 && (int64_t)ceil_div(rows, 128) * ceil_div(2 * I, 64) >= 256;
+      if (fuse_swiglu && (mode == 0 || dec_fill) && gemm_dma_swiglu_ok(gf)) {
         OAVSR_TRY(run_gemm(gf, st, false));
       } else {
         OAVSR_TRY(llm_gemm(m, ws, g, mode, st));
