@@ -62,16 +62,32 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 //         has the same bits whichever kernel produced it.
 template <typename T> __device__ __forceinline__ float gelu_act(float x);
 template <> __device__ __forceinline__ float gelu_act<float>(float x) { return gelu_erf(x); }
-template <> __device__ __forceinline__ float gelu_act<bf16_t>(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float pl = fmaf(1.061405429f, t, -1.453152027f);
-  pl = fmaf(pl, t, 1.421413741f);
-  pl = fmaf(pl, t, -0.284496736f);
-  pl = fmaf(pl, t, 0.254829592f);
-  pl *= t;
-  const float e = 1.0f - pl * __expf(-z * z);                 // erf(|x| / sqrt 2)
-  return 0.5f * x * (1.0f + copysignf(e, x));
+// Written for two elements at a time in packed fp32 math (v_pk_mul / v_pk_fma / v_pk_add; only the rcp / exp2 stay scalar):
+// that halves the VALU issue slots of the fc1 epilogues.  The scalar entry point is the same code on a duplicated lane.
+__device__ __forceinline__ f32x2 gelu_act2_bf16(f32x2 x) {
+  const f32x2 ax = f32x2{fabsf(x[0]), fabsf(x[1])};
+  const f32x2 z = ax * 0.70710678118654752440f;
+  const f32x2 den = __builtin_elementwise_fma(f32x2{0.3275911f, 0.3275911f}, z, f32x2{1.0f, 1.0f});
+  const f32x2 t = f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  f32x2 pl = __builtin_elementwise_fma(f32x2{1.061405429f, 1.061405429f}, t, f32x2{-1.453152027f, -1.453152027f});
+  pl = __builtin_elementwise_fma(pl, t, f32x2{1.421413741f, 1.421413741f});
+  pl = __builtin_elementwise_fma(pl, t, f32x2{-0.284496736f, -0.284496736f});
+  pl = __builtin_elementwise_fma(pl, t, f32x2{0.254829592f, 0.254829592f});
+  pl = pl * t;
+  const f32x2 nz2 = (-z) * z;
+  const f32x2 ex = f32x2{__expf(nz2[0]), __expf(nz2[1])};
+  const f32x2 e = __builtin_elementwise_fma(-pl, ex, f32x2{1.0f, 1.0f});   // erf(|x| / sqrt 2)
+  const f32x2 se = f32x2{copysignf(e[0], x[0]), copysignf(e[1], x[1])};
+  return (x * 0.5f) * (se + 1.0f);
+}
+template <> __device__ __forceinline__ float gelu_act<bf16_t>(float x) { return gelu_act2_bf16(f32x2{x, x})[0]; }
+template <typename T> __device__ __forceinline__ void gelu_act4(float* v) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = gelu_act<T>(v[q]);
+}
+template <> __device__ __forceinline__ void gelu_act4<bf16_t>(float* v) {
+  const f32x2 a = gelu_act2_bf16(f32x2{v[0], v[1]}), b = gelu_act2_bf16(f32x2{v[2], v[3]});
+  v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 

@@ -332,8 +332,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
       }
       switch (e_act) {                            // one uniform branch per four columns
         case ACT_GELU:
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = gelu_act<T>(v[q]);
+          gelu_act4<T>(v);
           break;
         case ACT_RELU:
 #pragma unroll
