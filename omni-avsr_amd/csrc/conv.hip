@@ -45,22 +45,22 @@ __global__ __launch_bounds__(kConvThreads) void conv3x3_c64_kernel(const bf16_t*
   if (tid < 64) { spar[tid] = scale[tid]; spar[64 + tid] = shift[tid]; spar[128 + tid] = slope ? slope[tid] : 1.f; }
   if (tid < 8) { Chunk16 z; z.v = u32x4{0u, 0u, 0u, 0u}; *reinterpret_cast<Chunk16*>(simg + (size_t)HW * 128 + tid * 16) = z; }
 
-  Chunk16 pre[kPre];
-  auto prefetch = [&](int img) {
-    const bf16_t* src = x + (size_t)img * HW * kC;
-#pragma unroll
-    for (int j = 0; j < kPre; ++j) {
-      const int i = tid + j * kConvThreads;
-      if (i < nchunk) pre[j] = *reinterpret_cast<const Chunk16*>(src + (size_t)i * 8);
-    }
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int j = 0; j < kPre; ++j) {
-      const int i = tid + j * kConvThreads;
-      if (i < nchunk) { const int p = i >> 3, c = i & 7; *reinterpret_cast<Chunk16*>(simg + p * 128 + ((c ^ (p & 7)) << 4)) = pre[j]; }
-    }
-  };
+  // next image, fetched into registers while the current one is computed.  (Plain unrolled loops over a vector array: as
+  // lambdas over a struct array the buffer stayed in scratch, turning the prefetch into load - wait - spill.)
+  u32x4 pre[kPre];
+#define OAVSR_CONV_PREFETCH(IMG)                                                                       \
+  {                                                                                                    \
+    const bf16_t* src_ = x + (size_t)(IMG) * HW * kC;                                                  \
+    _Pragma("unroll") for (int j = 0; j < kPre; ++j) {                                                 \
+      const int i = tid + j * kConvThreads; /* out-of-range slots re-read chunk 0, never committed */  \
+      pre[j] = *reinterpret_cast<const u32x4*>(src_ + (size_t)(i < nchunk ? i : 0) * 8);              \
+    }                                                                                                  \
+  }
+#define OAVSR_CONV_COMMIT()                                                                            \
+  _Pragma("unroll") for (int j = 0; j < kPre; ++j) {                                                   \
+    const int i = tid + j * kConvThreads;                                                              \
+    if (i < nchunk) { const int p_ = i >> 3, c_ = i & 7; *reinterpret_cast<u32x4*>(simg + p_ * 128 + ((c_ ^ (p_ & 7)) << 4)) = pre[j]; } \
+  }
 
   // the 4 pixel tiles of this wave: output pixel q = (wave*4 + i)*16 + r16
   int qy[4], qx[4], qv[4];
@@ -73,12 +73,12 @@ __global__ __launch_bounds__(kConvThreads) void conv3x3_c64_kernel(const bf16_t*
   }
 
   int img = blockIdx.x;
-  if (img < imgs) prefetch(img);
+  if (img < imgs) OAVSR_CONV_PREFETCH(img)
   for (; img < imgs; img += gridDim.x) {
     __syncthreads();                                          // every wave is done with the previous image
-    commit();
+    OAVSR_CONV_COMMIT()
     __syncthreads();
-    if (img + (int)gridDim.x < imgs) prefetch(img + gridDim.x);
+    if (img + (int)gridDim.x < imgs) OAVSR_CONV_PREFETCH(img + gridDim.x)
 
     f32x4 acc[4][4];
 #pragma unroll
