@@ -87,18 +87,36 @@ __global__ __launch_bounds__(kStemThreads) void stem_pool_kernel(const float* __
   const float* vbase = vid + (int64_t)f * 7744;
   for (int it = 0; it < 11; ++it) {
     // ---- 1. input window: rows 8*it-3 .. 8*it+9, columns -3 .. 92, frames t-2 .. t+2 ----
-    for (int q = tid; q < 5 * kWinRows * (kWinCols / 2); q += kStemThreads) {
-      const int dt = q / (kWinRows * (kWinCols / 2)), rem = q - dt * (kWinRows * (kWinCols / 2));
-      const int wr = rem / (kWinCols / 2), cp = rem - wr * (kWinCols / 2);
-      const int iy = 8 * it - 3 + wr, ix = 2 * cp - 3;
-      float v0 = 0.f, v1 = 0.f;
-      if ((unsigned)(fi.x + dt - 2) < (unsigned)fi.y && (unsigned)iy < 88u) {
+    // fully unrolled with unconditional loads (clamped address + select): all 26 loads of a thread are in flight together and
+    // the step pays the global latency once, not once per loop trip
+    constexpr int NQ = 5 * kWinRows * (kWinCols / 2);
+    constexpr int kFill = (NQ + kStemThreads - 1) / kStemThreads;
+    constexpr int kGrp = 7;                                // loads in flight per thread: 2 * kGrp (register budget: two workgroups per CU)
+#pragma unroll 1
+    for (int k0 = 0; k0 < kFill; k0 += kGrp) {
+      float pv0[kGrp], pv1[kGrp];
+#pragma unroll
+      for (int k = 0; k < kGrp; ++k) {
+        const int q = tid + (k0 + k) * kStemThreads, qq = q < NQ ? q : 0;
+        const int dt = qq / (kWinRows * (kWinCols / 2)), rem = qq - dt * (kWinRows * (kWinCols / 2));
+        const int wr = rem / (kWinCols / 2), cp = rem - wr * (kWinCols / 2);
+        const int iy = 8 * it - 3 + wr, ix = 2 * cp - 3;
+        const bool row = (unsigned)(fi.x + dt - 2) < (unsigned)fi.y && (unsigned)iy < 88u;
         const float* src = vbase + (int64_t)(dt - 2) * 7744 + iy * 88;
-        if ((unsigned)ix < 88u) v0 = src[ix];
-        if ((unsigned)(ix + 1) < 88u) v1 = src[ix + 1];
+        const bool ok0 = row && (unsigned)ix < 88u, ok1 = row && (unsigned)(ix + 1) < 88u;
+        const float a = *(ok0 ? src + ix : vbase), b = *(ok1 ? src + ix + 1 : vbase);
+        pv0[k] = ok0 ? a : 0.f; pv1[k] = ok1 ? b : 0.f;
       }
-      T* dst = swin + (dt * kWinRows + wr) * kWinCols + 2 * cp;
-      dst[0] = from_f32<T>(v0); dst[1] = from_f32<T>(v1);
+#pragma unroll
+      for (int k = 0; k < kGrp; ++k) {
+        const int q = tid + (k0 + k) * kStemThreads;
+        if (q < NQ) {
+          const int dt = q / (kWinRows * (kWinCols / 2)), rem = q - dt * (kWinRows * (kWinCols / 2));
+          const int wr = rem / (kWinCols / 2), cp = rem - wr * (kWinCols / 2);
+          T* dst = swin + (dt * kWinRows + wr) * kWinCols + 2 * cp;
+          dst[0] = from_f32<T>(pv0[k]); dst[1] = from_f32<T>(pv1[k]);
+        }
+      }
     }
     __syncthreads();
 
