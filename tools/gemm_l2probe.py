@@ -30,6 +30,13 @@ def run(tag, A, W):
 
 
 run("real operands", a, w)
+for pad in (64, 192, 320):   # row stride = K + pad elements: do power-of-two strides pile the tile's lines onto few L2 channels?
+    ap = torch.randn(M, K + pad, device=DEV, dtype=torch.bfloat16)[:, :K]
+    wp = (torch.randn(N, K + pad, device=DEV, dtype=torch.bfloat16) * 0.02)[:, :K]
+    run(f"row stride K + {pad}", ap, wp)
+    run(f"  only A padded (+{pad})", ap, w)
+    run(f"  only W padded (+{pad})", a, wp)
+run("real operands (again)", a, w)
 run("A rows aliased (stride 0)", a[:1].expand(M, K), w)
 run("W rows aliased", a, w[:1].expand(N, K))
 run("A and W aliased", a[:1].expand(M, K), w[:1].expand(N, K))
