@@ -117,10 +117,6 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const void* zp = g_zero_page;                          // source of out-of-range rows
   asm volatile("" : "+s"(zp));                           // opaque: held in SGPRs, not re-fetched from the GOT (s_load + s_waitcnt) for every DMA group
-  if (p.stagger > 0 && blockIdx.x < 256) {
-    const int d = ((blockIdx.x >> 3) & 7) * p.stagger;
-    for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(16);
-  }
   const int ntn = (p.N + BN - 1) / BN;
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2s), so give every XCD a CONTIGUOUS
   // range of logical tiles (= whole M-tile rows): the A panel of a row is then fetched by one L2 instead of all eight.
@@ -414,10 +410,7 @@ int launch_dma(const GemmArgs& a, hipStream_t st) {
   }
   int64_t nblk = (int64_t)ceil_div(a.M, BM) * ceil_div(a.N, BN);
   dim3 grid((unsigned)nblk, a.ksplit > 1 ? a.ksplit : 1, a.groups);
-  static const int stagger = [] { const char* e = getenv("OAVSR_GEMM_STAGGER"); return e ? atoi(e) : 0; }();
-  GemmArgs b = a;
-  b.stagger = (BM == 256 && BN == 256 && nblk > 256) ? stagger : 0;
-  hipLaunchKernelGGL(kern, grid, dim3(NWAVES * 64), smem, st, b);
+  hipLaunchKernelGGL(kern, grid, dim3(NWAVES * 64), smem, st, a);
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -40,7 +40,6 @@ struct GemmArgs {
   int swiglu_pairs = 0;
   // classic kernel only: split-K over blockIdx.y with fp32 partial slabs [ksplit][M][N] + deterministic reduce/epilogue kernel
   int ksplit = 1; float* partial = nullptr;
-  int stagger = 0;   // experiment: first-round workgroups start (index-in-XCD & 7) * stagger * ~0.5 us late
 };
 int launch_gemm(const GemmArgs& a, hipStream_t st);
 // LDS-DMA pipelined 256x128 variant (gemm2.hip); launch_gemm dispatches to it when the grid fills the chip
