@@ -709,10 +709,10 @@ int launch_attn_dma(const AttnArgs& a, hipStream_t st) {
   return 0;
 }
 
-template <typename T, int HD>
+template <typename T, int HD, int NWF = 0>
 int launch_dec_t(const DecodeAttnArgs& a, hipStream_t st) {
   constexpr int RB = HD * (int)sizeof(T);
-  constexpr int NW = (8 * 64 * RB <= 128 * 1024) ? 8 : 4;      // waves per workgroup: 8 x 64 keys in one pass when the V tiles fit
+  constexpr int NW = NWF ? NWF : (8 * 64 * RB <= 128 * 1024) ? 8 : 4;      // waves per workgroup: 8 x 64 keys in one pass when the V tiles fit
   constexpr size_t tiles = (size_t)NW * 64 * RB, merge = (size_t)(2 * NW * 16 + NW * HD * 16) * 4;
   constexpr size_t smem = 18 * RB + (tiles > merge ? tiles : merge);
   static_assert(smem <= 160 * 1024, "LDS");
@@ -752,6 +752,10 @@ int launch_decode_attention(const DecodeAttnArgs& a, hipStream_t st) {
   OAVSR_REQUIRE(a.head_dim == 64 || a.head_dim == 128, "decode attention: head_dim %d unsupported", a.head_dim);
   OAVSR_REQUIRE(a.n_heads % a.n_kv_heads == 0 && a.n_heads / a.n_kv_heads <= 8, "decode attention: GQA group must be <= 8");
   if (a.dtype == DT_F32) return a.head_dim == 64 ? launch_dec_t<float, 64>(a, st) : launch_dec_t<float, 128>(a, st);
+  // many rows (beam search: B * K x kv heads workgroups, several per CU): 4-wave workgroups with half the LDS pack more of them
+  // onto a CU than 8-wave ones
+  static const int nw4_rows = [] { const char* e = getenv("OAVSR_DEC_ATTN_NW4_WGS"); return e ? atoi(e) : 512; }();
+  if (a.head_dim == 64 && a.rows * a.n_kv_heads >= nw4_rows) return launch_dec_t<bf16_t, 64, 4>(a, st);
   return a.head_dim == 64 ? launch_dec_t<bf16_t, 64>(a, st) : launch_dec_t<bf16_t, 128>(a, st);
 }
 
