@@ -1,22 +1,32 @@
 #!/usr/bin/env python3
 """Headline benchmark (BASELINE.json): utterances/s of the Omni-AVSR inference hot path on synthetic 16 s clips.
 
-  python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py [--gpus N --steps K --warmup W]
 
-A "step" is one pass of the whole hot path (`AVSR_LLMs.forward(is_trainval=False)`: log-mel + Whisper encoder, ResNet +
-AV-HuBERT encoder, compressor + projectors, prompt splice, LLM prefill, 32 greedy decode steps with EOS suppressed so
-every run does the same work) over one batch of B utterances per GPU.  Inputs are resident in HBM before the timed
-region.  Workload = BASELINE.json configs[1]: AVSR, AV-HuBERT-Large + Whisper-medium.en + Llama-3.2-1B (Omni-LoRA
-task-specific + shared, rank 32 / alpha 4, LoRA on the video encoder), batch 8 x 16 s, compression rates (4, 4).
-Weights are seeded random tensors of the real architecture (no checkpoints offline).  dtype: bf16 storage / fp32
-accumulate (the reference evaluates in bf16-true, eval_OmniAVSR.py:19).
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process touches no GPU; it starts N ranks as a child
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` (one rank per GPU over RCCL), relays rank 0's JSON line and
+exits with the children's return code (non-zero when fewer than N devices exist).  Under torch.distributed.run (the driver's
+form) every rank reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
 
-Multi-GPU: the path shards by utterance with no data-path collective: every rank runs its own batch
-("weak" scaling); the only exchange is one all_gather of the hypotheses after the timed loop.
+A "step" is `--calls-per-step` (default 8) consecutive passes of the whole hot path (`AVSR_LLMs.forward(is_trainval=False)`:
+log-mel + Whisper encoder, ResNet + AV-HuBERT encoder, compressor + projectors, prompt splice, LLM prefill, 32 greedy decode
+steps with EOS suppressed so every run does the same work), each over its own batch of B utterances per GPU, rotating over
+`--input-sets` distinct input batches (so no batch's 107 MB of inputs stays resident in the 256 MB Infinity Cache).  Inputs
+are in HBM before the timed region.  Workload (default preset c1) = BASELINE.json configs[1]: AVSR, AV-HuBERT-Large +
+Whisper-medium.en + Llama-3.2-1B (Omni-LoRA task-specific + shared, rank 32 / alpha 4, LoRA on the video encoder), batch
+8 x 16 s per model call, compression rates (4, 4).  Presets c2 / c3 / c4 = configs[2..4] at their per-GPU batch (not the
+headline).  Weights are seeded random tensors of the real architecture (no checkpoints offline).  dtype: bf16 storage /
+fp32 accumulate (the reference evaluates in bf16-true, eval_OmniAVSR.py:19).
+
+Multi-GPU: the path shards by utterance with no data-path collective: every rank runs its own batches ("weak"
+scaling); the only exchange is one all_gather of the last call's hypotheses (omni_avsr_amd.dist.gather_hypotheses), inside the
+timed region before the closing barrier.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,85 +34,173 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-import torch  # noqa: E402
+import torch  # noqa: E402   (importing torch / counting devices does not initialise the GPU)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
+# BASELINE.json configs[i] -> what a rank runs.  batch = utterances per model call on ONE GPU (configs[3]: 32 over 4 GPUs,
+# configs[4]: 64 over 8 GPUs); rates = (audio, video) compression rates cycled call by call.
+PRESETS = {
+    "c1": dict(idx=1, llm="meta-llama/Llama-3.2-1B", task="audiovisual", batch=8, rates=[(4, 4)], ra=[4, 16], rv=[2, 4, 5], varlen=False),
+    "c2": dict(idx=2, llm="meta-llama/Llama-3.2-1B", task="video", batch=16, rates=[(4, 4)], ra=[4, 16], rv=[2, 4, 5], varlen=False),
+    "c3": dict(idx=3, llm="Qwen/Qwen2.5-7B", task="audiovisual", batch=8, rates=[(2, 2), (4, 4), (8, 8)], ra=[2, 4, 8], rv=[2, 4, 8], varlen=False),
+    "c4": dict(idx=4, llm="meta-llama/Meta-Llama-3.1-8B", task="audiovisual", batch=8, rates=[(4, 4)], ra=[4, 16], rv=[2, 4, 5], varlen=True),
+}
 
-def build_spec(args):
+
+def build_spec(args, pre):
     from omni_avsr_amd.config import spec_from_names
     return spec_from_names(
-        args.llm, "openai/whisper-medium.en", "large_vox_iter5", use_lora_avhubert=True,
-        intermediate_size=2048, compression_mode="avg-pooling", downsample_ratio_audio=[4, 16], downsample_ratio_video=[2, 4, 5],
+        args.llm or pre["llm"], "openai/whisper-medium.en" if pre["task"] != "video" else None,
+        "large_vox_iter5" if pre["task"] != "audio" else None, use_lora_avhubert=True,
+        intermediate_size=2048, compression_mode="avg-pooling", downsample_ratio_audio=pre["ra"], downsample_ratio_video=pre["rv"],
         is_matryoshka=True, is_single_matry_projector=False, lora_rank=32, lora_alpha=4, is_task_specific=True, shared_lora=True,
         prompt_len={"audio": 8, "video": 8, "audiovisual": 8}, max_dec_tokens=args.max_new, num_beams=1)
 
 
-def make_inputs(B, Tv, seed, device):
-    """video N(0,1) [B,T_v,88,88]; audio N(0,1), utterance-level layer-norm (transforms.py:123-125)."""
+def make_inputs(Tvs, seed, device):
+    """video N(0,1) [sum T_v,88,88]; audio N(0,1) [B, 640 max T_v], utterance-level layer-norm over the valid
+    samples (transforms.py:123-125), zeros behind them."""
     g = torch.Generator(device=device).manual_seed(seed)
-    video = torch.randn(B * Tv, 88, 88, generator=g, device=device, dtype=torch.float32)
-    audio = torch.randn(B, 640 * Tv, generator=g, device=device, dtype=torch.float32)
-    audio = torch.nn.functional.layer_norm(audio, (audio.shape[1],))
+    video = torch.randn(sum(Tvs), 88, 88, generator=g, device=device, dtype=torch.float32)
+    audio = torch.zeros(len(Tvs), 640 * max(Tvs), device=device, dtype=torch.float32)
+    for b, tv in enumerate(Tvs):
+        a = torch.randn(640 * tv, generator=g, device=device, dtype=torch.float32)
+        audio[b, : 640 * tv] = torch.nn.functional.layer_norm(a, (640 * tv,))
     return video, audio
 
 
-def cpu_baseline(spec, sd_cpu, Tv, max_new):
-    """The oracle (CPU fp32 restatement, kind 'port') timed on this host's cores on ONE utterance of the same workload."""
+def host_cpu():
+    """CPU model, physical cores (unique (package, core) pairs) and logical CPUs of the host."""
+    model, cores, logical = "unknown", set(), 0
+    try:
+        phys = core = None
+        for ln in open("/proc/cpuinfo"):
+            k, _, v = ln.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "processor":
+                logical += 1
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+                cores.add((phys, core))
+    except OSError:
+        pass
+    return model, (len(cores) or logical or os.cpu_count()), (logical or os.cpu_count())
+
+
+def cpu_baseline(spec, sd_cpu, Tv, max_new, task, rates):
+    """The oracle (CPU fp32 restatement, kind 'port': the reference has hard .cuda() calls, modeling_OmniAVSR.py:534) timed on this
+    host's cores on ONE utterance of the same workload.  Two decodes over the same encoder output: greedy (like for like with the
+    GPU line) and the reference's own algorithmic choices (eval_OmniAVSR.py:215-226: 15 beams; HF expands the prompt K-fold for the
+    prefill and Llama_LoRA.py:372-373 materialises the logits of every prompt position)."""
     from oracle import torch_oracle as O
     orc = O.OmniOracle(sd_cpu, spec.oracle_cfg())
     g = torch.Generator().manual_seed(7)
     video = torch.randn(1, Tv, 1, 88, 88, generator=g)
     audio = torch.nn.functional.layer_norm(torch.randn(1, 640 * Tv, generator=g), (640 * Tv,)).unsqueeze(-1)
-    inp = dict(video=video, audio=audio, lengths=torch.tensor([640 * Tv]), tokens=torch.full((1, 1), spec.ids["bos"]))
-    t0 = time.time()
+    inp = dict(video=video, audio=audio, lengths=torch.tensor([640 * Tv]), tokens=torch.full((1, 1), max(spec.ids["bos"], 0)))
+    mod = task if spec.is_task_specific else None
+    ids = spec.ids
+    model, phys, logical = host_cpu()
+    # Bounded sample (about 30-40 s of CPU work): the encoders + prompt of one utterance in full, then each decode for its prefill and
+    # a few steps; the remaining steps cost the same (one token against a cache that grows by < 10 %), so the decode time is
+    # prefill + (max_new - 1) x the mean measured step.
+    tg, tb = {}, {}
     with torch.no_grad():
-        out = orc.forward(inp, "audiovisual", 4, 4, num_beams=1, force_len=True)
-    dt = time.time() - t0
-    assert len(out[0]) == max_new
-    return dict(value=1.0 / dt, unit="utterances/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"1 utterance of the same workload (16 s clip, greedy, {max_new} tokens) in {dt:.1f} s, torch CPU fp32")
+        t0 = time.time()
+        emb = orc.prepare_inputs(inp, task, rates[0], rates[1])
+        t_enc = time.time() - t0
+        orc.llm.generate_greedy(emb, min(max_new, 7), ids["eos"], ids["pad"], mod, force_len=True, timing=tg)
+        orc.llm.generate_beam(emb, min(max_new, 4), 15, ids["eos"], ids["pad"], mod, reference_prefill=True, timing=tb)
+    t_greedy = tg["prefill"] + (max_new - 1) * sum(tg["steps"]) / max(1, len(tg["steps"]))
+    t_beam = tb["prefill"] + (max_new - 1) * sum(tb["steps"]) / max(1, len(tb["steps"]))
+    dur = Tv / 25.0
+    return dict(value=1.0 / (t_enc + t_greedy), unit="utterances/s", cores=phys, threads=torch.get_num_threads(), logical_cpus=logical,
+                cpu_model=model, kind="port",
+                sample=f"1 utterance of the same workload ({dur:.0f} s clip), torch CPU fp32: encoders + prompt {t_enc:.1f} s measured in full; greedy decode "
+                       f"{t_greedy:.1f} s = prefill {tg['prefill']:.1f} s + {max_new - 1} x {sum(tg['steps']) / max(1, len(tg['steps'])):.2f} s/step "
+                       f"({len(tg['steps'])} steps measured)",
+                reference_default=dict(value=1.0 / (t_enc + t_beam), unit="utterances/s", beams=15, rtf=round((t_enc + t_beam) / dur, 3),
+                                       sample=f"same encoder output, the reference's own decode (HF beam search K=15, K-fold prefill, logits of every prompt "
+                                              f"position): {t_beam:.1f} s = prefill {tb['prefill']:.1f} s + {max_new - 1} x "
+                                              f"{sum(tb['steps']) / max(1, len(tb['steps'])):.2f} s/step ({len(tb['steps'])} steps measured)"),
+                rtf=round((t_enc + t_greedy) / dur, 3))
 
 
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic_*.json: FETCH_SIZE and
-    WRITE_SIZE collected in separate runs, gfx950 read-side correction applied; counters cannot be read from inside this process)."""
+    WRITE_SIZE collected in separate runs, gfx950 read-side correction applied; counters cannot be read from inside this process).
+    The newest round's file wins."""
     import glob
-    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic_*.json"))):
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic_*.json"))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
         if d.get("kernel") == kernel:
-            return d.get("traffic_bytes_per_launch")
-    return None
+            best = d.get("traffic_bytes_per_launch")
+    return best
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
-    ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--calls-per-step", type=int, default=8, help="model calls (batches of --batch utterances) per step")
+    ap.add_argument("--input-sets", type=int, default=4, help="distinct input batches rotated through the timed loop")
+    ap.add_argument("--preset", default="c1", choices=sorted(PRESETS), help="c1 = BASELINE.json configs[1] (headline); c2..c4 = configs[2..4]")
+    ap.add_argument("--batch", type=int, default=None, help="utterances per model call per GPU (default: the preset's)")
     ap.add_argument("--frames", type=int, default=400, help="video frames per utterance (400 = 16 s)")
     ap.add_argument("--max-new", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--beams", type=int, default=1, help="1 = greedy (north-star decode); 15 = the reference's default HF beam search")
-    ap.add_argument("--llm", default="meta-llama/Llama-3.2-1B",
-                    help="LLM architecture (random-init); the headline number is quoted on Llama-3.2-1B.  E.g. meta-llama/Meta-Llama-3.1-8B, Qwen/Qwen2.5-7B")
+    ap.add_argument("--llm", default=None, help="override the preset's LLM architecture (random-init)")
     ap.add_argument("--decode-group", type=int, default=1,
-                    help="G > 1: G consecutive steps (batches) share ONE decode loop (encoders / prefill still run per batch of --batch; "
+                    help="G > 1: G consecutive calls share ONE decode loop (encoders / prefill still run per batch of --batch; "
                          "continuous batching of the decode phase).  Opt-in: not the configuration the headline number is quoted on")
     ap.add_argument("--no-stagger", action="store_true", help="let the encoder phases of in-flight batches share the chip (default: chained)")
-    ap.add_argument("--streams", type=int, default=3, help="batches in flight (one HIP stream + workspace each); 1 = strictly sequential steps")
-    args = ap.parse_args()
+    ap.add_argument("--streams", type=int, default=3, help="batches in flight (one HIP stream + workspace each); 1 = strictly sequential calls")
+    return ap.parse_args()
+
+
+def launch_ranks(args):
+    """Parent of a multi-GPU run: never touches the GPU (device_count() does not initialise it), starts the ranks as a child
+    process and hands their return code back."""
+    n = torch.cuda.device_count()
+    if n < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, this node has {n}", file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    if os.environ.get("OAVSR_BENCH_PRINT_LAUNCH") == "1":       # tests: show the command instead of running it
+        print(json.dumps(cmd), flush=True)
+        return 0
+    return subprocess.call(cmd)
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr, flush=True)
+        sys.exit(2)
     use_dist = world > 1 or os.environ.get("OAVSR_BENCH_FORCE_DIST") == "1"   # the latter: exercise the RCCL path under torchrun with one rank
     if use_dist:
         import torch.distributed as dist
@@ -110,56 +208,74 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
 
+    from omni_avsr_amd.dist import gather_hypotheses, pack_records
     from omni_avsr_amd.modeling import OmniEngine
     from omni_avsr_amd.synth import synth_state_dict
 
-    spec = build_spec(args)
+    pre = PRESETS[args.preset]
+    spec = build_spec(args, pre)
+    task = pre["task"]
+    use_a = task in ("audio", "audiovisual")
     t0 = time.time()
+    big = spec.llm.hidden > 2048                     # 7B / 8B: no CPU-baseline leg (the fp32 oracle would run for minutes)
     sd = synth_state_dict(spec, seed=1234, device=dev)
     eng = OmniEngine(spec, dtype=args.dtype, device=str(dev)).load_state_dict(sd)
     sd_cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not big:
         sd_cpu = {k: v.cpu() for k, v in sd.items()}
     del sd
     torch.cuda.empty_cache()
-    B, Tv = args.batch, args.frames
+    B, Tv = args.batch or pre["batch"], args.frames
     G = max(1, args.decode_group)
-    assert args.steps % G == 0 and args.beams == 1 or G == 1, "--decode-group needs greedy decode and steps divisible by G"
-    video, audio = make_inputs(B * G, Tv, 100 + rank, dev)
-    Tvs, Ts = [Tv] * (B * G), [640 * Tv] * (B * G)
+    calls = max(1, args.calls_per_step)
+    assert (calls % G == 0 and args.beams == 1) or G == 1, "--decode-group needs greedy decode and --calls-per-step divisible by G"
+    nsets = max(1, args.input_sets)
+    sets = []
+    for s in range(nsets):
+        if pre["varlen"]:     # configs[4]: utterance lengths U[1 s, 16 s]
+            gl = torch.Generator().manual_seed(1000 * rank + s)
+            Tvs = [int(x) for x in torch.randint(25, Tv + 1, (B * G,), generator=gl)]
+        else:
+            Tvs = [Tv] * (B * G)
+        video, audio = make_inputs(Tvs, 100 + 17 * rank + s, dev)
+        sets.append((video, audio, Tvs, [640 * t for t in Tvs]))
     setup_s = time.time() - t0
 
     # Independent batches are pipelined over `--streams` HIP streams (each with its own workspace): the latency-bound decode
-    # loop of one batch overlaps the MFMA-bound encoders / prefill of the next.  Every step still is one complete pass.
+    # loop of one batch overlaps the MFMA-bound encoders / prefill of the next.  Every call still is one complete pass.
     nstream = max(1, args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstream)]
     if nstream > 1 and not args.no_stagger:
         eng.serialize_encoders(True)
     results = [None] * nstream
 
-    def step(i=0):
+    def call(i):
         s = i % nstream
+        video, audio, Tvs, Ts = sets[i % nsets]
+        ra, rv = pre["rates"][i % len(pre["rates"])]
         with torch.cuda.stream(streams[s]):
-            results[s] = eng.generate("audiovisual", video, Tvs, audio, Ts, 4, 4, beams=args.beams, max_new=args.max_new, force_len=(args.beams == 1),
-                                      video_is_flat=True, slot=s, chunk=B if G > 1 else None)
+            results[s] = eng.generate(task, video, Tvs, audio if use_a else None, Ts if use_a else None, ra, rv, beams=args.beams,
+                                      max_new=args.max_new, force_len=(args.beams == 1), video_is_flat=True, slot=s, chunk=B if G > 1 else None)
         return results[s]
 
+    ncall = 0
     torch.cuda.synchronize()
-    for i in range(max(args.warmup, nstream)):
-        ids, lens = step(i)
+    for _ in range(max(args.warmup * (calls // G), nstream, nsets * len(pre["rates"]))):
+        ids, lens = call(ncall)
+        ncall += 1
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps // G):                 # one call = G steps (G batches of B) when --decode-group G
-        ids, lens = step(i)
+    for _ in range(args.steps * (calls // G)):       # one call = G batches of B when --decode-group G
+        ids, lens = call(ncall)
+        ncall += 1
     torch.cuda.synchronize()
+    n_last = B * G
+    # the path's only exchange step, inside the timed region: gather the hypotheses of the last call
+    hyp = gather_hypotheses(pack_records([rank * n_last + j for j in range(n_last)], ids, lens, args.max_new), world * n_last)
     if use_dist:
-        # the path's only exchange step, inside the timed region: gather the hypotheses of the last batch (K16)
-        rec = torch.cat([lens.view(-1, 1), ids], 1).contiguous()
-        gathered = [torch.empty_like(rec) for _ in range(world)]
-        dist.all_gather(gathered, rec)
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -167,13 +283,17 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    assert len(hyp) == world * n_last
     assert args.beams > 1 or int(lens.min()) == args.max_new
 
     roofline = None
     stages = None
     if rank == 0 and not args.no_roofline:
+        torch.cuda.synchronize()
         eng.profile(True)
-        step()
+        for _ in range(len(pre["rates"])):
+            call(ncall)
+            ncall += 1
         ents = eng.profile_read()
         eng.profile(False)
         tot_ms = sum(e["ms"] for e in ents) or 1.0
@@ -197,20 +317,28 @@ def main():
 
     cpu = None
     if sd_cpu is not None:
-        cpu = cpu_baseline(spec, sd_cpu, Tv, args.max_new)
+        cpu = cpu_baseline(spec, sd_cpu, Tv, args.max_new, task, pre["rates"][0])
 
     if rank == 0:
-        n_utt = world * B * args.steps
+        n_utt = world * B * calls * args.steps
         value = n_utt / elapsed
+        secs = sum(sum(s[2]) for s in sets) / (nsets * G) / 25.0            # mean audio seconds per model call
+        llm_name = (args.llm or pre["llm"]).split("/")[-1]
+        what = {"audiovisual": "AVSR, AV-HuBERT-Large + Whisper-medium.en", "video": "VSR, AV-HuBERT-Large visual branch", "audio": "ASR, Whisper-medium.en"}[task]
         line = {
             "metric": "utterances/s + real-time-factor, LRS3 AVSR 16s clips, Llama-3.2-1B, 1/2/4/8 GPU",
             "value": round(value, 3), "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "rtf": round(elapsed / (n_utt * Tv / 25.0), 6),
-            "config": {"workload": f"AVSR, AV-HuBERT-Large + Whisper-medium.en + {args.llm.split('/')[-1]} (Omni-LoRA ST r32/a4), batch={B} x {Tv / 25:.0f}s clips per GPU, "
-                                   f"compression (4,4), " + (f"greedy {args.max_new} new tokens (EOS suppressed)" if args.beams == 1 else f"HF beam search K={args.beams}, {args.max_new} steps") + (", BASELINE.json configs[1]" if args.llm.endswith("Llama-3.2-1B") else ", NOT the headline configuration (other LLM)"),
-                       "global_batch": world * B, "parallelism": f"utterance-sharded dp{world}", "streams_per_gpu": nstream, "decode_group": G, "setup_s": round(setup_s, 1)},
+            "rtf": round(elapsed / (world * calls * args.steps * secs), 6),
+            "config": {"workload": f"{what} + {llm_name} (Omni-LoRA ST r32/a4), batch={B} x "
+                                   + ("U[1,16]s" if pre["varlen"] else f"{Tv / 25:.0f}s") + " clips per model call per GPU, "
+                                   f"compression rates {pre['rates']}, "
+                                   + (f"greedy {args.max_new} new tokens (EOS suppressed)" if args.beams == 1 else f"HF beam search K={args.beams}, {args.max_new} steps")
+                                   + f", BASELINE.json configs[{pre['idx']}]" + ("" if args.preset == "c1" and not args.llm else " (NOT the headline configuration)"),
+                       "batch_per_call": B, "calls_per_step": calls, "ms_per_call": round(elapsed / (args.steps * calls) * 1e3, 3),
+                       "global_batch": world * B * calls, "input_sets": nsets, "timed_s": round(elapsed, 2),
+                       "parallelism": f"utterance-sharded dp{world}", "streams_per_gpu": nstream, "decode_group": G, "setup_s": round(setup_s, 1)},
             "roofline": roofline, "cpu_baseline": cpu, "stages": stages,
         }
         print(json.dumps(line), flush=True)

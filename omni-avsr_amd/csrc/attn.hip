@@ -752,10 +752,11 @@ int launch_decode_attention(const DecodeAttnArgs& a, hipStream_t st) {
   OAVSR_REQUIRE(a.head_dim == 64 || a.head_dim == 128, "decode attention: head_dim %d unsupported", a.head_dim);
   OAVSR_REQUIRE(a.n_heads % a.n_kv_heads == 0 && a.n_heads / a.n_kv_heads <= 8, "decode attention: GQA group must be <= 8");
   if (a.dtype == DT_F32) return a.head_dim == 64 ? launch_dec_t<float, 64>(a, st) : launch_dec_t<float, 128>(a, st);
-  // many rows (beam search: B * K x kv heads workgroups, several per CU): 4-wave workgroups with half the LDS pack more of them
-  // onto a CU than 8-wave ones
-  static const int nw4_rows = [] { const char* e = getenv("OAVSR_DEC_ATTN_NW4_WGS"); return e ? atoi(e) : 512; }();
-  if (a.head_dim == 64 && a.rows * a.n_kv_heads >= nw4_rows) return launch_dec_t<bf16_t, 64, 4>(a, st);
+  // beam search (B * K x kv heads workgroups, several per CU): 4-wave workgroups with half the LDS pack more of them onto a CU
+  // than 8-wave ones.  The choice follows the decode MODE (beams > 1), never the row count: the key -> wave partition and with
+  // it the fp32 merge order of a row is then the same whether its utterance is decoded alone or inside a batch.
+  static const int nw4 = [] { const char* e = getenv("OAVSR_DEC_ATTN_NW4"); return e ? atoi(e) : 1; }();
+  if (a.head_dim == 64 && nw4 && a.beams > 1) return launch_dec_t<bf16_t, 64, 4>(a, st);
   return a.head_dim == 64 ? launch_dec_t<bf16_t, 64>(a, st) : launch_dec_t<bf16_t, 128>(a, st);
 }
 

@@ -90,6 +90,7 @@ static const char* gemm_family(const GemmArgs& a, bool skinny) {
 
 // Split-K factors are STATIC per call site (functions of the layer's N and K, never of the row count), so that an utterance
 // gets the same bits whether it runs alone or inside a batch: the k-slices are summed in a fixed order by the reduce kernel.
+constexpr int kPrefillTailChunk = 8;    // rows per launch of the pruned last prefill layer / first lm_head (batch-independent kernels)
 constexpr int kVideoNarrowSplit = 2;   // AV-HuBERT out-proj / fc2: N = D leaves ~100 tiles for a batch of 8 x 400 frames
 constexpr int kLoraDnSplitMax = 8;     // LoRA down projections: N = k*r is one or two column tiles
 static int lora_dn_split(int K, int esz) {
@@ -273,6 +274,76 @@ static int resolve_convbn(const oavsr_model* m, const std::string& p, bool slope
   return (c.w && c.scale && c.shift && (!slope || c.slope)) ? 0 : -1;
 }
 
+// Every packed tensor must have exactly the byte size the config implies: the kernels take their extents (vocabulary rows of
+// lm_head / embed, projector widths, LoRA ranks ...) from the config, so a checkpoint of another shape would otherwise be read
+// past its end or with the wrong stride.  The reference's strict load_state_dict raises in that case (lightning_OmniAVSR.py:150).
+static int validate_sizes(const oavsr_model* m) {
+  const oavsr_config& c = m->cfg;
+  const uint64_t e = m->esz;
+  int bad = 0;
+  auto chk = [&](const std::string& n, uint64_t expect) {
+    if (bad) return;
+    auto it = m->t.find(n);
+    if (it == m->t.end()) return;                      // presence is checked by the resolver
+    if (it->second.second != expect) {
+      set_last_error("model_create: size mismatch for packed tensor '%s': the checkpoint holds %llu bytes, the config implies %llu",
+                     n.c_str(), (unsigned long long)it->second.second, (unsigned long long)expect);
+      bad = 1;
+    }
+  };
+  auto enc = [&](const std::string& p, uint64_t D, uint64_t F, uint64_t k2) {
+    chk(p + "ln1.w", D * 4); chk(p + "ln1.b", D * 4); chk(p + "ln2.w", D * 4); chk(p + "ln2.b", D * 4);
+    chk(p + "qkv.w", 3 * D * D * e); chk(p + "qkv.b", 3 * D * 4); chk(p + "o.w", D * D * e); chk(p + "o.b", D * 4);
+    chk(p + "fc1.w", F * D * e); chk(p + "fc1.b", F * 4); chk(p + "fc2.w", D * F * e); chk(p + "fc2.b", D * 4);
+    if (k2) { chk(p + "lora_dn.w", k2 * D * e); chk(p + "lora_up.w", 3 * D * k2 * e); }
+  };
+  if (m->has_video) {
+    const uint64_t D = c.av_dim;
+    chk("v.stem.w", 64 * 256 * e); chk("v.stem.scale", 64 * 4); chk("v.stem.shift", 64 * 4); chk("v.stem.slope", 64 * 4);
+    for (int i = 0; i < 8; ++i) {
+      const ResBlock& rb = m->blocks[i];
+      const std::string p = "v.l" + std::to_string(i / 2 + 1) + "." + std::to_string(i % 2);
+      chk(p + ".conv1.w", (uint64_t)rb.cout * 9 * rb.cin * e); chk(p + ".conv2.w", (uint64_t)rb.cout * 9 * rb.cout * e);
+      for (const char* cn : {".conv1", ".conv2"})
+        for (const char* f : {".scale", ".shift", ".slope"}) chk(p + cn + f, (uint64_t)rb.cout * 4);
+      if (rb.has_down) { chk(p + ".down.w", (uint64_t)rb.cout * rb.cin * e); chk(p + ".down.scale", (uint64_t)rb.cout * 4); chk(p + ".down.shift", (uint64_t)rb.cout * 4); }
+    }
+    chk("v.proj.w", D * 512 * e); chk("v.proj.b", D * 4); chk("v.ln.w", 2 * D * 4); chk("v.ln.b", 2 * D * 4);
+    chk("v.post.w", D * 2 * D * e); chk("v.post.b", D * 4);
+    chk("v.pos.w", D * (uint64_t)c.av_conv_pos * (D / std::max(1, c.av_conv_groups)) * e); chk("v.pos.b", D * 4);
+    chk("v.lnf.w", D * 4); chk("v.lnf.b", D * 4);
+    for (int i = 0; i < c.av_layers; ++i) enc("v.L" + std::to_string(i) + ".", D, c.av_ffn, c.av_lora_k2);
+  }
+  if (m->has_audio) {
+    const uint64_t D = c.wh_dim;
+    chk("a.conv1.w", D * 256 * e); chk("a.conv1.b", D * 4); chk("a.conv2.w", D * 3 * D * e); chk("a.conv2.b", D * 4);
+    chk("a.pos", 1500 * D * e); chk("a.lnf.w", D * 4); chk("a.lnf.b", D * 4);
+    for (int i = 0; i < c.wh_layers; ++i) enc("a.L" + std::to_string(i) + ".", D, c.wh_ffn, 0);
+  }
+  const uint64_t d = c.llm_hidden, I = c.llm_mlp, V = c.llm_vocab;
+  for (int which = 0; which < 2; ++which) {
+    const auto& vec = which == 0 ? m->proj_a : m->proj_v;
+    const uint64_t Denc = which == 0 ? c.wh_dim : c.av_dim;
+    const int* rates = which == 0 ? c.rates_audio : c.rates_video;
+    for (size_t i = 0; i < vec.size(); ++i) {
+      const std::string p = std::string(which == 0 ? "pa." : "pv.") + std::to_string(i) + ".";
+      const uint64_t Din = c.compression_stack ? Denc * rates[i] : Denc;      // stack mode: one projector per rate (or a single rate)
+      chk(p + "fc1.w", (uint64_t)c.proj_inter * Din * e); chk(p + "fc1.b", (uint64_t)c.proj_inter * 4);
+      chk(p + "fc2.w", d * c.proj_inter * e); chk(p + "fc2.b", d * 4); chk(p + "ln.w", d * 4); chk(p + "ln.b", d * 4);
+    }
+  }
+  const uint64_t nq = (uint64_t)c.llm_heads * c.llm_head_dim, nqkv = (uint64_t)(c.llm_heads + 2 * c.llm_kv_heads) * c.llm_head_dim;
+  chk("l.embed", V * d * e); chk("l.lm_head", V * d * e); chk("l.norm.w", d * 4); chk("l.inv_freq", (uint64_t)c.llm_head_dim / 2 * 4);
+  for (int i = 0; i < c.llm_layers; ++i) {
+    const std::string p = "l.L" + std::to_string(i) + ".";
+    chk(p + "ln1.w", d * 4); chk(p + "ln2.w", d * 4); chk(p + "qkv.w", nqkv * d * e); chk(p + "qkv.b", nqkv * 4);
+    chk(p + "o.w", d * nq * e); chk(p + "gu.w", 2 * I * d * e); chk(p + "down.w", d * I * e);
+    for (const char* tn : {"0", "1", "2", "x"}) { chk(p + "lora_dn." + tn + ".w", (uint64_t)c.lora_k2 * d * e); chk(p + "lora_up." + tn + ".w", nqkv * c.lora_k2 * e); }
+  }
+  for (int t = 0; t < 3; ++t) if (c.prompt_len[t] > 0) chk("l.prompt." + std::to_string(t), (uint64_t)c.prompt_len[t] * d * e);
+  return bad ? -1 : 0;
+}
+
 static int resolve_model(oavsr_model* m) {
   const oavsr_config& c = m->cfg;
   m->has_video = m->t.count("v.stem.w") > 0;
@@ -342,7 +413,7 @@ static int resolve_model(oavsr_model* m) {
   }
   for (int t = 0; t < 3; ++t) m->prompt[t] = c.prompt_len[t] > 0 ? m->ptr("l.prompt." + std::to_string(t), false) : nullptr;
 #undef GETM
-  return 0;
+  return validate_sizes(m);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -617,17 +688,24 @@ static int build_prompt_impl(const oavsr_model* m, oavsr_workspace* ws, int task
 // ------------------------------------------------------------------------------------------------
 // GEMM dispatch of the LLM stack: prefill rows -> tiled MFMA GEMM; decode with <= 32 rows -> weight-streaming skinny kernel
 // (RMSNorm / SwiGLU fused); decode with more rows (beam search: B*K) -> 128-row tiles with split-K so every CU streams weights.
+// Split-K factor of the 33+-row decode GEMMs (128 x 64 weight-streaming tiles, gemm2.hip): enough k-slices that N / 64 column
+// tiles x slices fill the 256 CUs.  A function of N and K ONLY (one M-tile's worth of column tiles), never of the row count, so
+// a row's fp32 summation order does not depend on how many other rows share the launch.
+static int decode_split(int N, int Ktot, int esz) {
+  const int ktiles = Ktot / (128 / esz);
+  int ks = 256 / std::max(1, ceil_div(N, 64));
+  ks = std::min(ks, std::max(1, ktiles / 2));
+  return std::max(1, std::min(ks, 16));
+}
+
 static int llm_gemm(const oavsr_model* m, oavsr_workspace* ws, GemmArgs& g, int mode /*0 prefill, 1 skinny, 2 split-K*/, hipStream_t st) {
   if (mode == 0) return run_gemm(g, st, false);
   if (mode == 1) return run_gemm(g, st, true);
-  const int esz = (int)m->esz;
-  const int ktiles = (g.K + g.K2) / (128 / esz);
-  const int tiles = ceil_div(g.M, 128) * ceil_div(g.N, 64);      // 128 x 64 weight-streaming tiles (gemm2.hip)
-  int ks = 256 / std::max(1, tiles);
-  ks = std::min(ks, std::max(1, ktiles / 2));
-  ks = std::min(ks, 16);
-  while (ks > 1 && (size_t)ks * g.M * g.N * 4 > ws->partial_bytes) --ks;
-  if (ks > 1) { g.ksplit = ks; g.partial = ws->partial; }
+  const int ks = decode_split(g.N, g.K + g.K2, (int)m->esz);
+  if (ks > 1) {
+    OAVSR_REQUIRE((size_t)ks * g.M * g.N * 4 <= ws->partial_bytes, "decode GEMM: split-K slabs (%d x %d x %d) exceed the workspace", ks, g.M, g.N);
+    g.ksplit = ks; g.partial = ws->partial;
+  }
   return run_gemm(g, st, false);
 }
 
@@ -645,7 +723,7 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
   const int mode = !decode ? 0 : (rows <= 32 ? 1 : 2);
   const bool fused_norm = mode == 1;       // RMSNorm folded into the skinny GEMMs (gain on the A fragments, rstd in the epilogue)
   static const bool prune_on = [] { const char* e = getenv("OAVSR_PREFILL_PRUNE"); return !(e && e[0] == '0'); }();
-  const bool can_prune = prune_on && !decode && last_rows && cu_last && B <= 32;
+  const bool can_prune = prune_on && !decode && last_rows && cu_last;
   if (pruned) *pruned = false;
   for (int li = 0; li < c.llm_layers; ++li) {
     const LlmLayer& L = m->llayers[li];
@@ -693,50 +771,66 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
       ProfScope ps("decode_attention", 0, 2.0 * rows * max_S * KV * hd * m->esz, st);
       OAVSR_TRY(launch_decode_attention(a, st));
     }
-    // tail of the layer: on all rows, or (pruned last prefill layer) on the B gathered rows with the decode-shaped kernels
-    const int trows = prune ? B : rows, tmode = prune ? 1 : mode;
+    // tail of the layer: on all rows, or (pruned last prefill layer) on the B gathered rows with the decode-shaped kernels, in
+    // chunks of 8 rows: every chunk then runs the same 8-column weight-streaming kernels whatever B is, so an utterance's first-token
+    // logits do not depend on its batch (a batch of 8 -- the benchmark configuration -- is one chunk)
+    const int tmode = prune ? 1 : mode;
     const bool tfused = tmode == 1;
-    void* xres = prune ? ws->lastx : ws->lx;
-    g = GemmArgs(); g.dtype = dt; g.M = trows; g.N = d; g.K = nq; g.A = ws->lattn; g.lda = nq; g.W = L.ow; g.ldw = nq;
-    g.residual = xres; g.ldr = d; g.C = xres; g.ldc = d;
-    OAVSR_TRY(llm_gemm(m, ws, g, tmode, st));
-    if (tfused) {   // RMSNorm + gate/up + SwiGLU in one launch
-      g = GemmArgs(); g.dtype = dt; g.M = trows; g.N = 2 * I; g.K = d; g.A = xres; g.lda = d; g.W = L.guw; g.ldw = d;
-      g.norm_gain = L.ln2w; g.norm_eps = c.llm_rms_eps; g.swiglu_pairs = 1; g.C = ws->lact; g.ldc = I;
-      OAVSR_TRY(run_gemm(g, st, true));
-    } else {
-      { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
-        OAVSR_TRY(launch_rmsnorm(dt, ws->lx, d, ws->lh, d, L.ln2w, rows, d, c.llm_rms_eps, st)); }
-      g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 2 * I; g.K = d; g.A = ws->lh; g.lda = d; g.W = L.guw; g.ldw = d; g.C = ws->lgu; g.ldc = 2 * I;
-      static const bool fuse_swiglu = [] { const char* e = getenv("OAVSR_FUSE_SWIGLU"); return !(e && e[0] == '0'); }();
-      GemmArgs gf = g; gf.swiglu_pairs = 1; gf.C = ws->lact; gf.ldc = I;
-      // prefill, and beam-search decode (33..128 rows) when the 128 x 64 tiles already fill the chip without split-K:
-      // SwiGLU in the GEMM epilogue, the [rows][2I] tensor never exists
-      const bool dec_fill = mode == 2 && (int64_t)ceil_div(rows, 128) * ceil_div(2 * I, 64) >= 256;
-      if (fuse_swiglu && (mode == 0 || dec_fill) && gemm_dma_swiglu_ok(gf)) {
-        OAVSR_TRY(run_gemm(gf, st, false));
+    const int tstep = prune ? kPrefillTailChunk : rows;
+    for (int r0 = 0; r0 < (prune ? B : rows); r0 += tstep) {
+      const int trows = std::min(tstep, (prune ? B : rows) - r0);
+      const size_t e = m->esz;
+      char* xres = (char*)(prune ? ws->lastx : ws->lx) + (size_t)r0 * d * e;
+      const char* attn_r = (const char*)ws->lattn + (size_t)r0 * nq * e;
+      char* act_r = (char*)ws->lact + (size_t)r0 * I * e;
+      g = GemmArgs(); g.dtype = dt; g.M = trows; g.N = d; g.K = nq; g.A = attn_r; g.lda = nq; g.W = L.ow; g.ldw = nq;
+      g.residual = xres; g.ldr = d; g.C = xres; g.ldc = d;
+      OAVSR_TRY(llm_gemm(m, ws, g, tmode, st));
+      if (tfused) {   // RMSNorm + gate/up + SwiGLU in one launch
+        g = GemmArgs(); g.dtype = dt; g.M = trows; g.N = 2 * I; g.K = d; g.A = xres; g.lda = d; g.W = L.guw; g.ldw = d;
+        g.norm_gain = L.ln2w; g.norm_eps = c.llm_rms_eps; g.swiglu_pairs = 1; g.C = act_r; g.ldc = I;
+        OAVSR_TRY(run_gemm(g, st, true));
       } else {
-        OAVSR_TRY(llm_gemm(m, ws, g, mode, st));
-        ProfScope ps("swiglu", 0, 3.0 * rows * I * m->esz, st);
-        OAVSR_TRY(launch_swiglu(dt, ws->lgu, 2 * I, ws->lact, I, rows, I, 1, st));
+        { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
+          OAVSR_TRY(launch_rmsnorm(dt, ws->lx, d, ws->lh, d, L.ln2w, rows, d, c.llm_rms_eps, st)); }
+        g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 2 * I; g.K = d; g.A = ws->lh; g.lda = d; g.W = L.guw; g.ldw = d; g.C = ws->lgu; g.ldc = 2 * I;
+        static const bool fuse_swiglu = [] { const char* e2 = getenv("OAVSR_FUSE_SWIGLU"); return !(e2 && e2[0] == '0'); }();
+        GemmArgs gf = g; gf.swiglu_pairs = 1; gf.C = ws->lact; gf.ldc = I;
+        // prefill, and beam-search decode (33..128 rows) when the 128 x 64 tiles already fill the chip without split-K:
+        // SwiGLU in the GEMM epilogue, the [rows][2I] tensor never exists
+        const bool dec_fill = mode == 2 && (int64_t)ceil_div(rows, 128) * ceil_div(2 * I, 64) >= 256;
+        if (fuse_swiglu && (mode == 0 || dec_fill) && gemm_dma_swiglu_ok(gf)) {
+          OAVSR_TRY(run_gemm(gf, st, false));
+        } else {
+          OAVSR_TRY(llm_gemm(m, ws, g, mode, st));
+          ProfScope ps("swiglu", 0, 3.0 * rows * I * m->esz, st);
+          OAVSR_TRY(launch_swiglu(dt, ws->lgu, 2 * I, ws->lact, I, rows, I, 1, st));
+        }
       }
+      g = GemmArgs(); g.dtype = dt; g.M = trows; g.N = d; g.K = I; g.A = act_r; g.lda = I; g.W = L.downw; g.ldw = I;
+      g.residual = xres; g.ldr = d; g.C = xres; g.ldc = d;
+      OAVSR_TRY(llm_gemm(m, ws, g, tmode, st));
     }
-    g = GemmArgs(); g.dtype = dt; g.M = trows; g.N = d; g.K = I; g.A = ws->lact; g.lda = I; g.W = L.downw; g.ldw = I;
-    g.residual = xres; g.ldr = d; g.C = xres; g.ldc = d;
-    OAVSR_TRY(llm_gemm(m, ws, g, tmode, st));
     if (prune && pruned) *pruned = true;
   }
   return 0;
 }
 
-static int lm_head_rows(const oavsr_model* m, oavsr_workspace* ws, const void* x, int rows, float* logits, hipStream_t st) {
+// chunk > 0 (prefill): the rows go through the fused weight-streaming kernel `chunk` at a time, whatever their number
+static int lm_head_rows(const oavsr_model* m, oavsr_workspace* ws, const void* x, int rows, float* logits, hipStream_t st, int chunk = 0) {
   const oavsr_config& c = m->cfg;
   const int d = c.llm_hidden;
   GemmArgs g; g.dtype = m->dtype; g.M = rows; g.N = c.llm_vocab; g.K = d; g.W = m->lm_head; g.ldw = d;
   g.C = logits; g.ldc = c.llm_vocab; g.out_f32 = 1;
-  if (rows <= 32) {          // final RMSNorm fused into the weight-streaming kernel
-    g.A = x; g.lda = d; g.norm_gain = m->norm_w; g.norm_eps = c.llm_rms_eps;
-    return run_gemm(g, st, true);
+  if (rows <= 32 || chunk > 0) {          // final RMSNorm fused into the weight-streaming kernel
+    const int step = chunk > 0 ? chunk : rows;
+    for (int r0 = 0; r0 < rows; r0 += step) {
+      g.M = std::min(step, rows - r0);
+      g.A = (const char*)x + (size_t)r0 * d * m->esz; g.lda = d; g.norm_gain = m->norm_w; g.norm_eps = c.llm_rms_eps;
+      g.C = logits + (size_t)r0 * c.llm_vocab;
+      OAVSR_TRY(run_gemm(g, st, true));
+    }
+    return 0;
   }
   { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
     OAVSR_TRY(launch_rmsnorm(m->dtype, x, d, ws->lh, d, m->norm_w, rows, d, c.llm_rms_eps, st)); }
@@ -775,7 +869,7 @@ static int prefill_impl(const oavsr_model* m, oavsr_workspace* ws, int task, int
   // last position of every utterance only (the reference materialises all positions, Llama_LoRA.py:372-373)
   if (!pruned) OAVSR_TRY(launch_copy_rows(m->dtype, ws->lx, c.llm_hidden, ws->last_rows, ws->lastx, c.llm_hidden, B, c.llm_hidden, st));
   float* lg = ws->logits + (size_t)utt0 * c.llm_vocab;
-  OAVSR_TRY(lm_head_rows(m, ws, ws->lastx, B, lg, st));
+  OAVSR_TRY(lm_head_rows(m, ws, ws->lastx, B, lg, st, kPrefillTailChunk));
   if (logits_out) OAVSR_CHECK_HIP(hipMemcpyAsync(logits_out, lg, (size_t)B * c.llm_vocab * 4, hipMemcpyDeviceToDevice, st));
   return 0;
 }
@@ -1042,7 +1136,12 @@ int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, 
   WANT(gs.tok, rows_dec * 4); WANT(gs.finished, rows_dec * 4); WANT(gs.out_ids, rows_dec * (size_t)max_new * 4); WANT(gs.out_len, rows_dec * 4);
   WANT(gs.step, 256); WANT(gs.pos, rows_dec * 4); WANT(gs.cpos, rows_dec * 4); WANT(gs.rope_cs, rows_dec * (size_t)(hd / 2) * sizeof(float2));
   {   // split-K partial slabs: decode GEMMs with > 32 rows, the narrow video-encoder projections, the LoRA down projections
-    size_t pb = rows_dec > 32 ? (size_t)32 << 20 : 0;
+    size_t pb = 0;
+    if (rows_dec > 32) {   // every decode GEMM call site: ks(N, K) x rows x N fp32 (decode_split)
+      const int es = (int)e, qkv = (int)nqkv, nq_ = H * hd;
+      const int sites[5][2] = {{c.lora_k2, d}, {qkv, d + c.lora_k2}, {d, nq_}, {2 * I, d}, {d, I}};
+      for (auto& s2 : sites) if (s2[0] > 0) pb = std::max(pb, (size_t)decode_split(s2[0], s2[1], es) * rows_dec * s2[0] * 4);
+    }
     if (m->has_video) pb = std::max(pb, (size_t)kVideoNarrowSplit * F * Dv * 4);
     if (m->has_video && c.av_lora_k2 > 0) pb = std::max(pb, (size_t)kLoraDnSplitMax * F * c.av_lora_k2 * 4);
     if (c.lora_k2 > 0) pb = std::max(pb, (size_t)kLoraDnSplitMax * ST * c.lora_k2 * 4);

@@ -374,7 +374,7 @@ __global__ __launch_bounds__(kThreads) void argmax_kernel(const float* __restric
   if (threadIdx.x == 0) {
     for (int w = 1; w < kWavesPerBlock; ++w) argmax_combine(best, bi, sv[w], si[w]);
     if (scratch) scratch[row * kArgChunks + blockIdx.x] = make_float2(best, __int_as_float(bi));
-    else out[row] = bi;
+    else out[row] = bi == 0x7fffffff ? 0 : bi;     // all-NaN row: no comparison ever succeeds; keep the index inside the vocabulary
   }
 }
 
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(64) void argmax_final_kernel(const float2* __restri
     int oi = __shfl_xor(bi, o, 64);
     argmax_combine(best, bi, ov, oi);
   }
-  if (threadIdx.x == 0) out[row] = bi;
+  if (threadIdx.x == 0) out[row] = bi == 0x7fffffff ? 0 : bi;   // all-NaN row (see argmax_kernel)
 }
 
 // Greedy bookkeeping, one thread per row (HF GenerationMixin greedy: finished rows emit pad).

@@ -33,9 +33,11 @@ def pack_records(utt_ids: Sequence[int], ids: torch.Tensor, lens: torch.Tensor, 
     return rec
 
 
-def gather_hypotheses(rec: torch.Tensor, n_total: int, group=None) -> Dict[int, List[int]]:
+def gather_hypotheses(rec: torch.Tensor, n_total: int, group=None, return_failed: bool = False):
     """All-gathers the per-rank records (ranks may own different counts: padded to the max) and returns
-    {utt_id: token ids} on every rank."""
+    {utt_id: token ids} on every rank.  A rank reports an utterance it could not decode as a record with n = -1
+    (`failed_record`); with `return_failed=True` the result is (hyp, failed utterance ids) -- failed = reported as failed by
+    their rank, or owned by nobody -- instead of an exception, so one bad clip does not lose a whole evaluation."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         allrec = rec.cpu()
@@ -50,13 +52,30 @@ def gather_hypotheses(rec: torch.Tensor, n_total: int, group=None) -> Dict[int, 
         dist.all_gather(outs, pad, group=group)
         allrec = torch.cat([o[: int(c.item())] for o, c in zip(outs, cnts)], 0).cpu()
     hyp: Dict[int, List[int]] = {}
+    failed: List[int] = []
     for row in allrec.tolist():
         uid, n = row[0], row[1]
         if uid < 0:
             continue
+        if n < 0:
+            failed.append(uid)
+            continue
         hyp[uid] = row[2:2 + n]
-    assert len(hyp) == n_total, f"gathered {len(hyp)} hypotheses, expected {n_total}"
+    if return_failed:
+        seen = set(hyp) | set(failed)
+        failed += [u for u in range(n_total) if u not in seen]
+        return hyp, sorted(set(failed))
+    if failed or len(hyp) != n_total:
+        raise RuntimeError(f"gathered {len(hyp)} hypotheses, expected {n_total}; failed utterance ids: {sorted(failed)}")
     return hyp
+
+
+def failed_record(utt_ids: Sequence[int], width: int, device="cpu") -> torch.Tensor:
+    """Records for utterances this rank could not decode (n = -1), same shape as `pack_records` rows."""
+    rec = torch.full((len(utt_ids), width + 2), -1, dtype=torch.int32, device=device)
+    if len(utt_ids):
+        rec[:, 0] = torch.tensor(list(utt_ids), dtype=torch.int32, device=device)
+    return rec
 
 
 def reduce_wer_counters(edits: int, words: int, device="cpu", group=None) -> Tuple[int, int]:

@@ -36,11 +36,39 @@ class _Inert:
         return _Inert()
 
 
+# Globals a checkpoint may legitimately reference.  Everything else (omegaconf nodes, fairseq dataclasses, and anything a hostile
+# file names: os.system, builtins.eval ...) resolves to the inert stand-in, so loading a .pt / .pth never runs foreign code.
+_SAFE_BUILTINS = {"set", "frozenset", "list", "dict", "tuple", "int", "float", "bool", "str", "bytes", "bytearray", "complex", "slice", "range", "object"}
+_SAFE_GLOBALS = {
+    "collections": {"OrderedDict", "defaultdict"},
+    "argparse": {"Namespace"},
+    "numpy": {"ndarray", "dtype"},
+    "numpy.core.multiarray": {"_reconstruct", "scalar"},
+    "numpy._core.multiarray": {"_reconstruct", "scalar"},
+    "torch": {"Size", "device", "dtype", "Tensor"},
+    "torch.nn.parameter": {"Parameter"},
+    "torch._tensor": {"_rebuild_from_type_v2"},
+    "torch.storage": {"UntypedStorage", "TypedStorage"},
+}
+
+
+def _safe_global(module: str, name: str) -> bool:
+    if module == "builtins":
+        return name in _SAFE_BUILTINS
+    if module == "torch._utils":
+        return name.startswith("_rebuild_")
+    if module == "torch" and (name.endswith("Storage") or name in ("float32", "float16", "bfloat16", "float64", "int64", "int32", "int16", "int8", "uint8", "bool")):
+        return True
+    return name in _SAFE_GLOBALS.get(module, ())
+
+
 class _LenientUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
+        if not _safe_global(module, name):
+            return _Inert
         try:
             return super().find_class(module, name)
-        except Exception:
+        except (ImportError, AttributeError):
             return _Inert
 
 

@@ -28,8 +28,9 @@ def _i32arr(xs: Sequence[int]):
 
 
 def whisper_keep_tokens(max_len: int) -> int:
-    """modeling_OmniAVSR.py:537 — `max(int(max_len/16000*50), 25)` evaluated with Python float semantics."""
-    return max(int(max_len / 16000 * 50), 25)
+    """modeling_OmniAVSR.py:537 — `audio_enc[:, :max(int(max_len/16000*50), 25)]` evaluated with Python float semantics; the
+    slice of the 1500-frame encoder output simply stops at 1500 for clips longer than 30 s."""
+    return min(max(int(max_len / 16000 * 50), 25), 1500)
 
 
 class OmniEngine:
@@ -83,6 +84,13 @@ class OmniEngine:
         """Accepts the reference's checkpoint layout (strict for the modules the spec declares)."""
         if not torch.cuda.is_available():
             raise RuntimeError("omni_avsr_amd needs a ROCm GPU (MI355X); there is no CPU path")
+        l = self.spec.llm
+        for key, want in (("llm.model.embed_tokens.weight", (l.vocab, l.hidden)), ("llm.lm_head.weight", (l.vocab, l.hidden))):
+            if key in sd and tuple(sd[key].shape) != want:
+                # what nn.Module.load_state_dict(strict=True) raises in the reference (lightning_OmniAVSR.py:150): the vocabulary must be
+                # the RESIZED one (modeling_OmniAVSR.py:214, +5 / +4 rows); build the spec with ingest.infer_spec to take it from the file
+                raise RuntimeError(f"size mismatch for {key}: copying a param with shape {tuple(sd[key].shape)} from checkpoint, "
+                                   f"the shape in current model is {want}")
         packed = pack_state_dict(sd, self.spec, self.dtype)
         # keep the true prompt lengths of the checkpoint
         for t, name in enumerate(("audio", "video", "audiovisual")):

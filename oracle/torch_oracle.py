@@ -17,6 +17,13 @@ Pinning:
 
 All weights come in a flat dict `sd` keyed exactly like `AVSR_LLMs.state_dict()`
 (SURVEY.md §5.4), all math is fp32 on CPU.
+
+bf16 emulation (`with bf16_emulation(): ...`): the same restatement with every tensor the bf16 engine keeps in
+bf16 rounded to bf16 at the point where the engine stores it (GEMM operands / weights, each kernel's output after its
+fused epilogue, soft-max probabilities before P.V, rotated q / k, the residual stream), fp32 accumulation everywhere else --
+the arithmetic of the reference's `bf16-true` evaluation (eval_OmniAVSR.py:19) with this engine's fusion boundaries.  It is
+the yardstick the bf16 engine is held to at a tight bound (tests/test_bf16_emulation_gpu.py); outside the context manager
+`_q` is the identity and nothing below changes by a bit.
 """
 from __future__ import annotations
 
@@ -34,6 +41,30 @@ Tensor = torch.Tensor
 # ----------------------------------------------------------------------------------------------
 
 
+class _Precision:
+    emu = False
+
+
+_P = _Precision()
+
+
+class bf16_emulation:
+    """Context manager: round to bf16 wherever the bf16 engine stores bf16 (see the module docstring)."""
+
+    def __enter__(self):
+        self.prev, _P.emu = _P.emu, True
+        return self
+
+    def __exit__(self, *a):
+        _P.emu = self.prev
+        return False
+
+
+def _q(x: Tensor) -> Tensor:
+    """Storage rounding of the bf16 engine; identity in fp32 mode."""
+    return x.bfloat16().float() if _P.emu else x
+
+
 def _ln(x: Tensor, w: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
     """torch.nn.LayerNorm in fp32 (fairseq/modules/layer_norm.py:29-34)."""
     return F.layer_norm(x.float(), (x.shape[-1],), w.float(), b.float(), eps)
@@ -45,9 +76,19 @@ def _gelu(x: Tensor) -> Tensor:
 
 
 def _linear(x: Tensor, sd: Dict[str, Tensor], key: str) -> Tensor:
-    w = sd[key + ".weight"].float()
+    """GEMM operand W in the compute dtype, bias fp32; the caller rounds the result where the engine's fused epilogue ends."""
+    w = _q(sd[key + ".weight"].float())
     b = sd.get(key + ".bias")
     return F.linear(x, w, None if b is None else b.float())
+
+
+def _softmax_pv(w: Tensor, v: Tensor) -> Tensor:
+    """softmax(w) @ v.  Emulation: the flash kernels round the un-normalised exponentials to bf16 for the P.V MFMA and keep
+    the row sum in fp32 (attn.hip)."""
+    if not _P.emu:
+        return F.softmax(w.float(), dim=-1) @ v
+    e = torch.exp(w - w.amax(dim=-1, keepdim=True))
+    return (_q(e) @ v) / e.sum(dim=-1, keepdim=True)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -72,26 +113,26 @@ def _prelu(x: Tensor, a: Tensor) -> Tensor:
 def resnet_frontend3d(sd, p: str, video: Tensor) -> Tensor:
     """resnet.py:137-141,158: Conv3d(1,64,(5,7,7),(1,2,2),(2,3,3)) -> BN3d -> PReLU -> MaxPool3d.
     video: [B,1,T,88,88] -> [B,64,T,22,22]"""
-    x = F.conv3d(video.float(), sd[p + "frontend3D.0.weight"].float(), None, stride=(1, 2, 2), padding=(2, 3, 3))
+    x = F.conv3d(_q(video.float()), _q(sd[p + "frontend3D.0.weight"].float()), None, stride=(1, 2, 2), padding=(2, 3, 3))
     x = _bn_eval(x, sd, p + "frontend3D.1")
     x = _prelu(x, sd[p + "frontend3D.2.weight"])
     x = F.max_pool3d(x, kernel_size=(1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1))
-    return x
+    return _q(x)
 
 
 def resnet_basic_block(sd, p: str, x: Tensor, stride: int, has_down: bool) -> Tensor:
     """resnet.py:61-74 BasicBlock.forward with PReLU."""
     residual = x
-    out = F.conv2d(x, sd[p + "conv1.weight"].float(), None, stride=stride, padding=1)
+    out = F.conv2d(x, _q(sd[p + "conv1.weight"].float()), None, stride=stride, padding=1)
     out = _bn_eval(out, sd, p + "bn1")
-    out = _prelu(out, sd[p + "relu1.weight"])
-    out = F.conv2d(out, sd[p + "conv2.weight"].float(), None, stride=1, padding=1)
+    out = _q(_prelu(out, sd[p + "relu1.weight"]))
+    out = F.conv2d(out, _q(sd[p + "conv2.weight"].float()), None, stride=1, padding=1)
     out = _bn_eval(out, sd, p + "bn2")
     if has_down:  # resnet.py:20-24: 1x1 conv stride s + BN
-        residual = F.conv2d(x, sd[p + "downsample.0.weight"].float(), None, stride=stride)
-        residual = _bn_eval(residual, sd, p + "downsample.1")
+        residual = F.conv2d(x, _q(sd[p + "downsample.0.weight"].float()), None, stride=stride)
+        residual = _q(_bn_eval(residual, sd, p + "downsample.1"))
     out = out + residual
-    return _prelu(out, sd[p + "relu2.weight"])
+    return _q(_prelu(out, sd[p + "relu2.weight"]))
 
 
 def resnet_trunk(sd, p: str, x: Tensor, return_stages: bool = False):
@@ -101,7 +142,7 @@ def resnet_trunk(sd, p: str, x: Tensor, return_stages: bool = False):
         x = resnet_basic_block(sd, f"{p}layer{li}.0.", x, stride, has_down=(li != 1))
         x = resnet_basic_block(sd, f"{p}layer{li}.1.", x, 1, has_down=False)
         stages.append(x)
-    x = x.mean(dim=(2, 3))
+    x = _q(x.mean(dim=(2, 3)))
     return (x, stages) if return_stages else x
 
 
@@ -135,16 +176,22 @@ def fairseq_mha(sd, p: str, x: Tensor, heads: int, lora: bool, scaling_lora: flo
     q = _linear(x, sd, p + "q_proj")
     k = _linear(x, sd, p + "k_proj")
     v = _linear(x, sd, p + "v_proj")
-    if lora:  # :485-494
+    if lora and not _P.emu:  # :485-494
         q = q + F.linear(F.linear(x, sd[p + "lora_down_Q.weight"].float()), sd[p + "lora_up_Q.weight"].float()) * scaling_lora
         v = v + F.linear(F.linear(x, sd[p + "lora_down_V.weight"].float()), sd[p + "lora_up_V.weight"].float()) * scaling_lora
-    q = q * (hd ** -0.5)                                     # :511 (after LoRA)
+    elif lora:               # engine: t = x A^T stored in bf16, the scale folded into the stored up-projection, one fp32 accumulator
+        q = q + F.linear(_q(F.linear(x, _q(sd[p + "lora_down_Q.weight"].float()))), _q(sd[p + "lora_up_Q.weight"].float() * scaling_lora))
+        v = v + F.linear(_q(F.linear(x, _q(sd[p + "lora_down_V.weight"].float()))), _q(sd[p + "lora_up_V.weight"].float() * scaling_lora))
+    q, k, v = _q(q), _q(k), _q(v)
+    if not _P.emu:
+        q = q * (hd ** -0.5)                                 # :511 (after LoRA)
     q = q.contiguous().view(T, B * heads, hd).transpose(0, 1)
     k = k.contiguous().view(T, B * heads, hd).transpose(0, 1)
     v = v.contiguous().view(T, B * heads, hd).transpose(0, 1)
     w = torch.bmm(q, k.transpose(1, 2))                      # :619
-    w = F.softmax(w.float(), dim=-1)                         # :647-650 fp32 softmax
-    a = torch.bmm(w, v)                                      # :654
+    if _P.emu:
+        w = w * (hd ** -0.5)                                 # engine: the scale multiplies the fp32 scores
+    a = _q(_softmax_pv(w, v))                                # :647-654 fp32 softmax, bmm
     a = a.transpose(0, 1).contiguous().view(T, B, C)
     return _linear(a, sd, p + "out_proj")
 
@@ -153,27 +200,27 @@ def w2v_transformer_encoder(sd, p: str, x: Tensor, layers: int, heads: int, conv
                             lora: bool, return_layers: bool = False):
     """TransformerEncoder.forward / extract_features wav2vec2.py:862-905 with layer_norm_first=True
     (large_vox_iter5.yaml:77). x: [B,T,C]."""
-    w = weight_norm_fold(sd[p + "pos_conv.0.weight_g"], sd[p + "pos_conv.0.weight_v"])
+    w = _q(weight_norm_fold(sd[p + "pos_conv.0.weight_g"], sd[p + "pos_conv.0.weight_v"]))
     xc = F.conv1d(x.transpose(1, 2), w, sd[p + "pos_conv.0.bias"].float(), padding=conv_pos // 2, groups=groups)
     if conv_pos % 2 == 0:                                     # SamePad same_pad.py:16-21
         xc = xc[:, :, :-1]
-    x = x + _gelu(xc).transpose(1, 2)                         # :875-877
+    x = _q(x + _gelu(xc).transpose(1, 2))                     # :875-877
     x = x.transpose(0, 1)                                     # T,B,C
     outs = []
     for i in range(layers):                                   # layer: wav2vec2.py:977-1006
         lp = f"{p}layers.{i}."
         res = x
-        h = _ln(x, sd[lp + "self_attn_layer_norm.weight"], sd[lp + "self_attn_layer_norm.bias"])
+        h = _q(_ln(x, sd[lp + "self_attn_layer_norm.weight"], sd[lp + "self_attn_layer_norm.bias"]))
         h = fairseq_mha(sd, lp + "self_attn.", h, heads, lora)
-        x = res + h
+        x = _q(res + h)
         res = x
-        h = _ln(x, sd[lp + "final_layer_norm.weight"], sd[lp + "final_layer_norm.bias"])
-        h = _gelu(_linear(h, sd, lp + "fc1"))
+        h = _q(_ln(x, sd[lp + "final_layer_norm.weight"], sd[lp + "final_layer_norm.bias"]))
+        h = _q(_gelu(_linear(h, sd, lp + "fc1")))
         h = _linear(h, sd, lp + "fc2")
-        x = res + h
+        x = _q(res + h)
         outs.append(x.transpose(0, 1))
     x = x.transpose(0, 1)
-    x = _ln(x, sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"])   # :865-866
+    x = _q(_ln(x, sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"]))   # :865-866
     return (x, outs) if return_layers else x
 
 
@@ -182,11 +229,11 @@ def avhubert_extract_finetune(sd, p: str, video: Tensor, cfg: dict, return_stage
     video: [B,1,T,88,88] -> [B,T,D]."""
     D = cfg["embed"]
     feat = res_encoder(sd, p + "feature_extractor_video.resnet.", video)            # [B,512,T]
-    fv = _linear(feat.transpose(1, 2), sd, p + "feature_extractor_video.proj")      # SubModel hubert.py:327
+    fv = _q(_linear(feat.transpose(1, 2), sd, p + "feature_extractor_video.proj"))  # SubModel hubert.py:327
     fa = torch.zeros_like(fv)                                                         # :709
     feats = torch.cat([fa, fv], dim=-1)                                               # :715 (audio first)
-    feats = _ln(feats, sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"])      # :721
-    x0 = _linear(feats, sd, p + "post_extract_proj")                                  # :728
+    feats = _q(_ln(feats, sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"]))  # :721
+    x0 = _q(_linear(feats, sd, p + "post_extract_proj"))                              # :728
     x = w2v_transformer_encoder(sd, p + "encoder.", x0, cfg["layers"], cfg["heads"], cfg["conv_pos"],
                                 cfg["conv_pos_groups"], cfg.get("use_lora", False), return_layers=return_stages)
     if return_stages:
@@ -253,28 +300,33 @@ def whisper_log_mel(wave: Tensor, n_samples: int = 480000) -> Tensor:
 def whisper_encoder(sd, p: str, mel: Tensor, layers: int, heads: int, return_layers: bool = False):
     """transformers WhisperEncoder.forward: conv1(k3,p1)+GELU, conv2(k3,s2,p1)+GELU, +pos-emb,
     pre-LN layers (k_proj without bias, q scaled by head_dim^-0.5), final LN.  mel: [B,80,3000] -> [B,1500,D]."""
-    x = _gelu(F.conv1d(mel.float(), sd[p + "conv1.weight"].float(), sd[p + "conv1.bias"].float(), padding=1))
-    x = _gelu(F.conv1d(x, sd[p + "conv2.weight"].float(), sd[p + "conv2.bias"].float(), stride=2, padding=1))
-    x = x.permute(0, 2, 1) + sd[p + "embed_positions.weight"].float()[None]
+    x = _q(_gelu(F.conv1d(_q(mel.float()), _q(sd[p + "conv1.weight"].float()), sd[p + "conv1.bias"].float(), padding=1)))
+    x = _gelu(F.conv1d(x, _q(sd[p + "conv2.weight"].float()), sd[p + "conv2.bias"].float(), stride=2, padding=1))
+    x = _q(x.permute(0, 2, 1) + _q(sd[p + "embed_positions.weight"].float())[None])
     B, T, C = x.shape
     hd = C // heads
     outs = []
     for i in range(layers):
         lp = f"{p}layers.{i}."
-        h = _ln(x, sd[lp + "self_attn_layer_norm.weight"], sd[lp + "self_attn_layer_norm.bias"])
-        q = _linear(h, sd, lp + "self_attn.q_proj") * (hd ** -0.5)
-        k = F.linear(h, sd[lp + "self_attn.k_proj.weight"].float())
+        h = _q(_ln(x, sd[lp + "self_attn_layer_norm.weight"], sd[lp + "self_attn_layer_norm.bias"]))
+        q = _linear(h, sd, lp + "self_attn.q_proj")
+        if not _P.emu:
+            q = q * (hd ** -0.5)
+        k = F.linear(h, _q(sd[lp + "self_attn.k_proj.weight"].float()))
         v = _linear(h, sd, lp + "self_attn.v_proj")
-        q = q.view(B, T, heads, hd).transpose(1, 2)
-        k = k.view(B, T, heads, hd).transpose(1, 2)
-        v = v.view(B, T, heads, hd).transpose(1, 2)
-        a = F.softmax(q @ k.transpose(-1, -2), dim=-1) @ v
+        q = _q(q).view(B, T, heads, hd).transpose(1, 2)
+        k = _q(k).view(B, T, heads, hd).transpose(1, 2)
+        v = _q(v).view(B, T, heads, hd).transpose(1, 2)
+        w = q @ k.transpose(-1, -2)
+        if _P.emu:
+            w = w * (hd ** -0.5)                              # engine: the scale multiplies the fp32 scores
+        a = _q(_softmax_pv(w, v)) if _P.emu else F.softmax(w, dim=-1) @ v
         a = a.transpose(1, 2).reshape(B, T, C)
-        x = x + _linear(a, sd, lp + "self_attn.out_proj")
-        h = _ln(x, sd[lp + "final_layer_norm.weight"], sd[lp + "final_layer_norm.bias"])
-        x = x + _linear(_gelu(_linear(h, sd, lp + "fc1")), sd, lp + "fc2")
+        x = _q(x + _linear(a, sd, lp + "self_attn.out_proj"))
+        h = _q(_ln(x, sd[lp + "final_layer_norm.weight"], sd[lp + "final_layer_norm.bias"]))
+        x = _q(x + _linear(_q(_gelu(_linear(h, sd, lp + "fc1"))), sd, lp + "fc2"))
         outs.append(x)
-    x = _ln(x, sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"])
+    x = _q(_ln(x, sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"]))
     return (x, outs) if return_layers else x
 
 
@@ -290,7 +342,7 @@ def compress(x: Tensor, rate: int, mode: str) -> Tensor:
     n = T // rate
     x = x[:, : n * rate].reshape(B, n, rate, C)
     if mode == "avg-pooling":
-        return x.mean(dim=2)
+        return _q(x.mean(dim=2))
     if mode == "stack":
         return x.reshape(B, n, rate * C)
     raise ValueError(mode)
@@ -300,10 +352,10 @@ def projector(sd, p: str, x: Tensor) -> Tensor:
     """Sequential(Linear, ReLU, Linear[, LayerNorm]) — index 3 exists only in the variants where the
     LayerNorm really is a Sequential member (modeling_OmniAVSR.py:102,111 vs the :104 quirk where it
     is swallowed as the Linear `bias` arg and never applied)."""
-    h = F.relu(_linear(x, sd, p + "0"))
-    h = _linear(h, sd, p + "2")
+    h = _q(F.relu(_linear(x, sd, p + "0")))
+    h = _q(_linear(h, sd, p + "2"))
     if p + "3.weight" in sd:
-        h = _ln(h, sd[p + "3.weight"], sd[p + "3.bias"])
+        h = _q(_ln(h, sd[p + "3.weight"], sd[p + "3.bias"]))
     return h
 
 
@@ -351,50 +403,89 @@ class LLMOracle:
         self.sd, self.cfg, self.p = sd, cfg, prefix
         self.inv_freq = rope_inv_freq(cfg["head_dim"], cfg["rope_theta"], cfg.get("rope_scaling"))
         self.scaling = cfg["lora_alpha"] / cfg["lora_rank"] if cfg.get("lora_rank") else 0.0   # Llama_LoRA.py:120
+        # bf16 emulation only: how many utterances share the engine call being emulated (the engine picks its decode kernels by
+        # the total row count B * K: weight-streaming kernels up to 32 rows, tiled split-K GEMMs beyond)
+        self.emu_batch = 1
 
-    def _lora(self, lp: str, which: str, x: Tensor, modality: Optional[str]) -> Tensor:
+    def _lora(self, lp: str, which: str, x: Tensor, modality: Optional[str], rstd: Optional[Tensor] = None) -> Tensor:
         sd, cfg = self.sd, self.cfg
         if cfg.get("task_specific"):                           # Llama_LoRA.py:250-251
             dn, up = f"{lp}lora_down_{which}.{modality}.weight", f"{lp}lora_up_{which}.{modality}.weight"
         else:
             dn, up = f"{lp}lora_down_{which}.weight", f"{lp}lora_up_{which}.weight"
-        out = F.linear(F.linear(x, sd[dn].float()), sd[up].float())
+        pairs = [(dn, up)]
         if cfg.get("shared"):                                  # :254-259
-            out = out + F.linear(F.linear(x, sd[f"{lp}lora_down_{which}_shared.weight"].float()),
-                                 sd[f"{lp}lora_up_{which}_shared.weight"].float())
-        return out * self.scaling
+            pairs.append((f"{lp}lora_down_{which}_shared.weight", f"{lp}lora_up_{which}_shared.weight"))
+        if not _P.emu:
+            out = F.linear(F.linear(x, sd[pairs[0][0]].float()), sd[pairs[0][1]].float())
+            for d_, u_ in pairs[1:]:
+                out = out + F.linear(F.linear(x, sd[d_].float()), sd[u_].float())
+            return out * self.scaling
+        # engine: t = x A^T stored in bf16 (rstd of the fused RMSNorm applied before the store), alpha / rank folded into the
+        # stored up-projection, all adapters summed in the QKV GEMM's fp32 accumulator
+        out = 0
+        for d_, u_ in pairs:
+            t = F.linear(x, _q(sd[d_].float()))
+            if rstd is not None:
+                t = t * rstd
+            out = out + F.linear(_q(t), _q(sd[u_].float() * self.scaling))
+        return out
 
     def embed(self, ids: Tensor) -> Tensor:
-        return self.sd[self.p + "model.embed_tokens.weight"].float()[ids]
+        return _q(self.sd[self.p + "model.embed_tokens.weight"].float()[ids])
 
     def forward(self, x: Tensor, pos0: int, cache: Optional[list], modality: Optional[str],
-                last_only: bool = False, return_hidden: bool = False):
+                last_only: bool = False, return_hidden: bool = False, skinny: Optional[bool] = None):
         """x: [B,S,d] embeddings, positions pos0..pos0+S-1, cache: list of (k,v) per layer
-        ([B,kvh,ctx,hd]) appended in place.  Returns fp32 logits [B,S,V] (Llama_LoRA.py:372-373)."""
+        ([B,kvh,ctx,hd]) appended in place.  Returns fp32 logits [B,S,V] (Llama_LoRA.py:372-373).
+        `skinny` (bf16 emulation only): the rows run through the engine's weight-streaming decode kernels (RMSNorm fused into
+        the GEMM: the gain multiplies the bf16 activations, 1/rms scales the fp32 accumulator; SwiGLU on unrounded gate / up) --
+        decode steps with <= 32 rows; default: S == 1."""
         sd, cfg, p = self.sd, self.cfg, self.p
         B, S, d = x.shape
         H, KV, hd = cfg["heads"], cfg["kv_heads"], cfg["head_dim"]
+        emu = _P.emu
+        if skinny is None:
+            skinny = S == 1 and B * self.emu_batch <= 32
+        # prefill: the engine prunes the last layer to each utterance's final row and sends it (and lm_head) through the fused
+        # weight-streaming kernels 8 rows at a time, whatever the batch; decode: those kernels serve up to 32 rows
+        few_rows = (last_only and S > 1) or B * S * self.emu_batch <= 32
         pos = torch.arange(pos0, pos0 + S, dtype=torch.float32)
         freqs = pos[:, None] * self.inv_freq[None, :]
         emb = torch.cat((freqs, freqs), dim=-1)
         cos, sin = emb.cos()[None, None], emb.sin()[None, None]
-        x = x.float()
+        x = _q(x.float())
         hiddens = []
+
+        def fused_norm(xx, gain):        # skinny.hip NORM prologue: (bf16(x * g), 1 / rms(x))
+            return _q(xx * gain.float()), torch.rsqrt(xx.pow(2).mean(-1, keepdim=True) + cfg["rms_eps"])
+
         for i in range(cfg["layers"]):
             lp = f"{p}model.layers.{i}."
             ap = lp + "self_attn."
-            h = _rms(x, sd[lp + "input_layernorm.weight"], cfg["rms_eps"])
-            q = _linear(h, sd, ap + "q_proj")
-            k = _linear(h, sd, ap + "k_proj")
-            v = _linear(h, sd, ap + "v_proj")
-            if cfg.get("lora_rank"):
-                q = q + self._lora(ap, "Q", h, modality)
-                v = v + self._lora(ap, "V", h, modality)
-            q = q.view(B, S, H, hd).transpose(1, 2)
-            k = k.view(B, S, KV, hd).transpose(1, 2)
-            v = v.view(B, S, KV, hd).transpose(1, 2)
-            q = q * cos + _rot_half(q) * sin                   # apply_rotary_pos_emb (:277)
-            k = k * cos + _rot_half(k) * sin
+            last = i == cfg["layers"] - 1
+            if emu and skinny:
+                h, rstd = fused_norm(x, sd[lp + "input_layernorm.weight"])
+                bias = lambda n: (sd[ap + n + ".bias"].float() if ap + n + ".bias" in sd else 0.0)    # noqa: E731
+                q = F.linear(h, _q(sd[ap + "q_proj.weight"].float())) * rstd + bias("q_proj")
+                k = F.linear(h, _q(sd[ap + "k_proj.weight"].float())) * rstd + bias("k_proj")
+                v = F.linear(h, _q(sd[ap + "v_proj.weight"].float())) * rstd + bias("v_proj")
+                if cfg.get("lora_rank"):
+                    q = q + self._lora(ap, "Q", h, modality, rstd)
+                    v = v + self._lora(ap, "V", h, modality, rstd)
+            else:
+                h = _q(_rms(x, sd[lp + "input_layernorm.weight"], cfg["rms_eps"]))
+                q = _linear(h, sd, ap + "q_proj")
+                k = _linear(h, sd, ap + "k_proj")
+                v = _linear(h, sd, ap + "v_proj")
+                if cfg.get("lora_rank"):
+                    q = q + self._lora(ap, "Q", h, modality)
+                    v = v + self._lora(ap, "V", h, modality)
+            q = _q(q).view(B, S, H, hd).transpose(1, 2)
+            k = _q(k).view(B, S, KV, hd).transpose(1, 2)
+            v = _q(v).view(B, S, KV, hd).transpose(1, 2)
+            q = _q(q * cos + _rot_half(q) * sin)               # apply_rotary_pos_emb (:277)
+            k = _q(k * cos + _rot_half(k) * sin)
             if cache is not None:
                 if cache[i] is not None:
                     k = torch.cat([cache[i][0], k], dim=2)
@@ -408,33 +499,48 @@ class LLMOracle:
                 qi = torch.arange(ctx - S, ctx)[:, None]
                 ki = torch.arange(ctx)[None, :]
                 w = w.masked_fill(ki > qi, float("-inf"))
-            a = F.softmax(w, dim=-1) @ vv
+            a = _q(_softmax_pv(w, vv)) if emu else F.softmax(w, dim=-1) @ vv
             a = a.transpose(1, 2).reshape(B, S, H * hd)
-            x = x + _linear(a, sd, ap + "o_proj")
-            h = _rms(x, sd[lp + "post_attention_layernorm.weight"], cfg["rms_eps"])
-            g = F.silu(_linear(h, sd, lp + "mlp.gate_proj")) * _linear(h, sd, lp + "mlp.up_proj")
-            x = x + _linear(g, sd, lp + "mlp.down_proj")
+            x = _q(x + _linear(a, sd, ap + "o_proj"))
+            # the engine prunes the LAST prefill layer to each utterance's final row and runs its MLP through the decode kernels
+            if emu and (skinny or (last and last_only and S > 1 and few_rows)):
+                h, rstd = fused_norm(x, sd[lp + "post_attention_layernorm.weight"])
+                g = F.silu(F.linear(h, _q(sd[lp + "mlp.gate_proj.weight"].float())) * rstd) * (F.linear(h, _q(sd[lp + "mlp.up_proj.weight"].float())) * rstd)
+            else:
+                h = _q(_rms(x, sd[lp + "post_attention_layernorm.weight"], cfg["rms_eps"]))
+                g = F.silu(_q(_linear(h, sd, lp + "mlp.gate_proj"))) * _q(_linear(h, sd, lp + "mlp.up_proj"))
+            x = _q(x + _linear(_q(g), sd, lp + "mlp.down_proj"))
             if return_hidden:
                 hiddens.append(x)
-        x = _rms(x, sd[p + "model.norm.weight"], cfg["rms_eps"])
         if last_only:
             x = x[:, -1:]
-        logits = F.linear(x, sd[p + "lm_head.weight"].float()).float()
+        W = _q(sd[p + "lm_head.weight"].float())
+        if emu and few_rows:                                   # lm_head with the final RMSNorm fused (<= 32 rows)
+            h, rstd = fused_norm(x, sd[p + "model.norm.weight"])
+            logits = (F.linear(h, W) * rstd).float()
+        else:
+            x = _q(_rms(x, sd[p + "model.norm.weight"], cfg["rms_eps"]))
+            logits = F.linear(x, W).float()
         return (logits, hiddens) if return_hidden else logits
 
     # -- generation ---------------------------------------------------------------------------
 
     def generate_greedy(self, embeds: Tensor, max_new: int, eos: int, pad: int, modality=None,
-                        force_len: bool = False, return_logits: bool = False):
+                        force_len: bool = False, return_logits: bool = False, timing: Optional[dict] = None):
         """HF greedy search (`generate(num_beams=1, do_sample=False)`), one utterance per row with its
         OWN prompt length handled by the caller (B=1 in the reference, data_module.py:238-242).
         embeds: [1,S,d].  Returns list of new token ids (EOS included, as HF returns it)."""
         assert embeds.shape[0] == 1
+        import time as _time
         cache = [None] * self.cfg["layers"]
+        t0 = _time.time()
         logits = self.forward(embeds, 0, cache, modality, last_only=True)[:, -1]
+        if timing is not None:                                  # bench.py's CPU baseline: seconds of the prefill and of every step
+            timing["prefill"], timing["steps"] = _time.time() - t0, []
         S = embeds.shape[1]
         out, all_logits = [], []
         for step in range(max_new):
+            t0 = _time.time()
             if return_logits:
                 all_logits.append(logits[0].clone())
             lg = logits[0].clone()
@@ -447,10 +553,26 @@ class LLMOracle:
             if step + 1 == max_new:
                 break
             logits = self.forward(self.embed(torch.tensor([[tok]])), S + step, cache, modality, last_only=True)[:, -1]
+            if timing is not None:
+                timing["steps"].append(_time.time() - t0)
         return (out, all_logits) if return_logits else out
 
+    def score_path(self, embeds: Tensor, tokens: List[int], modality=None) -> Tensor:
+        """Teacher forcing: the fp32 logits [len(tokens), V] the model assigns at every step when it is fed `tokens` (the path
+        another implementation decoded).  `logits[t, tokens[t]]` against `logits[t].max()` says how far that implementation's
+        choice is from this oracle's arg-max -- a tolerance-aware id check for reduced-precision runs."""
+        assert embeds.shape[0] == 1
+        cache = [None] * self.cfg["layers"]
+        S = embeds.shape[1]
+        logits = self.forward(embeds, 0, cache, modality, last_only=True)[:, -1]
+        out = [logits[0]]
+        for step, tok in enumerate(tokens[:-1]):
+            logits = self.forward(self.embed(torch.tensor([[int(tok)]])), S + step, cache, modality, last_only=True)[:, -1]
+            out.append(logits[0])
+        return torch.stack(out)
+
     def generate_beam(self, embeds: Tensor, max_new: int, num_beams: int, eos: int, pad: int, modality=None,
-                      length_penalty: float = 1.0) -> List[int]:
+                      length_penalty: float = 1.0, reference_prefill: bool = False, timing: Optional[dict] = None) -> List[int]:
         """transformers==4.43.1 `GenerationMixin._beam_search` + `BeamSearchScorer` with
         do_sample=False, early_stopping=False, length_penalty=1.0 and `inputs_embeds` only
         (=> input_ids start empty, decoder_prompt_len = 0); call site modeling_OmniAVSR.py:313-322.
@@ -458,12 +580,21 @@ class LLMOracle:
         assert embeds.shape[0] == 1
         K, V = num_beams, self.sd[self.p + "lm_head.weight"].shape[0]
         S = embeds.shape[1]
+        import time as _time
         cache = [None] * self.cfg["layers"]
-        # HF expands the prompt K-fold; rows are identical so run it once and replicate the cache.
-        logits = self.forward(embeds, 0, cache, modality, last_only=True)[:, -1]
-        logits = logits.repeat(K, 1)
-        for i in range(len(cache)):
-            cache[i] = (cache[i][0].repeat(K, 1, 1, 1), cache[i][1].repeat(K, 1, 1, 1))
+        t0 = _time.time()
+        if reference_prefill:
+            # exactly what the reference executes (bench.py's CPU baseline): HF expands the prompt K-fold
+            # (`_expand_inputs_for_generation`) and Llama_LoRA.py:372-373 computes fp32 logits of EVERY position
+            logits = self.forward(embeds.repeat(K, 1, 1), 0, cache, modality, last_only=False)[:, -1]
+        else:
+            # the K rows are identical, so run the prompt once and replicate the cache: same values
+            logits = self.forward(embeds, 0, cache, modality, last_only=True)[:, -1]
+            logits = logits.repeat(K, 1)
+            for i in range(len(cache)):
+                cache[i] = (cache[i][0].repeat(K, 1, 1, 1), cache[i][1].repeat(K, 1, 1, 1))
+        if timing is not None:
+            timing["prefill"], timing["steps"] = _time.time() - t0, []
         beam_scores = torch.full((K,), -1e9, dtype=torch.float32)
         beam_scores[0] = 0.0
         seqs: List[List[int]] = [[] for _ in range(K)]
@@ -472,6 +603,7 @@ class LLMOracle:
         done = False
         cur_len = 0
         while True:
+            t0 = _time.time()
             logp = F.log_softmax(logits, dim=-1) + beam_scores[:, None]
             top_s, top_i = torch.topk(logp.view(-1), 2 * K, largest=True, sorted=True)
             nb_scores, nb_tokens, nb_idx = [], [], []
@@ -512,6 +644,8 @@ class LLMOracle:
                 cache[i] = (cache[i][0][idx], cache[i][1][idx])
             x = self.embed(torch.tensor(nb_tokens)[:, None])
             logits = self.forward(x, S + cur_len - 1, cache, modality, last_only=True)[:, -1]
+            if timing is not None:
+                timing["steps"].append(_time.time() - t0)
         if not done:                                           # finalize: add all running beams
             for b in range(K):
                 score = float(beam_scores[b]) / (len(seqs[b]) ** length_penalty)

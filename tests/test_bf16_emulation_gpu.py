@@ -1,0 +1,89 @@
+"""-m gpu: the bf16 engine (the benchmarked arithmetic, = the reference's bf16-true evaluation) against the bf16-EMULATING
+oracle (oracle/torch_oracle.py `bf16_emulation`: fp32 math on CPU with every tensor rounded to bf16 exactly where the engine
+stores bf16, fp32 accumulation elsewhere).  What remains between the two is fp32 summation order and the handful of values it
+pushes across a bf16 rounding boundary, so the bounds are several times tighter than against the fp32 oracle
+(tests/test_stages_gpu.py keeps those looser checks):
+
+  encoder activations : max |err| <= 3 % and mean |err| <= 0.3 % of the activation scale (fp32 oracle bound: 12 %)
+  prefill logits      : max |err| <= 0.06 (fp32 oracle bound: 0.25)
+  token ids           : every token the engine decodes lies within 0.06 of the emulating oracle's arg-max logit when the oracle
+                        is teacher-forced along the engine's own path (replaces ">= 50 % of the tokens agree")
+
+on the tiny configuration (Llama and Qwen2, LoRA variants) and on ONE full-size 4 s clip (AV-HuBERT-Large + Whisper-medium +
+Llama-3.2-1B)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from omni_avsr_amd.config import spec_from_names, tiny_spec  # noqa: E402
+from omni_avsr_amd.modeling import OmniEngine  # noqa: E402
+from omni_avsr_amd.synth import synth_state_dict  # noqa: E402
+from oracle import torch_oracle as O  # noqa: E402
+
+ENC_MAX, ENC_MEAN, LOGIT_TOL = 0.03, 0.003, 0.06
+
+
+def rel(a, b):
+    """(max, mean) |a - b| relative to the scale of b"""
+    d = (a.float().cpu() - b.float()).abs()
+    sc = b.float().abs().max().item()
+    return d.max().item() / sc, d.mean().item() / sc
+
+
+def check_enc(name, got, ref):
+    mx, mn = rel(got, ref)
+    print(f"bf16 vs emulation, {name}: max {mx:.2e} mean {mn:.2e} of scale")
+    assert mx <= ENC_MAX and mn <= ENC_MEAN, f"{name}: max {mx:.3e} / mean {mn:.3e} of the activation scale"
+
+
+def run_case(spec, sd, Tv, Ts, rate_a, rate_v, seed, max_new, task="audiovisual"):
+    eng = OmniEngine(spec, dtype="bf16").load_state_dict(sd)
+    sd_cpu = {k: v.cpu().float() for k, v in sd.items()}
+    orc = O.OmniOracle(sd_cpu, spec.oracle_cfg())
+    g = torch.Generator().manual_seed(seed)
+    video = torch.randn(1, Tv, 1, 88, 88, generator=g)
+    audio = torch.nn.functional.layer_norm(torch.randn(1, Ts, generator=g), (Ts,)).unsqueeze(-1)
+    use_a, use_v = task != "video", task != "audio"
+    eng.ensure_workspace(1, Tv, Ts)
+    ids, lens = eng.generate(task, video, [Tv], audio, [Ts], rate_a, rate_v, beams=1, max_new=max_new, force_len=True)
+    got = ids[0, : int(lens[0])].cpu().tolist()
+    with torch.no_grad(), O.bf16_emulation():
+        if use_v:
+            _, venc, _ = eng.encode_video(video, [Tv], rate_v, return_enc=True)
+            check_enc("video encoder", venc, orc.encode_video(video, rate_v, return_stages=True)[1]["enc"][0])
+        if use_a:
+            _, aenc, _, _ = eng.encode_audio(audio, [Ts], rate_a, return_enc=True)
+            check_enc("whisper encoder", aenc[0], orc.encode_audio(audio, Ts, rate_a, return_stages=True)[1]["enc"][0])
+        a_out, na = eng.encode_audio(audio, [Ts], rate_a) if use_a else (None, None)
+        v_out, nv = eng.encode_video(video, [Tv], rate_v) if use_v else (None, None)
+        emb, S = eng.build_prompt(task, 1, na, eng.project("audio", rate_a, a_out) if use_a else None, nv,
+                                  eng.project("video", rate_v, v_out) if use_v else None)
+        logits = eng.prefill(task, emb, S)
+        tokens = torch.full((1, 1), spec.ids["bos"]) if spec.llm.family == "llama" else torch.zeros(1, 0, dtype=torch.long)
+        ref_emb = orc.prepare_inputs(dict(video=video, audio=audio, lengths=torch.tensor([Ts]), tokens=tokens), task, rate_a, rate_v)
+        check_enc("inputs_embeds", emb, ref_emb[0])
+        mod = task if spec.is_task_specific else None
+        path = orc.llm.score_path(ref_emb, got, mod)
+    el = (logits[0].cpu() - path[0]).abs().max().item()
+    print(f"bf16 vs emulation, prefill logits: max err {el:.3e}")
+    assert el <= LOGIT_TOL, f"prefill logits max err {el:.3e}"
+    gaps = [float(path[t].max() - path[t][got[t]]) for t in range(len(got))]
+    exact = sum(int(path[t].argmax()) == got[t] for t in range(len(got)))
+    print(f"bf16 vs emulation, ids: {exact}/{len(got)} equal the emulating oracle's arg-max on the engine's path, worst logit gap {max(gaps):.3e}")
+    assert max(gaps) <= LOGIT_TOL, f"decoded token {gaps.index(max(gaps))} is {max(gaps):.3e} below the emulating oracle's arg-max"
+
+
+@pytest.mark.parametrize("family,hd,ts,shared", [("llama", 64, True, True), ("qwen2", 128, True, True), ("llama", 128, False, False)])
+def test_tiny_bf16_engine_matches_bf16_emulation(family, hd, ts, shared):
+    spec = tiny_spec(family=family, head_dim=hd, task_specific=ts, shared=shared)
+    run_case(spec, synth_state_dict(spec, seed=1234), 12, 7680, 4, 2, seed=3, max_new=spec.max_dec_tokens)
+
+
+def test_fullsize_4s_clip_bf16_engine_matches_bf16_emulation():
+    spec = spec_from_names("meta-llama/Llama-3.2-1B", "openai/whisper-medium.en", "large_vox_iter5", use_lora_avhubert=True,
+                           intermediate_size=2048, compression_mode="avg-pooling", downsample_ratio_audio=[4, 16], downsample_ratio_video=[2, 4, 5],
+                           is_matryoshka=True, lora_rank=32, lora_alpha=4, is_task_specific=True, shared_lora=True,
+                           prompt_len={"audio": 8, "video": 8, "audiovisual": 8}, max_dec_tokens=32, num_beams=1)
+    sd = synth_state_dict(spec, seed=1234, device="cuda:0")
+    run_case(spec, sd, 100, 64000, 4, 4, seed=5, max_new=32)

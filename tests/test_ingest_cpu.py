@@ -57,3 +57,21 @@ def test_hf_safetensors_dir(tmp_path):
               open(d / "model.safetensors.index.json", "w"))
     sd = ingest.load_hf_safetensors(str(d), prefix="llm.")
     assert set(sd) == {"llm.model.embed_tokens.weight", "llm.lm_head.weight"}
+
+
+class _Boom:
+    def __reduce__(self):
+        import os as _os
+        return (_os.system, ("touch " + _Boom.marker,))
+
+
+def test_hostile_pickle_runs_nothing(tmp_path):
+    """A checkpoint that names os.system (or any global outside the allow-list) must load as inert data, not execute."""
+    _Boom.marker = str(tmp_path / "pwned")
+    p = tmp_path / "evil.pth"
+    torch.save({"model.w": torch.ones(2), "payload": _Boom()}, p)
+    sd = ingest.load_omni_checkpoint(str(p))
+    assert not os.path.exists(_Boom.marker)
+    assert set(sd) == {"w"} and torch.equal(sd["w"], torch.ones(2))
+    for mod, name in (("os", "system"), ("builtins", "eval"), ("builtins", "exec"), ("subprocess", "Popen"), ("posix", "system")):
+        assert not ingest._safe_global(mod, name)
