@@ -681,8 +681,12 @@ class OmniOracle:
         self.llm = LLMOracle(sd, cfg["llm"])
 
     # modeling_OmniAVSR.py:528-558
-    def encode_audio(self, audio: Tensor, max_len: int, rate: int, return_stages=False):
+    def encode_audio(self, audio: Tensor, max_len: int, rate: int, return_stages=False, mel_bf16: bool = False):
+        """`mel_bf16`: the reference casts the log-mel features to bf16 whatever the precision plugin (`.to(torch.bfloat16)`, :534);
+        the engine's f32 parity mode keeps them in fp32, its bf16 mode stores them in bf16 (= the emulation's `_q`)."""
         mel = whisper_log_mel(audio.squeeze(-1).float())
+        if mel_bf16:
+            mel = mel.bfloat16().float()
         enc = whisper_encoder(self.sd, "audio_encoder.", mel, self.cfg["whisper"]["layers"], self.cfg["whisper"]["heads"])
         n_keep = max(int(max_len / 16000 * 50), 25)            # :537
         enc_k = enc[:, :n_keep]
@@ -704,13 +708,13 @@ class OmniOracle:
         return f"{which}_proj."
 
     # modeling_OmniAVSR.py:397-458
-    def prepare_inputs(self, inputs: dict, modality: str, rate_a: int, rate_v: int) -> Tensor:
+    def prepare_inputs(self, inputs: dict, modality: str, rate_a: int, rate_v: int, mel_bf16: bool = False) -> Tensor:
         c, ids = self.cfg, self.cfg["ids"]
         B = inputs["tokens"].shape[0]
         E = self.llm.embed
-        a_feat = self.encode_audio(inputs["audio"], int(max(inputs["lengths"])), rate_a) if modality in ("audio", "audiovisual") else None
+        a_feat = self.encode_audio(inputs["audio"], int(max(inputs["lengths"])), rate_a, mel_bf16=mel_bf16) if modality in ("audio", "audiovisual") else None
         v_feat = self.encode_video(inputs["video"], rate_v) if modality in ("video", "audiovisual") else None
-        prompt = self.sd[f"prompt_{modality}"].float().expand(B, -1, -1)
+        prompt = _q(self.sd[f"prompt_{modality}"].float()).expand(B, -1, -1)
         if c["family"] == "qwen2":
             text = prompt                                      # :417
         else:

@@ -74,3 +74,45 @@ def test_compressor_semantics():
     assert torch.equal(O.compress(x, 3, "avg-pooling"), ref)
     st = O.compress(x, 3, "stack")
     assert st.shape == (2, 2, 9) and torch.equal(st[0, 1], x[0, 3:6].reshape(-1))
+
+
+def test_glue_prepare_inputs_against_executed_reference():
+    """tests/golden/glue_prepare_inputs.npz: `inputs_embeds` returned by the reference's OWN `AVSR_LLMs.prepare_inputs` /
+    `encode_audio` / `encode_video` (modeling_OmniAVSR.py:397-458,528-558,461-483), executed in the build container by
+    oracle/gen_golden_glue.py -- six constructor variants (per-rate / single projector, swallowed LayerNorm, stack mode, Llama with
+    BOS / Qwen without, audio-only, video-only)."""
+    from oracle.gen_golden_glue import CASES, CASE_TV, glue_inputs
+    g = np.load(os.path.join(GOLD, "glue_prepare_inputs.npz"))
+    for name, (kw, _llm_name, modality, ra, rv) in CASES.items():
+        spec = tiny_spec(**kw)
+        sd = synth_state_dict(spec, seed=int(g["seed"]))
+        orc = O.OmniOracle(sd, spec.oracle_cfg())
+        inp = glue_inputs(spec, int(g["input_seed"]), Tv=CASE_TV.get(name, int(g["Tv"])), Ts=int(g["Ts"]))
+        if not spec.is_matryoshka:
+            ra, rv = spec.rates("audio")[0], spec.rates("video")[0]
+        with torch.no_grad():
+            emb = orc.prepare_inputs(inp, modality, ra, rv, mel_bf16=True)      # the reference casts the log-mel to bf16 (:534)
+        assert emb.shape[1:] == g[name].shape, name
+        assert np.abs(emb[0].numpy() - g[name]).max() < 2e-4, name
+
+
+@pytest.mark.parametrize("family", ["llama", "qwen2"])
+def test_decoder_layer_against_executed_reference(family):
+    """tests/golden/glue_decoder_layer.npz: outputs of the reference's own `LlamaDecoderLayer_lora.forward` ->
+    `LlamaSdpaAttention_lora.forward` (Llama_LoRA.py:587-655,214-316) and the Qwen twins (Qwen_LoRA.py:388-450,529-619) with
+    task-specific + shared LoRA: a prefill over S positions and one decode step against the cache."""
+    g = np.load(os.path.join(GOLD, "glue_decoder_layer.npz"))
+    spec = tiny_spec(family=family, head_dim=64 if family == "llama" else 128, task_specific=True, shared=True)
+    sd = synth_state_dict(spec, seed=int(g["seed"]), modalities=())
+    sd1 = {k: v for k, v in sd.items() if not k.startswith("llm.model.layers.1.")}
+    llm = O.LLMOracle(sd1, dict(spec.oracle_cfg()["llm"], layers=1))
+    gen = torch.Generator().manual_seed(int(g["input_seed"]))
+    S = int(g["S"])
+    x = torch.randn(1, S, spec.llm.hidden, generator=gen)
+    x1 = torch.randn(1, 1, spec.llm.hidden, generator=gen)
+    cache = [None]
+    with torch.no_grad():
+        _, h = llm.forward(x, 0, cache, "audiovisual", return_hidden=True)
+        _, h1 = llm.forward(x1, S, cache, "audiovisual", return_hidden=True)
+    assert np.abs(h[0][0].numpy() - g[f"{family}_prefill"]).max() < 2e-5
+    assert np.abs(h1[0][0].numpy() - g[f"{family}_step"]).max() < 2e-5

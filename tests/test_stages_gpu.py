@@ -224,19 +224,8 @@ def test_greedy_hipgraph_replay_matches_eager():
         assert torch.equal(ids0.cpu(), ids1) and torch.equal(lens0.cpu(), lens1)
 
 
-def test_generate_bf16_close_to_oracle():
-    """Throughput mode: token agreement with the fp32 oracle is reported, first token must match."""
-    spec, sd, eng, orc = make("bf16", family="llama", task_specific=True, shared=True)
-    Tv, Ts = [12, 9], [7680, 5000]
-    video, audio = inputs(Tv=Tv, Ts=Ts)
-    ids, lens = eng.generate("audiovisual", video, Tv, audio, Ts, 4, 2, beams=1, max_new=spec.max_dec_tokens, force_len=True)
-    ref = orc.forward(dict(video=video, audio=audio, lengths=torch.tensor(Ts), video_lens=torch.tensor(Tv), tokens=torch.full((2, 1), spec.ids["bos"])),
-                      "audiovisual", 4, 2, num_beams=1, force_len=True)
-    ids = ids.cpu()
-    agree = sum(int(ids[b, i]) == ref[b][i] for b in range(2) for i in range(len(ref[b])))
-    total = sum(len(r) for r in ref)
-    print(f"bf16 vs fp32-oracle token agreement: {agree}/{total}")
-    assert agree >= total // 2
+# bf16 end to end: tests/test_bf16_emulation_gpu.py holds the bf16 engine to the bf16-emulating oracle (quantitative bounds on
+# activations, logits and a tolerance-aware id check) on the tiny and on the full-size configuration.
 
 
 def test_shim_forward_matches_engine_and_errors():
