@@ -128,7 +128,8 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
   // columns (W slice read once, A by every XCD): memory-side reads are A + 8 W vs 8 A + W bytes.
   const int ntm = (p.M + BM - 1) / BM;
   const bool nmajor = p.M < p.N;
-  const int mt = nmajor ? bid % ntm : bid / ntn, nt_ = nmajor ? bid / ntm : bid - (bid / ntn) * ntn;
+  int mt = nmajor ? bid % ntm : bid / ntn, nt_ = nmajor ? bid / ntm : bid - (bid / ntn) * ntn;
+  if (p.tile_order == 1) blocked_tile(bid, ntm, ntn, mt, nt_);
   const int m0 = mt * BM, n0 = nt_ * BN;
   const int g = blockIdx.z;
 
@@ -410,7 +411,11 @@ int launch_dma(const GemmArgs& a, hipStream_t st) {
   }
   int64_t nblk = (int64_t)ceil_div(a.M, BM) * ceil_div(a.N, BN);
   dim3 grid((unsigned)nblk, a.ksplit > 1 ? a.ksplit : 1, a.groups);
-  hipLaunchKernelGGL(kern, grid, dim3(NWAVES * 64), smem, st, a);
+  // row-major by default: the blocked order only pays on deep-K shapes (fc2 126 -> 118 us), which the ping-pong kernel takes anyway
+  static const int order = [] { const char* e = getenv("OAVSR_GEMM_TILE_ORDER"); return e ? atoi(e) : 0; }();
+  GemmArgs b = a;
+  b.tile_order = order;
+  hipLaunchKernelGGL(kern, grid, dim3(NWAVES * 64), smem, st, b);
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -460,7 +465,10 @@ static int dma_tile_choice(const GemmArgs& a) {
 template <typename T>
 int launch_dma_mode(const GemmArgs& a, hipStream_t st) {
   // 256x256: 16 waves (4 x 4) of 64 x 64, 2 stages; dense only.  256x128: 8 waves (4 x 2) of 64 x 64, 3 stages.
-  if (dma_tile_choice(a) == 2) return launch_dma<T, A_DENSE, 256, 256, 2, 4, 16>(a, st);
+  if (dma_tile_choice(a) == 2) {
+    if (gemm_8p_eligible(a)) return launch_gemm_8p(a, st);        // 8-wave ping-pong schedule (gemm3.hip), bf16
+    return launch_dma<T, A_DENSE, 256, 256, 2, 4, 16>(a, st);
+  }
   if (dma_tile_choice(a) == 5) return launch_dma<T, A_DENSE, 256, 192, 2, 4, 12, 8>(a, st);   // 12 waves (4 x 3) of 64 x 64; 8 of them issue the DMA
   if (dma_tile_choice(a) == 6) return launch_dma<T, A_DENSE, 192, 256, 2, 3, 12, 8>(a, st);   // 12 waves (3 x 4) of 64 x 64
   if (dma_tile_choice(a) == 4) {
@@ -489,6 +497,7 @@ bool gemm_dma_swiglu_ok(const GemmArgs& a) {
 const char* gemm_dma_variant(const GemmArgs& a) {
   const int c = dma_tile_choice(a);
   if (c == 4) return a.ksplit > 1 ? "dma_splitk_128x64" : "dma_128x64";
+  if (c == 2 && gemm_8p_eligible(a)) return "8p_256x256";
   return a.ksplit > 1 ? "dma_splitk_256x128" : c == 2 ? "dma_256x256" : c == 5 ? "dma_256x192" : c == 6 ? "dma_192x256" : "dma_256x128";
 }
 

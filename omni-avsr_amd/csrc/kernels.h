@@ -40,13 +40,36 @@ struct GemmArgs {
   int swiglu_pairs = 0;
   // classic kernel only: split-K over blockIdx.y with fp32 partial slabs [ksplit][M][N] + deterministic reduce/epilogue kernel
   int ksplit = 1; float* partial = nullptr;
+  // LDS-DMA kernels: order in which an XCD's contiguous range of workgroups walks the output tiles.  0: row-major (or column-major when
+  // M < N); 1: blocks of 8 M-tiles x 4 N-tiles, so the 32 tiles an XCD's CUs work on at one time share 8 A panels and 4 W panels in
+  // its L2 (12 panel fetches per k-step for 64 panel reads).  Speed only, never results.  Set by the launcher.
+  int tile_order = 0;
 };
+// (mt, nt) of linear tile index bid in the blocked order above; bijective for any ntm x ntn
+__host__ __device__ inline void blocked_tile(int bid, int ntm, int ntn, int& mt, int& nt) {
+  constexpr int GM = 8, GN = 4;
+  const int per = GM * ntn, full = ntm / GM;
+  int g = bid / per;
+  if (g > full) g = full;
+  const int gr = g < full ? GM : ntm - full * GM;
+  const int r = bid - g * per;
+  int chunk = r / (gr * GN);
+  if (chunk * GN + GN > ntn && ntn % GN) chunk = ntn / GN;
+  const int gc = (ntn - chunk * GN) < GN ? (ntn - chunk * GN) : GN;
+  const int rr = r - chunk * gr * GN;
+  mt = g * GM + rr / gc;
+  nt = chunk * GN + rr % gc;
+}
 int launch_gemm(const GemmArgs& a, hipStream_t st);
 // LDS-DMA pipelined 256x128 variant (gemm2.hip); launch_gemm dispatches to it when the grid fills the chip
 bool gemm_dma_eligible(const GemmArgs& a);
 bool gemm_dma_swiglu_ok(const GemmArgs& a);
 const char* gemm_dma_variant(const GemmArgs& a);
 int launch_gemm_dma(const GemmArgs& a, hipStream_t st);
+// 256 x 256 tile with the 8-wave ping-pong k loop (gemm3.hip): dense bf16, no split-K / groups; picked by launch_gemm_dma
+bool gemm_8p_eligible(const GemmArgs& a);      // the dispatcher's rule (deep K)
+bool gemm_8p_supported(const GemmArgs& a);     // what the kernel can compute at all
+int launch_gemm_8p(const GemmArgs& a, hipStream_t st);
 
 // Skinny (decode) GEMM: M <= 128 rows, weights streamed once.  Same math/epilogue subset.
 int launch_gemm_skinny(const GemmArgs& a, hipStream_t st);

@@ -1321,6 +1321,10 @@ int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream) {
   g.rowinfo = (const int4*)d->rowinfo; g.taps = d->taps; g.Kvalid = d->Kvalid; g.frameinfo = (const int2*)d->frameinfo;
   g.norm_gain = d->norm_gain; g.norm_eps = d->norm_eps; g.swiglu_pairs = d->swiglu_pairs;
   g.ksplit = d->ksplit < 1 ? 1 : d->ksplit; g.partial = d->partial;
+  if (d->skinny == 2) {      // tests: the 8-wave ping-pong 256 x 256 kernel whatever the dispatcher's rule says
+    OAVSR_REQUIRE(gemm_8p_supported(g), "op_gemm: shape / layout not supported by the ping-pong kernel");
+    return launch_gemm_8p(g, (hipStream_t)stream);
+  }
   return d->skinny ? launch_gemm_skinny(g, (hipStream_t)stream) : launch_gemm(g, (hipStream_t)stream);
 }
 

@@ -1,6 +1,7 @@
 """-m gpu: every HIP kernel, called through the C ABI, against a plain PyTorch fp32 reference of the same op.
 Tolerances: f32 (exact-f32 MFMA) 1e-4 abs on unit-scale outputs; bf16 2e-2 (8-bit mantissa inputs)."""
 import ctypes as C
+import os
 import math
 
 import pytest
@@ -721,3 +722,75 @@ def test_beam_topk_fast_and_fallback(rows, V, K, mode):
     order = torch.argsort(torch.stack([-x, torch.arange(V).expand(rows, V).float()], -1)[..., 0], dim=-1, stable=True)[:, :twoK]
     assert torch.equal(te[:, :twoK].long(), order), "candidate tokens differ from a stable descending sort"
     close(ve[:, :twoK], torch.gather(lp, 1, order), 1e-4, what="candidate scores")
+
+
+# ------------------------------------------------------------------------------------------------ 8-wave ping-pong GEMM (gemm3.hip)
+@pytest.mark.parametrize("M,N,K,K2", [(4096, 4096, 1024, 0), (12000, 3072, 256, 0), (5000, 3072 + 40, 512, 128), (3001, 8192, 64, 64)])
+def test_gemm_8p_pipeline(M, N, K, K2):
+    """>= 144 tiles of 256 x 256 -> the 8-wave ping-pong kernel: ragged M / N edges, a second K segment, 1..16 k-tiles (the DMA runs two
+    k-tiles ahead and fills its tail with dummy loads), fused epilogue."""
+    dtype = "bf16"
+    a, ar = q(rnd(M, K, seed=1), dtype)
+    w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
+    r, rr = q(rnd(M, N, seed=5), dtype)
+    bias = rnd(N, seed=7)
+    kw, ref = {}, ar @ wr.T
+    if K2:
+        a2, a2r = q(rnd(M, K2, seed=3), dtype)
+        w2, w2r = q(rnd(N, K2, seed=4) / math.sqrt(K2), dtype)
+        kw = dict(A2=a2, W2=w2)
+        ref = ref + a2r @ w2r.T
+    out = gemm(dtype, a, w, bias=bias.to(DEV), act=1, residual=r, res_after_act=1, skinny=2, **kw)
+    close(out, F.gelu(ref + bias) + rr, tol(dtype) * 2, what="gemm 8p")
+    out2 = gemm(dtype, a, w, bias=bias.to(DEV), act=1, residual=r, res_after_act=1, skinny=2, **kw)
+    assert torch.equal(out, out2), "two launches of the ping-pong GEMM differ (race in the k-loop schedule)"
+
+
+def test_gemm_8p_identity_layout():
+    """A = I with an asymmetric W: catches a swapped quadrant / fragment map of the four-quadrant wave tile."""
+    n = 4096
+    a, _ = q(torch.eye(n), "bf16")
+    wv = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 253) / 64.0
+    w, wr = q(wv, "bf16")
+    out = gemm("bf16", a, w, skinny=2)
+    close(out, wr.T, 1e-6, what="gemm 8p identity")
+
+
+def test_gemm_8p_bitwise_equals_16_wave_kernel(tmp_path):
+    """Same accumulation order per output element as the 16-wave 256 x 256 kernel (OAVSR_GEMM_8P=0 / 2, read once per process): the two
+    must agree bit for bit, so a tensor has the same bits whichever kernel the dispatcher picked."""
+    import subprocess
+    import sys
+    script = f"""
+import sys, math, torch
+sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r}); sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+from gpu_util import gemm, DEV
+g = torch.Generator().manual_seed(11)
+a = torch.randn(6000, 1024, generator=g).to(DEV, torch.bfloat16)
+w = (torch.randn(4096, 1024, generator=g) / 32).to(DEV, torch.bfloat16)
+a2 = torch.randn(6000, 128, generator=g).to(DEV, torch.bfloat16)
+w2 = (torch.randn(4096, 128, generator=g) / 11).to(DEV, torch.bfloat16)
+b = torch.randn(4096, generator=g).to(DEV)
+out = gemm("bf16", a, w, A2=a2, W2=w2, bias=b, act=1)
+torch.save(out.cpu(), sys.argv[1])
+"""
+    outs = []
+    for flag in ("2", "0"):
+        f = str(tmp_path / f"o{flag}.pt")
+        r = subprocess.run([sys.executable, "-c", script, f], env=dict(os.environ, OAVSR_GEMM_8P=flag), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(f))
+    assert torch.equal(outs[0], outs[1]), f"ping-pong vs 16-wave kernel: max diff {(outs[0].float() - outs[1].float()).abs().max().item():.3e}"
+
+
+def test_gemm_8p_fused_swiglu_equals_gemm_plus_swiglu_kernel():
+    dtype, M, I, K = "bf16", 2504, 4096, 192
+    x, xr = q(rnd(M, K, seed=1), dtype)
+    wg, _ = q(rnd(I, K, seed=2) / math.sqrt(K), dtype)
+    wu, _ = q(rnd(I, K, seed=3) / math.sqrt(K), dtype)
+    inter = torch.stack([wg.reshape(-1, 16, K), wu.reshape(-1, 16, K)], 1).reshape(2 * I, K).contiguous()
+    fused = gemm(dtype, x, inter, swiglu_pairs=1, skinny=2)
+    gu = gemm(dtype, x, inter)
+    two = torch.empty(M, I, dtype=tdt(dtype), device=DEV)
+    L.check(L.load().oavsr_op_swiglu(dcode(dtype), P(gu), 2 * I, P(two), I, M, I, 1, stream()))
+    assert torch.equal(fused, two), f"ping-pong fused SwiGLU differs from gemm + swiglu: {(fused.float() - two.float()).abs().max().item():.3e}"
