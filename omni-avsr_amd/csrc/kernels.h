@@ -73,6 +73,19 @@ int launch_gemm_8p(const GemmArgs& a, hipStream_t st);
 
 // Skinny (decode) GEMM: M <= 128 rows, weights streamed once.  Same math/epilogue subset.
 int launch_gemm_skinny(const GemmArgs& a, hipStream_t st);
+// Two dependent skinny GEMMs (M <= 8) fused into one launch (skinny.hip): kind 0 = LoRA down -> QKV (stage 0's output is stage 1's A2),
+// kind 1 = gate/up + SwiGLU -> down_proj (stage 0's output is stage 1's A).  Same bits as the two separate launches.
+struct SkinnySync {            // device-side view of one stage's hand-off
+  const int* wait_ctr = nullptr; int wait_n = 0;   // consumer: wait until *wait_ctr >= *step * wait_n
+  int* signal_ctr = nullptr; int signal_n = 0;      // producer: signal_ctr[32 * (1 + bid % 8)] += 1; the shard's last arriver bumps signal_ctr[0]
+  const int* step = nullptr;                        // device scalar: decode step (1-based), the counters are zeroed once per decode call
+  int a1_sc1 = 0, a2_sc1 = 0;                       // which A segment was produced inside this launch (read through L2)
+  int* err = nullptr;                               // set if the bounded spin gives up
+};
+constexpr int kChainCtrInts = 9 * 32;               // one fused launch: top counter + 8 shard counters, 128-byte lines
+struct SkinnyChain { int* counter = nullptr; const int* step = nullptr; int* err = nullptr; int feeds_a2 = 0; };
+bool skinny_chain_supported(const GemmArgs& a0, const GemmArgs& a1, int kind);
+int launch_gemm_skinny_chain2(const GemmArgs& a0, const GemmArgs& a1, const SkinnyChain& c, int kind, hipStream_t st);
 
 // ---- attention ---------------------------------------------------------------------------------
 struct AttnArgs {

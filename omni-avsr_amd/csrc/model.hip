@@ -114,6 +114,16 @@ static int run_gemm(const GemmArgs& a, hipStream_t st, bool skinny = false) {
   return skinny ? launch_gemm_skinny(a, st) : launch_gemm(a, st);
 }
 
+// two dependent decode GEMMs in one launch (skinny.hip: skinny_chain2_kernel)
+static int run_gemm_chain(const GemmArgs& a0, const GemmArgs& a1, int kind, const SkinnyChain& c, hipStream_t st) {
+  const double esz = a0.dtype == DT_F32 ? 4 : 2;
+  const double w0 = (double)a0.N * (a0.K + a0.K2), w1 = (double)a1.N * (a1.K + a1.K2);
+  char name[48];
+  snprintf(name, sizeof(name), "skinny_chain_%s_%s", kind == 0 ? "lora_qkv" : "mlp", a0.dtype == DT_F32 ? "f32" : "bf16");
+  ProfScope ps(name, 2.0 * a0.M * (w0 + w1), esz * (w0 + w1), st);
+  return launch_gemm_skinny_chain2(a0, a1, c, kind, st);
+}
+
 // ------------------------------------------------------------------------------------------------
 // model
 // ------------------------------------------------------------------------------------------------
@@ -196,6 +206,7 @@ struct oavsr_workspace {
   void *kpre, *vpre, *ktail, *vtail; int max_prefix = 0; size_t kpre_layer = 0, ktail_layer = 0;
   int *pos, *slot, *cpos, *cu_s, *prefix_len, *last_rows;
   int *amax; void* amax_scratch; GreedyState gs;
+  int* sync = nullptr; size_t sync_bytes = 0;   // (2 * layers) x kChainCtrInts stage counters of the fused decode launches + an error line; zeroed per decode call
   // beam search state
   float *beam_scores, *cand_val, *partial; int *cand_tok, *topk_flag, *hyp_n, *hyp_len, *hyp_tok, *seq[2], *anc[2]; double* hyp_score; size_t partial_bytes = 0;
   int max_tok_enc = 0, max_S_total = 0;
@@ -731,19 +742,27 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
     if (!fused_norm) { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
       OAVSR_TRY(launch_rmsnorm(dt, ws->lx, d, ws->lh, d, L.ln1w, rows, d, c.llm_rms_eps, st)); }
     const void* hin = fused_norm ? ws->lx : ws->lh;
-    GemmArgs g;
+    GemmArgs g, gl;
+    // greedy decode with <= 8 rows: dependent weight-streaming GEMMs share a launch (LoRA down -> QKV, gate/up -> down_proj)
+    const bool chain_ok = decode && mode == 1 && beams == 1 && rows <= 8 && step && ws->sync;
+    SkinnyChain ch; ch.step = step; ch.err = ws->sync ? ws->sync + (size_t)2 * c.llm_layers * kChainCtrInts : nullptr;
     if (c.lora_k2 > 0) {
-      g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = c.lora_k2; g.K = d; g.A = hin; g.lda = d; g.W = L.lora_dn[tl]; g.ldw = d;
-      g.C = ws->llora; g.ldc = c.lora_k2;
-      if (fused_norm) { g.norm_gain = L.ln1w; g.norm_eps = c.llm_rms_eps; }
-      if (mode == 0) set_split(g, ws, lora_dn_split(d, (int)m->esz));
-      OAVSR_TRY(llm_gemm(m, ws, g, mode, st));
+      gl = GemmArgs(); gl.dtype = dt; gl.M = rows; gl.N = c.lora_k2; gl.K = d; gl.A = hin; gl.lda = d; gl.W = L.lora_dn[tl]; gl.ldw = d;
+      gl.C = ws->llora; gl.ldc = c.lora_k2;
+      if (fused_norm) { gl.norm_gain = L.ln1w; gl.norm_eps = c.llm_rms_eps; }
+      if (mode == 0) set_split(gl, ws, lora_dn_split(d, (int)m->esz));
     }
     g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = nqkv; g.K = d; g.A = hin; g.lda = d; g.W = L.qkvw; g.ldw = d; g.col_bias = L.qkvb;
     if (c.lora_k2 > 0) { g.A2 = ws->llora; g.lda2 = c.lora_k2; g.W2 = L.lora_up[tl]; g.ldw2 = c.lora_k2; g.K2 = c.lora_k2; }
     if (fused_norm) { g.norm_gain = L.ln1w; g.norm_eps = c.llm_rms_eps; }
     g.C = ws->lqkv; g.ldc = nqkv;
-    OAVSR_TRY(llm_gemm(m, ws, g, mode, st));
+    if (c.lora_k2 > 0 && chain_ok && skinny_chain_supported(gl, g, 0)) {
+      ch.counter = ws->sync + (size_t)(2 * li) * kChainCtrInts; ch.feeds_a2 = 1;
+      OAVSR_TRY(run_gemm_chain(gl, g, 0, ch, st));
+    } else {
+      if (c.lora_k2 > 0) OAVSR_TRY(llm_gemm(m, ws, gl, mode, st));
+      OAVSR_TRY(llm_gemm(m, ws, g, mode, st));
+    }
     if (!decode) {   // decode: RoPE + cache append are fused into the decode-attention kernel
       RopeArgs r; r.dtype = dt; r.rows = rows; r.n_heads = H; r.n_kv_heads = KV; r.head_dim = hd; r.qkv = ws->lqkv; r.ld = nqkv;
       r.inv_freq = m->inv_freq; r.pos = pos; r.slot = ws->slot; r.cpos = cpos;
@@ -786,10 +805,19 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
       g = GemmArgs(); g.dtype = dt; g.M = trows; g.N = d; g.K = nq; g.A = attn_r; g.lda = nq; g.W = L.ow; g.ldw = nq;
       g.residual = xres; g.ldr = d; g.C = xres; g.ldc = d;
       OAVSR_TRY(llm_gemm(m, ws, g, tmode, st));
+      bool mlp_chained = false;
       if (tfused) {   // RMSNorm + gate/up + SwiGLU in one launch
         g = GemmArgs(); g.dtype = dt; g.M = trows; g.N = 2 * I; g.K = d; g.A = xres; g.lda = d; g.W = L.guw; g.ldw = d;
         g.norm_gain = L.ln2w; g.norm_eps = c.llm_rms_eps; g.swiglu_pairs = 1; g.C = act_r; g.ldc = I;
-        OAVSR_TRY(run_gemm(g, st, true));
+        GemmArgs gd; gd.dtype = dt; gd.M = trows; gd.N = d; gd.K = I; gd.A = act_r; gd.lda = I; gd.W = L.downw; gd.ldw = I;
+        gd.residual = xres; gd.ldr = d; gd.C = xres; gd.ldc = d;
+        if (chain_ok && !prune && skinny_chain_supported(g, gd, 1)) {      // ... and down_proj behind it in the same launch
+          ch.counter = ws->sync + (size_t)(2 * li + 1) * kChainCtrInts; ch.feeds_a2 = 0;
+          OAVSR_TRY(run_gemm_chain(g, gd, 1, ch, st));
+          mlp_chained = true;
+        } else {
+          OAVSR_TRY(run_gemm(g, st, true));
+        }
       } else {
         { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
           OAVSR_TRY(launch_rmsnorm(dt, ws->lx, d, ws->lh, d, L.ln2w, rows, d, c.llm_rms_eps, st)); }
@@ -807,9 +835,11 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
           OAVSR_TRY(launch_swiglu(dt, ws->lgu, 2 * I, ws->lact, I, rows, I, 1, st));
         }
       }
-      g = GemmArgs(); g.dtype = dt; g.M = trows; g.N = d; g.K = I; g.A = act_r; g.lda = I; g.W = L.downw; g.ldw = I;
-      g.residual = xres; g.ldr = d; g.C = xres; g.ldc = d;
-      OAVSR_TRY(llm_gemm(m, ws, g, tmode, st));
+      if (!mlp_chained) {
+        g = GemmArgs(); g.dtype = dt; g.M = trows; g.N = d; g.K = I; g.A = act_r; g.lda = I; g.W = L.downw; g.ldw = I;
+        g.residual = xres; g.ldr = d; g.C = xres; g.ldc = d;
+        OAVSR_TRY(llm_gemm(m, ws, g, tmode, st));
+      }
     }
     if (prune && pruned) *pruned = true;
   }
@@ -906,6 +936,7 @@ static int decode_greedy(const oavsr_model* m, oavsr_workspace* ws, int task, in
   for (int b = 0; b < B; ++b) slot[b] = b;
   OAVSR_TRY(h2d(ws->slot, slot, sizeof(int) * B, st));
   const int banned = force_len ? c.id_eos : -1;
+  OAVSR_CHECK_HIP(hipMemsetAsync(ws->sync, 0, ws->sync_bytes, st));   // stage counters of the fused launches: step s expects s x n arrivals
   OAVSR_TRY(launch_argmax(ws->logits, c.llm_vocab, B, c.llm_vocab, banned, ws->amax, ws->amax_scratch, st));
   OAVSR_TRY(launch_greedy_update(ws->amax, gs, B, max_new, c.id_eos, c.id_pad, st));
   auto one_step = [&]() -> int {
@@ -1133,6 +1164,8 @@ int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, 
   WANT(ktail, ws->ktail_layer * c.llm_layers); WANT(vtail, ws->ktail_layer * c.llm_layers);
   WANT(pos, Rl * 4); WANT(slot, Rl * 4); WANT(cpos, Rl * 4); WANT(cu_s, (max_B + 1) * 4); WANT(prefix_len, max_B * 4); WANT(last_rows, max_B * 4);
   WANT(amax, rows_dec * 4); WANT(amax_scratch, rows_dec * 64 * 8);
+  ws->sync_bytes = ((size_t)2 * c.llm_layers * kChainCtrInts + 32) * 4;
+  WANT(sync, ws->sync_bytes);
   WANT(gs.tok, rows_dec * 4); WANT(gs.finished, rows_dec * 4); WANT(gs.out_ids, rows_dec * (size_t)max_new * 4); WANT(gs.out_len, rows_dec * 4);
   WANT(gs.step, 256); WANT(gs.pos, rows_dec * 4); WANT(gs.cpos, rows_dec * 4); WANT(gs.rope_cs, rows_dec * (size_t)(hd / 2) * sizeof(float2));
   {   // split-K partial slabs: decode GEMMs with > 32 rows, the narrow video-encoder projections, the LoRA down projections

@@ -19,6 +19,7 @@
 // the activation side; the two diagonal 8x8 blocks of the result are the even / odd partial sums (the off-diagonal blocks
 // are discarded).  One wave load then covers 8 weight rows x one whole 128-byte line.
 #include <stdlib.h>
+#include <algorithm>
 #include "kernels.h"
 
 namespace oavsr {
@@ -42,15 +43,36 @@ template <> struct MmaS<float> {
   }
 };
 
-template <typename T, int MT, int NT, bool NORM, int U, bool HALF, int W>
-__global__ __launch_bounds__(W * 64, (MT == 1 && U * NT <= 8) ? 4 : 2) void skinny_kernel(const GemmArgs p) {
+// 16 bytes through L2 (sc1): the only legal way to read what another workgroup of the SAME launch has stored (a CU's vector L1 is never
+// refreshed by other CUs' stores; MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility")
+__device__ __forceinline__ Chunk16 ld16_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  Chunk16 c;
+  c.v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 16);     // buffer_load_dwordx4 ... sc1 (aux bit 4 = sc1 on gfx950)
+  return c;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t raw_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ void st4_sc1(void* ptr, unsigned v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(ptr), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One workgroup's tile of the weight-streaming GEMM.  CHAIN: the tile is a stage of a fused launch (skinny_chain2_kernel below):
+//   * cs.wait_ctr: its activations are produced by lower-numbered workgroups of the same launch -- the weight loads go out first, then
+//     one lane polls the stage's top counter (target = *cs.step x cs.wait_n: the counters only ever grow, decode step s expects s x n arrivals),
+//     the workgroup barrier follows and the activations are read with sc1 loads;
+//   * cs.signal_ctr: the outputs are stored write-through (sc1), every wave drains its stores, the workgroup meets at a barrier and
+//     one lane bumps the counter (the MI355X hand-off recipe with sc1 stores / an agent-scope atomic add / sc1 polls and loads).
+// Workgroups are dispatched in block-id order, so a consumer only ever waits for workgroups that are already resident or done; the
+// spin is bounded and raises *cs.err instead of hanging if that assumption should ever fail.
+template <typename T, int MT, int NT, bool NORM, int U, bool HALF, int W, bool CHAIN>
+__device__ __forceinline__ void skinny_body(const GemmArgs& p, const int bid, char* smem, const SkinnySync& cs) {
   constexpr int kWaves = W, kThreads = W * 64;
   static_assert(!HALF || MT == 1, "HALF mode: at most 8 rows");
   constexpr int KBE = 64 / (int)sizeof(T);       // elements per 64-byte k block
   constexpr int VEC = TypeInfo<T>::kVec;
   // U = k blocks in flight per wave
   constexpr int MR = MT * 16, NC = NT * 16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sred = reinterpret_cast<float*>(smem);   // [8][MR][NC]
   float* sred2 = sred + kWaves * MR * NC;         // [8][MR][NC]   (NORM && K2)
   float* sssq = sred2 + (NORM ? kWaves * MR * NC : 0);   // [8][MR]
@@ -60,7 +82,7 @@ __global__ __launch_bounds__(W * 64, (MT == 1 && U * NT <= 8) ? 4 : 2) void skin
   const int r16 = lane & 15, g = lane >> 4;
   const int hi = HALF ? (r16 >> 3) : 0, rw = HALF ? (r16 & 7) : r16;   // k-block parity, row within the operand tile
   constexpr int TW = HALF ? 8 : 16;                                    // output columns per MFMA tile
-  const int n0 = blockIdx.x * (NT * TW);
+  const int n0 = bid * (NT * TW);
   const T* A1 = reinterpret_cast<const T*>(p.A);
   const T* A2 = reinterpret_cast<const T*>(p.A2);
   const T* W1 = reinterpret_cast<const T*>(p.W);
@@ -79,6 +101,44 @@ __global__ __launch_bounds__(W * 64, (MT == 1 && U * NT <= 8) ? 4 : 2) void skin
     }
   }
 
+  // HALF: the loop walks PAIRS of k blocks (nkb1 is even there, so a pair never straddles the two K segments)
+  const int nsteps = HALF ? (nkb + 1) / 2 : nkb;
+  Chunk16 bf[U][NT], af[U][MT];
+  // The weight stream does not depend on anything this kernel waits for, so the first trip's loads go out before the gain is staged
+  // and before the epilogue operands / activations are fetched: their HBM latency runs under those L2 round trips.
+  auto load_w = [&](int kb0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kb = HALF ? 2 * (kb0 + kWaves * u) + hi : kb0 + kWaves * u;
+      const bool in = kb < nkb;
+      const bool s1 = kb < nkb1;
+      const T* Wb = s1 ? W1 : W2;
+      const int64_t ldw = s1 ? p.ldw : p.ldw2;
+      const int k = (s1 ? kb : kb - nkb1) * KBE + g * VEC;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + j * TW + rw;
+        if (in && n < p.N) bf[u][j].v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Wb + (int64_t)n * ldw + k));   // streamed once
+        else bf[u][j] = zchunk();
+      }
+    }
+  };
+  if (wave < nsteps) load_w(wave);
+  if (CHAIN && cs.wait_ctr) {
+    // The weights are in flight; lane 0 first lets its own share land (by then the producers are usually done: the counter is not
+    // hammered by hundreds of early pollers, whose requests would queue in front of the producers' atomic adds), then polls the top
+    // counter with a back-off.
+    if (tid == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int target = *cs.step * cs.wait_n;
+      int spins = 0;
+      while (__hip_atomic_load(cs.wait_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1 << 20)) { if (cs.err) *cs.err = 1; break; }
+      }
+    }
+    if (!GAIN_LDS) __syncthreads();                      // (with a staged gain the barrier below does it)
+  }
   if (GAIN_LDS) {                                        // K floats, 16 B per thread and trip; read back after the first barrier-free
     for (int i = tid * 4; i < p.K; i += kThreads * 4)   // use is safe: every wave waits on its own operands, then on this barrier
       *reinterpret_cast<f32x4*>(sgain + i) = *reinterpret_cast<const f32x4*>(p.norm_gain + i);
@@ -96,29 +156,29 @@ __global__ __launch_bounds__(W * 64, (MT == 1 && U * NT <= 8) ? 4 : 2) void skin
       if (p.col_bias) pre_bias = p.col_bias[n];
     }
   }
-  // HALF: the loop walks PAIRS of k blocks (nkb1 is even there, so a pair never straddles the two K segments)
-  const int nsteps = HALF ? (nkb + 1) / 2 : nkb;
   for (int kb0 = wave; kb0 < nsteps; kb0 += kWaves * U) {
-    Chunk16 bf[U][NT], af[U][MT];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int kb = HALF ? 2 * (kb0 + kWaves * u) + hi : kb0 + kWaves * u;
       const bool in = kb < nkb;
       const bool s1 = kb < nkb1;
       const T* Ab = s1 ? A1 : A2;
-      const T* Wb = s1 ? W1 : W2;
-      const int64_t lda = s1 ? p.lda : p.lda2, ldw = s1 ? p.ldw : p.ldw2;
+      const int64_t lda = s1 ? p.lda : p.lda2;
       const int k = (s1 ? kb : kb - nkb1) * KBE + g * VEC;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n = n0 + j * TW + rw;
-        if (in && n < p.N) bf[u][j].v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Wb + (int64_t)n * ldw + k));   // streamed once
-        else bf[u][j] = zchunk();
-      }
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int m = i * 16 + rw;
-        af[u][i] = (in && m < p.M) ? *reinterpret_cast<const Chunk16*>(Ab + (int64_t)m * lda + k) : zchunk();
+        if (CHAIN && (cs.a1_sc1 | cs.a2_sc1)) {
+          // produced inside this launch: 16-byte sc1 buffer loads.  The segment test is made provably wave-uniform (a scalar branch
+          // between the two kernel-argument descriptors; a per-lane descriptor would be loaded in a waterfall loop).
+          const bool s1u = __builtin_amdgcn_readfirstlane((int)((HALF ? 2 * (kb0 + kWaves * u) : kb0 + kWaves * u) < nkb1)) != 0;
+          const unsigned off = (unsigned)(((int64_t)m * lda + k) * (int64_t)sizeof(T));
+          if (!(in && m < p.M)) af[u][i] = zchunk();
+          else if (s1u) af[u][i] = cs.a1_sc1 ? ld16_sc1(raw_rsrc(p.A), off) : *reinterpret_cast<const Chunk16*>(A1 + (int64_t)m * lda + k);
+          else af[u][i] = cs.a2_sc1 ? ld16_sc1(raw_rsrc(p.A2), off) : *reinterpret_cast<const Chunk16*>(A2 + (int64_t)m * lda + k);
+        } else {
+          af[u][i] = (in && m < p.M) ? *reinterpret_cast<const Chunk16*>(Ab + (int64_t)m * lda + k) : zchunk();
+        }
       }
     }
 #pragma unroll
@@ -150,6 +210,7 @@ __global__ __launch_bounds__(W * 64, (MT == 1 && U * NT <= 8) ? 4 : 2) void skin
           else MmaS<T>::run(af[u][i], bf[u][j], acc[i][j]);
         }
     }
+    if (kb0 + kWaves * U < nsteps) load_w(kb0 + kWaves * U);      // next trip's weights: requested as soon as the registers are free
   }
   // partial sums -> LDS (C layout: col = lane&15, row = 4*(lane>>4)+r)
 #pragma unroll
@@ -202,6 +263,61 @@ __global__ __launch_bounds__(W * 64, (MT == 1 && U * NT <= 8) ? 4 : 2) void skin
     const int n = n0 + nn;
     return fmaf(raw(m, nn), p.col_scale ? p.col_scale[n] : 1.f, p.col_bias ? p.col_bias[n] : 0.f);
   };
+  if (CHAIN && cs.signal_ctr) {
+    // producer stage: same values as the plain epilogues below, stored as 4-byte write-through words (two bf16 columns or one f32), then
+    // drain -> barrier -> one agent-scope add
+    constexpr int CPW = 4 / (int)sizeof(T);              // output columns per stored word
+    const int ocols = p.swiglu_pairs ? OC / 2 : OC;
+    for (int idx = tid; idx < OR * (ocols / CPW); idx += kThreads) {
+      const int m = idx / (ocols / CPW), q0 = (idx - m * (ocols / CPW)) * CPW;
+      float y[CPW];
+      int ncol0 = 0;
+      bool ok = m < p.M;
+#pragma unroll
+      for (int c = 0; c < CPW; ++c) {
+        const int q = q0 + c;
+        if (p.swiglu_pairs) {
+          const int pblk = q >> 4, i = q & 15;
+          if (c == 0) ncol0 = (n0 >> 1) + q;
+          ok = ok && (n0 + pblk * 32 + i < p.N);
+          y[c] = ok ? silu(value(m, pblk * 32 + i)) * value(m, pblk * 32 + 16 + i) : 0.f;
+        } else {
+          const int n = n0 + q;
+          if (c == 0) ncol0 = n;
+          ok = ok && n < p.N;
+          float v = ok ? value(m, q) : 0.f;
+          const float res = (ok && R) ? to_f32(R[(int64_t)m * p.ldr + n]) : 0.f;
+          if (!p.res_after_act) v += res;
+          switch (p.act) {
+            case ACT_GELU: v = gelu_act<T>(v); break;
+            case ACT_RELU: v = fmaxf(v, 0.f); break;
+            case ACT_PRELU: v = v >= 0.f ? v : p.prelu[ok ? n : 0] * v; break;
+            case ACT_SILU: v = silu(v); break;
+            default: break;
+          }
+          if (p.res_after_act) v += res;
+          y[c] = v;
+        }
+      }
+      if (!ok) continue;                                 // (N and the tile width are even: a word never straddles the edge)
+      if (p.out_f32 || sizeof(T) == 4) st4_sc1(reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + ncol0, __float_as_uint(y[0]));
+      else {
+        const bf16x2 h = {(bf16_t)y[0], (bf16_t)y[CPW - 1]};
+        st4_sc1(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + ncol0, __builtin_bit_cast(unsigned, h));
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its write-through stores ...
+    __syncthreads();                                     // ... before the lane that signals for all of them
+    // fan-in in two levels (one counter would serialise hundreds of arrivals at ~12 ns each): eight shard counters on lines of their
+    // own, picked by bid % 8 (= the XCD under round-robin placement; speed only); the last arriver of a shard bumps the top counter
+    if (tid == 0) {
+      const int shard = bid & 7, step = *cs.step;
+      const int mine = (cs.signal_n + 7 - shard) >> 3;                 // stage-0 workgroups in this shard
+      const int old = __hip_atomic_fetch_add(cs.signal_ctr + 32 * (1 + shard), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old + 1 == step * mine) __hip_atomic_fetch_add(cs.signal_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
   if (p.swiglu_pairs) {
     // weight rows interleaved [gate block b | up block b] in 16-row blocks; out column = (n0/32 + pblk)*16 + i
     for (int idx = tid; idx < OR * (OC / 2); idx += kThreads) {
@@ -234,6 +350,47 @@ __global__ __launch_bounds__(W * 64, (MT == 1 && U * NT <= 8) ? 4 : 2) void skin
     if (p.out_f32) reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n] = y;
     else reinterpret_cast<T*>(p.C)[(int64_t)m * p.ldc + n] = from_f32<T>(y);
   }
+}
+
+template <typename T, int MT, int NT, bool NORM, int U, bool HALF, int W>
+__global__ __launch_bounds__(W * 64, (MT == 1 && U * NT <= 8) ? 4 : 2) void skinny_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  skinny_body<T, MT, NT, NORM, U, HALF, W, false>(p, blockIdx.x, smem, SkinnySync());
+}
+
+// Two dependent weight-streaming GEMMs of a decode step (<= 8 rows, 8-column tiles) in ONE launch: blocks [0, nb0) are the tiles of
+// stage 0, the rest those of stage 1, which consume stage 0's output (LoRA down -> QKV; gate/up + SwiGLU -> down_proj).  A kernel
+// boundary costs 4-5 us of launch / drain / first-byte latency on this chip -- as much as streaming the smaller projections takes --
+// and inside one launch stage 1's weight stream starts while stage 0 is still computing.
+template <typename T, bool NORM0, int NT0, int U0, bool NORM1, int NT1, int U1>
+__global__ __launch_bounds__(kMaxWaves * 64, 4) void skinny_chain2_kernel(const GemmArgs g0, const GemmArgs g1, const int nb0, const SkinnySync s0,
+                                                                           const SkinnySync s1) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x < nb0) skinny_body<T, 1, NT0, NORM0, U0, true, kMaxWaves, true>(g0, blockIdx.x, smem, s0);
+  else skinny_body<T, 1, NT1, NORM1, U1, true, kMaxWaves, true>(g1, (int)blockIdx.x - nb0, smem, s1);
+}
+
+template <int MT, int NT, bool NORM, int W>
+constexpr int sk_smem0() { return W * MT * 16 * NT * 16 * 4 * (NORM ? 2 : 1) + (NORM ? W * MT * 16 * 4 : 0); }
+
+template <typename T, bool NORM0, int NT0, int U0, bool NORM1, int NT1, int U1>
+int launch_chain2(const GemmArgs& a0, const GemmArgs& a1, const SkinnyChain& c, hipStream_t st) {
+  constexpr int m0 = sk_smem0<1, NT0, NORM0, kMaxWaves>(), m1 = sk_smem0<1, NT1, NORM1, kMaxWaves>();
+  const int smem = std::max(m0 + (NORM0 && m0 <= 96 * 1024 ? a0.K * 4 : 0), m1 + (NORM1 && m1 <= 96 * 1024 ? a1.K * 4 : 0));
+  OAVSR_REQUIRE(smem <= 160 * 1024, "skinny chain: K too deep for the fused RMSNorm prologue");
+  auto kern = skinny_chain2_kernel<T, NORM0, NT0, U0, NORM1, NT1, U1>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const int nb0 = ceil_div(a0.N, NT0 * 8), nb1 = ceil_div(a1.N, NT1 * 8);
+  SkinnySync s0, s1;
+  s0.signal_ctr = c.counter; s0.signal_n = nb0; s0.step = c.step; s0.err = c.err;
+  s1.wait_ctr = c.counter; s1.wait_n = nb0 < 8 ? nb0 : 8; s1.step = c.step; s1.err = c.err; s1.a1_sc1 = c.feeds_a2 ? 0 : 1; s1.a2_sc1 = c.feeds_a2 ? 1 : 0;
+  hipLaunchKernelGGL(kern, dim3(nb0 + nb1), dim3(kMaxWaves * 64), smem, st, a0, a1, nb0, s0, s1);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
 }
 
 template <typename T, int MT, int NT, bool NORM, int U, bool HALF = false, int W = kMaxWaves>
@@ -297,6 +454,34 @@ int launch_sk_t(const GemmArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+// HALF (8-column tile) eligibility of one stage, as launch_sk decides it for M <= 8
+static bool chain_stage_ok(const GemmArgs& a, int nt) {
+  const int esz = a.dtype == DT_F32 ? 4 : 2, kbe = 64 / esz, vec = 16 / esz;
+  if (a.M < 1 || a.M > 8 || a.amode != A_DENSE || a.groups != 1 || a.K <= 0 || a.K % kbe || a.K2 % kbe || (a.K / kbe) % 2) return false;
+  if (a.lda % vec || a.ldw % vec || (((uintptr_t)a.A | (uintptr_t)a.W) & 15)) return false;
+  if (a.K2 && (a.lda2 % vec || a.ldw2 % vec || (((uintptr_t)a.A2 | (uintptr_t)a.W2) & 15))) return false;
+  if (a.N % 2 || a.ldc % 2 || ((uintptr_t)a.C & 3)) return false;                      // 4-byte write-through stores
+  if (nt == 1) return !a.swiglu_pairs && a.N >= 64 && a.N / 16 < 384 && a.N < 8192;   // launch_sk's NT = 1 HALF rule
+  return a.swiglu_pairs && a.N >= 8192 && a.N < 65536 && a.N % 32 == 0;               // NT = 4: gate / up with the SwiGLU epilogue
+}
+
+bool skinny_chain_supported(const GemmArgs& a0, const GemmArgs& a1, int kind) {
+  // Off by default.  Measured on MI355X (round 2, Llama-3.2-1B, 8 rows): the in-launch seam -- sc1 stores, drain, two-level fan-in, poll,
+  // sc1 activation loads -- costs what the kernel boundary it replaces costs (4-5 us): LoRA down -> QKV +1 % sequential / -2 % with three
+  // batches in flight, gate/up -> down -3 % / -5 % (its 256 consumers can only start when the 512 producers have left the CUs).
+  // OAVSR_SKINNY_CHAIN: 0 off, 1 both fusions, 2 / 3 only LoRA->QKV / gate-up->down.
+  static const int on = [] { const char* e = getenv("OAVSR_SKINNY_CHAIN"); return e ? atoi(e) : 0; }();
+  if (!on || (on == 2 && kind != 0) || (on == 3 && kind != 1) || !half_enabled() || a0.dtype != a1.dtype) return false;
+  if (kind == 0) return a0.norm_gain && a1.norm_gain && a1.K2 > 0 && chain_stage_ok(a0, 1) && chain_stage_ok(a1, 1);   // LoRA down -> QKV
+  return a0.norm_gain && !a1.norm_gain && chain_stage_ok(a0, 4) && chain_stage_ok(a1, 1);                               // gate/up -> down
+}
+
+int launch_gemm_skinny_chain2(const GemmArgs& a0, const GemmArgs& a1, const SkinnyChain& c, int kind, hipStream_t st) {
+  OAVSR_REQUIRE(skinny_chain_supported(a0, a1, kind) && c.counter && c.step, "skinny chain: unsupported shapes");
+  if (kind == 0) return a0.dtype == DT_F32 ? launch_chain2<float, true, 1, 8, true, 1, 8>(a0, a1, c, st) : launch_chain2<bf16_t, true, 1, 8, true, 1, 8>(a0, a1, c, st);
+  return a0.dtype == DT_F32 ? launch_chain2<float, true, 4, 2, false, 1, 8>(a0, a1, c, st) : launch_chain2<bf16_t, true, 4, 2, false, 1, 8>(a0, a1, c, st);
+}
 
 int launch_gemm_skinny(const GemmArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0) return 0;

@@ -79,3 +79,44 @@ def test_fullsize_batch_invariance_and_determinism(dtype):
         _, venc1, _ = eng.encode_video(v1, [t], 4, return_enc=True)
         assert torch.equal(venc1, venc_b[off:off + t]), f"utterance {b}: video encoder output depends on its batch mates"
         off += t
+
+
+def test_fused_decode_launches_equal_separate_launches(tmp_path):
+    """Opt-in (OAVSR_SKINNY_CHAIN=1, read once per process; off by default because it does not pay, see skinny.hip): greedy decode with
+    <= 8 rows fuses LoRA-down -> QKV and gate/up -> down_proj into single launches with in-kernel hand-offs.  Same arithmetic => identical ids, at the full model size, with three
+    batches in flight on three streams (hand-offs under uneven load) and run twice."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = f"""
+import sys, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+from test_fullsize_gpu import full_spec, clips
+from omni_avsr_amd.modeling import OmniEngine
+from omni_avsr_amd.synth import synth_state_dict
+spec = full_spec()
+eng = OmniEngine(spec, dtype="bf16").load_state_dict(synth_state_dict(spec, seed=1234, device="cuda:0", dtype=torch.bfloat16))
+outs = []
+streams = [torch.cuda.Stream() for _ in range(3)]
+sets = [clips([100, 61, 80, 100, 33, 100, 75, 90][: 8 - s], seed=20 + s) for s in range(3)]
+for rep in range(2):
+    res = []
+    for s in range(3):
+        video, audio, Ts = sets[s]
+        Tv = [100, 61, 80, 100, 33, 100, 75, 90][: 8 - s]
+        with torch.cuda.stream(streams[s]):
+            res.append(eng.generate("audiovisual", video, Tv, audio, Ts, 4, 4, beams=1, max_new=32, force_len=True, slot=s))
+    torch.cuda.synchronize()
+    outs.append([r[0].cpu() for r in res])
+assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])), "two rounds differ"
+torch.save(outs[0], sys.argv[1])
+"""
+    got = []
+    for flag in ("1", "0"):
+        f = str(tmp_path / f"ids{flag}.pt")
+        r = subprocess.run([sys.executable, "-c", script, f], env=dict(os.environ, OAVSR_SKINNY_CHAIN=flag), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        got.append(torch.load(f))
+    for a, b in zip(got[0], got[1]):
+        assert torch.equal(a, b), "fused launches decode different ids than separate launches"
