@@ -198,7 +198,7 @@ __device__ __forceinline__ void skinny_body(const GemmArgs& p, const int bid, ch
           float f[VEC];
           chunk_to_f32<T>(af[u][i], f);
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) { ssq[i] += f[e] * f[e]; f[e] *= gn[e]; }
+          for (int e = 0; e < VEC; ++e) { ssq[i] = fmaf(f[e], f[e], ssq[i]); f[e] *= gn[e]; }   // explicit FMA: same bits in every variant
           af[u][i] = chunk_from_f32<T>(f);
         }
       }
@@ -255,7 +255,7 @@ __device__ __forceinline__ void skinny_body(const GemmArgs& p, const int bid, ch
           if (HALF) y2 += sred2[(w * MR + m + 8) * NC + lc + 8];
         }
       }
-      y = y * rsqrtf(s / (float)p.K + p.norm_eps) + y2;
+      y = fmaf(y, rsqrtf(s / (float)p.K + p.norm_eps), y2);
     }
     return y;
   };
@@ -352,6 +352,227 @@ __device__ __forceinline__ void skinny_body(const GemmArgs& p, const int bid, ch
   }
 }
 
+// 8-column tiles for 9..32 rows (MT = 1: up to 16 rows, MT = 2: up to 32).  The weight fragment is HALF mode's -- MFMA rows 0-7 hold the
+// tile's 8 columns for the EVEN k block of a pair, rows 8-15 the same columns for the ODD block, so a wave load is 8 weight rows x one whole
+// 128-byte line and N / 8 workgroups fill the chip where 16-column tiles left half the CUs idle -- but the activation operand keeps all
+// 16 rows: two MFMAs per pair, one with the even-block activations (its result columns 0-7 are the even partial sums), one with the
+// odd-block activations (columns 8-15 = the odd partial sums); the other halves are discarded.  MFMA time is irrelevant here, the
+// weight stream is what costs.  The partial sums are combined exactly as HALF mode combines them (per wave: even, then odd), so a row
+// gets the same bits from this kernel as from the <= 8-row kernel: greedy decode does not depend on the batch up to 32 rows.
+template <typename T, int MT, int NT, bool NORM, int U, int W>
+__global__ __launch_bounds__(W * 64, (NT <= 2 && MT == 1) ? 4 : 2) void skinny_r16_kernel(const GemmArgs p) {
+  constexpr int kWaves = W, kThreads = W * 64;
+  constexpr int KBE = 64 / (int)sizeof(T);
+  constexpr int VEC = TypeInfo<T>::kVec;
+  constexpr int MR = MT * 16, NC = NT * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sred = reinterpret_cast<float*>(smem);                   // [8][MR][NC]   columns 0-7 of a 16-block: even partials, 8-15: odd
+  float* sred2 = sred + kWaves * MR * NC;                         // [8][MR][NC]   (NORM && K2)
+  float* sssq = sred2 + (NORM ? kWaves * MR * NC : 0);            // [2][8][MR]    sum of squares per (parity, wave, row)
+  float* sgain = sssq + (NORM ? 2 * kWaves * MR : 0);             // [K]
+  constexpr bool GAIN_LDS = NORM && (kWaves * MR * NC * 8 + 2 * kWaves * MR * 4) <= 96 * 1024;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int par = r16 >> 3, cw = r16 & 7;                         // weight operand: k-block parity, column within the tile
+  const int n0 = blockIdx.x * (NT * 8);
+  const T* A1 = reinterpret_cast<const T*>(p.A);
+  const T* A2 = reinterpret_cast<const T*>(p.A2);
+  const T* W1 = reinterpret_cast<const T*>(p.W);
+  const T* W2 = reinterpret_cast<const T*>(p.W2);
+  const int nkb1 = p.K / KBE, nkb = nkb1 + p.K2 / KBE;
+  const int nsteps = (nkb + 1) / 2;                               // pairs of k blocks (nkb1 even: a pair never straddles the segments)
+
+  f32x4 acc[MT][NT][2], acc2[NORM ? MT : 1][NORM ? NT : 1][2];
+  float ssq[MT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      ssq[i][q] = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        acc[i][j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (NORM) acc2[i][j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  Chunk16 bf[U][NT], af[U][MT][2];
+  auto load_w = [&](int kb0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kb = 2 * (kb0 + kWaves * u) + par;
+      const bool in = kb < nkb, s1 = kb < nkb1;
+      const T* Wb = s1 ? W1 : W2;
+      const int64_t ldw = s1 ? p.ldw : p.ldw2;
+      const int k = (s1 ? kb : kb - nkb1) * KBE + g * VEC;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + j * 8 + cw;
+        if (in && n < p.N) bf[u][j].v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Wb + (int64_t)n * ldw + k));
+        else bf[u][j] = zchunk();
+      }
+    }
+  };
+  if (wave < nsteps) load_w(wave);
+  if (GAIN_LDS) {
+    for (int i = tid * 4; i < p.K; i += kThreads * 4)
+      *reinterpret_cast<f32x4*>(sgain + i) = *reinterpret_cast<const f32x4*>(p.norm_gain + i);
+    __syncthreads();
+  }
+  for (int kb0 = wave; kb0 < nsteps; kb0 += kWaves * U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int kb = 2 * (kb0 + kWaves * u) + q;
+        const bool in = kb < nkb, s1 = kb < nkb1;
+        const T* Ab = s1 ? A1 : A2;
+        const int64_t lda = s1 ? p.lda : p.lda2;
+        const int k = (s1 ? kb : kb - nkb1) * KBE + g * VEC;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int m = i * 16 + r16;
+          af[u][i][q] = (in && m < p.M) ? *reinterpret_cast<const Chunk16*>(Ab + (int64_t)m * lda + k) : zchunk();
+        }
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool s1 = 2 * (kb0 + kWaves * u) < nkb1;               // wave-uniform
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int kb = 2 * (kb0 + kWaves * u) + q;
+        if (NORM && s1 && kb < nkb) {
+          const int k = kb * KBE + g * VEC;
+          float gn[VEC];
+#pragma unroll
+          for (int e = 0; e < VEC; e += 4) {
+            f32x4 t = *reinterpret_cast<const f32x4*>((GAIN_LDS ? sgain : p.norm_gain) + k + e);
+            gn[e] = t[0]; gn[e + 1] = t[1]; gn[e + 2] = t[2]; gn[e + 3] = t[3];
+          }
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            float f[VEC];
+            chunk_to_f32<T>(af[u][i][q], f);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { ssq[i][q] = fmaf(f[e], f[e], ssq[i][q]); f[e] *= gn[e]; }
+            af[u][i][q] = chunk_from_f32<T>(f);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            if (NORM && !s1) MmaS<T>::run(af[u][i][q], bf[u][j], acc2[i][j][q]);
+            else MmaS<T>::run(af[u][i][q], bf[u][j], acc[i][j][q]);
+          }
+      }
+    }
+    if (kb0 + kWaves * U < nsteps) load_w(kb0 + kWaves * U);
+  }
+  // partial sums -> LDS (C layout: col = lane & 15, row = 4 * (lane >> 4) + r): columns 0-7 from the even-block MFMA, 8-15 from the odd one
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = (wave * MR + i * 16 + g * 4 + r) * NC + j * 16 + r16;
+        sred[o] = par ? acc[i][j][1][r] : acc[i][j][0][r];
+        if (NORM && p.K2) sred2[o] = par ? acc2[i][j][1][r] : acc2[i][j][0][r];
+      }
+  if (NORM) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float v = ssq[i][q];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (g == 0) sssq[(q * kWaves + wave) * MR + i * 16 + r16] = v;
+      }
+  }
+  __syncthreads();
+  constexpr int OC = NT * 8;
+  auto raw = [&](int m, int nn) -> float {
+    float y = 0.f;
+    const int lc = (nn >> 3) * 16 + (nn & 7);
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+      y += sred[(w * MR + m) * NC + lc];
+      y += sred[(w * MR + m) * NC + lc + 8];
+    }
+    if (NORM) {
+      float s = 0.f, y2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) {
+        s += sssq[w * MR + m];
+        s += sssq[(kWaves + w) * MR + m];
+      }
+      if (p.K2) {
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+          y2 += sred2[(w * MR + m) * NC + lc];
+          y2 += sred2[(w * MR + m) * NC + lc + 8];
+        }
+      }
+      y = fmaf(y, rsqrtf(s / (float)p.K + p.norm_eps), y2);
+    }
+    return y;
+  };
+  auto value = [&](int m, int nn) -> float {
+    const int n = n0 + nn;
+    return fmaf(raw(m, nn), p.col_scale ? p.col_scale[n] : 1.f, p.col_bias ? p.col_bias[n] : 0.f);
+  };
+  const T* R = reinterpret_cast<const T*>(p.residual);
+  if (p.swiglu_pairs) {
+    for (int idx = tid; idx < MR * (OC / 2); idx += kThreads) {
+      const int m = idx / (OC / 2), q = idx - m * (OC / 2);
+      const int pblk = q >> 4, i = q & 15;
+      const int ncol = (n0 >> 1) + q;
+      if (m >= p.M || n0 + pblk * 32 + i >= p.N) continue;
+      float y = silu(value(m, pblk * 32 + i)) * value(m, pblk * 32 + 16 + i);
+      if (p.out_f32) reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + ncol] = y;
+      else reinterpret_cast<T*>(p.C)[(int64_t)m * p.ldc + ncol] = from_f32<T>(y);
+    }
+    return;
+  }
+  for (int idx = tid; idx < MR * OC; idx += kThreads) {
+    const int m = idx / OC, nn = idx - m * OC;
+    const int n = n0 + nn;
+    if (m >= p.M || n >= p.N) continue;
+    float y = value(m, nn);
+    const float res = R ? to_f32(R[(int64_t)m * p.ldr + n]) : 0.f;
+    if (!p.res_after_act) y += res;
+    switch (p.act) {
+      case ACT_GELU: y = gelu_act<T>(y); break;
+      case ACT_RELU: y = fmaxf(y, 0.f); break;
+      case ACT_PRELU: y = y >= 0.f ? y : p.prelu[n] * y; break;
+      case ACT_SILU: y = silu(y); break;
+      default: break;
+    }
+    if (p.res_after_act) y += res;
+    if (p.out_f32) reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n] = y;
+    else reinterpret_cast<T*>(p.C)[(int64_t)m * p.ldc + n] = from_f32<T>(y);
+  }
+}
+
+template <typename T, int MT, int NT, bool NORM, int U, int W = kMaxWaves>
+int launch_r16(const GemmArgs& a, hipStream_t st) {
+  constexpr int smem0 = W * MT * 16 * NT * 16 * 4 * (NORM ? 2 : 1) + (NORM ? 2 * W * MT * 16 * 4 : 0);
+  static_assert(smem0 <= 160 * 1024, "LDS");
+  constexpr bool gain_lds = NORM && smem0 <= 96 * 1024;
+  const int smem = smem0 + (gain_lds ? a.K * 4 : 0);
+  OAVSR_REQUIRE(smem <= 160 * 1024, "skinny gemm: K=%d too deep for the fused RMSNorm prologue", a.K);
+  auto kern = skinny_r16_kernel<T, MT, NT, NORM, U, W>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(ceil_div(a.N, NT * 8)), dim3(W * 64), smem, st, a);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 template <typename T, int MT, int NT, bool NORM, int U, bool HALF, int W>
 __global__ __launch_bounds__(W * 64, (MT == 1 && U * NT <= 8) ? 4 : 2) void skinny_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -442,6 +663,20 @@ template <typename T, bool NORM>
 int launch_sk_t(const GemmArgs& a, hipStream_t st) {
   const int mt = ceil_div(a.M, 16);
   const bool wide = a.N >= 8192;           // enough columns to fill the chip with 64-column workgroups
+  // 9..32 rows: 8-column tiles with 16-row activation operands (skinny_r16_kernel) wherever the <= 8-row path would use its 8-column tiles
+  static const int r16_on = [] { const char* e = getenv("OAVSR_SKINNY_R16"); return e ? atoi(e) : 1; }();
+  constexpr int kbe = 64 / (int)sizeof(T);
+  if (r16_on && half_enabled() && a.M > 8 && mt <= 2 && (a.K / kbe) % 2 == 0) {
+    if (wide && (!a.swiglu_pairs || a.N % 32 == 0)) {
+      // same wave count as the <= 8-row kernel picks for this N (4 waves for the many-round lm_head): the k blocks are dealt over
+      // the waves, so the wave count is part of the summation order
+      if (a.N >= 65536) return mt <= 1 ? launch_r16<T, 1, 4, NORM, 2, 4>(a, st) : launch_r16<T, 2, 4, NORM, 2, 4>(a, st);
+      return mt <= 1 ? launch_r16<T, 1, 4, NORM, 2>(a, st) : launch_r16<T, 2, 4, NORM, 2>(a, st);
+    }
+    // narrow N: two 8-column tiles per workgroup (N / 16 workgroups, as many as the 16-column kernel launched, and the activation rows --
+    // 2 - 4 x the weight bytes of a tile at these row counts -- are fetched once per 16 columns); each tile sums exactly as above
+    if (!a.swiglu_pairs && a.N >= 64 && a.N / 16 < 384) return mt <= 1 ? launch_r16<T, 1, 2, NORM, 4>(a, st) : launch_r16<T, 2, 2, NORM, 2>(a, st);
+  }
   if (a.swiglu_pairs) {
     OAVSR_REQUIRE(mt <= 2 && a.N % 32 == 0, "skinny gemm: fused SwiGLU needs M <= 32 and N %% 32 == 0");
     if (mt <= 1) return wide ? launch_sk<T, 1, 4, NORM>(a, st) : launch_sk<T, 1, 2, NORM>(a, st);

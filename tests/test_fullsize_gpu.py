@@ -79,6 +79,13 @@ def test_fullsize_batch_invariance_and_determinism(dtype):
         _, venc1, _ = eng.encode_video(v1, [t], 4, return_enc=True)
         assert torch.equal(venc1, venc_b[off:off + t]), f"utterance {b}: video encoder output depends on its batch mates"
         off += t
+    # ... and inside a batch of 12 (9..32 decode rows: the 16-row-operand kernels; lm_head with 4 waves as for <= 8 rows)
+    Tv12 = Tv + [61, 40, 33, 61, 50, 61, 27, 61]
+    video12, audio12, Ts12 = clips(Tv12, seed=9)
+    video12[:4, : video.shape[1]], audio12[:4, : audio.shape[1]] = video, audio
+    ids12, _ = eng.generate("audiovisual", video12, Tv12, audio12, Ts12, 4, 4, beams=1, max_new=32, force_len=True)
+    for b in range(4):
+        assert ids12[b].tolist() == ids_b[b].tolist(), f"utterance {b} decodes differently inside a batch of 12"
 
 
 def test_fused_decode_launches_equal_separate_launches(tmp_path):

@@ -4,10 +4,11 @@ batches, so "alone" and "inside a batch" must agree.
 Contract:
   * encoders, projector, prompt and prefill: bit-identical for any batch (static split-K, var-len kernels) -- asserted on the
     prefill logits in both dtypes;
-  * decode: the kernel family follows the decode regime, never the data: greedy rows <= 8 | 9..32 | > 32, beam search rows
-    <= 32 | > 32 (decode attention: one wave layout per mode; split-K factors functions of N and K only).  Inside a regime the
-    ids are bit-identical in both dtypes; across regimes the fp32 summation order differs, so bit-identity is asserted in f32
-    mode (1e-6-level differences do not move an arg-max here) and not claimed for bf16."""
+  * decode: the kernel family follows the decode regime, never the data: rows <= 32 (weight-streaming kernels; the 9..32-row
+    kernel sums its partials exactly as the <= 8-row kernel does) | > 32 (tiled split-K GEMMs, split factors functions of N and K
+    only); decode attention: one wave layout per mode (greedy / beam).  Inside a regime the ids are bit-identical in both dtypes;
+    across the 32-row boundary the fp32 summation order differs, so bit-identity is asserted in f32 mode (1e-6-level differences do
+    not move an arg-max here) and not claimed for bf16."""
 import pytest
 import torch
 
@@ -46,12 +47,12 @@ def test_greedy_alone_vs_batches_crossing_kernel_regimes(dtype):
     alone = gen(eng, 1, 1, spec.max_dec_tokens, base)
     same_regime = [gen(eng, B, 1, spec.max_dec_tokens, base) for B in (2, 5, 8)]            # <= 8 rows: 8-column tiles
     assert all(r == alone for r in same_regime), f"greedy ids depend on the batch inside the <= 8-row regime: {alone} vs {same_regime}"
-    mid = [gen(eng, B, 1, spec.max_dec_tokens, base) for B in (9, 20, 32)]                  # 9..32 rows: 16-column tiles
-    assert all(r == mid[0] for r in mid), f"greedy ids depend on the batch inside the 9..32-row regime: {mid}"
+    mid = [gen(eng, B, 1, spec.max_dec_tokens, base) for B in (9, 20, 32)]                  # 9..32 rows: 8-column tiles, 16-row operands
+    assert all(r == alone for r in mid), f"greedy ids of an utterance change between 1 and 9..32 rows: {alone} vs {mid}"
     big = [gen(eng, B, 1, spec.max_dec_tokens, base) for B in (33, 70, 130)]               # > 32 rows: split-K tiles, 1 and 2 M-tiles
     assert all(r == big[0] for r in big), f"greedy ids depend on the batch inside the > 32-row regime: {big}"
     if dtype == "f32":
-        assert mid[0] == alone and big[0] == alone, f"f32 ids differ across decode regimes: {alone} / {mid[0]} / {big[0]}"
+        assert big[0] == alone, f"f32 ids differ across the 32-row boundary: {alone} / {big[0]}"
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])

@@ -794,3 +794,50 @@ def test_gemm_8p_fused_swiglu_equals_gemm_plus_swiglu_kernel():
     two = torch.empty(M, I, dtype=tdt(dtype), device=DEV)
     L.check(L.load().oavsr_op_swiglu(dcode(dtype), P(gu), 2 * I, P(two), I, M, I, 1, stream()))
     assert torch.equal(fused, two), f"ping-pong fused SwiGLU differs from gemm + swiglu: {(fused.float() - two.float()).abs().max().item():.3e}"
+
+
+# ------------------------------------------------------------------------------------------------ 8-column decode tiles for 9..32 rows
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,K2,norm", [(9, 2048, 2048, 0, False), (16, 3072, 2048, 128, True), (24, 2048, 8192, 0, False), (32, 136, 256, 64, True),
+                                           (17, 128256 // 8, 512, 0, True), (12, 16384 + 40, 128, 0, False)])
+def test_gemm_skinny_r16_tiles(dtype, M, N, K, K2, norm):
+    """9..32 rows through 8-column tiles (skinny_r16_kernel): vs the fp32 reference, and the first 8 rows bit-identical to what the
+    <= 8-row kernel computes for them alone (same partial-sum order => greedy decode does not depend on the batch up to 32 rows)."""
+    x, xr = q(rnd(M, K, seed=1) * 1.3, dtype)
+    w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
+    r, rr = q(rnd(M, N, seed=5), dtype)
+    gain = (rnd(K, seed=3) * 0.1 + 1)
+    eps = 1e-5
+    kw, kw8 = {}, {}
+    h = gain * xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + eps) if norm else xr
+    ref = h @ wr.T + rr
+    if K2:
+        a2, a2r = q(rnd(M, K2, seed=6), dtype)
+        w2, w2r = q(rnd(N, K2, seed=7) / math.sqrt(K2), dtype)
+        kw, kw8 = dict(A2=a2, W2=w2), dict(A2=a2[:8].contiguous(), W2=w2)
+        ref = ref + a2r @ w2r.T
+    if norm:
+        gd = gain.to(DEV)
+        kw.update(norm_gain=gd, norm_eps=eps)
+        kw8.update(norm_gain=gd, norm_eps=eps)
+    out = gemm(dtype, x, w, residual=r, skinny=True, **kw)
+    close(out, ref, tol(dtype) * 2, what="skinny r16 gemm")
+    out8 = gemm(dtype, x[:8].contiguous(), w, residual=r[:8].contiguous(), skinny=True, **kw8)
+    assert torch.equal(out[:8], out8), f"rows 0-7 differ from the <= 8-row kernel: {(out[:8].float() - out8.float()).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,I,K", [(16, 8192, 2048), (24, 4096, 256), (32, 8192, 128)])
+def test_gemm_skinny_r16_swiglu(dtype, M, I, K):
+    x, xr = q(rnd(M, K, seed=1), dtype)
+    wg, wgr = q(rnd(I, K, seed=2) / math.sqrt(K), dtype)
+    wu, wur = q(rnd(I, K, seed=3) / math.sqrt(K), dtype)
+    inter = torch.stack([wg.reshape(-1, 16, K), wu.reshape(-1, 16, K)], 1).reshape(2 * I, K).contiguous()
+    gain = (rnd(K, seed=4) * 0.1 + 1)
+    eps = 1e-6
+    h = gain * xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + eps)
+    gd = gain.to(DEV)
+    out = gemm(dtype, x, inter, skinny=True, norm_gain=gd, norm_eps=eps, swiglu_pairs=1)
+    close(out, F.silu(h @ wgr.T) * (h @ wur.T), tol(dtype) * 2, rtol=(8e-3 if dtype == "bf16" else 0.0), what="skinny r16 rmsnorm+swiglu")
+    out8 = gemm(dtype, x[:8].contiguous(), inter, skinny=True, norm_gain=gd, norm_eps=eps, swiglu_pairs=1)
+    assert torch.equal(out[:8], out8), "rows 0-7 differ from the <= 8-row kernel"
