@@ -94,6 +94,52 @@ def collate_test(samples: Sequence[Dict[str, torch.Tensor]], modality: str, bos_
     return batch
 
 
+# ---- lightning_OmniAVSR.py:53-91 : tokenizer surgery ---------------------------------------------------------------
+DEFAULT_PAD_TOKEN = "<pad>"
+AUDIO_SOS, AUDIO_EOS, VIDEO_SOS, VIDEO_EOS = "<audio>", "</audio>", "<video>", "</video>"
+LLAMA3_NAMES = ("meta-llama/Meta-Llama-3-8B", "meta-llama/Meta-Llama-3.1-8B", "meta-llama/Llama-3.2-1B", "meta-llama/Llama-3.2-3B")
+
+
+def prepare_tokenizer(tokenizer, llm_model: str):
+    """What `ModelModule_LLM.__init__` does to the HF tokenizer before the model is built (lightning_OmniAVSR.py:53-91):
+      * Llama-3.x: the fast tokenizer ignores add_eos_token, so the post-processor is replaced by `bos $A eos` (:59-71);
+        Qwen (no BOS): `$A eos` (:72-81);
+      * Llama: add `<pad>` + the four audio / video tags (+5 rows of embed_tokens / lm_head after `resize_token_embeddings`,
+        modeling_OmniAVSR.py:214); Qwen: the four tags (+4), pad stays None (:84-88);
+      * padding on the right (:91).
+    Returns pad_id (None for Qwen), exactly what the reference passes to AVSR_LLMs."""
+    from tokenizers.processors import TemplateProcessing
+    if llm_model in LLAMA3_NAMES:
+        bos, eos = tokenizer.bos_token, tokenizer.eos_token
+        tokenizer._tokenizer.post_processor = TemplateProcessing(
+            single=f"{bos}:0 $A:0 {eos}:0", pair=f"{bos}:0 $A:0 {eos}:0 {bos}:1 $B:1 {eos}:1",
+            special_tokens=[(f"{bos}", tokenizer.bos_token_id), (f"{eos}", tokenizer.eos_token_id)])
+    elif "Qwen" in llm_model:
+        eos = tokenizer.eos_token
+        tokenizer._tokenizer.post_processor = TemplateProcessing(
+            single=f"$A:0 {eos}:0", pair=f"$A:0 {eos}:0 $B:1 {eos}:1", special_tokens=[(f"{eos}", tokenizer.eos_token_id)])
+    if "llama" in llm_model:
+        tokenizer.add_special_tokens({"pad_token": DEFAULT_PAD_TOKEN, "additional_special_tokens": [AUDIO_SOS, AUDIO_EOS, VIDEO_SOS, VIDEO_EOS]})
+        pad_id = tokenizer.convert_tokens_to_ids(DEFAULT_PAD_TOKEN)
+    else:
+        tokenizer.add_special_tokens({"additional_special_tokens": [AUDIO_SOS, AUDIO_EOS, VIDEO_SOS, VIDEO_EOS]})
+        pad_id = None
+    tokenizer.padding_side = "right"
+    return pad_id
+
+
+def special_ids_from_tokenizer(tokenizer, llm_model: str) -> Dict[str, int]:
+    """The token ids the inference branch reads from `tokenizer.vocab` (modeling_OmniAVSR.py:312-322,422-445): Llama decodes with
+    eos `<|end_of_text|>`, bos `<|begin_of_text|>`, pad `<pad>`; Qwen with eos = pad = `<|endoftext|>` and no BOS."""
+    v = tokenizer.vocab
+    ids = dict(audio_sos=v[AUDIO_SOS], audio_eos=v[AUDIO_EOS], video_sos=v[VIDEO_SOS], video_eos=v[VIDEO_EOS])
+    if "Qwen" in llm_model:
+        ids.update(bos=-1, eos=v["<|endoftext|>"], pad=v["<|endoftext|>"])
+    else:
+        ids.update(bos=v["<|begin_of_text|>"], eos=v["<|end_of_text|>"], pad=v[DEFAULT_PAD_TOKEN])
+    return ids
+
+
 # ---- lightning_OmniAVSR.py:40-42,201-219 ---------------------------------------------------------------------------
 def edit_distance(a: Sequence, b: Sequence) -> int:
     """torchaudio.functional.edit_distance: Levenshtein distance with unit costs."""
@@ -128,6 +174,7 @@ class WerMeter:
     total_edit_distance: int = 0
     total_length: int = 0
     per_utt: List[Tuple[str, str, int, int]] = field(default_factory=list)
+    failed: List[int] = field(default_factory=list)      # utterance ids whose batch raised (reported; not in the counters)
 
     def update(self, gold_text: str, generated_text: str):
         e = compute_word_level_distance(gold_text, generated_text)
@@ -153,7 +200,12 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
     model.modality = modality
     for idxs in make_batches(owned, batch_size):
         batch = collate_test([samples[i][0] for i in idxs], modality, bos_id)
-        ids = model(batch, is_trainval=False, modality=modality if getattr(model, "is_task_specific", False) else None, **forward_kw)
+        try:
+            ids = model(batch, is_trainval=False, modality=modality if getattr(model, "is_task_specific", False) else None, **forward_kw)
+        except (RuntimeError, ValueError) as e:           # a bad clip must not lose the evaluation: report its batch, go on
+            meter.failed.extend(idxs)
+            print(f"evaluate: batch {idxs} failed: {e}")
+            continue
         texts = to_text(ids)
         for i, t in zip(idxs, texts):
             meter.update(samples[i][1], t)

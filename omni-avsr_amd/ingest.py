@@ -110,6 +110,55 @@ def load_hf_safetensors(model_dir: str, prefix: str = "") -> Dict[str, torch.Ten
     return sd
 
 
+def resize_token_embeddings(sd: Dict[str, torch.Tensor], new_rows: int, added: Optional[torch.Tensor] = None, prefix: str = "llm.") -> Dict[str, torch.Tensor]:
+    """`self.llm.resize_token_embeddings(len(self.tokenizer))` (modeling_OmniAVSR.py:214) on a plain state dict: embed_tokens and lm_head
+    grow to `new_rows` (+5 rows for Llama: <pad> and the four audio / video tags, +4 for Qwen; lightning_OmniAVSR.py:83-88).
+    The added rows are `added` [n_new, hidden] when given -- the trained values every `model_avg_N.pth` already carries -- else the
+    mean of the existing rows (HF draws them at random; a mean keeps an untrained model's logits finite and the result deterministic)."""
+    out = dict(sd)
+    ek, hk = prefix + "model.embed_tokens.weight", prefix + "lm_head.weight"
+    tied = hk not in sd or sd[hk].data_ptr() == sd[ek].data_ptr()
+    for k in ((ek,) if tied else (ek, hk)):
+        w = sd[k]
+        n_new = new_rows - w.shape[0]
+        if n_new < 0:
+            raise ValueError(f"{k} has {w.shape[0]} rows, more than the tokenizer's {new_rows}")
+        if n_new:
+            extra = added.to(w.dtype) if added is not None else w.float().mean(0, keepdim=True).expand(n_new, -1).to(w.dtype)
+            if extra.shape != (n_new, w.shape[1]):
+                raise ValueError(f"added rows have shape {tuple(extra.shape)}, expected {(n_new, w.shape[1])}")
+            out[k] = torch.cat([w, extra], 0)
+    if tied:
+        out[hk] = out[ek]
+    return out
+
+
+def assemble_state_dict(avhubert_pt: Optional[str] = None, whisper_dir: Optional[str] = None, llm_dir: Optional[str] = None,
+                        adapter_pth: Optional[str] = None, vocab_rows: Optional[int] = None) -> Dict[str, torch.Tensor]:
+    """Builds the `AVSR_LLMs.state_dict()` layout from the separate artefacts the reference's constructor pulls in
+    (modeling_OmniAVSR.py:59-60,118-147,200-214): the AV-HuBERT fairseq `.pt`, the Whisper / LLM HF directories, and a checkpoint with
+    whatever training produced (projectors, LoRA factors, prompt buffers, the added embedding rows under `llm.added_rows`)."""
+    sd: Dict[str, torch.Tensor] = {}
+    if avhubert_pt:
+        sd.update(load_fairseq_avhubert(avhubert_pt))
+    if whisper_dir:
+        w = load_hf_safetensors(whisper_dir)
+        sd.update({"audio_encoder." + k[len("model.encoder."):] if k.startswith("model.encoder.") else "audio_encoder." + k[len("encoder."):]: v
+                   for k, v in w.items() if k.startswith(("model.encoder.", "encoder."))})
+    if llm_dir:
+        sd.update(load_hf_safetensors(llm_dir, prefix="llm."))
+        if "llm.lm_head.weight" not in sd:                                      # tie_word_embeddings checkpoints ship one tensor
+            sd["llm.lm_head.weight"] = sd["llm.model.embed_tokens.weight"]
+    added = None
+    if adapter_pth:
+        ad = load_omni_checkpoint(adapter_pth)
+        added = ad.pop("llm.added_rows", None)
+        sd.update(ad)
+    if vocab_rows is not None and llm_dir:
+        sd = resize_token_embeddings(sd, vocab_rows, added)
+    return sd
+
+
 def infer_spec(sd: Dict[str, torch.Tensor], llm_model: str, compression_mode: str = "avg-pooling", lora_alpha: int = 1,
                downsample_ratio_audio=None, downsample_ratio_video=None, max_dec_tokens: int = 32, num_beams: int = 15,
                ids: Optional[Dict[str, int]] = None) -> OmniSpec:

@@ -319,8 +319,12 @@ class AVSR_LLMs:
                 is_task_specific=bool(is_task_specific), shared_lora=shared, max_dec_tokens=max_dec_tokens, num_beams=num_beams)
             assert spec.llm.hidden == hidden_size, "hidden_size does not match the LLM (lightning_OmniAVSR.py:28-37)"
             if tokenizer is not None:
-                v = tokenizer.vocab
-                spec.ids.update(audio_sos=v["<audio>"], audio_eos=v["</audio>"], video_sos=v["<video>"], video_eos=v["</video>"])
+                # every id the inference branch looks up in tokenizer.vocab (:312-322,422-445), and the embedding rows after
+                # `resize_token_embeddings(len(tokenizer))` (:214)
+                from .harness import special_ids_from_tokenizer
+                spec.ids.update(special_ids_from_tokenizer(tokenizer, llm_model))
+                import dataclasses
+                spec.llm = dataclasses.replace(spec.llm, vocab=len(tokenizer))
         self.spec = spec
         self.engine = OmniEngine(spec, dtype=dtype, device=device)
 
@@ -356,6 +360,10 @@ class AVSR_LLMs:
         if lora_task != task:
             raise NotImplementedError("LoRA task different from the input modality is not supported")
         use_a, use_v = task in ("audio", "audiovisual"), task in ("video", "audiovisual")
+        if getattr(self, "_omni_matry_map_quirk", True) and not self.is_matryoshka and not getattr(self.spec, "is_single_matry_projector", False):
+            # the reference's inference branch indexes `self.matry_map_*`, which its constructor only creates in the matryoshka branches
+            # (modeling_OmniAVSR.py:429,447 vs :66-70,92-94): without --is-matryoshka it needs --is-single-matry-projector
+            raise AttributeError("'AVSR_LLMs' object has no attribute 'matry_map_" + ("video" if use_v else "audio") + "'")
         if use_a and ra not in self.spec.rates("audio"):
             raise KeyError(ra)        # matry_map_audio[...] modeling_OmniAVSR.py:447,556
         if use_v and rv not in self.spec.rates("video"):

@@ -27,6 +27,7 @@ class AVSR_LLMs(_OmniShim):
                  remove_layernorm_from_projector=False, is_matryoshka=False, *, prompt_ids: Optional[Sequence[int]] = None,
                  spec: Optional[OmniSpec] = None, dtype: str = "bf16", device: str = "cuda:0"):
         self.modality = modality
+        self._omni_matry_map_quirk = False      # modeling_LlamaAVSR.py's non-matryoshka inference branch has its own projector call
         self.max_dec_tokens, self.num_beams = max_dec_tokens, num_beams
         self.llm_model, self.tokenizer, self.prompt = llm_model, tokenizer, prompt
         self.is_matryoshka, self.is_task_specific = bool(is_matryoshka), False

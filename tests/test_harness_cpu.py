@@ -55,3 +55,65 @@ def test_wer_and_collate():
     assert b["video"].shape == (2, 5, 1, 88, 88) and b["audio"].shape == (2, 3200, 1)
     assert b["lengths"].tolist() == [1920, 3200] and b["video_lengths"].tolist() == [3, 5] and b["tokens"].tolist() == [[128000], [128000]]
     assert H.collate_test([{"audio": torch.ones(10, 1)}], "audio", -1)["tokens"].shape == (1, 0)      # Qwen: no BOS
+
+
+def _toy_tokenizer(family):
+    """A fast tokenizer with the special tokens of the real families (no hub access offline): word-level vocabulary."""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    words = ["hello", "world", "the", "cat", "sat", "[UNK]"]
+    specials = ["<|begin_of_text|>", "<|end_of_text|>"] if family == "llama" else ["<|endoftext|>"]
+    vocab = {w: i for i, w in enumerate(words + specials)}
+    tk = Tokenizer(models.WordLevel(vocab, unk_token="[UNK]"))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    kw = dict(bos_token="<|begin_of_text|>", eos_token="<|end_of_text|>") if family == "llama" else dict(eos_token="<|endoftext|>")
+    return PreTrainedTokenizerFast(tokenizer_object=tk, unk_token="[UNK]", **kw), len(vocab)
+
+
+def test_tokenizer_surgery_follows_lightning_module():
+    """lightning_OmniAVSR.py:53-91: post-processor template, added tokens (+5 Llama / +4 Qwen), right padding, pad id; and the ids the
+    inference branch reads from tokenizer.vocab (modeling_OmniAVSR.py:312-322)."""
+    tok, n0 = _toy_tokenizer("llama")
+    pad_id = H.prepare_tokenizer(tok, "meta-llama/Llama-3.2-1B")
+    assert len(tok) == n0 + 5 and pad_id == tok.vocab["<pad>"] == n0 and tok.padding_side == "right"
+    assert [tok.vocab[t] for t in ("<audio>", "</audio>", "<video>", "</video>")] == [n0 + 1, n0 + 2, n0 + 3, n0 + 4]
+    ids = tok("hello world").input_ids
+    assert ids == [tok.bos_token_id, 0, 1, tok.eos_token_id]                      # bos $A eos  (:59-71)
+    sp = H.special_ids_from_tokenizer(tok, "meta-llama/Llama-3.2-1B")
+    assert sp == dict(bos=tok.vocab["<|begin_of_text|>"], eos=tok.vocab["<|end_of_text|>"], pad=n0, audio_sos=n0 + 1, audio_eos=n0 + 2,
+                      video_sos=n0 + 3, video_eos=n0 + 4)
+    assert tok.batch_decode([[tok.bos_token_id, 2, 3, 4, tok.eos_token_id, n0]], skip_special_tokens=True, clean_up_tokenization_spaces=False) == ["the cat sat"]
+    tq, q0 = _toy_tokenizer("qwen")
+    assert H.prepare_tokenizer(tq, "Qwen/Qwen2.5-7B") is None and len(tq) == q0 + 4
+    assert tq("the cat").input_ids == [2, 3, tq.eos_token_id]                     # $A eos, no BOS  (:72-81)
+    sq = H.special_ids_from_tokenizer(tq, "Qwen/Qwen2.5-7B")
+    assert sq["bos"] == -1 and sq["eos"] == sq["pad"] == tq.vocab["<|endoftext|>"] and sq["video_eos"] == q0 + 3
+
+
+def test_resize_token_embeddings_and_assemble(tmp_path):
+    from omni_avsr_amd import ingest
+    emb = torch.arange(12.0).reshape(4, 3)
+    sd = {"llm.model.embed_tokens.weight": emb, "llm.lm_head.weight": emb}           # tied
+    out = ingest.resize_token_embeddings(sd, 6)
+    assert out["llm.model.embed_tokens.weight"].shape == (6, 3) and out["llm.lm_head.weight"].data_ptr() == out["llm.model.embed_tokens.weight"].data_ptr()
+    assert torch.allclose(out["llm.model.embed_tokens.weight"][4:], emb.mean(0, keepdim=True).expand(2, 3))
+    added = torch.ones(2, 3) * 7
+    out2 = ingest.resize_token_embeddings({"llm.model.embed_tokens.weight": emb, "llm.lm_head.weight": emb + 1}, 6, added)
+    assert torch.equal(out2["llm.model.embed_tokens.weight"][4:], added) and torch.equal(out2["llm.lm_head.weight"][:4], emb + 1)
+    import pytest
+    with pytest.raises(ValueError):
+        ingest.resize_token_embeddings(sd, 3)
+
+
+def test_evaluate_reports_failed_batches():
+    class Boom:
+        is_task_specific = False
+
+        def __call__(self, batch, **kw):
+            if batch["video"].shape[1] == 7:
+                raise RuntimeError("bad clip")
+            return torch.tensor([[1, 2]] * batch["video"].shape[0])
+
+    samples = [({"video": torch.zeros(t, 1, 88, 88)}, "w1 w2") for t in (5, 7, 5, 5)]
+    m = H.evaluate(Boom(), samples, "video", lambda ids: ["w1 w2"] * ids.shape[0], batch_size=1)
+    assert m.failed == [1] and m.total_length == 6 and m.total_edit_distance == 0
