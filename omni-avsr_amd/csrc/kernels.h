@@ -73,6 +73,7 @@ int launch_gemm_8p(const GemmArgs& a, hipStream_t st);
 
 // Skinny (decode) GEMM: M <= 128 rows, weights streamed once.  Same math/epilogue subset.
 int launch_gemm_skinny(const GemmArgs& a, hipStream_t st);
+bool skinny_uses_r16(const GemmArgs& a);     // 9..32 rows on 8-column tiles (skinny_r16_kernel)
 // Two dependent skinny GEMMs (M <= 8) fused into one launch (skinny.hip): kind 0 = LoRA down -> QKV (stage 0's output is stage 1's A2),
 // kind 1 = gate/up + SwiGLU -> down_proj (stage 0's output is stage 1's A).  Same bits as the two separate launches.
 struct SkinnySync {            // device-side view of one stage's hand-off

@@ -718,6 +718,15 @@ int launch_gemm_skinny_chain2(const GemmArgs& a0, const GemmArgs& a1, const Skin
   return a0.dtype == DT_F32 ? launch_chain2<float, true, 4, 2, false, 1, 8>(a0, a1, c, st) : launch_chain2<bf16_t, true, 4, 2, false, 1, 8>(a0, a1, c, st);
 }
 
+// which weight-streaming kernel launch_gemm_skinny picks for 9..32 rows (profiling family names follow the kernel that runs)
+bool skinny_uses_r16(const GemmArgs& a) {
+  static const int r16_on = [] { const char* e = getenv("OAVSR_SKINNY_R16"); return e ? atoi(e) : 1; }();
+  const int esz = a.dtype == DT_F32 ? 4 : 2, kbe = 64 / esz, mt = ceil_div(a.M, 16);
+  if (!(r16_on && half_enabled() && a.M > 8 && mt <= 2 && (a.K / kbe) % 2 == 0)) return false;
+  if (a.N >= 8192 && (!a.swiglu_pairs || a.N % 32 == 0)) return true;
+  return !a.swiglu_pairs && a.N >= 64 && a.N / 16 < 384;
+}
+
 int launch_gemm_skinny(const GemmArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0) return 0;
   const int esz = a.dtype == DT_F32 ? 4 : 2;

@@ -373,6 +373,10 @@ class AVSR_LLMs:
         Tv = lengths = None
         if use_v:
             Tv = [int(x) for x in inputs["video_lengths"]] if "video_lengths" in inputs else [video.shape[1]] * video.shape[0]
+            if not self.is_matryoshka and self.spec.compression_mode == "stack" and rv != 1 and any(t % rv for t in Tv):
+                # the non-matryoshka video stack branch has no remainder handling: torch.stack raises on the ragged last group
+                # (modeling_OmniAVSR.py:517-520; the audio branch and both matryoshka branches drop the remainder)
+                raise RuntimeError("stack expects each tensor to be equal size")
         if use_a:
             B = audio.shape[0]
             if B == 1:
