@@ -226,6 +226,17 @@ __global__ __launch_bounds__(kThreads) void attn_varlen_kernel(const AttnArgs p)
 //      v_exp_f32 with the softmax scale folded into one fma.
 __device__ __attribute__((aligned(256))) unsigned int g_attn_zero_page[64];
 
+// max over lanes l, l^16, l^32, l^48 with the gfx950 row / half swaps: v_permlane16_swap exchanges rows 1 <-> 0' and 3 <-> 2' of the two
+// operands (rows = 16 lanes), v_permlane32_swap the upper half of one with the lower half of the other; with both operands holding x,
+// max(a, b) afterwards is the xor-16 (xor-32) butterfly step.  The hardware needs 2 wait states between a VALU write and the swap.
+__device__ __forceinline__ float xor_max_16_32(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1\n\tv_max_f32 %0, %0, %1\n\tv_mov_b32 %1, %0\n\ts_nop 1\n\t"
+               "v_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_max_f32 %0, %0, %1"
+               : "+v"(a), "+v"(b));
+  return a;
+}
+
 template <int QT>
 __global__ __launch_bounds__(kThreads, 2) void attn_dma_kernel(const AttnArgs p) {
   constexpr int HD = 64, RB = 128, NDT = 4, NSTAGE = 3;
@@ -256,35 +267,32 @@ __global__ __launch_bounds__(kThreads, 2) void attn_dma_kernel(const AttnArgs p)
 
   // DMA: wave w fills 1-KiB segments w and w+4 (8 key rows each) of the K and of the V image; lane i lands at physical
   // chunk i&7 of row seg*8 + (i>>3) and therefore fetches logical chunk (i&7) ^ (i>>3)   [chunk ^ (row & 7) swizzle].
-  // issue() is called for tiles 0, 1, 2, ... in order, so the source pointers / key indices / ring slot are running state
-  // (a 64-bit add per pointer instead of re-deriving the address); rows past klen read the zero page.
+  // Addressing is all scalar per tile: K and V of this (sequence, kv head) are buffer resources whose num_records ends with the last valid
+  // key row, a lane's byte offset inside the first tile is a constant VGPR, and the tile advance is an SGPR offset (buffer_load ... lds
+  // with soffset) -- no per-tile vector address arithmetic, and rows past klen read as zeros by the hardware range check.
   const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
-  const char* zp = reinterpret_cast<const char*>(g_attn_zero_page);
-  asm volatile("" : "+s"(zp));                           // opaque: keeps the address in SGPRs instead of a GOT load per tile
-  const char* kp[2];
-  const char* vp[2];
-  int dkey[2];
+  const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(K + (int64_t)k0 * p.ldk), 0,
+                                                                       klen > 0 ? (int)(((int64_t)klen - 1) * p.ldk * 2 + RB) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(V + (int64_t)k0 * p.ldv), 0,
+                                                                       klen > 0 ? (int)(((int64_t)klen - 1) * p.ldv * 2 + RB) : 0, 0x00020000);
+  int kvo[2], vvo[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    dkey[h] = (wave + 4 * h) * 8 + lrow;
-    kp[h] = reinterpret_cast<const char*>(K + (int64_t)(k0 + dkey[h]) * p.ldk + lchunk * 8);
-    vp[h] = reinterpret_cast<const char*>(V + (int64_t)(k0 + dkey[h]) * p.ldv + lchunk * 8);
+    const int key = (wave + 4 * h) * 8 + lrow;
+    kvo[h] = (key * (int)p.ldk + lchunk * 8) * 2;
+    vvo[h] = (key * (int)p.ldv + lchunk * 8) * 2;
   }
-  const int64_t kstep = (int64_t)KT * p.ldk * 2, vstep = (int64_t)KT * p.ldv * 2;
+  const int kstep = KT * (int)p.ldk * 2, vstep = KT * (int)p.ldv * 2;
+  int ksoff = 0, vsoff = 0;                              // scalar: byte offset of the next tile to issue
   unsigned dslot = 0;                                    // LDS byte offset of the ring slot the next issue() fills
   auto issue = [&]() {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const bool in = dkey[h] < klen;
-      const char* ks = in ? kp[h] : zp;
-      const char* vs = in ? vp[h] : zp;
       char* dst = smem + (dslot + (wave + 4 * h) * 1024);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks,
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vs,
-                                       (__attribute__((address_space(3))) void*)(dst + KT * RB), 16, 0, 0);
-      kp[h] += kstep; vp[h] += vstep; dkey[h] += KT;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)dst, 16, kvo[h], ksoff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (__attribute__((address_space(3))) void*)(dst + KT * RB), 16, vvo[h], vsoff, 0, 0);
     }
+    ksoff += kstep; vsoff += vstep;
     dslot = dslot == (NSTAGE - 1) * kStage ? 0u : dslot + kStage;
   };
 
@@ -334,7 +342,11 @@ __global__ __launch_bounds__(kThreads, 2) void attn_dma_kernel(const AttnArgs p)
   }
 
   unsigned cslot = 0;                                    // ring slot of the tile being consumed
-  for (int t = 0; t < ntile; ++t) {
+  // One key tile.  MASKED is a compile-time property of the call site: the leading tiles of a wave are fully visible to all its queries and
+  // run a body WITHOUT any masking code -- as a run-time branch inside one body the compiler if-converted the visibility selects into
+  // the common path (~150 extra VALU instructions per tile, as many as the softmax itself).
+  auto tile = [&](const int t, auto masked_tag) __attribute__((always_inline)) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
     // tile t has landed once only tile t+1's 4 DMA instructions of this wave are still outstanding
     if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -369,8 +381,8 @@ __global__ __launch_bounds__(kThreads, 2) void attn_dma_kernel(const AttnArgs p)
 #pragma unroll
     for (int j = 0; j < QT; ++j) {
       const int qmin = qt0 + (wave * QT + j) * 16;
-      const bool need_mask = kt0 + KT > klen || (p.causal && kt0 + KT - 1 > qmin + shift);     // wave-uniform
-      if (need_mask) {
+      const bool need_mask = MASKED && (kt0 + KT > klen || (p.causal && kt0 + KT - 1 > qmin + shift));     // wave-uniform
+      if constexpr (MASKED) if (need_mask) {
         int key0 = kt0 + 4 * g;
         asm volatile("" : "+v"(key0));                    // pins the index / compare chain inside this rarely taken branch
 #pragma unroll
@@ -387,23 +399,23 @@ __global__ __launch_bounds__(kThreads, 2) void attn_dma_kernel(const AttnArgs p)
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[j][kt][r]);
-      mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      mt = xor_max_16_32(mt);                             // over the 4 lane groups, VALU only (no LDS round trip as with ds_bpermute)
       mt *= sc;                                           // sc > 0: max(s) * sc == max(s * sc)
       const float m_new = fmaxf(m_run[j], mt);
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
       const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_use);
-      // exponent argument and row sum as 2-wide packed fp32 (v_pk_fma_f32 / v_pk_add_f32): half the VALU issue slots
-      f32x2 lsum2 = f32x2{0.f, 0.f};
-      const f32x2 sc2 = f32x2{sc, sc}, nm2 = f32x2{-m_use, -m_use};
+      // exponent argument and row sum in plain (unpacked) fp32: beside MFMAs a v_pk_fma_f32 / v_pk_add_f32 costs ~20 cycles more than the two
+      // scalar instructions it replaces (MI355X_MICROARCH.md, price of one filler beside MFMAs); the file is built with -fno-slp-vectorize
+      // so that the compiler does not re-pack them.  Two partial sums keep the add chains short.
+      float lsum2[2] = {0.f, 0.f};
+      const float nm = -m_use;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const f32x2 x = __builtin_elementwise_fma(f32x2{s[j][kt][2 * h], s[j][kt][2 * h + 1]}, sc2, nm2);
-          const f32x2 e = f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-          s[j][kt][2 * h] = e[0]; s[j][kt][2 * h + 1] = e[1];
-          lsum2 += e;
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(fmaf(s[j][kt][r], sc, nm));
+          s[j][kt][r] = e;
+          lsum2[r & 1] += e;
         }
       const float lsum = lsum2[0] + lsum2[1];
       l_run[j] = l_run[j] * alpha + lsum;
@@ -440,7 +452,18 @@ __global__ __launch_bounds__(kThreads, 2) void attn_dma_kernel(const AttnArgs p)
       }
     }
     asm volatile("" ::: "memory");
+  };
+  // tiles [0, t_full): inside klen and, if causal, entirely visible to this wave's first (lowest) query tile -- hence to all of them
+  int t_full = klen / KT;
+  if (p.causal) {
+    const int vis = qt0 + wave * QT * 16 + shift + 1;    // keys visible to the wave's lowest query row
+    const int tc = vis > 0 ? vis / KT : 0;
+    t_full = tc < t_full ? tc : t_full;
   }
+  t_full = __builtin_amdgcn_readfirstlane(t_full < ntile ? t_full : ntile);
+  int t = 0;
+  for (; t < t_full; ++t) tile(t, std::false_type{});
+  for (; t < ntile; ++t) tile(t, std::true_type{});
   // ---- finalize: l over the 4 lane groups, write O[q][d = dt*16 + 4g + r] ----
 #pragma unroll
   for (int j = 0; j < QT; ++j) {

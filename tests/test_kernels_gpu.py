@@ -450,6 +450,36 @@ def test_attention_varlen(dtype, hd, H, KV, causal):
     close(out, ref, tol(dtype), what="attention")
 
 
+def test_attention_short_sequences_after_nan_poisoned_lds():
+    """The bf16 / head_dim 64 kernel relies on the buffer range check for key rows past a sequence's end (they must land in LDS as
+    zeros: a masked probability of 0 times a stale NaN would poison the output).  Poison the LDS of every CU with NaN patterns first
+    (a big GEMM on NaN inputs stages them through all of its LDS), then run many short ragged sequences (1024 workgroups, so every CU
+    takes several)."""
+    hd, H, KV = 64, 8, 8
+    g = torch.Generator().manual_seed(3)
+    lens = [int(x) for x in torch.randint(1, 150, (128,), generator=g)]
+    cu = [0]
+    for n in lens:
+        cu.append(cu[-1] + n)
+    rows, nq, nkv = cu[-1], H * hd, KV * hd
+    qkvd, qkvr = q(rnd(rows, nq + 2 * nkv, seed=12), "bf16")
+    out = torch.empty(rows, nq, dtype=torch.bfloat16, device=DEV)
+    cud = torch.tensor(cu, dtype=torch.int32, device=DEV)
+    d = L.AttnDesc()
+    d.dtype, d.head_dim, d.n_heads, d.n_kv_heads, d.n_seqs, d.max_q, d.causal = dcode("bf16"), hd, H, KV, len(lens), max(lens), 0
+    d.Q, d.K, d.V, d.O = qkvd.data_ptr(), qkvd.data_ptr() + nq * 2, qkvd.data_ptr() + (nq + nkv) * 2, out.data_ptr()
+    d.ldq = d.ldk = d.ldv = nq + 2 * nkv
+    d.ldo = nq
+    d.cu_q, d.cu_k, d.scale = cud.data_ptr(), cud.data_ptr(), 1.0 / math.sqrt(hd)
+    nan = torch.full((4096, 1024), float("nan"), dtype=torch.bfloat16, device=DEV)
+    for _ in range(3):
+        gemm("bf16", nan, nan)                       # 256 x 256 tiles on every CU: both operands are NaN everywhere in LDS
+        L.check(L.load().oavsr_op_attention(C.byref(d), stream()))
+        assert torch.isfinite(out.float()).all(), "key rows past the end of a sequence were not zero-filled"
+    ref = _attn_ref(qkvr[:, :nq], qkvr[:, nq:nq + nkv], qkvr[:, nq + nkv:], cu, cu, H, KV, hd, 1.0 / math.sqrt(hd), 0)
+    close(out, ref, tol("bf16"), what="attention after NaN-poisoned LDS")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_softmax_spike(dtype):
     """One key dominates late in the sequence: exercises the online-softmax rescale branch."""
