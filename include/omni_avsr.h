@@ -173,6 +173,12 @@ typedef struct oavsr_gemm_desc {
   /* classic kernel only: split-K with fp32 partial slabs [ksplit][M][N] and a deterministic reduce + epilogue pass */
   int32_t ksplit;
   float* partial;
+  /* split-K only (optional): the reduce pass also writes RMSNorm(C row) * rn_gain to rn_out (row stride rn_ld) -- the consumer's
+     normalised input, Llama_LoRA.py:618-640 (residual add, then the next RMSNorm).  Plain epilogue (no activation, C in `dtype`). */
+  void* rn_out;
+  int64_t rn_ld;
+  const float* rn_gain;
+  float rn_eps;
 } oavsr_gemm_desc;
 int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream);
 

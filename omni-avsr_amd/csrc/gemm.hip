@@ -321,6 +321,63 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
   }
 }
 
+// Split-K reduce + epilogue + RMSNorm of the finished row, one workgroup per row (beam-search decode: o_proj -> ln2, down_proj -> the next
+// layer's ln1 / the final norm).  The slab sum and the epilogue are splitk_reduce_kernel's expressions in the same order (same C bits);
+// the norm reads the values as rounded to T, like the separate rmsnorm kernel that this replaces would have read them from memory
+// (Llama_LoRA.py:618-640: residual add, then the next RMSNorm).  Sum of squares: per thread in column order, wave_sum, the 4 wave
+// partials in wave order -- fixed, so deterministic and independent of the row count.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_rmsnorm_kernel(const GemmArgs p) {
+  constexpr int VEC = TypeInfo<T>::kVec;
+  __shared__ float wsum[4];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const int64_t total = (int64_t)p.M * p.N;
+  const T* R = reinterpret_cast<const T*>(p.residual);
+  T* Cr = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc;
+  float ss = 0.f;
+  for (int c = tid * VEC; c < p.N; c += 256 * VEC) {
+    float y[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) y[e] = 0.f;
+    const float* ps = p.partial + (int64_t)m * p.N + c;
+    for (int s = 0; s < p.ksplit; ++s) {
+#pragma unroll
+      for (int e = 0; e < VEC; e += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ps + (int64_t)s * total + e);
+        y[e] += v[0]; y[e + 1] += v[1]; y[e + 2] += v[2]; y[e + 3] += v[3];
+      }
+    }
+    float res[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) res[e] = 0.f;
+    if (R) chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(R + (int64_t)m * p.ldr + c), res);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      y[e] = fmaf(y[e], p.col_scale ? p.col_scale[c + e] : 1.f, p.col_bias ? p.col_bias[c + e] : 0.f);
+      y[e] += res[e];
+    }
+    const Chunk16 out = chunk_from_f32<T>(y);
+    *reinterpret_cast<Chunk16*>(Cr + c) = out;
+    chunk_to_f32<T>(out, y);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) ss += y[e] * y[e];
+  }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) wsum[tid >> 6] = ss;
+  __syncthreads();
+  const float tot = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+  const float rstd = rsqrtf(tot / (float)p.N + p.rn_eps);
+  T* Yr = reinterpret_cast<T*>(p.rn_out) + (int64_t)m * p.rn_ld;
+  for (int c = tid * VEC; c < p.N; c += 256 * VEC) {
+    float x[VEC], o[VEC];
+    chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(Cr + c), x);     // this thread's own stores
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] = p.rn_gain[c + e] * (x[e] * rstd);
+    *reinterpret_cast<Chunk16*>(Yr + c) = chunk_from_f32<T>(o);
+  }
+}
+
+
 template <typename T, int AMODE>
 int launch_tile(const GemmArgs& a, hipStream_t st) {
   if (a.N <= 64) return launch_one<T, 128, 64, 2, 2, AMODE>(a, st);
@@ -340,6 +397,13 @@ int launch_mode(const GemmArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+bool splitk_rmsnorm_ok(const GemmArgs& a) {
+  const int vec = a.dtype == DT_F32 ? 4 : 8;
+  return a.ksplit > 1 && a.rn_out && a.rn_gain && !a.out_f32 && a.act == ACT_NONE && a.N % vec == 0 && a.ldc % vec == 0 && a.rn_ld % vec == 0 &&
+         (!a.residual || a.ldr % vec == 0) && ((uintptr_t)a.C & 15) == 0 && ((uintptr_t)a.rn_out & 15) == 0 && ((uintptr_t)a.partial & 15) == 0 &&
+         (!a.residual || ((uintptr_t)a.residual & 15) == 0);
+}
 
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0) return 0;
@@ -365,6 +429,13 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     static const bool dma_sk = [] { const char* e = getenv("OAVSR_GEMM_DMA"); return !(e && e[0] == '0'); }();
     if (dma_sk && gemm_dma_eligible(a)) OAVSR_TRY(launch_gemm_dma(a, st));   // same k order as the classic kernel
     else OAVSR_TRY(a.dtype == DT_F32 ? launch_mode<float>(a, st) : launch_mode<bf16_t>(a, st));
+    if (a.rn_out) {
+      OAVSR_REQUIRE(splitk_rmsnorm_ok(a), "gemm: split-K reduce + RMSNorm needs a plain bf16 / f32 epilogue on 16-byte rows");
+      if (a.dtype == DT_F32) hipLaunchKernelGGL(splitk_reduce_rmsnorm_kernel<float>, dim3(a.M), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL(splitk_reduce_rmsnorm_kernel<bf16_t>, dim3(a.M), dim3(256), 0, st, a);
+      OAVSR_CHECK_HIP(hipGetLastError());
+      return 0;
+    }
     int64_t total = (int64_t)a.M * a.N;
     int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     if (a.dtype == DT_F32) hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(grid), dim3(256), 0, st, a);

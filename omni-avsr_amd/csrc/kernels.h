@@ -37,6 +37,9 @@ struct GemmArgs {
   const int2* frameinfo = nullptr;
   // skinny kernel only: fused RMSNorm prologue (gain[K], eps) and SwiGLU epilogue on 16-row interleaved gate/up weights
   const float* norm_gain = nullptr; float norm_eps = 0.f;
+  // split-K only: the reduce pass also writes RMSNorm(C row) * rn_gain to rn_out (the consumer's normalised input): one launch instead of
+  // reduce + rmsnorm.  Needs !out_f32, no activation, N % (16 bytes of T) == 0.
+  void* rn_out = nullptr; int64_t rn_ld = 0; const float* rn_gain = nullptr; float rn_eps = 0.f;
   int swiglu_pairs = 0;
   // classic kernel only: split-K over blockIdx.y with fp32 partial slabs [ksplit][M][N] + deterministic reduce/epilogue kernel
   int ksplit = 1; float* partial = nullptr;
@@ -73,6 +76,7 @@ int launch_gemm_8p(const GemmArgs& a, hipStream_t st);
 
 // Skinny (decode) GEMM: M <= 128 rows, weights streamed once.  Same math/epilogue subset.
 int launch_gemm_skinny(const GemmArgs& a, hipStream_t st);
+bool splitk_rmsnorm_ok(const GemmArgs& a);      // gemm.hip: can the split-K reduce pass also write RMSNorm(C) (rn_* fields)?
 bool skinny_uses_r16(const GemmArgs& a);     // 9..32 rows on 8-column tiles (skinny_r16_kernel)
 // Two dependent skinny GEMMs (M <= 8) fused into one launch (skinny.hip): kind 0 = LoRA down -> QKV (stage 0's output is stage 1's A2),
 // kind 1 = gate/up + SwiGLU -> down_proj (stage 0's output is stage 1's A).  Same bits as the two separate launches.

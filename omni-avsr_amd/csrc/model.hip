@@ -725,13 +725,23 @@ static int decode_split(int N, int Ktot, int esz) {
   return std::max(1, std::min(ks, 16));
 }
 
-static int llm_gemm(const oavsr_model* m, oavsr_workspace* ws, GemmArgs& g, int mode /*0 prefill, 1 skinny, 2 split-K*/, hipStream_t st) {
+// rn_gain (mode 2 only): ask the split-K reduce pass to also write RMSNorm(C) * rn_gain to ws->lh; *normed says whether it did (a GEMM
+// that needs no split has no reduce pass: the caller then runs the rmsnorm kernel as before).
+static int llm_gemm(const oavsr_model* m, oavsr_workspace* ws, GemmArgs& g, int mode /*0 prefill, 1 skinny, 2 split-K*/, hipStream_t st,
+                    const float* rn_gain = nullptr, bool* normed = nullptr) {
+  if (normed) *normed = false;
   if (mode == 0) return run_gemm(g, st, false);
   if (mode == 1) return run_gemm(g, st, true);
   const int ks = decode_split(g.N, g.K + g.K2, (int)m->esz);
   if (ks > 1) {
     OAVSR_REQUIRE((size_t)ks * g.M * g.N * 4 <= ws->partial_bytes, "decode GEMM: split-K slabs (%d x %d x %d) exceed the workspace", ks, g.M, g.N);
     g.ksplit = ks; g.partial = ws->partial;
+    static const bool fuse_rn = [] { const char* e = getenv("OAVSR_REDUCE_NORM"); return !(e && e[0] == '0'); }();
+    if (fuse_rn && rn_gain && normed) {
+      g.rn_out = ws->lh; g.rn_ld = g.N; g.rn_gain = rn_gain; g.rn_eps = m->cfg.llm_rms_eps;
+      if (splitk_rmsnorm_ok(g)) *normed = true;
+      else { g.rn_out = nullptr; g.rn_gain = nullptr; }
+    }
   }
   return run_gemm(g, st, false);
 }
@@ -742,7 +752,7 @@ static int llm_gemm(const oavsr_model* m, oavsr_workspace* ws, GemmArgs& g, int 
 // decode-shaped kernels; *pruned tells the caller that ws->lastx already holds the final hidden rows.
 static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int rows, bool decode, int B, int beams, int max_S,
                       const int* pos, const int* cpos, const int* anc, const int* step, hipStream_t st, const float2* rope_cs = nullptr,
-                      const int* last_rows = nullptr, const int* cu_last = nullptr, bool* pruned = nullptr) {
+                      const int* last_rows = nullptr, const int* cu_last = nullptr, bool* pruned = nullptr, bool* final_normed = nullptr) {
   const oavsr_config& c = m->cfg;
   const int dt = m->dtype, d = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, hd = c.llm_head_dim, I = c.llm_mlp;
   const int nq = H * hd, nqkv = (H + 2 * KV) * hd;
@@ -752,11 +762,14 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
   static const bool prune_on = [] { const char* e = getenv("OAVSR_PREFILL_PRUNE"); return !(e && e[0] == '0'); }();
   const bool can_prune = prune_on && !decode && last_rows && cu_last;
   if (pruned) *pruned = false;
+  if (final_normed) *final_normed = false;
+  bool have_h = false;                     // mode 2: ws->lh already holds ln1(x) of this layer, written by the previous down_proj's reduce pass
   for (int li = 0; li < c.llm_layers; ++li) {
     const LlmLayer& L = m->llayers[li];
     const bool prune = can_prune && li == c.llm_layers - 1;
-    if (!fused_norm) { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
+    if (!fused_norm && !have_h) { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
       OAVSR_TRY(launch_rmsnorm(dt, ws->lx, d, ws->lh, d, L.ln1w, rows, d, c.llm_rms_eps, st)); }
+    have_h = false;
     const void* hin = fused_norm ? ws->lx : ws->lh;
     GemmArgs g, gl;
     // greedy decode with <= 8 rows: dependent weight-streaming GEMMs share a launch (LoRA down -> QKV, gate/up -> down_proj)
@@ -820,7 +833,8 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
       char* act_r = (char*)ws->lact + (size_t)r0 * I * e;
       g = GemmArgs(); g.dtype = dt; g.M = trows; g.N = d; g.K = nq; g.A = attn_r; g.lda = nq; g.W = L.ow; g.ldw = nq;
       g.residual = xres; g.ldr = d; g.C = xres; g.ldc = d;
-      OAVSR_TRY(llm_gemm(m, ws, g, tmode, st));
+      bool h2 = false;                     // mode 2: ln2(x) written by o_proj's reduce pass
+      OAVSR_TRY(llm_gemm(m, ws, g, tmode, st, tmode == 2 ? L.ln2w : nullptr, &h2));
       bool mlp_chained = false;
       if (tfused) {   // RMSNorm + gate/up + SwiGLU in one launch
         g = GemmArgs(); g.dtype = dt; g.M = trows; g.N = 2 * I; g.K = d; g.A = xres; g.lda = d; g.W = L.guw; g.ldw = d;
@@ -835,7 +849,7 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
           OAVSR_TRY(run_gemm(g, st, true));
         }
       } else {
-        { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
+        if (!h2) { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
           OAVSR_TRY(launch_rmsnorm(dt, ws->lx, d, ws->lh, d, L.ln2w, rows, d, c.llm_rms_eps, st)); }
         g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 2 * I; g.K = d; g.A = ws->lh; g.lda = d; g.W = L.guw; g.ldw = d; g.C = ws->lgu; g.ldc = 2 * I;
         static const bool fuse_swiglu = [] { const char* e2 = getenv("OAVSR_FUSE_SWIGLU"); return !(e2 && e2[0] == '0'); }();
@@ -854,7 +868,13 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
       if (!mlp_chained) {
         g = GemmArgs(); g.dtype = dt; g.M = trows; g.N = d; g.K = I; g.A = act_r; g.lda = I; g.W = L.downw; g.ldw = I;
         g.residual = xres; g.ldr = d; g.C = xres; g.ldc = d;
-        OAVSR_TRY(llm_gemm(m, ws, g, tmode, st));
+        // mode 2: the reduce pass also writes the next consumer's normalised rows (next layer's ln1, or the final norm before lm_head)
+        const bool last = li == c.llm_layers - 1;
+        const float* next_gain = tmode != 2 ? nullptr : (!last ? m->llayers[li + 1].ln1w : (final_normed ? m->norm_w : nullptr));
+        bool hn = false;
+        OAVSR_TRY(llm_gemm(m, ws, g, tmode, st, next_gain, &hn));
+        if (hn && !last) have_h = true;
+        if (hn && last) *final_normed = true;
       }
     }
     if (prune && pruned) *pruned = true;
@@ -863,7 +883,8 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
 }
 
 // chunk > 0 (prefill): the rows go through the fused weight-streaming kernel `chunk` at a time, whatever their number
-static int lm_head_rows(const oavsr_model* m, oavsr_workspace* ws, const void* x, int rows, float* logits, hipStream_t st, int chunk = 0) {
+static int lm_head_rows(const oavsr_model* m, oavsr_workspace* ws, const void* x, int rows, float* logits, hipStream_t st, int chunk = 0,
+                        bool normed = false /* ws->lh already holds the final-norm rows (written by the last down_proj's reduce pass) */) {
   const oavsr_config& c = m->cfg;
   const int d = c.llm_hidden;
   GemmArgs g; g.dtype = m->dtype; g.M = rows; g.N = c.llm_vocab; g.K = d; g.W = m->lm_head; g.ldw = d;
@@ -878,7 +899,7 @@ static int lm_head_rows(const oavsr_model* m, oavsr_workspace* ws, const void* x
     }
     return 0;
   }
-  { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
+  if (!normed) { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
     OAVSR_TRY(launch_rmsnorm(m->dtype, x, d, ws->lh, d, m->norm_w, rows, d, c.llm_rms_eps, st)); }
   g.A = ws->lh; g.lda = d;
   return run_gemm(g, st, false);
@@ -1021,8 +1042,10 @@ static int decode_beam(const oavsr_model* m, oavsr_workspace* ws, int task, int 
   // one step reads ping-pong side `cur` of the sequence / ancestry tables and writes the other one
   auto one_step = [&](int cur) -> int {
     OAVSR_TRY(launch_embed(m->dtype, m->embed, c.llm_hidden, ws->gs.tok, ws->lx, c.llm_hidden, R, c.llm_hidden, st));
-    OAVSR_TRY(llm_layers(m, ws, task, R, true, B, K, maxS + max_new, ws->gs.pos, ws->gs.cpos, anc[cur], ws->gs.step, st));
-    OAVSR_TRY(lm_head_rows(m, ws, ws->lx, R, ws->logits, st));
+    bool fnorm = false;
+    OAVSR_TRY(llm_layers(m, ws, task, R, true, B, K, maxS + max_new, ws->gs.pos, ws->gs.cpos, anc[cur], ws->gs.step, st, nullptr, nullptr, nullptr, nullptr,
+                         R > 32 ? &fnorm : nullptr));
+    OAVSR_TRY(lm_head_rows(m, ws, ws->lx, R, ws->logits, st, 0, fnorm));
     ProfScope ps("beam_search", 0, (double)R * c.llm_vocab * 16, st);
     OAVSR_TRY(launch_beam_topk(ws->logits, c.llm_vocab, R, c.llm_vocab, K, ws->beam_scores, ws->cand_val, ws->cand_tok, ws->topk_flag, st));
     return launch_beam_step(a, 0, seq[cur], anc[cur], seq[cur ^ 1], anc[cur ^ 1], st);
@@ -1378,6 +1401,8 @@ int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream) {
   g.rowinfo = (const int4*)d->rowinfo; g.taps = d->taps; g.Kvalid = d->Kvalid; g.frameinfo = (const int2*)d->frameinfo;
   g.norm_gain = d->norm_gain; g.norm_eps = d->norm_eps; g.swiglu_pairs = d->swiglu_pairs;
   g.ksplit = d->ksplit < 1 ? 1 : d->ksplit; g.partial = d->partial;
+  g.rn_out = d->rn_out; g.rn_ld = d->rn_ld; g.rn_gain = d->rn_gain; g.rn_eps = d->rn_eps;
+  OAVSR_REQUIRE(!g.rn_out || g.ksplit > 1, "gemm: rn_out needs split-K (ksplit > 1)");
   if (d->skinny == 2) {      // tests: the 8-wave ping-pong 256 x 256 kernel whatever the dispatcher's rule says
     OAVSR_REQUIRE(gemm_8p_supported(g), "op_gemm: shape / layout not supported by the ping-pong kernel");
     return launch_gemm_8p(g, (hipStream_t)stream);

@@ -57,6 +57,7 @@ class GemmDesc(C.Structure):
         ("rowinfo", C.c_void_p), ("taps", C.c_int32), ("Kvalid", C.c_int32), ("frameinfo", C.c_void_p),
         ("skinny", C.c_int32), ("norm_gain", C.c_void_p), ("norm_eps", C.c_float), ("swiglu_pairs", C.c_int32),
         ("ksplit", C.c_int32), ("partial", C.c_void_p),
+        ("rn_out", C.c_void_p), ("rn_ld", C.c_int64), ("rn_gain", C.c_void_p), ("rn_eps", C.c_float),
     ]
 
 

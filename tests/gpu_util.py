@@ -53,7 +53,7 @@ def gemm(dtype, A, W, *, A2=None, W2=None, scale=None, bias=None, prelu=None, ac
     d.groups = groups
     d.skinny = int(skinny)
     for k, v in geom.items():
-        if k in ("rowinfo", "frameinfo", "norm_gain", "partial"):
+        if k in ("rowinfo", "frameinfo", "norm_gain", "partial", "rn_out", "rn_gain"):
             setattr(d, k, P(v))
         elif k != "groups":
             setattr(d, k, v)

@@ -67,6 +67,31 @@ def test_gemm_splitk(dtype, M, N, K, K2, S):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,S", [(120, 2048, 8192, 16), (120, 2048, 2048, 8), (45, 4096, 1024, 4), (33, 3584, 512, 2), (300, 2048, 512, 3)])
+def test_gemm_splitk_reduce_with_rmsnorm(dtype, M, N, K, S):
+    """Split-K whose reduce pass also writes RMSNorm(C) * gain (beam-search decode: o_proj -> ln2, down_proj -> the next ln1).  C must be
+    bit-identical to the plain reduce pass; the normalised rows are checked against fp32 torch on the rounded C."""
+    a, _ = q(rnd(M, K, seed=1), dtype)
+    w, _ = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
+    r, _ = q(rnd(M, N, seed=5), dtype)
+    gain = (rnd(N, seed=6) * 0.1 + 1).to(DEV)
+    part = torch.empty(S * M * N, dtype=torch.float32, device=DEV)
+    ref_c = gemm(dtype, a, w, residual=r, ksplit=S, partial=part)
+    h = torch.full((M, N), float("nan"), dtype=tdt(dtype), device=DEV)
+    for _ in range(2):
+        out = gemm(dtype, a, w, residual=r, ksplit=S, partial=part, rn_out=h, rn_ld=N, rn_gain=gain, rn_eps=1e-5)
+        assert torch.equal(out, ref_c), "C differs from the plain reduce pass"
+        x = out.float()
+        ref_h = x * torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-5) * gain
+        close(h, ref_h.cpu(), tol(dtype) if dtype == "bf16" else 1e-5, rtol=0.0, what="reduce + rmsnorm")
+    # in-place residual (C aliases the residual rows), as the decoder uses it
+    r2 = r.clone()
+    h2 = torch.empty_like(h)
+    gemm(dtype, a, w, residual=r2, ksplit=S, partial=part, C_out=r2, rn_out=h2, rn_ld=N, rn_gain=gain, rn_eps=1e-5)
+    assert torch.equal(r2, ref_c) and torch.equal(h2, h)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K,K2", [(4096, 2048, 512, 0), (3000, 3072 + 40, 384, 128), (12000, 1024, 256, 0)])
 def test_gemm_dma_pipeline(dtype, M, N, K, K2):
     """Shapes large enough to take the LDS-DMA 256x128 3-stage kernel (gemm2.hip): ragged M/N edges, 2nd K segment, epilogue."""
