@@ -474,6 +474,8 @@ int launch_dma_mode(const GemmArgs& a, hipStream_t st) {
   if (dma_tile_choice(a) == 4) {
     // every workgroup re-reads the A rows of its k range: 64-column tiles move 2 B of A per byte of W, 128-column tiles 1 B --
     // worth it as soon as N / 128 still gives every CU several workgroups (lm_head)
+    static const int wide = [] { const char* e = getenv("OAVSR_GEMM_M128_WIDE"); return e ? atoi(e) : 1; }();
+    if (wide && a.N >= 256 * 256 && a.ksplit <= 1) return launch_dma<T, A_DENSE, 128, 256, 3, 2, 8>(a, st);   // 8 waves (2 x 4) of 64 x 64: 0.5 B of A per byte of W
     if (a.N >= 256 * 128 && a.ksplit <= 1) return launch_dma<T, A_DENSE, 128, 128, 3, 2, 4>(a, st);   // 4 waves (2 x 2) of 64 x 64
     return launch_dma<T, A_DENSE, 128, 64, 4, 4, 4>(a, st);     // 4 waves (4 x 1) of 32 x 64, 4 stages of 24 KiB
   }

@@ -38,7 +38,7 @@ def close(out, ref, atol, rtol=0.0, what=""):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (200, 96, 256), (1, 64, 128), (333, 300, 384), (64, 1000, 128)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (200, 96, 256), (1, 64, 128), (333, 300, 384), (64, 1000, 128), (120, 65536 + 88, 256), (100, 33000, 128)])
 def test_gemm_dense(dtype, M, N, K):
     a, ar = q(rnd(M, K, seed=1), dtype)
     w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
