@@ -94,6 +94,39 @@ def collate_test(samples: Sequence[Dict[str, torch.Tensor]], modality: str, bos_
     return batch
 
 
+class FlatCollator:
+    """collate_test for the HIP-backed model without the padded video tensor: the valid frames of the batch go back to back into a pinned
+    staging buffer ("video_flat", [sum T, 88, 88]; the engine's input layout) and the waveforms right-padded into another one, so the
+    host-to-device copies are asynchronous and the host never touches a [B, T_max, 1, 88, 88] tensor (for 8 x 16 s clips: 99 MB that
+    pad_sequence writes and the engine would immediately re-pack).  One collator per in-flight slot: its buffers are reused by every batch
+    of that slot, so the previous batch of the slot must have been consumed (evaluate() drains a slot before it refills it)."""
+
+    def __init__(self, batch_size: int, tv_max: int, ts_max: int, pin: bool = True):
+        pin = pin and torch.cuda.is_available()
+        self.video = torch.empty(batch_size * max(tv_max, 1), 88, 88, dtype=torch.float32, pin_memory=pin)
+        self.audio = torch.empty(batch_size, max(ts_max, 1), dtype=torch.float32, pin_memory=pin)
+
+    def __call__(self, samples: Sequence[Dict[str, torch.Tensor]], modality: str, bos_id: Optional[int]) -> Dict[str, torch.Tensor]:
+        B = len(samples)
+        batch: Dict[str, torch.Tensor] = {}
+        batch["tokens"] = torch.full((B, 1), bos_id, dtype=torch.long) if bos_id is not None and bos_id >= 0 else torch.zeros(B, 0, dtype=torch.long)
+        if modality in ("audio", "audiovisual"):
+            lens = [int(s["audio"].shape[0]) for s in samples]
+            a = self.audio[:B, : max(lens)]
+            a.zero_()
+            for b, s in enumerate(samples):
+                a[b, : lens[b]].copy_(s["audio"][:, 0] if s["audio"].dim() == 2 else s["audio"])
+            batch["lengths"], batch["audio"] = torch.tensor(lens), a
+        if modality in ("video", "audiovisual"):
+            tv = [int(s["video"].shape[0]) for s in samples]
+            o = 0
+            for s, t in zip(samples, tv):
+                self.video[o:o + t].copy_(s["video"][:, 0])
+                o += t
+            batch["video_lengths"], batch["video_flat"] = torch.tensor(tv), self.video[:o]
+        return batch
+
+
 # ---- lightning_OmniAVSR.py:53-91 : tokenizer surgery ---------------------------------------------------------------
 DEFAULT_PAD_TOKEN = "<pad>"
 AUDIO_SOS, AUDIO_EOS, VIDEO_SOS, VIDEO_EOS = "<audio>", "</audio>", "<video>", "</video>"
@@ -189,24 +222,76 @@ class WerMeter:
 
 
 def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], modality: str, to_text: Callable[[torch.Tensor], List[str]],
-             batch_size: int = 8, bos_id: Optional[int] = None, rank: int = 0, world: int = 1, **forward_kw) -> WerMeter:
+             batch_size: int = 8, bos_id: Optional[int] = None, rank: int = 0, world: int = 1, in_flight: int = 1, **forward_kw) -> WerMeter:
     """Evaluation loop of eval_OmniAVSR.py:273-357 for one (task, rates) cell, utterance-sharded over `world` ranks
      and batched (the reference runs batch 1).  `samples`: [(transformed sample dict, gold text)].
+    `in_flight` > 1 keeps that many batches in flight on their own HIP streams / workspaces (the encoders of one overlap the decode loop
+    of the others; same ids, same counters, ~1.4x the throughput on MI355X) -- needs the HIP-backed model (`model.engine`).
     Returns this rank's WerMeter; combine with dist.reduce_wer_counters."""
     from .dist import make_batches, shard_utterances
     dur = [float((s.get("video") if "video" in s else s["audio"]).shape[0]) / (1.0 if "video" in s else 640.0) for s, _ in samples]
     owned = shard_utterances(dur, world, rank)
     meter = WerMeter()
     model.modality = modality
-    for idxs in make_batches(owned, batch_size):
-        batch = collate_test([samples[i][0] for i in idxs], modality, bos_id)
-        try:
-            ids = model(batch, is_trainval=False, modality=modality if getattr(model, "is_task_specific", False) else None, **forward_kw)
-        except (RuntimeError, ValueError) as e:           # a bad clip must not lose the evaluation: report its batch, go on
-            meter.failed.extend(idxs)
-            print(f"evaluate: batch {idxs} failed: {e}")
-            continue
-        texts = to_text(ids)
-        for i, t in zip(idxs, texts):
+    kw_mod = modality if getattr(model, "is_task_specific", False) else None
+    batches = list(make_batches(owned, batch_size))
+
+    def score(idxs, ids):
+        for i, t in zip(idxs, to_text(ids)):
             meter.update(samples[i][1], t)
+
+    if in_flight <= 1 or not batches:
+        for idxs in batches:
+            batch = collate_test([samples[i][0] for i in idxs], modality, bos_id)
+            try:
+                ids = model(batch, is_trainval=False, modality=kw_mod, **forward_kw)
+            except (RuntimeError, ValueError) as e:           # a bad clip must not lose the evaluation: report its batch, go on
+                meter.failed.extend(idxs)
+                print(f"evaluate: batch {idxs} failed: {e}")
+                continue
+            score(idxs, ids)
+        return meter
+
+    eng = model.engine
+    dev = eng.device
+    streams = [torch.cuda.Stream(device=dev) for _ in range(in_flight)]
+    # one workspace per slot, sized for the longest owned clip: nothing is re-created while other slots are busy
+    tv_max = max([int(samples[i][0]["video"].shape[0]) for i in owned if "video" in samples[i][0]] or [1])
+    ts_max = max([int(samples[i][0]["audio"].shape[0]) for i in owned if "audio" in samples[i][0]] or [16000])
+    eng.reserve(in_flight, batch_size, tv_max, ts_max, getattr(model, "num_beams", 1), getattr(model, "max_dec_tokens", None))
+    # 2 x in_flight + 1 staging sets: while the main thread launches batch n and waits for the oldest one, a helper thread collates batch
+    # n + 1 into the set that the batch drained last released (the reference gets the same overlap from its DataLoader workers)
+    from concurrent.futures import ThreadPoolExecutor
+    limit = 2 * in_flight                                     # calls queued at most: a slot's stream orders its own calls, so the host may run one round ahead
+    nset = limit + 1
+    collators = [FlatCollator(batch_size, tv_max, ts_max) for _ in range(nset)]
+    pool = ThreadPoolExecutor(1)
+    collate = lambda n: collators[n % nset]([samples[i][0] for i in batches[n]], modality, bos_id)      # noqa: E731
+    eng.serialize_encoders(True)
+    pending = []                                              # [(slot, idxs, PendingIds)], oldest first
+    try:
+        fut = pool.submit(collate, 0)
+        for n, idxs in enumerate(batches):
+            slot = n % in_flight
+            while len(pending) >= limit:                      # frees the staging set batch n + 1 is about to be collated into
+                _, done_idxs, p = pending.pop(0)
+                score(done_idxs, p.result())
+            batch = fut.result()
+            if n + 1 < len(batches):
+                fut = pool.submit(collate, n + 1)
+            try:
+                with torch.cuda.stream(streams[slot]):
+                    p = model(batch, is_trainval=False, modality=kw_mod, slot=slot, sync=False, **forward_kw)
+            except (RuntimeError, ValueError) as e:
+                meter.failed.extend(idxs)
+                print(f"evaluate: batch {idxs} failed: {e}")
+                torch.cuda.synchronize(dev)                   # whatever was queued from the staging set must be done before it is refilled
+                continue
+            pending.append((slot, idxs, p))
+        for _, done_idxs, p in pending:
+            score(done_idxs, p.result())
+    finally:
+        pool.shutdown(wait=True)
+        torch.cuda.synchronize(dev)
+        eng.serialize_encoders(False)
     return meter

@@ -147,6 +147,13 @@ class OmniEngine:
         self._slots[slot] = (ptr, (B, Tv, Ts, beams, max_new))
         return ptr
 
+    def reserve(self, slots: int, B: int, Tv: int, Ts: int, beams: int = 1, max_new: Optional[int] = None):
+        """Size the workspaces of slots 0..slots-1 once (e.g. for the longest clip of a dataset): later calls that fit reuse them, so no
+        workspace is re-created while other slots have work in flight."""
+        for s_ in range(slots):
+            self._slot_workspace(s_, B, Tv, Ts, beams, max_new or self.spec.max_dec_tokens)
+        return self
+
     def close(self):
         for ptr, _ in self._slots.values():
             if ptr:
@@ -252,10 +259,12 @@ class OmniEngine:
         keep = None
         if use_v:
             flat = video if video_is_flat else self._flat_video(video, Tv)
+            if flat.device != self.device or flat.dtype != torch.float32 or not flat.is_contiguous():
+                flat = flat.to(self.device, torch.float32, non_blocking=True).contiguous()     # pinned host buffers copy asynchronously
         if use_a:
             a = audio if audio.dim() == 2 else audio[..., 0]
             if a.device != self.device or a.dtype != torch.float32 or not a.is_contiguous():
-                a = a.to(self.device, torch.float32).contiguous()
+                a = a.to(self.device, torch.float32, non_blocking=True).contiguous()
             keep = [whisper_keep_tokens(int(n)) for n in lengths]
         ws = self._slot_workspace(slot, B, max(Tv) if use_v else 1, int(max(lengths)) if use_a else 16000, beams, max_new)
         ids = torch.empty(B, max_new, dtype=torch.int32, device=self.device)
@@ -281,6 +290,28 @@ class OmniEngine:
         n = self.lib.oavsr_profile_read(arr, 256)
         return [dict(name=arr[i].name.decode(), launches=int(arr[i].launches), ms=float(arr[i].ms), flops=float(arr[i].flops),
                      bytes=float(arr[i].bytes)) for i in range(max(n, 0))]
+
+
+class PendingIds:
+    """Result of `AVSR_LLMs.forward(..., sync=False)`: the call has been queued on the caller's current HIP stream; `result()` waits for it
+    and returns what the synchronous forward returns (ids [B, n] int64 on the device, n = longest hypothesis)."""
+
+    def __init__(self, ids: torch.Tensor, lens: torch.Tensor, stream: "torch.cuda.Stream"):
+        self._ids, self._lens, self._stream = ids, lens, stream
+        self._event = torch.cuda.Event()
+        self._event.record(stream)
+
+    def done(self) -> bool:
+        return self._event.query()
+
+    def result(self) -> torch.Tensor:
+        self._event.synchronize()
+        with torch.cuda.stream(self._stream):                # the tensors belong to that stream's allocator pool
+            n = int(self._lens.cpu().max())
+            out = self._ids[:, :n].to(torch.long)
+        self._stream.synchronize()
+        out.record_stream(torch.cuda.current_stream(out.device))
+        return out
 
 
 class AVSR_LLMs:
@@ -346,7 +377,9 @@ class AVSR_LLMs:
         return self.forward(*a, **k)
 
     def forward(self, inputs, is_trainval=True, modality=None, test_ratio_matry_audio=None, test_ratio_matry_video=None,
-                force_len: bool = False):
+                force_len: bool = False, slot: int = 0, sync: bool = True):
+        """`slot` / `sync` are not reference arguments: `sync=False` queues the call on the caller's current HIP stream with workspace
+        `slot` and returns a PendingIds (harness.evaluate(in_flight=k) keeps k batches in flight that way, as bench.py does)."""
         if is_trainval:
             raise NotImplementedError("training branch (modeling_OmniAVSR.py:265-306) is out of scope of the inference hot path")
         task = self.modality
@@ -368,7 +401,10 @@ class AVSR_LLMs:
             raise KeyError(ra)        # matry_map_audio[...] modeling_OmniAVSR.py:447,556
         if use_v and rv not in self.spec.rates("video"):
             raise KeyError(rv)
-        video = inputs.get("video") if use_v else None
+        # "video_flat" (not a reference key; harness.collate_flat): the valid frames of all utterances back to back, [sum T, 88, 88] f32 --
+        # what the engine consumes, without the padded [B, T, 1, 88, 88] detour; needs "video_lengths"
+        video_is_flat = use_v and "video_flat" in inputs
+        video = (inputs["video_flat"] if video_is_flat else inputs.get("video")) if use_v else None
         audio = inputs.get("audio") if use_a else None
         Tv = lengths = None
         if use_v:
@@ -386,7 +422,9 @@ class AVSR_LLMs:
         # `model.encoder_chunk = 8` (not a reference attribute): large evaluation batches run their encoders / prefill in chunks of
         # that many utterances and share one decode loop (oavsr_generate_chunked; identical ids)
         ids, lens = self.engine.generate(task, video, Tv, audio, lengths, ra, rv, self.num_beams, self.max_dec_tokens, force_len,
-                                         chunk=getattr(self, "encoder_chunk", None))
+                                         video_is_flat=video_is_flat, slot=slot, chunk=getattr(self, "encoder_chunk", None))
+        if not sync:
+            return PendingIds(ids, lens, torch.cuda.current_stream(self.engine.device))
         lens_h = lens.cpu()
         n = int(lens_h.max())
         return ids[:, :n].to(torch.long)

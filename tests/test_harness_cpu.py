@@ -117,3 +117,20 @@ def test_evaluate_reports_failed_batches():
     samples = [({"video": torch.zeros(t, 1, 88, 88)}, "w1 w2") for t in (5, 7, 5, 5)]
     m = H.evaluate(Boom(), samples, "video", lambda ids: ["w1 w2"] * ids.shape[0], batch_size=1)
     assert m.failed == [1] and m.total_length == 6 and m.total_edit_distance == 0
+
+
+def test_flat_collator_matches_collate_test():
+    """FlatCollator (pinned staging, engine layout) carries the same data as the reference-format collate: the valid frames back to back,
+    the waveforms right-padded with zeros, the same lengths -- also when its buffers are reused by a shorter batch."""
+    import torch
+    from omni_avsr_amd import harness as H
+    g = torch.Generator().manual_seed(0)
+    col = H.FlatCollator(3, 12, 12 * 640, pin=False)
+    for frames in ([9, 12, 7], [5, 3]):
+        samples = [dict(video=torch.randn(n, 1, 88, 88, generator=g), audio=torch.randn(n * 640, 1, generator=g)) for n in frames]
+        ref = H.collate_test(samples, "audiovisual", 5)
+        got = col(samples, "audiovisual", 5)
+        assert torch.equal(got["tokens"], ref["tokens"]) and torch.equal(got["lengths"], ref["lengths"]) and torch.equal(got["video_lengths"], ref["video_lengths"])
+        assert torch.equal(got["audio"], ref["audio"][..., 0])
+        flat = torch.cat([ref["video"][b, :n, 0] for b, n in enumerate(frames)], 0)
+        assert torch.equal(got["video_flat"], flat)

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""harness.evaluate on the headline model with HOST inputs (collate + host-to-device copies inside the timed loop: the PCIe-inclusive rate
+of the caller-side loop), sequential vs batches in flight.  Synthetic 16 s clips, random-init weights, greedy, 32 tokens (EOS is not
+suppressed here, so hypotheses may be shorter)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench as BN
+from omni_avsr_amd import harness as H
+from omni_avsr_amd.modeling import AVSR_LLMs, OmniEngine
+from omni_avsr_amd.synth import synth_state_dict
+
+
+class A:
+    llm = None; max_new = 32; beams = 1; dtype = "bf16"
+
+
+pre = BN.PRESETS["c1"]
+spec = BN.build_spec(A, pre)
+eng = OmniEngine(spec, dtype="bf16").load_state_dict(synth_state_dict(spec, seed=1234, device="cuda:0"))
+m = AVSR_LLMs.__new__(AVSR_LLMs)
+m.modality, m.max_dec_tokens, m.num_beams = "audiovisual", 32, 1
+m.is_matryoshka, m.is_task_specific, m.spec, m.engine = True, True, spec, eng
+m.downsample_ratio_audio, m.downsample_ratio_video = spec.downsample_ratio_audio, spec.downsample_ratio_video
+n_utt = int(sys.argv[1]) if len(sys.argv) > 1 else 96
+g = torch.Generator().manual_seed(0)
+samples = []
+for i in range(n_utt):
+    v = torch.randn(400, 1, 88, 88, generator=g)
+    a = torch.nn.functional.layer_norm(torch.randn(256000, generator=g), (256000,))[:, None]
+    samples.append(({"video": v, "audio": a}, "gold"))
+to_text = lambda ids: [" ".join(str(int(t)) for t in row) for row in ids.cpu()]      # noqa: E731
+out = {}
+for k in (1, 3, 1, 3):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    meter = H.evaluate(m, samples, "audiovisual", to_text, batch_size=8, bos_id=spec.ids["bos"], in_flight=k, test_ratio_matry_audio=4, test_ratio_matry_video=4)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    hyp = sorted(h for _, h, _, _ in meter.per_utt)
+    assert out.setdefault("hyp", hyp) == hyp, "hypotheses differ between the modes"
+    print(f"in_flight={k}: {n_utt / dt:7.1f} utt/s  ({dt / (n_utt / 8) * 1e3:.1f} ms per batch of 8, host inputs)", flush=True)
