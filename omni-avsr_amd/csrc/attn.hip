@@ -220,12 +220,14 @@ __global__ __launch_bounds__(kThreads) void attn_varlen_kernel(const AttnArgs p)
 
 // ------------------------------------------------------------------------------------------------
 // (1b) attn_dma_kernel: the bf16 / head_dim 64 fast path of (1).  Same math and fragment layouts; what changes is the data
-//      movement: K/V tiles (64 keys x 128 B each) go HBM -> LDS by LDS-DMA through a 3-stage ring, two tiles ahead of their
-//      use, with ONE barrier per tile (counted vmcnt, never a drain); a wave owns QT query tiles of 16 rows so every K / V^T
-//      fragment read from LDS feeds QT MFMAs; masking is skipped on tiles that are fully visible; exp2 is the bare
-//      v_exp_f32 with the softmax scale folded into one fma.
-__device__ __attribute__((aligned(256))) unsigned int g_attn_zero_page[64];
-
+//      movement and the instruction count of the soft-max, which is what bounds this kernel (VALU issue, not MFMA):
+//      * K/V tiles (64 keys x 128 B each) go HBM -> LDS by LDS-DMA (buffer_load ... lds) through a 3-stage ring, two tiles ahead of
+//        their use, with ONE barrier per tile (counted vmcnt, never a drain); addressing is a constant VGPR offset per lane plus a
+//        scalar tile offset, rows past the sequence end are zero-filled by the buffer range check;
+//      * a wave owns QT query tiles of 16 rows so every K / V^T fragment read from LDS feeds QT MFMAs;
+//      * two loop bodies: the leading, fully visible tiles run one with no masking code at all, the edge tiles the masked one;
+//      * row max across the lane groups with v_permlane16/32_swap (no LDS round trip); exp2 is the bare v_exp_f32 with the softmax
+//        scale folded into one fma; plain (unpacked) fp32 math.
 // max over lanes l, l^16, l^32, l^48 with the gfx950 row / half swaps: v_permlane16_swap exchanges rows 1 <-> 0' and 3 <-> 2' of the two
 // operands (rows = 16 lanes), v_permlane32_swap the upper half of one with the lower half of the other; with both operands holding x,
 // max(a, b) afterwards is the xor-16 (xor-32) butterfly step.  The hardware needs 2 wait states between a VALU write and the swap.
