@@ -104,7 +104,7 @@ class FlatCollator:
     def __init__(self, batch_size: int, tv_max: int, ts_max: int, pin: bool = True):
         pin = pin and torch.cuda.is_available()
         self.video = torch.empty(batch_size * max(tv_max, 1), 88, 88, dtype=torch.float32, pin_memory=pin)
-        self.audio = torch.empty(batch_size, max(ts_max, 1), dtype=torch.float32, pin_memory=pin)
+        self.audio = torch.empty(batch_size * max(ts_max, 1), dtype=torch.float32, pin_memory=pin)      # carved into a CONTIGUOUS [B, longest] per batch
 
     def __call__(self, samples: Sequence[Dict[str, torch.Tensor]], modality: str, bos_id: Optional[int]) -> Dict[str, torch.Tensor]:
         B = len(samples)
@@ -112,7 +112,7 @@ class FlatCollator:
         batch["tokens"] = torch.full((B, 1), bos_id, dtype=torch.long) if bos_id is not None and bos_id >= 0 else torch.zeros(B, 0, dtype=torch.long)
         if modality in ("audio", "audiovisual"):
             lens = [int(s["audio"].shape[0]) for s in samples]
-            a = self.audio[:B, : max(lens)]
+            a = self.audio[: B * max(lens)].view(B, max(lens))      # contiguous: a strided pinned view would be copied through a pageable temporary
             a.zero_()
             for b, s in enumerate(samples):
                 a[b, : lens[b]].copy_(s["audio"][:, 0] if s["audio"].dim() == 2 else s["audio"])

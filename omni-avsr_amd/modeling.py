@@ -260,11 +260,11 @@ class OmniEngine:
         if use_v:
             flat = video if video_is_flat else self._flat_video(video, Tv)
             if flat.device != self.device or flat.dtype != torch.float32 or not flat.is_contiguous():
-                flat = flat.to(self.device, torch.float32, non_blocking=True).contiguous()     # pinned host buffers copy asynchronously
+                flat = flat.to(self.device, torch.float32, non_blocking=flat.is_pinned()).contiguous()     # pinned staging buffers copy asynchronously
         if use_a:
             a = audio if audio.dim() == 2 else audio[..., 0]
             if a.device != self.device or a.dtype != torch.float32 or not a.is_contiguous():
-                a = a.to(self.device, torch.float32, non_blocking=True).contiguous()
+                a = a.to(self.device, torch.float32, non_blocking=a.is_pinned()).contiguous()
             keep = [whisper_keep_tokens(int(n)) for n in lengths]
         ws = self._slot_workspace(slot, B, max(Tv) if use_v else 1, int(max(lengths)) if use_a else 16000, beams, max_new)
         ids = torch.empty(B, max_new, dtype=torch.int32, device=self.device)
