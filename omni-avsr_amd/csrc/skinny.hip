@@ -75,9 +75,11 @@ __device__ __forceinline__ void skinny_body(const GemmArgs& p, const int bid, ch
   constexpr int MR = MT * 16, NC = NT * 16;
   float* sred = reinterpret_cast<float*>(smem);   // [8][MR][NC]
   float* sred2 = sred + kWaves * MR * NC;         // [8][MR][NC]   (NORM && K2)
-  float* sssq = sred2 + (NORM ? kWaves * MR * NC : 0);   // [8][MR]
+  float* sssq = sred2 + ((NORM && p.K2) ? kWaves * MR * NC : 0);   // [8][MR]   (the second image exists only with a second K segment)
   float* sgain = sssq + (NORM ? kWaves * MR : 0);        // [K]  norm gain, staged once per workgroup (small tiles only)
-  constexpr bool GAIN_LDS = NORM && (kWaves * MR * NC * 8 + kWaves * MR * 4) <= 96 * 1024;
+  // staged norm gain: pays for single-round launches (8-wave workgroups); the many-round lm_head tiles (4 waves) read it from L2 instead --
+  // no staging pass and no barrier in front of every tile's stream (109 -> 105 us).  Same values either way.
+  constexpr bool GAIN_LDS = NORM && W == kMaxWaves && (kWaves * MR * NC * 8 + kWaves * MR * 4) <= 96 * 1024;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, g = lane >> 4;
   const int hi = HALF ? (r16 >> 3) : 0, rw = HALF ? (r16 & 7) : r16;   // k-block parity, row within the operand tile
@@ -619,8 +621,9 @@ int launch_sk_u(const GemmArgs& a, hipStream_t st) {
   constexpr int kWaves = W, kThreads = W * 64;
   constexpr int smem0 = kWaves * MT * 16 * NT * 16 * 4 * (NORM ? 2 : 1) + (NORM ? kWaves * MT * 16 * 4 : 0);
   static_assert(smem0 <= 160 * 1024, "LDS");
-  constexpr bool gain_lds = NORM && smem0 <= 96 * 1024;
-  const int smem = smem0 + (gain_lds ? a.K * 4 : 0);   // + the staged norm gain
+  constexpr bool gain_lds = NORM && W == kMaxWaves && smem0 <= 96 * 1024;     // as skinny_body's GAIN_LDS
+  // the partial sums of the un-normalised second K segment get their own LDS image only when there is one
+  const int smem = smem0 - ((NORM && !a.K2) ? kWaves * MT * 16 * NT * 16 * 4 : 0) + (gain_lds ? a.K * 4 : 0);   // + the staged norm gain
   OAVSR_REQUIRE(smem <= 160 * 1024, "skinny gemm: K=%d too deep for the fused RMSNorm prologue", a.K);
   auto kern = skinny_kernel<T, MT, NT, NORM, U, HALF, W>;
   static bool attr_set = false;
@@ -648,6 +651,8 @@ int launch_sk(const GemmArgs& a, hipStream_t st) {
     const bool want = NT == 1 ? (a.N >= 64 && a.N / 16 < 384) : true;
     if (half_enabled() && want && a.M <= 8 && (!a.swiglu_pairs || a.N % 32 == 0) && (a.K / kbe) % 2 == 0) {   // ragged N: loads and stores are guarded
       // many rounds of wide tiles (lm_head): 4-wave workgroups overlap their reduce / epilogue phases better (110 -> 101 us)
+      // (deeper request queues per wave -- U = 4 / 8, the whole k range of a wave in one go -- were measured: 18.4 -> 26.3 us gate/up,
+      //  109 -> 148 us lm_head; the 200+ VGPRs they need leave one workgroup per CU)
       if (NT == 4 && a.N >= 65536) return launch_sk_u<T, 1, NT, NORM, U0, true, 4>(a, st);
       return launch_sk_u<T, 1, NT, NORM, U0, true>(a, st);
     }
