@@ -24,11 +24,6 @@ constexpr int KT = 64;   // keys per LDS tile
 
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
-}
-
 // 8-byte transposing LDS read with an immediate offset; the caller orders it with an explicit s_waitcnt lgkmcnt
 template <int OFF>
 __device__ __forceinline__ u32x2 lds_tr16_b64(unsigned addr) {

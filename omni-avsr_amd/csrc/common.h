@@ -1,6 +1,7 @@
 // Shared device/host helpers for the Omni-AVSR gfx950 kernels.
 // One code path only: CDNA4 (wave64, MFMA 16x16, 160 KiB LDS).  No CUDA compatibility layer.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -52,6 +53,12 @@ template <> __device__ __forceinline__ Chunk16 chunk_from_f32<bf16_t>(const floa
 #pragma unroll
   for (int i = 0; i < 8; ++i) h[i] = (bf16_t)in[i];
   Chunk16 c; c.v = __builtin_bit_cast(u32x4, h); return c;
+}
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

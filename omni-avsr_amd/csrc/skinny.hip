@@ -20,6 +20,7 @@
 // are discarded).  One wave load then covers 8 weight rows x one whole 128-byte line.
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include "kernels.h"
 
 namespace oavsr {
@@ -575,6 +576,160 @@ int launch_r16(const GemmArgs& a, hipStream_t st) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// lm_head-shaped GEMV (<= 8 rows, one K segment, thousands of 32-column tiles, plain epilogue): the SAME tile arithmetic as skinny_body's
+// HALF / NT = 4 / 4-wave variant -- same lane <-> element mapping, same k order per wave, same cross-wave sums, hence the same bits --
+// run by PERSISTENT workgroups that walk tiles bid, bid + grid, ...:
+//   * the activation fragments of a wave (its k blocks of the <= 8 rows, times the norm gain) and the rows' 1 / rms do not depend on the
+//     tile: loaded, normalised and reduced ONCE per workgroup instead of once per tile;
+//   * the weight stream never drains: the first trip of the next tile is requested before the last trip of the current one is consumed,
+//     so a wave that waits at the tile's barrier (partial sums -> LDS -> 256 outputs) already has 8 KiB in flight again; the LDS image
+//     is double-buffered, one barrier per tile.
+// AS = k steps (pairs of 64-byte k blocks) per wave: 8 covers K <= 2048 (bf16), 16 K <= 4096.
+template <typename T, bool NORM, int AS>
+__global__ __launch_bounds__(256, AS <= 8 ? 3 : 2) void skinny_persist_kernel(const GemmArgs p, const int ntiles) {
+  constexpr int W = 4, NT = 4, U = 2, TPT = AS / U, MR = 16, NC = 64;
+  constexpr int KBE = 64 / (int)sizeof(T), VEC = TypeInfo<T>::kVec;
+  static_assert(TPT % 2 == 0, "the weight double buffer alternates per trip");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sred = reinterpret_cast<float*>(smem);            // [2][W][MR][NC]
+  float* sssq = sred + 2 * W * MR * NC;                    // [W][MR]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4, hi = r16 >> 3, rw = r16 & 7;
+  const T* A1 = reinterpret_cast<const T*>(p.A);
+  const T* W1 = reinterpret_cast<const T*>(p.W);
+  const int nsteps = (p.K / KBE) / 2;                      // K / KBE is even (launcher)
+
+  Chunk16 bf[2][U][NT];
+  auto issue = [&](const int tile, const int trip, auto buf_c) __attribute__((always_inline)) {
+    constexpr int B = decltype(buf_c)::value;
+    const int n0 = tile * (NT * 8);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int st = wave + W * (trip * U + u);
+      const int k = (2 * st + hi) * KBE + g * VEC;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + j * 8 + rw;
+        if (st < nsteps && n < p.N) bf[B][u][j].v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W1 + (int64_t)n * p.ldw + k));
+        else bf[B][u][j] = zchunk();
+      }
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) issue(tile, 0, std::integral_constant<int, 0>{});     // the stream starts before anything else is fetched
+
+  // ---- once per workgroup: this wave's activation fragments (x gain), the rows' sums of squares
+  Chunk16 afn[AS];
+  float ssq = 0.f;
+#pragma unroll
+  for (int i = 0; i < AS; ++i) {
+    const int st = wave + W * i;
+    const int k = (2 * st + hi) * KBE + g * VEC;
+    afn[i] = (st < nsteps && rw < p.M) ? *reinterpret_cast<const Chunk16*>(A1 + (int64_t)rw * p.lda + k) : zchunk();
+  }
+  if (NORM) {
+#pragma unroll
+    for (int i = 0; i < AS; ++i) {
+      const int st = wave + W * i;
+      if (st < nsteps) {
+        const int k = (2 * st + hi) * KBE + g * VEC;
+        float gn[VEC], f[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e += 4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(p.norm_gain + k + e);
+          gn[e] = t[0]; gn[e + 1] = t[1]; gn[e + 2] = t[2]; gn[e + 3] = t[3];
+        }
+        chunk_to_f32<T>(afn[i], f);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { ssq = fmaf(f[e], f[e], ssq); f[e] *= gn[e]; }   // the expressions of skinny_body, in its order
+        afn[i] = chunk_from_f32<T>(f);
+      }
+    }
+    float v = ssq;
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (g == 0) sssq[wave * MR + r16] = v;
+    __syncthreads();
+  }
+  // one output element per thread and tile: row m, column nn of the 8 x 32 tile
+  const int m = tid >> 5, nn = tid & 31;
+  const int lc = (nn >> 3) * 16 + (nn & 7);
+  float rs = 1.f;
+  if (NORM) {
+    float sq = 0.f;
+#pragma unroll
+    for (int w = 0; w < W; ++w) { sq += sssq[w * MR + m]; sq += sssq[w * MR + m + 8]; }
+    rs = rsqrtf(sq / (float)p.K + p.norm_eps);
+  }
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int par = 0;
+  for (; tile < ntiles; tile += gridDim.x) {
+    static_for<0, TPT>([&](auto TR) {
+      constexpr int trip = decltype(TR)::value;
+      if constexpr (trip + 1 < TPT) issue(tile, trip + 1, std::integral_constant<int, (trip + 1) & 1>{});
+      else if (tile + (int)gridDim.x < ntiles) issue(tile + (int)gridDim.x, 0, std::integral_constant<int, 0>{});
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) MmaS<T>::run(afn[trip * U + u], bf[trip & 1][u][j], acc[j]);
+    });
+    float* sr = sred + par * (W * MR * NC);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sr[(wave * MR + g * 4 + r) * NC + j * 16 + r16] = acc[j][r];
+      acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    const int n = tile * (NT * 8) + nn;
+    if (m < p.M && n < p.N) {
+      float y = 0.f;
+#pragma unroll
+      for (int w = 0; w < W; ++w) { y += sr[(w * MR + m) * NC + lc]; y += sr[(w * MR + m + 8) * NC + lc + 8]; }
+      if (NORM) y = fmaf(y, rs, 0.f);
+      y = fmaf(y, p.col_scale ? p.col_scale[n] : 1.f, p.col_bias ? p.col_bias[n] : 0.f);
+      if (p.out_f32) reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n] = y;
+      else reinterpret_cast<T*>(p.C)[(int64_t)m * p.ldc + n] = from_f32<T>(y);
+    }
+    par ^= 1;
+  }
+}
+
+template <typename T, bool NORM>
+int launch_persist(const GemmArgs& a, hipStream_t st) {
+  constexpr int kbe = 64 / (int)sizeof(T);
+  const int nsteps = (a.K / kbe) / 2;
+  const int ntiles = ceil_div(a.N, 32);
+  static const int ncu = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
+  constexpr int smem = (2 * 4 * 16 * 64 + 4 * 16) * 4;
+  // Tiles are dealt statically (tile = bid + i * grid), so the launch ends with its most loaded CU: take the workgroups-per-CU count
+  // (up to what the registers allow) for which a CU walks the fewest tiles -- lm_head, 4008 tiles on 256 CUs: 3 x 6 = 18 with three
+  // workgroups per CU, 2 x 8 = 16 with two.
+  const int max_per_cu = nsteps <= 4 * 8 ? 3 : 2;
+  int per_cu = max_per_cu, best = INT32_MAX;
+  for (int c = max_per_cu; c >= 1; --c) {
+    const int load = c * ceil_div(ntiles, c * ncu);
+    if (load < best) { best = load; per_cu = c; }
+  }
+  const int grid = ntiles < per_cu * ncu ? ntiles : per_cu * ncu;
+  if (nsteps <= 4 * 8) hipLaunchKernelGGL((skinny_persist_kernel<T, NORM, 8>), dim3(grid), dim3(256), smem, st, a, ntiles);
+  else hipLaunchKernelGGL((skinny_persist_kernel<T, NORM, 16>), dim3(grid), dim3(256), smem, st, a, ntiles);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// the shapes skinny_persist_kernel serves (everything else stays on skinny_kernel): plain epilogue, one K segment, many tiles
+static bool persist_eligible(const GemmArgs& a) {
+  static const int on = [] { const char* e = getenv("OAVSR_SKINNY_PERSIST"); return e ? atoi(e) : 1; }();
+  const int esz = a.dtype == DT_F32 ? 4 : 2, kbe = 64 / esz;
+  return on && a.M <= 8 && a.K2 == 0 && !a.swiglu_pairs && !a.residual && a.act == ACT_NONE && a.N >= 65536 && (a.K / kbe) % 2 == 0 &&
+         (a.K / kbe) / 2 <= 4 * 16;
+}
+
 template <typename T, int MT, int NT, bool NORM, int U, bool HALF, int W>
 __global__ __launch_bounds__(W * 64, (MT == 1 && U * NT <= 8) ? 4 : 2) void skinny_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -653,6 +808,7 @@ int launch_sk(const GemmArgs& a, hipStream_t st) {
       // many rounds of wide tiles (lm_head): 4-wave workgroups overlap their reduce / epilogue phases better (110 -> 101 us)
       // (deeper request queues per wave -- U = 4 / 8, the whole k range of a wave in one go -- were measured: 18.4 -> 26.3 us gate/up,
       //  109 -> 148 us lm_head; the 200+ VGPRs they need leave one workgroup per CU)
+      if (NT == 4 && persist_eligible(a)) return launch_persist<T, NORM>(a, st);     // same bits, persistent workgroups
       if (NT == 4 && a.N >= 65536) return launch_sk_u<T, 1, NT, NORM, U0, true, 4>(a, st);
       return launch_sk_u<T, 1, NT, NORM, U0, true>(a, st);
     }

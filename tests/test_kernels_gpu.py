@@ -838,6 +838,47 @@ torch.save(out.cpu(), sys.argv[1])
     assert torch.equal(outs[0], outs[1]), f"ping-pong vs 16-wave kernel: max diff {(outs[0].float() - outs[1].float()).abs().max().item():.3e}"
 
 
+def test_skinny_persistent_lm_head_bitwise_equals_tile_kernel(tmp_path):
+    """lm_head-shaped GEMVs (<= 8 rows, N >= 65536) run on persistent workgroups (skinny_persist_kernel) that keep the tile arithmetic of
+    the per-tile kernel: identical bits (OAVSR_SKINNY_PERSIST=1 / 0, read once per process) for both dtypes, both depths (K = 2048: 8
+    k steps per wave; K = 3584 / 4096: the 16-step variant incl. its ragged last trips), ragged N, 1..8 rows, with and without the
+    fused RMSNorm, f32 and bf16 outputs -- and the value agrees with fp32 torch."""
+    import subprocess
+    import sys
+    script = f"""
+import sys, math, torch
+sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r}); sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+from gpu_util import gemm, DEV
+g = torch.Generator().manual_seed(5)
+outs = []
+for dtype, td in (("bf16", torch.bfloat16), ("f32", torch.float32)):
+    for M, N, K, norm, of32 in ((8, 128256, 2048, True, True), (5, 65536 + 24, 2048, False, False), (1, 70000, 4096, True, True),
+                                (8, 152064 // 2, 3584, True, False), (3, 65536, 1024, True, True)):
+        if dtype == "f32" and K > 2048: continue                      # f32: 16 elements per 64-byte k block, the 16-step variant covers K <= 2048
+        x = torch.randn(M, K, generator=g).to(DEV, td)
+        w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV, td)
+        kw = dict(norm_gain=(torch.randn(K, generator=g) * 0.1 + 1).to(DEV), norm_eps=1e-5) if norm else {{}}
+        bias = torch.randn(N, generator=g).to(DEV) if not norm else None
+        out = gemm(dtype, x, w, skinny=True, out_f32=of32, bias=bias, **kw)
+        xf = x.float()
+        if norm: xf = (xf * kw["norm_gain"]).to(td).float() * torch.rsqrt((x.float() ** 2).mean(-1, keepdim=True) + 1e-5)
+        ref = xf @ w.float().T + (bias if bias is not None else 0)
+        err = (out.float() - ref).abs().max().item()
+        assert err < (3e-2 if dtype == "bf16" else 2e-4), (dtype, M, N, K, err)
+        outs.append(out.cpu())
+torch.save(outs, sys.argv[1])
+"""
+    got = []
+    for flag in ("1", "0"):
+        f = str(tmp_path / f"o{flag}.pt")
+        r = subprocess.run([sys.executable, "-c", script, f], env=dict(os.environ, OAVSR_SKINNY_PERSIST=flag), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got.append(torch.load(f))
+    assert len(got[0]) == len(got[1]) >= 8
+    for i, (a_, b_) in enumerate(zip(got[0], got[1])):
+        assert torch.equal(a_, b_), f"case {i}: persistent vs per-tile kernel differ by {(a_.float() - b_.float()).abs().max().item():.3e}"
+
+
 def test_gemm_8p_fused_swiglu_equals_gemm_plus_swiglu_kernel():
     dtype, M, I, K = "bf16", 2504, 4096, 192
     x, xr = q(rnd(M, K, seed=1), dtype)
