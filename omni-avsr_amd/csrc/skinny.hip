@@ -823,7 +823,10 @@ int launch_sk(const GemmArgs& a, hipStream_t st) {
 template <typename T, bool NORM>
 int launch_sk_t(const GemmArgs& a, hipStream_t st) {
   const int mt = ceil_div(a.M, 16);
-  const bool wide = a.N >= 8192;           // enough columns to fill the chip with 64-column workgroups
+  // 32-column workgroups once they fill the chip; below that 8-column ones: they re-read the activation rows four times as often per
+  // weight byte, but measured with 32-column tiles for N = 2048 / 3072 the decode step is 25 % slower alone and 1.5 % slower with three
+  // batches in flight (64 - 96 workgroups per launch: the chain of dependent launches gets longer, which costs more than the CU time saved)
+  const bool wide = a.N >= 8192;
   // 9..32 rows: 8-column tiles with 16-row activation operands (skinny_r16_kernel) wherever the <= 8-row path would use its 8-column tiles
   static const int r16_on = [] { const char* e = getenv("OAVSR_SKINNY_R16"); return e ? atoi(e) : 1; }();
   constexpr int kbe = 64 / (int)sizeof(T);
