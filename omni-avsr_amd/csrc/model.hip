@@ -1231,6 +1231,9 @@ int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, 
   total += 4096;
   if (hipMalloc((void**)&ws->arena, total) != hipSuccess) { set_last_error("workspace_create: hipMalloc(%zu bytes) failed", total); delete ws; return -2; }
   ws->arena_bytes = total;
+  // Start from zeros rather than from whatever the recycled device memory holds (the kernels guard their ragged edges themselves; this
+  // keeps a missed guard from turning into run-to-run differences).
+  if (hipMemset(ws->arena, 0, total) != hipSuccess) { set_last_error("workspace_create: hipMemset failed"); hipFree(ws->arena); delete ws; return -2; }
   for (auto& r : reqs) { *r.p = ws->take(std::max<size_t>(r.bytes, 256)); if (!*r.p) { set_last_error("workspace arena overflow"); hipFree(ws->arena); delete ws; return -1; } }
   // decode uses gs.pos / gs.cpos as the row position arrays of the layer stack
   ws->host_bytes = (size_t)(F * sizeof(int2) + ST * 8 * sizeof(int) + rows_dec * (size_t)(max_new + 16) * sizeof(int) + 1 * 1024 * 1024);
@@ -1242,6 +1245,10 @@ int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, 
   ws->host = ws->host_base;
   hipEventCreateWithFlags(&ws->host_ev[0], hipEventDisableTiming);
   hipEventCreateWithFlags(&ws->host_ev[1], hipEventDisableTiming);
+  // The device-side initialisation above runs on the null stream (a device-to-device hipMemcpy may return before it has executed), and the
+  // callers' non-blocking streams do not wait for that stream: a workspace created while another call of the same model was in flight was
+  // used before its position table had been written (wrong tokens, found by tests/test_stages_gpu.py).  Creation is rare: wait here.
+  if (hipDeviceSynchronize() != hipSuccess) { set_last_error("workspace_create: device synchronisation failed"); oavsr_workspace_destroy(ws); return -2; }
   *out = ws;
   return 0;
 }

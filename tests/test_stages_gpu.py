@@ -221,7 +221,34 @@ def test_greedy_hipgraph_replay_matches_eager():
         outs.append((ids1.cpu(), lens1.cpu()))
     torch.cuda.synchronize()
     for ids1, lens1 in outs:
-        assert torch.equal(ids0.cpu(), ids1) and torch.equal(lens0.cpu(), lens1)
+        assert torch.equal(ids0.cpu(), ids1) and torch.equal(lens0.cpu(), lens1), f"eager {ids0.cpu().tolist()} {lens0.cpu().tolist()} vs graph {ids1.tolist()} {lens1.tolist()}"
+
+
+def test_workspace_created_while_another_call_is_in_flight():
+    """A second slot's workspace is created (device-side tables written on the null stream) while the first call of the same engine is
+    still running; the non-blocking stream that uses it must not start before that initialisation is done.  Repeated over several
+    engines because whether the two calls really overlap depends on which hardware queue the new stream lands on."""
+    Tv, Ts = [12, 9], [7680, 5000]
+    video, audio = inputs(Tv=Tv, Ts=Ts)
+    ref = None
+    for k in range(6):
+        spec, sd, eng, orc = make("f32", family="llama", task_specific=True, shared=True)
+        vd, ad = video.cuda(), audio.cuda()
+        torch.cuda.synchronize()
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        with torch.cuda.stream(sa):
+            ids0, _ = eng.generate("audiovisual", vd, Tv, ad, Ts, 4, 2, beams=1, max_new=spec.max_dec_tokens, slot=0)
+        with torch.cuda.stream(sb):
+            ids1, _ = eng.generate("audiovisual", vd, Tv, ad, Ts, 4, 2, beams=1, max_new=spec.max_dec_tokens, slot=1)
+        torch.cuda.synchronize()
+        if ref is None:
+            with torch.no_grad():
+                ref = orc.forward(dict(video=video, audio=audio, lengths=torch.tensor(Ts), video_lens=torch.tensor(Tv),
+                                       tokens=torch.full((2, 1), spec.ids["bos"])), "audiovisual", 4, 2, num_beams=1)
+        for name, ids in (("first", ids0), ("second", ids1)):
+            got = [row[: len(r)] for row, r in zip(ids.cpu().tolist(), ref)]
+            assert got == ref, f"engine {k}, {name} call: {got} vs {ref}"
+        del eng
 
 
 # bf16 end to end: tests/test_bf16_emulation_gpu.py holds the bf16 engine to the bf16-emulating oracle (quantitative bounds on
