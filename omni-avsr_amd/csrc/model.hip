@@ -1118,6 +1118,8 @@ int oavsr_model_create(const oavsr_config* cfg, const void* blob_dev, uint64_t b
       set_last_error("model_create: stem repack failed"); oavsr_model_destroy(m); return -2;
     }
   }
+  // (as in workspace_create: what was put on the null stream above must be done before a caller's non-blocking stream reads it)
+  if (hipDeviceSynchronize() != hipSuccess) { set_last_error("model_create: device synchronisation failed"); oavsr_model_destroy(m); return -2; }
   *out = m;
   return 0;
 }
