@@ -1,10 +1,10 @@
 #!/bin/bash
-# bench.py under a few runtime / engine switches; prints utt/s and ms per call.  usage: knob_scan.sh  (edit the list below)
-run() { echo "== $* $EXTRA"; env "$@" timeout 300 python bench.py --no-cpu-baseline --no-roofline --no-grouped $EXTRA 2>&1 | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['config']['ms_per_call'])"; }
-for i in 1 2; do
-EXTRA="" run OAVSR_EXP_PERSIST_SWIGLU=0
-EXTRA="" run OAVSR_EXP_PERSIST_SWIGLU=1 OAVSR_EXP_PERSIST_PER_CU=1
-EXTRA="" run OAVSR_EXP_PERSIST_SWIGLU=1
+# A/B runs of bench.py under environment / command-line switches.  One configuration per line on stdin: "VAR=val VAR2=val | extra args"
+# (either side may be empty); prints utt/s and ms per call for each.  Example:
+#   printf 'OAVSR_SKINNY_PERSIST=0 |\nOAVSR_SKINNY_PERSIST=1 |\n | --streams 1\n' | bash tools/knob_scan.sh
+while IFS='|' read -r envs extra; do
+  [ -z "$envs$extra" ] && continue
+  echo "== $envs | $extra"
+  env $envs timeout 300 python bench.py --no-cpu-baseline --no-roofline --no-grouped $extra 2>&1 | tail -1 |
+    python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['config']['ms_per_call'])"
 done
-EXTRA="--streams 1" run OAVSR_EXP_PERSIST_SWIGLU=0
-EXTRA="--streams 1" run OAVSR_EXP_PERSIST_SWIGLU=1 OAVSR_EXP_PERSIST_PER_CU=1
