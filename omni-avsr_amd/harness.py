@@ -222,11 +222,15 @@ class WerMeter:
 
 
 def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], modality: str, to_text: Callable[[torch.Tensor], List[str]],
-             batch_size: int = 8, bos_id: Optional[int] = None, rank: int = 0, world: int = 1, in_flight: int = 1, **forward_kw) -> WerMeter:
+             batch_size: int = 8, bos_id: Optional[int] = None, rank: int = 0, world: int = 1, in_flight: int = 1, decode_group: int = 1,
+             **forward_kw) -> WerMeter:
     """Evaluation loop of eval_OmniAVSR.py:273-357 for one (task, rates) cell, utterance-sharded over `world` ranks
      and batched (the reference runs batch 1).  `samples`: [(transformed sample dict, gold text)].
     `in_flight` > 1 keeps that many batches in flight on their own HIP streams / workspaces (the encoders of one overlap the decode loop
     of the others; same ids, same counters, ~1.4x the throughput on MI355X) -- needs the HIP-backed model (`model.engine`).
+    `decode_group` = G > 1 (HIP-backed model): a call takes G x batch_size utterances, runs encoders / prefill in chunks of batch_size and
+    ONE decode loop over all rows (`model.encoder_chunk`): the LLM weights are streamed once per step for G batches; keep G x batch_size x
+    num_beams <= 32 rows for ids that are bit-identical to the ungrouped loop (invariance contract).
     Returns this rank's WerMeter; combine with dist.reduce_wer_counters."""
     from .dist import make_batches, shard_utterances
     dur = [float((s.get("video") if "video" in s else s["audio"]).shape[0]) / (1.0 if "video" in s else 640.0) for s, _ in samples]
@@ -234,6 +238,10 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
     meter = WerMeter()
     model.modality = modality
     kw_mod = modality if getattr(model, "is_task_specific", False) else None
+    chunk_prev = getattr(model, "encoder_chunk", None)
+    if decode_group > 1:
+        model.encoder_chunk = batch_size
+        batch_size = batch_size * decode_group
     batches = list(make_batches(owned, batch_size))
 
     def score(idxs, ids):
@@ -250,6 +258,8 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
                 print(f"evaluate: batch {idxs} failed: {e}")
                 continue
             score(idxs, ids)
+        if decode_group > 1:
+            model.encoder_chunk = chunk_prev
         return meter
 
     eng = model.engine
@@ -294,4 +304,6 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
         pool.shutdown(wait=True)
         torch.cuda.synchronize(dev)
         eng.serialize_encoders(False)
+        if decode_group > 1:
+            model.encoder_chunk = chunk_prev
     return meter

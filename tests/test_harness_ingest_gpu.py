@@ -83,10 +83,12 @@ def test_manifest_to_wer_through_the_engine(tmp_path):
     m1 = H.evaluate(model, pairs, "audiovisual", to_text, batch_size=2, bos_id=spec.ids["bos"], rank=1, world=2, test_ratio_matry_audio=4, test_ratio_matry_video=2)
     assert m0.total_edit_distance + m1.total_edit_distance == meter.total_edit_distance and m0.total_length + m1.total_length == meter.total_length
     # batches kept in flight on their own streams / workspaces (what bench.py measures): same hypotheses, same counters
-    for k in (2, 3):
-        mp = H.evaluate(model, pairs, "audiovisual", to_text, batch_size=2, bos_id=spec.ids["bos"], in_flight=k, test_ratio_matry_audio=4, test_ratio_matry_video=2)
-        assert sorted(mp.per_utt) == sorted(meter.per_utt), f"in_flight={k}: hypotheses differ from the sequential loop"
+    for k, grp in ((2, 1), (3, 1), (1, 2), (2, 2)):
+        mp = H.evaluate(model, pairs, "audiovisual", to_text, batch_size=2, bos_id=spec.ids["bos"], in_flight=k, decode_group=grp,
+                        test_ratio_matry_audio=4, test_ratio_matry_video=2)
+        assert sorted(mp.per_utt) == sorted(meter.per_utt), f"in_flight={k}, decode_group={grp}: hypotheses differ from the sequential loop"
         assert (mp.total_edit_distance, mp.total_length, mp.failed) == (meter.total_edit_distance, meter.total_length, [])
+    assert getattr(model, "encoder_chunk", None) is None
 
 
 def _decode(eng, spec, seed=5):

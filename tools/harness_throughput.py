@@ -32,12 +32,13 @@ for i in range(n_utt):
     samples.append(({"video": v, "audio": a}, "gold"))
 to_text = lambda ids: [" ".join(str(int(t)) for t in row) for row in ids.cpu()]      # noqa: E731
 out = {}
-for k in (1, 3, 1, 3):
+for k, grp in ((1, 1), (3, 1), (3, 3), (3, 1), (3, 3)):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    meter = H.evaluate(m, samples, "audiovisual", to_text, batch_size=8, bos_id=spec.ids["bos"], in_flight=k, test_ratio_matry_audio=4, test_ratio_matry_video=4)
+    meter = H.evaluate(m, samples, "audiovisual", to_text, batch_size=8, bos_id=spec.ids["bos"], in_flight=k, decode_group=grp,
+                       test_ratio_matry_audio=4, test_ratio_matry_video=4)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     hyp = sorted(h for _, h, _, _ in meter.per_utt)
     assert out.setdefault("hyp", hyp) == hyp, "hypotheses differ between the modes"
-    print(f"in_flight={k}: {n_utt / dt:7.1f} utt/s  ({dt / (n_utt / 8) * 1e3:.1f} ms per batch of 8, host inputs)", flush=True)
+    print(f"in_flight={k} decode_group={grp}: {n_utt / dt:7.1f} utt/s  ({dt / (n_utt / 8) * 1e3:.1f} ms per batch of 8, host inputs)", flush=True)
