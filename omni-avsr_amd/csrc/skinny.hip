@@ -699,6 +699,180 @@ __global__ __launch_bounds__(256, AS <= 8 ? 3 : 2) void skinny_persist_kernel(co
   }
 }
 
+// The same for 9..32 rows: skinny_r16_kernel's tile arithmetic (16-row activation operands, one MFMA per k-block parity; MT = 1: <= 16 rows,
+// MT = 2: <= 32) on persistent 4-wave workgroups.  Here the activation fragments are as many bytes per tile as the weights (32 rows x K
+// against 32 columns x K), so fetching and normalising them once per workgroup instead of once per tile halves what a CU pulls in.
+template <typename T, int MT, bool NORM, int AS>
+__global__ __launch_bounds__(256, (MT == 1 && AS <= 8) ? 2 : 1) void skinny_persist_r16_kernel(const GemmArgs p, const int ntiles) {
+  constexpr int W = 4, NT = 4, U = 2, TPT = AS / U, MR = MT * 16, NC = 64;
+  constexpr int KBE = 64 / (int)sizeof(T), VEC = TypeInfo<T>::kVec;
+  static_assert(TPT % 2 == 0, "the weight double buffer alternates per trip");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sred = reinterpret_cast<float*>(smem);            // [2][W][MR][NC]
+  float* sssq = sred + 2 * W * MR * NC;                    // [2][W][MR]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4, par = r16 >> 3, cw = r16 & 7;
+  const T* A1 = reinterpret_cast<const T*>(p.A);
+  const T* W1 = reinterpret_cast<const T*>(p.W);
+  const int nsteps = (p.K / KBE) / 2;
+
+  Chunk16 bf[2][U][NT];
+  auto issue = [&](const int tile, const int trip, auto buf_c) __attribute__((always_inline)) {
+    constexpr int B = decltype(buf_c)::value;
+    const int n0 = tile * (NT * 8);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int st = wave + W * (trip * U + u);
+      const int k = (2 * st + par) * KBE + g * VEC;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + j * 8 + cw;
+        if (st < nsteps && n < p.N) bf[B][u][j].v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W1 + (int64_t)n * p.ldw + k));
+        else bf[B][u][j] = zchunk();
+      }
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) issue(tile, 0, std::integral_constant<int, 0>{});
+
+  // ---- once per workgroup: activation fragments (both k-block parities of every step, x gain), sums of squares per (row, parity)
+  Chunk16 afn[AS][MT][2];
+  float ssq[MT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) { ssq[i][0] = 0.f; ssq[i][1] = 0.f; }
+#pragma unroll
+  for (int s_ = 0; s_ < AS; ++s_) {
+    const int st = wave + W * s_;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int k = (2 * st + q) * KBE + g * VEC;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int m = i * 16 + r16;
+        afn[s_][i][q] = (st < nsteps && m < p.M) ? *reinterpret_cast<const Chunk16*>(A1 + (int64_t)m * p.lda + k) : zchunk();
+      }
+    }
+  }
+  if (NORM) {
+#pragma unroll
+    for (int s_ = 0; s_ < AS; ++s_) {
+      const int st = wave + W * s_;
+      if (st < nsteps) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int k = (2 * st + q) * KBE + g * VEC;
+          float gn[VEC];
+#pragma unroll
+          for (int e = 0; e < VEC; e += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(p.norm_gain + k + e);
+            gn[e] = t[0]; gn[e + 1] = t[1]; gn[e + 2] = t[2]; gn[e + 3] = t[3];
+          }
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            float f[VEC];
+            chunk_to_f32<T>(afn[s_][i][q], f);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { ssq[i][q] = fmaf(f[e], f[e], ssq[i][q]); f[e] *= gn[e]; }   // skinny_r16_kernel's expressions and order
+            afn[s_][i][q] = chunk_from_f32<T>(f);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float v = ssq[i][q];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (g == 0) sssq[(q * W + wave) * MR + i * 16 + r16] = v;
+      }
+    __syncthreads();
+  }
+  // MT * 2 output elements per thread and tile: idx = tid + t * 256 -> row idx / 32, column idx % 32
+  constexpr int OPT = MR * 32 / 256;
+  float rs[OPT];
+#pragma unroll
+  for (int t = 0; t < OPT; ++t) {
+    rs[t] = 1.f;
+    if (NORM) {
+      const int m = (tid + t * 256) >> 5;
+      float sq = 0.f;
+#pragma unroll
+      for (int w = 0; w < W; ++w) { sq += sssq[w * MR + m]; sq += sssq[(W + w) * MR + m]; }
+      rs[t] = rsqrtf(sq / (float)p.K + p.norm_eps);
+    }
+  }
+
+  f32x4 acc[MT][NT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { acc[i][j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][j][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  int parity = 0;
+  for (; tile < ntiles; tile += gridDim.x) {
+    static_for<0, TPT>([&](auto TR) {
+      constexpr int trip = decltype(TR)::value;
+      if constexpr (trip + 1 < TPT) issue(tile, trip + 1, std::integral_constant<int, (trip + 1) & 1>{});
+      else if (tile + (int)gridDim.x < ntiles) issue(tile + (int)gridDim.x, 0, std::integral_constant<int, 0>{});
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) MmaS<T>::run(afn[trip * U + u][i][q], bf[trip & 1][u][j], acc[i][j][q]);
+    });
+    float* sr = sred + parity * (W * MR * NC);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sr[(wave * MR + i * 16 + g * 4 + r) * NC + j * 16 + r16] = par ? acc[i][j][1][r] : acc[i][j][0][r];
+        acc[i][j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < OPT; ++t) {
+      const int idx = tid + t * 256, m = idx >> 5, nn = idx & 31;
+      const int n = tile * (NT * 8) + nn;
+      if (m < p.M && n < p.N) {
+        const int lc = (nn >> 3) * 16 + (nn & 7);
+        float y = 0.f;
+#pragma unroll
+        for (int w = 0; w < W; ++w) { y += sr[(w * MR + m) * NC + lc]; y += sr[(w * MR + m) * NC + lc + 8]; }
+        if (NORM) y = fmaf(y, rs[t], 0.f);
+        y = fmaf(y, p.col_scale ? p.col_scale[n] : 1.f, p.col_bias ? p.col_bias[n] : 0.f);
+        if (p.out_f32) reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n] = y;
+        else reinterpret_cast<T*>(p.C)[(int64_t)m * p.ldc + n] = from_f32<T>(y);
+      }
+    }
+    parity ^= 1;
+  }
+}
+
+template <typename T, int MT, bool NORM>
+int launch_persist_r16(const GemmArgs& a, hipStream_t st) {
+  constexpr int kbe = 64 / (int)sizeof(T);
+  const int nsteps = (a.K / kbe) / 2;
+  const int ntiles = ceil_div(a.N, 32);
+  static const int ncu = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
+  constexpr int smem = (2 * 4 * MT * 16 * 64 + 2 * 4 * MT * 16) * 4;
+  const int max_per_cu = (MT == 1 && nsteps <= 4 * 8) ? 2 : 1;
+  int per_cu = max_per_cu, best = INT32_MAX;
+  for (int c = max_per_cu; c >= 1; --c) {
+    const int load = c * ceil_div(ntiles, c * ncu);
+    if (load < best) { best = load; per_cu = c; }
+  }
+  const int grid = ntiles < per_cu * ncu ? ntiles : per_cu * ncu;
+  if (nsteps <= 4 * 8) hipLaunchKernelGGL((skinny_persist_r16_kernel<T, MT, NORM, 8>), dim3(grid), dim3(256), smem, st, a, ntiles);
+  else hipLaunchKernelGGL((skinny_persist_r16_kernel<T, MT, NORM, 16>), dim3(grid), dim3(256), smem, st, a, ntiles);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 template <typename T, bool NORM>
 int launch_persist(const GemmArgs& a, hipStream_t st) {
   constexpr int kbe = 64 / (int)sizeof(T);
@@ -723,10 +897,11 @@ int launch_persist(const GemmArgs& a, hipStream_t st) {
 }
 
 // the shapes skinny_persist_kernel serves (everything else stays on skinny_kernel): plain epilogue, one K segment, many tiles
-static bool persist_eligible(const GemmArgs& a) {
+static bool persist_eligible(const GemmArgs& a, int max_rows = 8) {
   static const int on = [] { const char* e = getenv("OAVSR_SKINNY_PERSIST"); return e ? atoi(e) : 1; }();
   const int esz = a.dtype == DT_F32 ? 4 : 2, kbe = 64 / esz;
-  return on && a.M <= 8 && a.K2 == 0 && !a.swiglu_pairs && !a.residual && a.act == ACT_NONE && a.N >= 65536 && (a.K / kbe) % 2 == 0 &&
+  if (max_rows > 8 && (a.K / kbe) / 2 > 4 * 8 && a.M > 16) return false;     // 32 rows x 16 steps of resident fragments do not fit the register file
+  return on && a.M <= max_rows && a.K2 == 0 && !a.swiglu_pairs && !a.residual && a.act == ACT_NONE && a.N >= 65536 && (a.K / kbe) % 2 == 0 &&
          (a.K / kbe) / 2 <= 4 * 16;
 }
 
@@ -834,6 +1009,7 @@ int launch_sk_t(const GemmArgs& a, hipStream_t st) {
     if (wide && (!a.swiglu_pairs || a.N % 32 == 0)) {
       // same wave count as the <= 8-row kernel picks for this N (4 waves for the many-round lm_head): the k blocks are dealt over
       // the waves, so the wave count is part of the summation order
+      if (a.N >= 65536 && persist_eligible(a, 32)) return mt <= 1 ? launch_persist_r16<T, 1, NORM>(a, st) : launch_persist_r16<T, 2, NORM>(a, st);
       if (a.N >= 65536) return mt <= 1 ? launch_r16<T, 1, 4, NORM, 2, 4>(a, st) : launch_r16<T, 2, 4, NORM, 2, 4>(a, st);
       return mt <= 1 ? launch_r16<T, 1, 4, NORM, 2>(a, st) : launch_r16<T, 2, 4, NORM, 2>(a, st);
     }
