@@ -702,9 +702,11 @@ __global__ __launch_bounds__(256, AS <= 8 ? 3 : 2) void skinny_persist_kernel(co
 // The same for 9..32 rows: skinny_r16_kernel's tile arithmetic (16-row activation operands, one MFMA per k-block parity; MT = 1: <= 16 rows,
 // MT = 2: <= 32) on persistent 4-wave workgroups.  Here the activation fragments are as many bytes per tile as the weights (32 rows x K
 // against 32 columns x K), so fetching and normalising them once per workgroup instead of once per tile halves what a CU pulls in.
-template <typename T, int MT, bool NORM, int AS>
-__global__ __launch_bounds__(256, (MT == 1 && AS <= 8) ? 2 : 1) void skinny_persist_r16_kernel(const GemmArgs p, const int ntiles) {
-  constexpr int W = 4, NT = 4, U = 2, TPT = AS / U, MR = MT * 16, NC = 64;
+// W = 4 for the lm_head class (N >= 65536), W = 8 for the other wide GEMVs (gate / up with the SwiGLU epilogue): the wave count is part of
+// the summation order, so each form keeps the count of the per-tile kernel it replaces.
+template <typename T, int MT, bool NORM, int AS, int W = 4, bool SWIGLU = false>
+__global__ __launch_bounds__(W * 64, (W == 4 && MT == 1 && AS <= 8) ? 2 : 1) void skinny_persist_r16_kernel(const GemmArgs p, const int ntiles) {
+  constexpr int NT = 4, U = 2, TPT = AS / U, MR = MT * 16, NC = 64, kThreads = W * 64;
   constexpr int KBE = 64 / (int)sizeof(T), VEC = TypeInfo<T>::kVec;
   static_assert(TPT % 2 == 0, "the weight double buffer alternates per trip");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -789,14 +791,15 @@ __global__ __launch_bounds__(256, (MT == 1 && AS <= 8) ? 2 : 1) void skinny_pers
       }
     __syncthreads();
   }
-  // MT * 2 output elements per thread and tile: idx = tid + t * 256 -> row idx / 32, column idx % 32
-  constexpr int OPT = MR * 32 / 256;
+  // MR * 32 / threads output elements per thread and tile: idx = tid + t * threads -> row idx / 32, column idx % 32
+  static_assert(MR * 32 % kThreads == 0, "outputs per thread");
+  constexpr int OPT = MR * 32 / kThreads;
   float rs[OPT];
 #pragma unroll
   for (int t = 0; t < OPT; ++t) {
     rs[t] = 1.f;
     if (NORM) {
-      const int m = (tid + t * 256) >> 5;
+      const int m = (tid + t * kThreads) >> 5;
       float sq = 0.f;
 #pragma unroll
       for (int w = 0; w < W; ++w) { sq += sssq[w * MR + m]; sq += sssq[(W + w) * MR + m]; }
@@ -836,15 +839,26 @@ __global__ __launch_bounds__(256, (MT == 1 && AS <= 8) ? 2 : 1) void skinny_pers
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < OPT; ++t) {
-      const int idx = tid + t * 256, m = idx >> 5, nn = idx & 31;
+      const int idx = tid + t * kThreads, m = idx >> 5, nn = idx & 31;
       const int n = tile * (NT * 8) + nn;
-      if (m < p.M && n < p.N) {
+      float y = 0.f;
+      if (n < p.N) {
         const int lc = (nn >> 3) * 16 + (nn & 7);
-        float y = 0.f;
 #pragma unroll
         for (int w = 0; w < W; ++w) { y += sr[(w * MR + m) * NC + lc]; y += sr[(w * MR + m) * NC + lc + 8]; }
         if (NORM) y = fmaf(y, rs[t], 0.f);
         y = fmaf(y, p.col_scale ? p.col_scale[n] : 1.f, p.col_bias ? p.col_bias[n] : 0.f);
+      }
+      if (SWIGLU) {
+        // weight rows interleaved [gate block | up block] in 16-row blocks: column nn < 16 is a gate, nn + 16 (16 lanes up) its up value
+        const float up = __shfl_down(y, 16, 64);
+        if (nn < 16 && m < p.M && n + 16 < p.N) {
+          const float o = silu(y) * up;
+          const int ncol = tile * (NT * 4) + nn;
+          if (p.out_f32) reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + ncol] = o;
+          else reinterpret_cast<T*>(p.C)[(int64_t)m * p.ldc + ncol] = from_f32<T>(o);
+        }
+      } else if (m < p.M && n < p.N) {
         if (p.out_f32) reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n] = y;
         else reinterpret_cast<T*>(p.C)[(int64_t)m * p.ldc + n] = from_f32<T>(y);
       }
@@ -853,22 +867,31 @@ __global__ __launch_bounds__(256, (MT == 1 && AS <= 8) ? 2 : 1) void skinny_pers
   }
 }
 
-template <typename T, int MT, bool NORM>
+template <typename T, int MT, bool NORM, int W = 4, bool SWIGLU = false>
 int launch_persist_r16(const GemmArgs& a, hipStream_t st) {
   constexpr int kbe = 64 / (int)sizeof(T);
   const int nsteps = (a.K / kbe) / 2;
   const int ntiles = ceil_div(a.N, 32);
   static const int ncu = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
-  constexpr int smem = (2 * 4 * MT * 16 * 64 + 2 * 4 * MT * 16) * 4;
-  const int max_per_cu = (MT == 1 && nsteps <= 4 * 8) ? 2 : 1;
+  constexpr int smem = (2 * W * MT * 16 * 64 + 2 * W * MT * 16) * 4;
+  constexpr int AS0 = W == 4 ? 8 : 4;                       // k steps per wave of the shallow variant; the deep one holds twice as many
+  const int max_per_cu = (W == 4 && MT == 1 && nsteps <= W * AS0) ? 2 : 1;
   int per_cu = max_per_cu, best = INT32_MAX;
   for (int c = max_per_cu; c >= 1; --c) {
     const int load = c * ceil_div(ntiles, c * ncu);
     if (load < best) { best = load; per_cu = c; }
   }
   const int grid = ntiles < per_cu * ncu ? ntiles : per_cu * ncu;
-  if (nsteps <= 4 * 8) hipLaunchKernelGGL((skinny_persist_r16_kernel<T, MT, NORM, 8>), dim3(grid), dim3(256), smem, st, a, ntiles);
-  else hipLaunchKernelGGL((skinny_persist_r16_kernel<T, MT, NORM, 16>), dim3(grid), dim3(256), smem, st, a, ntiles);
+  auto kern = nsteps <= W * AS0 ? skinny_persist_r16_kernel<T, MT, NORM, AS0, W, SWIGLU> : skinny_persist_r16_kernel<T, MT, NORM, 2 * AS0, W, SWIGLU>;
+  if (smem > 64 * 1024) {
+    static bool attr_set[2] = {false, false};
+    const int which = nsteps <= W * AS0 ? 0 : 1;
+    if (!attr_set[which]) {
+      OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+      attr_set[which] = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(W * 64), smem, st, a, ntiles);
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -897,6 +920,16 @@ int launch_persist(const GemmArgs& a, hipStream_t st) {
 }
 
 // the shapes skinny_persist_kernel serves (everything else stays on skinny_kernel): plain epilogue, one K segment, many tiles
+// 9..32 rows, 8-wave form: the wide GEMVs below the lm_head class -- gate / up (SwiGLU epilogue) with at least two tiles per CU
+static bool persist_r16_w8_eligible(const GemmArgs& a) {
+  static const int on = [] { const char* e = getenv("OAVSR_SKINNY_PERSIST"); return e ? atoi(e) : 1; }();
+  const int esz = a.dtype == DT_F32 ? 4 : 2, kbe = 64 / esz;
+  static const int ncu = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
+  return on && a.M > 8 && a.M <= 32 && a.K2 == 0 && a.swiglu_pairs && !a.out_f32 && !a.residual && a.act == ACT_NONE && a.N % 32 == 0 &&
+         a.N < 65536 && ceil_div(a.N, 32) >= 2 * ncu && (a.K / kbe) % 2 == 0 && (a.K / kbe) / 2 <= 8 * 8 &&
+         !(a.M > 16 && (a.K / kbe) / 2 > 8 * 4);          // 32 rows x 8 steps of resident fragments: over the 256 registers of an 8-wave workgroup
+}
+
 static bool persist_eligible(const GemmArgs& a, int max_rows = 8) {
   static const int on = [] { const char* e = getenv("OAVSR_SKINNY_PERSIST"); return e ? atoi(e) : 1; }();
   const int esz = a.dtype == DT_F32 ? 4 : 2, kbe = 64 / esz;
@@ -1011,6 +1044,7 @@ int launch_sk_t(const GemmArgs& a, hipStream_t st) {
       // the waves, so the wave count is part of the summation order
       if (a.N >= 65536 && persist_eligible(a, 32)) return mt <= 1 ? launch_persist_r16<T, 1, NORM>(a, st) : launch_persist_r16<T, 2, NORM>(a, st);
       if (a.N >= 65536) return mt <= 1 ? launch_r16<T, 1, 4, NORM, 2, 4>(a, st) : launch_r16<T, 2, 4, NORM, 2, 4>(a, st);
+      if (persist_r16_w8_eligible(a)) return mt <= 1 ? launch_persist_r16<T, 1, NORM, 8, true>(a, st) : launch_persist_r16<T, 2, NORM, 8, true>(a, st);
       return mt <= 1 ? launch_r16<T, 1, 4, NORM, 2>(a, st) : launch_r16<T, 2, 4, NORM, 2>(a, st);
     }
     // narrow N: two 8-column tiles per workgroup (N / 16 workgroups, as many as the 16-column kernel launched, and the activation rows --

@@ -882,6 +882,44 @@ torch.save(outs, sys.argv[1])
         assert torch.equal(a_, b_), f"case {i}: persistent vs per-tile kernel differ by {(a_.float() - b_.float()).abs().max().item():.3e}"
 
 
+def test_skinny_persistent_gate_up_bitwise_equals_tile_kernel(tmp_path):
+    """gate / up with the fused RMSNorm + SwiGLU at 9..32 rows: persistent 8-wave workgroups (skinny_persist_r16_kernel<.., 8, true>) against
+    the per-tile kernel, bit for bit (OAVSR_SKINNY_PERSIST=1 / 0), and against fp32 torch."""
+    import subprocess
+    import sys
+    script = f"""
+import sys, math, torch
+sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r}); sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+from gpu_util import gemm, DEV
+g = torch.Generator().manual_seed(7)
+outs = []
+for dtype, td in (("bf16", torch.bfloat16), ("f32", torch.float32)):
+    for M, I, K in ((16, 8192, 2048), (24, 8192, 2048), (9, 8192 + 512, 1024), (32, 8192, 2048), (12, 18944, 3584)):
+        if dtype == "f32" and K > 2048: continue
+        x = torch.randn(M, K, generator=g).to(DEV, td)
+        wg_ = (torch.randn(I, K, generator=g) / math.sqrt(K)).to(td)
+        wu_ = (torch.randn(I, K, generator=g) / math.sqrt(K)).to(td)
+        w = torch.stack([wg_.view(I // 16, 16, K), wu_.view(I // 16, 16, K)], 1).reshape(2 * I, K).to(DEV)     # [gate block | up block] by 16 rows
+        gain = (torch.randn(K, generator=g) * 0.1 + 1).to(DEV)
+        out = gemm(dtype, x, w, skinny=True, norm_gain=gain, norm_eps=1e-5, swiglu_pairs=1)
+        xn = (x.float() * gain).to(td).float() * torch.rsqrt((x.float() ** 2).mean(-1, keepdim=True) + 1e-5)
+        ref = torch.nn.functional.silu(xn @ wg_.float().T.to(DEV)) * (xn @ wu_.float().T.to(DEV))
+        err = (out.float() - ref).abs().max().item()
+        assert err < (4e-2 if dtype == "bf16" else 2e-4), (dtype, M, I, K, err)
+        outs.append(out.cpu())
+torch.save(outs, sys.argv[1])
+"""
+    got = []
+    for flag in ("1", "0"):
+        f = str(tmp_path / f"o{flag}.pt")
+        r = subprocess.run([sys.executable, "-c", script, f], env=dict(os.environ, OAVSR_SKINNY_PERSIST=flag), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got.append(torch.load(f))
+    assert len(got[0]) == len(got[1]) >= 9
+    for i, (a_, b_) in enumerate(zip(got[0], got[1])):
+        assert torch.equal(a_, b_), f"case {i}: persistent vs per-tile kernel differ by {(a_.float() - b_.float()).abs().max().item():.3e}"
+
+
 def test_gemm_8p_fused_swiglu_equals_gemm_plus_swiglu_kernel():
     dtype, M, I, K = "bf16", 2504, 4096, 192
     x, xr = q(rnd(M, K, seed=1), dtype)
