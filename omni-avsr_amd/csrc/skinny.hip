@@ -586,9 +586,11 @@ int launch_r16(const GemmArgs& a, hipStream_t st) {
 //     so a wave that waits at the tile's barrier (partial sums -> LDS -> 256 outputs) already has 8 KiB in flight again; the LDS image
 //     is double-buffered, one barrier per tile.
 // AS = k steps (pairs of 64-byte k blocks) per wave: 8 covers K <= 2048 (bf16), 16 K <= 4096.
-template <typename T, bool NORM, int AS>
-__global__ __launch_bounds__(256, AS <= 8 ? 3 : 2) void skinny_persist_kernel(const GemmArgs p, const int ntiles) {
-  constexpr int W = 4, NT = 4, U = 2, TPT = AS / U, MR = 16, NC = 64;
+// W = 4: the lm_head class; W = 8 with the SwiGLU epilogue: gate / up (the wave count is part of the summation order: each form keeps the
+// count of the per-tile kernel it replaces; with 8 waves only the first 256 threads own an output element).
+template <typename T, bool NORM, int AS, int W = 4, bool SWIGLU = false>
+__global__ __launch_bounds__(W * 64, W == 8 ? 1 : (AS <= 8 ? 3 : 2)) void skinny_persist_kernel(const GemmArgs p, const int ntiles) {
+  constexpr int NT = 4, U = 2, TPT = AS / U, MR = 16, NC = 64;
   constexpr int KBE = 64 / (int)sizeof(T), VEC = TypeInfo<T>::kVec;
   static_assert(TPT % 2 == 0, "the weight double buffer alternates per trip");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -652,8 +654,9 @@ __global__ __launch_bounds__(256, AS <= 8 ? 3 : 2) void skinny_persist_kernel(co
     if (g == 0) sssq[wave * MR + r16] = v;
     __syncthreads();
   }
-  // one output element per thread and tile: row m, column nn of the 8 x 32 tile
-  const int m = tid >> 5, nn = tid & 31;
+  // one output element per thread (of the first 256) and tile: row m, column nn of the 8 x 32 tile
+  const int m = (tid >> 5) & 7, nn = tid & 31;
+  const bool owner = tid < 256;
   const int lc = (nn >> 3) * 16 + (nn & 7);
   float rs = 1.f;
   if (NORM) {
@@ -686,12 +689,23 @@ __global__ __launch_bounds__(256, AS <= 8 ? 3 : 2) void skinny_persist_kernel(co
     }
     __syncthreads();
     const int n = tile * (NT * 8) + nn;
-    if (m < p.M && n < p.N) {
-      float y = 0.f;
+    float y = 0.f;
+    if (owner && n < p.N) {
 #pragma unroll
       for (int w = 0; w < W; ++w) { y += sr[(w * MR + m) * NC + lc]; y += sr[(w * MR + m + 8) * NC + lc + 8]; }
       if (NORM) y = fmaf(y, rs, 0.f);
       y = fmaf(y, p.col_scale ? p.col_scale[n] : 1.f, p.col_bias ? p.col_bias[n] : 0.f);
+    }
+    if (SWIGLU) {
+      // weight rows interleaved [gate block | up block] in 16-row blocks: column nn < 16 is a gate, nn + 16 (16 lanes up) its up value
+      const float up = __shfl_down(y, 16, 64);
+      if (owner && nn < 16 && m < p.M && n + 16 < p.N) {
+        const float o = silu(y) * up;
+        const int ncol = tile * (NT * 4) + nn;
+        if (p.out_f32) reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + ncol] = o;
+        else reinterpret_cast<T*>(p.C)[(int64_t)m * p.ldc + ncol] = from_f32<T>(o);
+      }
+    } else if (owner && m < p.M && n < p.N) {
       if (p.out_f32) reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n] = y;
       else reinterpret_cast<T*>(p.C)[(int64_t)m * p.ldc + n] = from_f32<T>(y);
     }
@@ -896,30 +910,49 @@ int launch_persist_r16(const GemmArgs& a, hipStream_t st) {
   return 0;
 }
 
-template <typename T, bool NORM>
+template <typename T, bool NORM, int W = 4, bool SWIGLU = false>
 int launch_persist(const GemmArgs& a, hipStream_t st) {
   constexpr int kbe = 64 / (int)sizeof(T);
   const int nsteps = (a.K / kbe) / 2;
   const int ntiles = ceil_div(a.N, 32);
   static const int ncu = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
-  constexpr int smem = (2 * 4 * 16 * 64 + 4 * 16) * 4;
+  constexpr int smem = (2 * W * 16 * 64 + W * 16) * 4;
+  constexpr int AS0 = W == 4 ? 8 : 4;
   // Tiles are dealt statically (tile = bid + i * grid), so the launch ends with its most loaded CU: take the workgroups-per-CU count
   // (up to what the registers allow) for which a CU walks the fewest tiles -- lm_head, 4008 tiles on 256 CUs: 3 x 6 = 18 with three
   // workgroups per CU, 2 x 8 = 16 with two.
-  const int max_per_cu = nsteps <= 4 * 8 ? 3 : 2;
+  const int max_per_cu = W == 8 ? 1 : (nsteps <= W * AS0 ? 3 : 2);
   int per_cu = max_per_cu, best = INT32_MAX;
   for (int c = max_per_cu; c >= 1; --c) {
     const int load = c * ceil_div(ntiles, c * ncu);
     if (load < best) { best = load; per_cu = c; }
   }
   const int grid = ntiles < per_cu * ncu ? ntiles : per_cu * ncu;
-  if (nsteps <= 4 * 8) hipLaunchKernelGGL((skinny_persist_kernel<T, NORM, 8>), dim3(grid), dim3(256), smem, st, a, ntiles);
-  else hipLaunchKernelGGL((skinny_persist_kernel<T, NORM, 16>), dim3(grid), dim3(256), smem, st, a, ntiles);
+  auto kern = nsteps <= W * AS0 ? skinny_persist_kernel<T, NORM, AS0, W, SWIGLU> : skinny_persist_kernel<T, NORM, 2 * AS0, W, SWIGLU>;
+  if (smem > 64 * 1024) {
+    static bool attr_set[2] = {false, false};
+    const int which = nsteps <= W * AS0 ? 0 : 1;
+    if (!attr_set[which]) {
+      OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+      attr_set[which] = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(W * 64), smem, st, a, ntiles);
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
-// the shapes skinny_persist_kernel serves (everything else stays on skinny_kernel): plain epilogue, one K segment, many tiles
+// <= 8 rows, 8-wave form: gate / up (SwiGLU epilogue) with at least two tiles per CU (one persistent workgroup per CU walks them: 18.5 ->
+// 17.7 us per launch, +2 % with three batches in flight, neutral alone).  OAVSR_SKINNY_PERSIST_GU=0: the per-tile kernel.
+static bool persist_w8_eligible(const GemmArgs& a) {
+  static const int on = [] { const char* e = getenv("OAVSR_SKINNY_PERSIST"); return e ? atoi(e) : 1; }();
+  static const int gu = [] { const char* e = getenv("OAVSR_SKINNY_PERSIST_GU"); return e ? atoi(e) : 1; }();
+  const int esz = a.dtype == DT_F32 ? 4 : 2, kbe = 64 / esz;
+  static const int ncu = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
+  return on && gu && a.M <= 8 && a.K2 == 0 && a.swiglu_pairs && !a.out_f32 && !a.residual && a.act == ACT_NONE && a.N % 32 == 0 && a.N < 65536 &&
+         ceil_div(a.N, 32) >= 2 * ncu && (a.K / kbe) % 2 == 0 && (a.K / kbe) / 2 <= 8 * 8;
+}
+
 // 9..32 rows, 8-wave form: the wide GEMVs below the lm_head class -- gate / up (SwiGLU epilogue) with at least two tiles per CU
 static bool persist_r16_w8_eligible(const GemmArgs& a) {
   static const int on = [] { const char* e = getenv("OAVSR_SKINNY_PERSIST"); return e ? atoi(e) : 1; }();
@@ -1017,6 +1050,7 @@ int launch_sk(const GemmArgs& a, hipStream_t st) {
       // (deeper request queues per wave -- U = 4 / 8, the whole k range of a wave in one go -- were measured: 18.4 -> 26.3 us gate/up,
       //  109 -> 148 us lm_head; the 200+ VGPRs they need leave one workgroup per CU)
       if (NT == 4 && persist_eligible(a)) return launch_persist<T, NORM>(a, st);     // same bits, persistent workgroups
+      if (NT == 4 && persist_w8_eligible(a)) return launch_persist<T, NORM, 8, true>(a, st);
       if (NT == 4 && a.N >= 65536) return launch_sk_u<T, 1, NT, NORM, U0, true, 4>(a, st);
       return launch_sk_u<T, 1, NT, NORM, U0, true>(a, st);
     }
