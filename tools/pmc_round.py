@@ -25,6 +25,8 @@ FAMILY = [  # rocprof kernel-name pattern -> bench.py family name
     (r"skinny_kernel<[^>]*, 1, true, 8, true, 8>|skinny_kernelIDF16bLi1ELi1ELb1ELi8ELb1ELi8E", "skinny_mt1_nt1_norm_bf16"),
     (r"skinny_kernel<[^>]*, 4, true, 2, true, 8>|skinny_kernelIDF16bLi1ELi4ELb1ELi2ELb1ELi8E", "skinny_mt1_nt4_norm_swiglu_bf16"),
     (r"skinny_kernel<[^>]*, 4, true, 2, true, 4>|skinny_kernelIDF16bLi1ELi4ELb1ELi2ELb1ELi4E", "skinny_mt1_nt4_norm_bf16"),
+    (r"skinny_persist_kernel<.*, 4, 8, true>|skinny_persist_kernelI.*Li4ELi8ELb1E", "skinny_mt1_nt4_norm_swiglu_bf16"),     # gate / up, <= 8 rows (round 2: persistent)
+    (r"skinny_persist_kernel<.*, 8, 4, false>|skinny_persist_kernelI.*Li8ELi4ELb0E", "skinny_mt1_nt4_norm_bf16"),           # lm_head, <= 8 rows (round 2: persistent)
     (r"decode_attn_kernel", "decode_attention"),
     (r"attn_dma_kernel", "attention_bf16"),
 ]
@@ -71,8 +73,9 @@ for f in sorted(set(fa) | set(sa)):
     write = wa[f].get("WRITE_SIZE", 0.0) / max(wc[f].get("WRITE_SIZE", 0), 1)
     ns = max(sc[f].get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0), 1)
     mops = sa[f].get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) / ns
-    d = dict(note="rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*; separate runs, each with --kernel-trace) over `bench.py --streams 1 --steps 1 "
-                  "--warmup 1 --calls-per-step 2 --no-cpu-baseline --no-roofline`; traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B (gfx950 read-side "
+    what = "tools/skinny_mix.py 8" if "skinny" in tag else "tools/gemm_mix.py" if "gemm" in tag else \
+        "bench.py --streams 1 --steps 1 --warmup 1 --calls-per-step 2 --no-cpu-baseline --no-roofline"
+    d = dict(note="rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*; separate runs, each with --kernel-trace) over `" + what + "`; traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B (gfx950 read-side "
                   "correction; the counters sit on the L2's memory side, Infinity-Cache hits included); mfma flops = SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512; "
                   "mfma_util = mfma flops / avg duration / 2.5 PFLOP/s (profiled passes run ~3 % below the un-profiled clock)",
              kernel=f, rocprof_name=names.get(f), launches=nl, fetch_kib_per_launch=round(fetch, 1), write_kib_per_launch=round(write, 1),
