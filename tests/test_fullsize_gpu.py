@@ -88,6 +88,26 @@ def test_fullsize_batch_invariance_and_determinism(dtype):
         assert ids12[b].tolist() == ids_b[b].tolist(), f"utterance {b} decodes differently inside a batch of 12"
 
 
+def test_fullsize_grouped_decode_equals_separate_calls():
+    """harness decode_group / bench --decode-group: 24 utterances in one call (encoders / prefill in chunks of 8, ONE decode loop over 24 rows:
+    the 32-row forms of the decode kernels, persistent lm_head and gate / up included) decode the ids of three separate calls of 8."""
+    spec = full_spec()
+    sd = synth_state_dict(spec, seed=1234, device="cuda:0", dtype=torch.bfloat16)
+    eng = OmniEngine(spec, dtype="bf16").load_state_dict(sd)
+    del sd
+    torch.cuda.empty_cache()
+    g = torch.Generator().manual_seed(21)
+    Tv = [int(x) for x in torch.randint(30, 101, (24,), generator=g)]
+    video, audio, Ts = clips(Tv, seed=22)
+    ids_g, _ = eng.generate("audiovisual", video, Tv, audio, Ts, 4, 4, beams=1, max_new=32, force_len=True, chunk=8)
+    ids_g = ids_g.cpu()
+    for c in range(3):
+        sl = slice(8 * c, 8 * c + 8)
+        tmax = max(Tv[sl])
+        ids_c, _ = eng.generate("audiovisual", video[sl, :tmax], Tv[sl], audio[sl, : 640 * tmax], Ts[sl], 4, 4, beams=1, max_new=32, force_len=True)
+        assert torch.equal(ids_c.cpu(), ids_g[sl]), f"utterances {8 * c}..{8 * c + 7}: grouped decode differs from the separate call"
+
+
 def test_fused_decode_launches_equal_separate_launches(tmp_path):
     """Opt-in (OAVSR_SKINNY_CHAIN=1, read once per process; off by default because it does not pay, see skinny.hip): greedy decode with
     <= 8 rows fuses LoRA-down -> QKV and gate/up -> down_proj into single launches with in-kernel hand-offs.  Same arithmetic => identical ids, at the full model size, with three
