@@ -168,6 +168,12 @@ def parse_args():
     ap.add_argument("--decode-group", type=int, default=1,
                     help="G > 1: G consecutive calls share ONE decode loop (encoders / prefill still run per batch of --batch; "
                          "continuous batching of the decode phase).  Opt-in: not the configuration the headline number is quoted on")
+    ap.add_argument("--no-scheduler", action="store_true",
+                    help="round-2 mode: every call runs its own decode loop on its own stream (default: the engine's decode scheduler merges the "
+                         "decode rows of the calls in flight; greedy only)")
+    ap.add_argument("--sched-rows", type=int, default=32, help="rows per decode step of the engine's scheduler (<= 32)")
+    ap.add_argument("--sched-slots", type=int, default=64, help="row slots of the scheduler's pool")
+    ap.add_argument("--sched-stride", type=int, default=0, help="steps per admission (0 = automatic)")
     ap.add_argument("--no-stagger", action="store_true", help="let the encoder phases of in-flight batches share the chip (default: chained)")
     ap.add_argument("--streams", type=int, default=3, help="batches in flight (one HIP stream + workspace each); 1 = strictly sequential calls")
     return ap.parse_args()
@@ -277,22 +283,43 @@ def main():
     if nstream > 1 and not args.no_stagger:
         eng.serialize_encoders(True)
     results = [None] * nstream
+    # The decode scheduler (default): every call is still one batch of B utterances submitted on its own stream; the engine merges the
+    # decode rows of the calls in flight into one step loop (oavsr_generate_submit).  Caller-side nothing is grouped (decode_group 1).
+    use_sched = not args.no_scheduler and args.beams == 1 and G == 1 and B <= args.sched_rows
+    eng.sched_rows, eng.sched_slots, eng.sched_stride = args.sched_rows, args.sched_slots, args.sched_stride
+    pending = []
 
     def call(i):
         s = i % nstream
         video, audio, Tvs, Ts = sets[i % nsets]
         ra, rv = pre["rates"][i % len(pre["rates"])]
         with torch.cuda.stream(streams[s]):
-            results[s] = eng.generate(task, video, Tvs, audio if use_a else None, Ts if use_a else None, ra, rv, beams=args.beams,
-                                      max_new=args.max_new, force_len=(args.beams == 1), video_is_flat=True, slot=s, chunk=B if G > 1 else None)
+            if use_sched:
+                ids_, lens_, ticket = eng.submit(task, video, Tvs, audio if use_a else None, Ts if use_a else None, ra, rv, max_new=args.max_new,
+                                                 force_len=True, video_is_flat=True, slot=s)
+                pending.append((s, ticket))
+                if len(pending) > 2 * nstream + 8:            # every step of that call was issued long ago: a stream-side wait, no host sync
+                    s0, t0_ = pending.pop(0)
+                    with torch.cuda.stream(streams[s0]):
+                        eng.wait(t0_)
+                results[s] = (ids_, lens_)
+            else:
+                results[s] = eng.generate(task, video, Tvs, audio if use_a else None, Ts if use_a else None, ra, rv, beams=args.beams,
+                                          max_new=args.max_new, force_len=(args.beams == 1), video_is_flat=True, slot=s, chunk=B if G > 1 else None)
         return results[s]
+
+    def drain():
+        if use_sched:
+            eng.flush()
+            pending.clear()
+        torch.cuda.synchronize()
 
     ncall = 0
     torch.cuda.synchronize()
     for _ in range(max(args.warmup * (calls // G), nstream, nsets * len(pre["rates"]))):
         ids, lens = call(ncall)
         ncall += 1
-    torch.cuda.synchronize()
+    drain()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -300,7 +327,7 @@ def main():
     for _ in range(args.steps * (calls // G)):       # one call = G batches of B when --decode-group G
         ids, lens = call(ncall)
         ncall += 1
-    torch.cuda.synchronize()
+    drain()
     n_last = B * G
     # the path's only exchange step, inside the timed region: gather the hypotheses of the last call
     hyp = gather_hypotheses(pack_records([rank * n_last + j for j in range(n_last)], ids, lens, args.max_new), world * n_last)
@@ -323,6 +350,7 @@ def main():
         for _ in range(len(pre["rates"])):
             call(ncall)
             ncall += 1
+        drain()
         ents = eng.profile_read()
         eng.profile(False)
         tot_ms = sum(e["ms"] for e in ents) or 1.0
@@ -376,7 +404,8 @@ def main():
                                    + f", BASELINE.json configs[{pre['idx']}]" + ("" if args.preset == "c1" and not args.llm else " (NOT the headline configuration)"),
                        "batch_per_call": B, "calls_per_step": calls, "ms_per_call": round(elapsed / (args.steps * calls) * 1e3, 3),
                        "global_batch": world * B * calls, "input_sets": nsets, "timed_s": round(elapsed, 2),
-                       "parallelism": f"utterance-sharded dp{world}", "streams_per_gpu": nstream, "decode_group": G, "setup_s": round(setup_s, 1)},
+                       "parallelism": f"utterance-sharded dp{world}", "streams_per_gpu": nstream, "decode_group": G, "setup_s": round(setup_s, 1),
+                       "decode_scheduler": (dict(rows_per_step_cap=args.sched_rows, slots=args.sched_slots, **eng.scheduler_stats()) if use_sched else None)},
             "roofline": roofline, "cpu_baseline": cpu, "decode_group3": grouped, "stages": stages,
         }
         print(json.dumps(line), flush=True)

@@ -30,6 +30,7 @@ extern "C" {
 
 typedef struct oavsr_model oavsr_model;
 typedef struct oavsr_workspace oavsr_workspace;
+typedef struct oavsr_scheduler oavsr_scheduler;
 typedef void* oavsr_stream; /* hipStream_t */
 
 /* Mirrors the ctor arguments of AVSR_LLMs (modeling_OmniAVSR.py:28-34) + the HF configs it pulls in. */
@@ -133,6 +134,40 @@ int oavsr_generate_chunked(const oavsr_model* m, oavsr_workspace* ws, int32_t ta
                            const float* wav_dev, int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host, int32_t B, int32_t chunk_B,
                            int32_t rate_audio, int32_t rate_video, int32_t beams, int32_t max_new, int32_t force_len, int32_t* out_ids_dev,
                            int32_t* out_len_dev, oavsr_stream stream);
+
+/* ---- decode scheduler: continuous batching of the greedy decode phase across independent calls ------------------------------
+ * The reference evaluates one utterance per forward() (eval_OmniAVSR.py:18-24, datamodule/data_module.py:238-242): nothing to mirror,
+ * this is the engine's own serving layer under the same per-utterance results.  Calls keep arriving one batch at a time on the caller's
+ * streams (encoders + prefill of a call run there, as in oavsr_generate); the decode rows of every submitted call live in row slots of
+ * ONE pool per model, and one step loop on the scheduler's own stream serves all admitted rows (up to max_rows <= 32 per step, each row
+ * at its own step), so the LLM weights are streamed once per step for all of them.  Rows join after their call's prefill and leave after
+ * their own max_new tokens.  The schedule is fixed by the host at submission time in units of steps -- no host thread, no host
+ * synchronisation, no device-side queue -- and the ids of an utterance are bit-identical to oavsr_generate on that utterance alone.
+ * Greedy decode only (beam search keeps its own per-call loop: oavsr_generate). */
+/* n_slots: row slots of the pool (>= max_rows; extra blocks let the prefill of later calls run ahead of the step loop);
+ * max_prefix: longest prompt (rows) a slot can hold; max_new: longest hypothesis. */
+int oavsr_scheduler_create(const oavsr_model* m, int32_t n_slots, int32_t max_rows, int32_t max_prefix, int32_t max_new,
+                           oavsr_scheduler** out);
+void oavsr_scheduler_destroy(oavsr_scheduler* s);
+uint64_t oavsr_scheduler_bytes(const oavsr_scheduler* s);
+/* oavsr_generate(beams = 1) split in two: submit queues encoders + prefill on `stream` (workspace ws, as oavsr_generate) and the
+ * admission of the B rows on the scheduler's stream; it returns a ticket.  out_ids_dev / out_len_dev ([B][max_new] / [B] int32) are
+ * written by the scheduler's stream when the call's last step has run and must stay valid until oavsr_generate_wait. */
+int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_workspace* ws, int32_t task, const float* video_dev,
+                          const int32_t* Tv_host, const float* wav_dev, int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host,
+                          int32_t B, int32_t rate_audio, int32_t rate_video, int32_t max_new, int32_t force_len, int32_t* out_ids_dev,
+                          int32_t* out_len_dev, oavsr_stream stream, int64_t* ticket_out);
+/* Issues whatever steps the call still needs (other admitted rows ride along) and makes `stream` wait for its results: work queued on
+ * `stream` afterwards sees out_ids_dev / out_len_dev.  No host synchronisation. */
+int oavsr_generate_wait(oavsr_scheduler* s, int64_t ticket, oavsr_stream stream);
+/* Issues the remaining steps of every admitted call. */
+int oavsr_scheduler_flush(oavsr_scheduler* s);
+/* Pacing: steps the loop advances per admission before it waits for the new call's prefill.  0 (default) = ceil((max_new - 1) / k) with
+ * k = max_rows / B calls sharing a step in the steady state; 1 = lowest latency (rows join as early as possible, fewer rows per weight
+ * pass); larger = fewer, fuller steps.  Scheduling only: results never depend on it. */
+int oavsr_scheduler_set_stride(oavsr_scheduler* s, int32_t steps);
+/* out4 = {steps issued, sum over steps of live rows, calls submitted, step graphs instantiated} */
+int oavsr_scheduler_stats(const oavsr_scheduler* s, uint64_t* out4);
 
 /* ---- profiling hook (bench.py roofline): per-kernel-family HIP-event timing of every launch ---------------- */
 typedef struct oavsr_prof_entry {

@@ -504,9 +504,12 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnAr
   char* sv = svnew + RB;                             // [NW waves][64][RB]  V tiles; reused for the merge
   const int row = blockIdx.x, kvh = blockIdx.y;
   const int G = p.n_heads / p.n_kv_heads;
-  const int utt = row / p.beams;
+  // srow: the row's STATE slot (position, cache rows).  Identity, except under the decode scheduler, whose compact activation rows
+  // (Q / O) map onto the row slots of its pool through rowmap (greedy only: the slot is also the utterance and the tail row).
+  const int srow = p.rowmap ? p.rowmap[row] : row;
+  const int utt = srow / p.beams;
   const int plen = p.prefix_len[utt];
-  const int ntail = *p.step;
+  const int ntail = p.step ? *p.step : p.cpos[srow] + 1;      // no shared step counter: every row is at its own step (scheduler)
   const int ctx = plen + ntail;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qi = lane & 15, g = lane >> 4;
@@ -514,12 +517,12 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnAr
   T* Kt = reinterpret_cast<T*>(const_cast<void*>(p.Kt));
   T* Vt = reinterpret_cast<T*>(const_cast<void*>(p.Vt));
   // fused append: the new token's key index; its K/V come from LDS (sknew/svnew), never from the just-written cache row
-  const int newkey = p.inv_freq ? plen + p.cpos[row] : -1;
+  const int newkey = p.inv_freq ? plen + p.cpos[srow] : -1;
 
   auto kv_row = [&](const void* pre, const void* tail, int j) -> const char* {
     if (j < plen) return reinterpret_cast<const char*>(pre) + (((int64_t)utt * p.n_kv_heads + kvh) * p.max_prefix + j) * RB;
     const int t = j - plen;
-    const int src = p.anc ? p.anc[(int64_t)row * p.max_tail + t] : row;
+    const int src = p.anc ? p.anc[(int64_t)row * p.max_tail + t] : srow;
     return reinterpret_cast<const char*>(tail) + (((int64_t)src * p.n_kv_heads + kvh) * p.max_tail + t) * RB;
   };
   // K fragments straight from the cache (A operand row = key (lane & 15), 16-byte chunk blk*4 + g); V row of key kt0 + lane
@@ -552,11 +555,11 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnAr
   for (int i = tid + G * HD; i < 16 * HD; i += kDecThreads) reinterpret_cast<T*>(sq)[i] = from_f32<T>(0.f);   // rows >= G
   if (p.inv_freq) {
     constexpr int half = HD / 2;
-    const float pos = (float)p.pos[row];
+    const float pos = (float)p.pos[srow];
     for (int i = tid; i < (G + 1) * half; i += kDecThreads) {
       const int h = i / half, d = i - h * half;
       float sn, cs;
-      if (p.rope_cs) { const float2 t = p.rope_cs[(int64_t)row * half + d]; cs = t.x; sn = t.y; }
+      if (p.rope_cs) { const float2 t = p.rope_cs[(int64_t)srow * half + d]; cs = t.x; sn = t.y; }
       else sincosf(pos * p.inv_freq[d], &sn, &cs);
       const T* src = h < G ? qrow + (int64_t)(kvh * G + h) * HD : qrow + (int64_t)(p.n_heads + kvh) * HD;
       const float x0 = to_f32(src[d]), x1 = to_f32(src[d + half]);
@@ -565,13 +568,13 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnAr
         T* dst = reinterpret_cast<T*>(sq + h * RB);     // sq rows are read as B operand with row = lane & 15: no swizzle
         dst[d] = r0; dst[d + half] = r1;
       } else {
-        T* kd = Kt + (((int64_t)row * p.n_kv_heads + kvh) * p.max_tail + p.cpos[row]) * HD;
+        T* kd = Kt + (((int64_t)srow * p.n_kv_heads + kvh) * p.max_tail + p.cpos[srow]) * HD;
         kd[d] = r0; kd[d + half] = r1;
         reinterpret_cast<T*>(sknew)[d] = r0; reinterpret_cast<T*>(sknew)[d + half] = r1;
       }
     }
     const T* vsrc = qrow + (int64_t)(p.n_heads + p.n_kv_heads + kvh) * HD;
-    T* vd = Vt + (((int64_t)row * p.n_kv_heads + kvh) * p.max_tail + p.cpos[row]) * HD;
+    T* vd = Vt + (((int64_t)srow * p.n_kv_heads + kvh) * p.max_tail + p.cpos[srow]) * HD;
     for (int i = tid; i < HD; i += kDecThreads) { const T v = vsrc[i]; vd[i] = v; reinterpret_cast<T*>(svnew)[i] = v; }
   } else {
     for (int i = tid; i < G * HD; i += kDecThreads) reinterpret_cast<T*>(sq)[i] = qrow[(int64_t)kvh * G * HD + i];
@@ -771,6 +774,8 @@ int launch_decode_attention(const DecodeAttnArgs& a, hipStream_t st) {
   if (a.rows <= 0) return 0;
   OAVSR_REQUIRE(a.head_dim == 64 || a.head_dim == 128, "decode attention: head_dim %d unsupported", a.head_dim);
   OAVSR_REQUIRE(a.n_heads % a.n_kv_heads == 0 && a.n_heads / a.n_kv_heads <= 8, "decode attention: GQA group must be <= 8");
+  OAVSR_REQUIRE(!a.rowmap || (a.beams == 1 && !a.anc), "decode attention: a row map needs greedy rows (beams == 1, no ancestry table)");
+  OAVSR_REQUIRE(a.step || a.cpos, "decode attention: per-row tail lengths come from cpos[] when there is no step counter");
   if (a.dtype == DT_F32) return a.head_dim == 64 ? launch_dec_t<float, 64>(a, st) : launch_dec_t<float, 128>(a, st);
   // beam search (B * K x kv heads workgroups, several per CU): 4-wave workgroups with half the LDS pack more of them onto a CU
   // than 8-wave ones.  The choice follows the decode MODE (beams > 1), never the row count: the key -> wave partition and with

@@ -124,7 +124,8 @@ struct DecodeAttnArgs {
   const void* Kt = nullptr; const void* Vt = nullptr;   // tail caches   [row][kvh][max_tail][hd]
   int max_tail = 0;
   const int* prefix_len = nullptr;   // [utts] device
-  const int* step = nullptr;         // device scalar: number of tail tokens INCLUDING the current one
+  const int* step = nullptr;         // device scalar: number of tail tokens INCLUDING the current one (nullptr: cpos[row] + 1 per row)
+  const int* rowmap = nullptr;       // [rows] state slot of each activation row (decode scheduler; nullptr: identity; needs beams == 1, no anc)
   const int* anc = nullptr;          // [rows][max_tail] row that holds tail position t (null: own row)
   const float2* rope_cs = nullptr;   // [rows][hd/2] {cos, sin} of pos[row] (optional; else sincosf(pos * inv_freq) in the kernel)
   float scale = 1.f;
@@ -208,6 +209,41 @@ struct GreedyState {
   float2* rope_cs = nullptr; const float* inv_freq = nullptr; int rope_half = 0;
 };
 int launch_greedy_update(const int* argmax, GreedyState s, int B, int max_new, int eos, int pad, hipStream_t st);
+
+// ---- decode scheduler: continuous batching of the greedy decode (model.hip) ---------------------------------------------
+// State of the scheduler's ROW SLOTS (one slot = one utterance being decoded: its KV rows, position, hypothesis so far).  A decode
+// step runs on compact activation rows 0..R-1; rowmap[r] names the slot row r belongs to.  Slot `scratch_slot` backs the padding rows
+// of a step (R is rounded up to a multiple of 8): it is never updated.
+struct SchedState {
+  int* tok = nullptr;        // [slots + 1] input token of the row's next step
+  int* finished = nullptr;   // [slots + 1]
+  int* out_ids = nullptr;    // [slots + 1][out_ld]
+  int* out_len = nullptr;    // [slots + 1]
+  int* nstep = nullptr;      // [slots + 1] tokens generated so far (the row's own step counter)
+  int* limit = nullptr;      // [slots + 1] max_new of the call the row belongs to
+  int* pos = nullptr;        // [slots + 1] absolute position of the next token
+  int* cpos = nullptr;       // [slots + 1] tail-cache position of the next token
+  float2* rope_cs = nullptr; // [slots + 1][rope_half] {cos, sin} of pos
+  const float* inv_freq = nullptr; int rope_half = 0;
+  int out_ld = 0, scratch_slot = 0;
+};
+struct IntPack32 { int v[32]; };
+// dst[i] = v[i], i < n <= 32 (kernel arguments by value: no pinned staging, replay-safe ordering on the stream)
+int launch_set_ints(int* dst, const IntPack32& v, int n, hipStream_t st);
+// a call's rows enter the pool: slot0 + b gets pos = S[b] - 1, cpos = -1, nstep = 0, finished = 0, out_len = 0, out_ids row = pad
+int launch_sched_init_slots(const SchedState& s, int slot0, int B, const IntPack32& S, int limit, int pad, hipStream_t st);
+// first stage of the two-stage arg-max only (partials [rows][64] {value, index}); any V
+int launch_argmax_partial(const float* logits, int64_t ld, int rows, int V, int banned, void* partials, hipStream_t st);
+// One launch for the tail of a decode step, one workgroup per row: final arg-max over the row's partials -> HF greedy bookkeeping of
+// the row's slot (the expressions of greedy_update_kernel with the slot's own step counter) -> RoPE table of the next position ->
+// (lx != nullptr) the next step's input row lx[r] = embed[tok].  rowmap == nullptr: row r is slot slot0 + r.
+int launch_sched_tail(const void* partials, const SchedState& s, const int* rowmap, int slot0, int rows, int eos, int pad, int dtype,
+                      const void* embed, int64_t ldt, void* lx, int64_t ldx, int D, hipStream_t st);
+// lx[r] = embed[tok[rowmap[r]]] (membership of the step changed: the input rows are regathered in the new order)
+int launch_sched_embed(const SchedState& s, const int* rowmap, int rows, int dtype, const void* embed, int64_t ldt, void* lx, int64_t ldx,
+                       int D, hipStream_t st);
+// a call leaves the pool: out_ids[b][0..max_new) / out_len[b] <- slot slot0 + b
+int launch_sched_retire(const SchedState& s, int slot0, int B, int max_new, int* out_ids, int* out_len, hipStream_t st);
 
 // ---- beam search (beam.hip) ------------------------------------------------------------------------
 struct BeamArgs {

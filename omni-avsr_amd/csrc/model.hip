@@ -227,6 +227,10 @@ struct oavsr_workspace {
   float *beam_scores, *cand_val, *partial; int *cand_tok, *topk_flag, *hyp_n, *hyp_len, *hyp_tok, *seq[2], *anc[2]; double* hyp_score; size_t partial_bytes = 0;
   int max_tok_enc = 0, max_S_total = 0;
   int S_host[1024]; int B_cur = 0;
+  // where the prefill in flight puts its prefix KV rows / last-token logits / prefix lengths: this workspace's own caches (default) or
+  // the row slots of a decode scheduler's pool (set by prefill_impl for the duration of the call)
+  void *pf_k = nullptr, *pf_v = nullptr; size_t pf_layer = 0; int pf_max_prefix = 0;
+  const int* rowmap = nullptr;                 // decode scheduler only: activation row -> row slot (DecodeAttnArgs::rowmap)
 
   void* take(size_t bytes) {
     size_t off = align_up(used, 256);
@@ -240,6 +244,58 @@ struct oavsr_workspace {
     host_used = off + n * sizeof(T);
     return reinterpret_cast<T*>(host + off);
   }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Decode scheduler: continuous batching of the greedy decode phase across independent generate calls (include/omni_avsr.h).
+//
+// The reference decodes one utterance at a time (eval_OmniAVSR.py:18-24, datamodule/data_module.py:238-242); a decode step is bound by
+// streaming the LLM weights once, whatever the number of rows (<= 32) it serves.  Calls therefore keep arriving on their own streams
+// (encoders + prefill per call, unchanged), but their decode rows live in ROW SLOTS of one pool per model -- prefix KV written there by
+// the call's prefill, tail KV, position / step / hypothesis per slot -- and ONE step loop on the scheduler's own stream serves every
+// admitted row: rows join after their prefill (event) and leave after their own max_new tokens, at step granularity.
+//
+// The schedule is decided by the host at submission time, in units of steps (no device-side queues, no host thread, no host sync):
+//   submit(call i):  [stream of the call]  wait(slots free) -> encoders -> prefill into the slots -> record E_i
+//                    [scheduler stream]    n steps for the rows already admitted -> wait(E_i) -> admit(i)
+// with n = ceil((max_new - 1) / k), k = row capacity / rows of the call: the loop advances by 1/k of a hypothesis per admission, so in the
+// steady state k calls share every weight pass and the n steps run beside the next call's MFMA-bound phase.  Steps not yet issued when
+// the caller asks for a result are issued then (oavsr_generate_wait / oavsr_scheduler_flush).
+// Results do not depend on the schedule: the <= 32-row decode kernels give a row the same bits wherever it sits and whatever shares the
+// step (tests/test_invariance_gpu.py, tests/test_scheduler_gpu.py).
+// ------------------------------------------------------------------------------------------------
+struct SchedCall {
+  int64_t ticket = -1;
+  int task = 0, B = 0, slot0 = 0, limit = 0, remaining = 0, banned = -1;
+  int32_t *out_ids = nullptr, *out_len = nullptr;
+  hipEvent_t prefilled = nullptr, done = nullptr;
+  bool retired = true;
+};
+
+struct oavsr_scheduler {
+  const oavsr_model* m = nullptr;
+  hipStream_t st = nullptr;                    // the step loop's stream
+  oavsr_workspace* dws = nullptr;              // activation scratch of a step + the pool (kpre / vpre / ktail / vtail, prefix_len), indexed by row slot
+  char* arena = nullptr; size_t arena_bytes = 0;
+  int n_slots = 0, max_rows = 0, max_prefix = 0, max_new = 0;
+  SchedState ss;
+  int* rowmap = nullptr;                       // device [32]
+  float* logits_pre = nullptr;                 // [n_slots][vocab] last-prompt-position logits, written by the calls' prefills
+  void* partials = nullptr;                    // [32][64] float2 arg-max partials
+  std::vector<int64_t> slot_owner;             // ticket that last owned the slot (-1: never used)
+  std::vector<char> slot_used;
+  std::vector<uint64_t> slot_freed_at;         // allocation prefers the block freed longest ago (its owner's last step is furthest back in the queue)
+  uint64_t free_seq = 0;
+  static constexpr int kRing = 1024;
+  std::vector<SchedCall> ring;
+  std::vector<int> active;                     // ring indices in admission order
+  int64_t next_ticket = 0;
+  bool map_dirty = true;                       // membership changed since the last step: rowmap + input rows must be rebuilt
+  int cur_R = 0;
+  std::vector<std::pair<DecodeGraphKey, hipGraphExec_t>> graphs;
+  uint64_t steps_issued = 0, row_steps = 0, calls = 0;     // statistics (oavsr_scheduler_stats)
+  int stride = 0;                              // steps issued per admission; 0 = ceil((max_new - 1) / (max_rows / B)) (oavsr_scheduler_set_stride)
+  std::mutex mu;
 };
 
 namespace oavsr {
@@ -795,7 +851,7 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
     if (!decode) {   // decode: RoPE + cache append are fused into the decode-attention kernel
       RopeArgs r; r.dtype = dt; r.rows = rows; r.n_heads = H; r.n_kv_heads = KV; r.head_dim = hd; r.qkv = ws->lqkv; r.ld = nqkv;
       r.inv_freq = m->inv_freq; r.pos = pos; r.slot = ws->slot; r.cpos = cpos;
-      r.kcache = (char*)ws->kpre + li * ws->kpre_layer; r.vcache = (char*)ws->vpre + li * ws->kpre_layer; r.max_ctx = ws->max_prefix;
+      r.kcache = (char*)ws->pf_k + li * ws->pf_layer; r.vcache = (char*)ws->pf_v + li * ws->pf_layer; r.max_ctx = ws->pf_max_prefix;
       { ProfScope ps("rope_kv", 0, 2.0 * rows * nqkv * m->esz, st);
         OAVSR_TRY(launch_rope_kv(r, st)); }
       AttnArgs a; a.dtype = dt; a.head_dim = hd; a.n_heads = H; a.n_kv_heads = KV; a.n_seqs = B;
@@ -815,7 +871,7 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
       a.Kp = (char*)ws->kpre + li * ws->kpre_layer; a.Vp = (char*)ws->vpre + li * ws->kpre_layer; a.max_prefix = ws->max_prefix;
       a.Kt = (char*)ws->ktail + li * ws->ktail_layer; a.Vt = (char*)ws->vtail + li * ws->ktail_layer; a.max_tail = ws->max_new;
       a.prefix_len = ws->prefix_len; a.step = step; a.anc = anc; a.scale = 1.0f / sqrtf((float)hd);
-      a.inv_freq = m->inv_freq; a.pos = pos; a.cpos = cpos; a.rope_cs = rope_cs;
+      a.inv_freq = m->inv_freq; a.pos = pos; a.cpos = cpos; a.rope_cs = rope_cs; a.rowmap = ws->rowmap;
       ProfScope ps("decode_attention", 0, 2.0 * rows * max_S * KV * hd * m->esz, st);
       OAVSR_TRY(launch_decode_attention(a, st));
     }
@@ -905,27 +961,33 @@ static int lm_head_rows(const oavsr_model* m, oavsr_workspace* ws, const void* x
   return run_gemm(g, st, false);
 }
 
+// Where a prefill puts what the decode loop needs: the row slots slot0.. of a decode scheduler's pool instead of the workspace's own caches.
+struct PrefillDest { void *kpre, *vpre; size_t layer_bytes; int max_prefix; float* logits; int* prefix_len; int slot0; };
+
 // utt0: first utterance slot of this call (prefix-cache index, logits row); > 0 only for the chunked generate, whose chunks are
 // prefilled one after another into consecutive slots and then decoded together.
 static int prefill_impl(const oavsr_model* m, oavsr_workspace* ws, int task, int B, const void* embeds, const int32_t* S, float* logits_out,
-                        hipStream_t st, int utt0 = 0) {
+                        hipStream_t st, int utt0 = 0, const PrefillDest* dest = nullptr) {
   const oavsr_config& c = m->cfg;
   OAVSR_REQUIRE(B >= 1 && utt0 >= 0 && utt0 + B <= ws->max_B, "prefill: B=%d (+%d) exceeds workspace (%d)", B, utt0, ws->max_B);
   int total = 0, maxS = 0;
-  for (int b = 0; b < B; ++b) { OAVSR_REQUIRE(S[b] >= 1 && S[b] <= ws->max_prefix, "prefill: S[%d]=%d exceeds prefix cache (%d)", b, S[b], ws->max_prefix); total += S[b]; maxS = std::max(maxS, S[b]); }
+  ws->pf_k = dest ? dest->kpre : ws->kpre; ws->pf_v = dest ? dest->vpre : ws->vpre;
+  ws->pf_layer = dest ? dest->layer_bytes : ws->kpre_layer; ws->pf_max_prefix = dest ? dest->max_prefix : ws->max_prefix;
+  const int slot_base = dest ? dest->slot0 : utt0;
+  for (int b = 0; b < B; ++b) { OAVSR_REQUIRE(S[b] >= 1 && S[b] <= ws->pf_max_prefix, "prefill: S[%d]=%d exceeds prefix cache (%d)", b, S[b], ws->pf_max_prefix); total += S[b]; maxS = std::max(maxS, S[b]); }
   OAVSR_REQUIRE(total <= ws->max_S_total, "prefill: too many prompt rows");
   int* pos = ws->stage<int>(total); int* slot = ws->stage<int>(total); int* cu = ws->stage<int>(B + 1); int* last = ws->stage<int>(B);
   int* plen = ws->stage<int>(B);
   OAVSR_REQUIRE(pos && slot && cu && last && plen, "host staging exhausted");
   int r = 0; cu[0] = 0;
-  for (int b = 0; b < B; ++b) { for (int i = 0; i < S[b]; ++i) { pos[r] = i; slot[r] = utt0 + b; ++r; } cu[b + 1] = r; last[b] = r - 1; plen[b] = S[b]; ws->S_host[utt0 + b] = S[b]; }
-  ws->B_cur = utt0 + B;
+  for (int b = 0; b < B; ++b) { for (int i = 0; i < S[b]; ++i) { pos[r] = i; slot[r] = slot_base + b; ++r; } cu[b + 1] = r; last[b] = r - 1; plen[b] = S[b]; ws->S_host[utt0 + b] = S[b]; }
+  ws->B_cur = dest ? 0 : utt0 + B;             // a pool-bound prefill leaves nothing for this workspace's own decode
   OAVSR_TRY(h2d(ws->pos, pos, sizeof(int) * total, st));
   OAVSR_TRY(h2d(ws->cpos, pos, sizeof(int) * total, st));
   OAVSR_TRY(h2d(ws->slot, slot, sizeof(int) * total, st));
   OAVSR_TRY(h2d(ws->cu_s, cu, sizeof(int) * (B + 1), st));
   OAVSR_TRY(h2d(ws->last_rows, last, sizeof(int) * B, st));
-  OAVSR_TRY(h2d(ws->prefix_len + utt0, plen, sizeof(int) * B, st));
+  OAVSR_TRY(h2d(dest ? dest->prefix_len + dest->slot0 : ws->prefix_len + utt0, plen, sizeof(int) * B, st));
   if (embeds != ws->lx) OAVSR_CHECK_HIP(hipMemcpyAsync(ws->lx, embeds, (size_t)total * c.llm_hidden * m->esz, hipMemcpyDeviceToDevice, st));
   int* cul = ws->stage<int>(B + 1);
   OAVSR_REQUIRE(cul, "host staging exhausted");
@@ -935,7 +997,7 @@ static int prefill_impl(const oavsr_model* m, oavsr_workspace* ws, int task, int
   OAVSR_TRY(llm_layers(m, ws, task, total, false, B, 1, maxS, ws->pos, ws->cpos, nullptr, nullptr, st, nullptr, ws->last_rows, ws->cu_b, &pruned));
   // last position of every utterance only (the reference materialises all positions, Llama_LoRA.py:372-373)
   if (!pruned) OAVSR_TRY(launch_copy_rows(m->dtype, ws->lx, c.llm_hidden, ws->last_rows, ws->lastx, c.llm_hidden, B, c.llm_hidden, st));
-  float* lg = ws->logits + (size_t)utt0 * c.llm_vocab;
+  float* lg = dest ? dest->logits + (size_t)dest->slot0 * c.llm_vocab : ws->logits + (size_t)utt0 * c.llm_vocab;
   OAVSR_TRY(lm_head_rows(m, ws, ws->lastx, B, lg, st, kPrefillTailChunk));
   if (logits_out) OAVSR_CHECK_HIP(hipMemcpyAsync(logits_out, lg, (size_t)B * c.llm_vocab * 4, hipMemcpyDeviceToDevice, st));
   return 0;
@@ -1311,15 +1373,12 @@ int oavsr_decode(const oavsr_model* m, oavsr_workspace* ws, int32_t task, int32_
   return decode_greedy(m, ws, task, B, max_new, force_len, out_ids_dev, out_len_dev, (hipStream_t)stream);
 }
 
-static int generate_impl(const oavsr_model* m, oavsr_workspace* ws, int32_t task, const float* video_dev, const int32_t* Tv_host, const float* wav_dev,
-                         int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host, int32_t B, int32_t chunk_B, int32_t rate_audio,
-                         int32_t rate_video, int32_t beams, int32_t max_new, int32_t force_len, int32_t* out_ids_dev, int32_t* out_len_dev,
-                         hipStream_t st) {
-  OAVSR_REQUIRE(m && ws && out_ids_dev && out_len_dev, "generate: null argument");
-  OAVSR_REQUIRE(beams >= 1 && !(beams > 1 && force_len), "generate: bad num_beams / force_len");
-  OAVSR_REQUIRE(B >= 1 && B <= ws->max_B, "generate: B=%d exceeds workspace (%d)", B, ws->max_B);
-  OAVSR_REQUIRE(chunk_B >= 1, "generate: chunk_B must be >= 1");
-  CallScope cs(ws, st);
+// Everything of a generate() call up to and including the prefill: encoders + projector + prompt + prefill per chunk of chunk_B
+// utterances (the launch shapes of a batch-of-chunk_B request); each chunk's prefix KV / last-token logits land in its own slots of the
+// workspace -- or (dest) in the row slots of a decode scheduler's pool.  S_out (optional): prompt rows per utterance.
+static int encode_prefill(const oavsr_model* m, oavsr_workspace* ws, int32_t task, const float* video_dev, const int32_t* Tv_host, const float* wav_dev,
+                          int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host, int32_t B, int32_t chunk_B, int32_t rate_audio,
+                          int32_t rate_video, hipStream_t st, const PrefillDest* dest, int* S_out) {
   // Concurrent generate() calls on different streams: the MFMA-bound encoder + prefill phases gain nothing from sharing
   // the chip with each other, so they are chained one after another; only the latency-bound decode loop of one call
   // overlaps the encoders of the next.
@@ -1328,9 +1387,6 @@ static int generate_impl(const oavsr_model* m, oavsr_workspace* ws, int32_t task
   const bool use_v = task == OAVSR_TASK_VIDEO || task == OAVSR_TASK_AUDIOVISUAL;
   if (use_a) OAVSR_REQUIRE(wav_dev && Ts_host && keep_host, "generate: audio inputs missing");
   if (use_v) OAVSR_REQUIRE(video_dev && Tv_host, "generate: video inputs missing");
-  // encoders + projector + prompt + prefill run per chunk of chunk_B utterances (the shapes of a batch-of-chunk_B request);
-  // each chunk's prefix KV / last-token logits land in its own slots, then ONE decode loop serves all B rows: the LLM weights
-  // are streamed once per step for the whole group instead of once per chunk.
   int64_t frames_before = 0;
   for (int b0 = 0; b0 < B; b0 += chunk_B) {
     const int Bc = std::min<int>(chunk_B, B - b0);
@@ -1349,12 +1405,29 @@ static int generate_impl(const oavsr_model* m, oavsr_workspace* ws, int32_t task
     }
     std::vector<int> S(Bc);
     OAVSR_TRY(build_prompt_impl(m, ws, task, Bc, use_a ? na.data() : nullptr, ws->tok_a, use_v ? nv.data() : nullptr, ws->tok_v, ws->lx, S.data(), st));
-    OAVSR_TRY(prefill_impl(m, ws, task, Bc, ws->lx, S.data(), nullptr, st, b0));
+    PrefillDest d;
+    if (dest) { d = *dest; d.slot0 += b0; }
+    OAVSR_TRY(prefill_impl(m, ws, task, Bc, ws->lx, S.data(), nullptr, st, b0, dest ? &d : nullptr));
+    if (S_out) for (int b = 0; b < Bc; ++b) S_out[b0 + b] = S[b];
   }
   if (m->serialize_enc) {
     OAVSR_CHECK_HIP(hipEventRecord(m->enc_done, st));
     m->enc_last = st; m->enc_recorded = true;
   }
+  return 0;
+}
+
+static int generate_impl(const oavsr_model* m, oavsr_workspace* ws, int32_t task, const float* video_dev, const int32_t* Tv_host, const float* wav_dev,
+                         int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host, int32_t B, int32_t chunk_B, int32_t rate_audio,
+                         int32_t rate_video, int32_t beams, int32_t max_new, int32_t force_len, int32_t* out_ids_dev, int32_t* out_len_dev,
+                         hipStream_t st) {
+  OAVSR_REQUIRE(m && ws && out_ids_dev && out_len_dev, "generate: null argument");
+  OAVSR_REQUIRE(beams >= 1 && !(beams > 1 && force_len), "generate: bad num_beams / force_len");
+  OAVSR_REQUIRE(B >= 1 && B <= ws->max_B, "generate: B=%d exceeds workspace (%d)", B, ws->max_B);
+  OAVSR_REQUIRE(chunk_B >= 1, "generate: chunk_B must be >= 1");
+  CallScope cs(ws, st);
+  // ONE decode loop then serves all B rows: the LLM weights are streamed once per step for the whole group instead of once per chunk.
+  OAVSR_TRY(encode_prefill(m, ws, task, video_dev, Tv_host, wav_dev, wav_ld, Ts_host, keep_host, B, chunk_B, rate_audio, rate_video, st, nullptr, nullptr));
   if (beams > 1) return decode_beam(m, ws, task, B, beams, max_new, out_ids_dev, out_len_dev, st);
   return decode_greedy(m, ws, task, B, max_new, force_len, out_ids_dev, out_len_dev, st);
 }
@@ -1372,6 +1445,251 @@ int oavsr_generate_chunked(const oavsr_model* m, oavsr_workspace* ws, int32_t ta
                            int32_t* out_len_dev, oavsr_stream stream) {
   return generate_impl(m, ws, task, video_dev, Tv_host, wav_dev, wav_ld, Ts_host, keep_host, B, chunk_B, rate_audio, rate_video, beams, max_new,
                        force_len, out_ids_dev, out_len_dev, (hipStream_t)stream);
+}
+
+// ---- decode scheduler (struct oavsr_scheduler, above) --------------------------------------------------------------------------------
+static int sched_rows(const oavsr_scheduler* s) { int r = 0; for (int i : s->active) r += s->ring[i].B; return r; }
+static int sched_min_remaining(const oavsr_scheduler* s) { int r = 1 << 30; for (int i : s->active) r = std::min(r, s->ring[i].remaining); return s->active.empty() ? 0 : r; }
+static int sched_max_remaining(const oavsr_scheduler* s) { int r = 0; for (int i : s->active) r = std::max(r, s->ring[i].remaining); return r; }
+
+// one decode step over the R compact rows of the current membership (every launch on the scheduler's stream; hipGraph-capturable)
+static int sched_one_step(oavsr_scheduler* s, int R, int task, int banned) {
+  const oavsr_model* m = s->m; const oavsr_config& c = m->cfg; oavsr_workspace* w = s->dws;
+  OAVSR_TRY(llm_layers(m, w, task, R, true, R, 1, s->max_prefix + s->max_new, s->ss.pos, s->ss.cpos, nullptr, nullptr, s->st, s->ss.rope_cs));
+  OAVSR_TRY(lm_head_rows(m, w, w->lx, R, w->logits, s->st));
+  { ProfScope ps("argmax_partial", 0, (double)R * c.llm_vocab * 4, s->st);
+    OAVSR_TRY(launch_argmax_partial(w->logits, c.llm_vocab, R, c.llm_vocab, banned, s->partials, s->st)); }
+  ProfScope ps("sched_tail", 0, 2.0 * R * c.llm_hidden * m->esz, s->st);
+  return launch_sched_tail(s->partials, s->ss, s->rowmap, 0, R, c.id_eos, c.id_pad, m->dtype, m->embed, c.llm_hidden, w->lx, c.llm_hidden, c.llm_hidden, s->st);
+}
+
+// membership changed (a call joined or left): new row map (padding rows -> the scratch slot), input rows regathered in the new order
+static int sched_sync_membership(oavsr_scheduler* s) {
+  if (!s->map_dirty) return 0;
+  const oavsr_config& c = s->m->cfg;
+  IntPack32 map;
+  int r = 0;
+  for (int i : s->active) { const SchedCall& k = s->ring[i]; for (int b = 0; b < k.B; ++b) map.v[r++] = k.slot0 + b; }
+  const int R = std::max(8, (r + 7) / 8 * 8);
+  OAVSR_REQUIRE(R <= 32, "scheduler: %d rows in the step", r);
+  for (; r < R; ++r) map.v[r] = s->n_slots;
+  OAVSR_TRY(launch_set_ints(s->rowmap, map, R, s->st));
+  OAVSR_TRY(launch_sched_embed(s->ss, s->rowmap, R, s->m->dtype, s->m->embed, c.llm_hidden, s->dws->lx, c.llm_hidden, c.llm_hidden, s->st));
+  s->cur_R = R; s->map_dirty = false;
+  return 0;
+}
+
+static int sched_retire(oavsr_scheduler* s, int idx) {
+  SchedCall& k = s->ring[idx];
+  OAVSR_TRY(launch_sched_retire(s->ss, k.slot0, k.B, k.limit, k.out_ids, k.out_len, s->st));
+  OAVSR_CHECK_HIP(hipEventRecord(k.done, s->st));
+  ++s->free_seq;
+  for (int b = 0; b < k.B; ++b) { s->slot_used[k.slot0 + b] = 0; s->slot_freed_at[k.slot0 + b] = s->free_seq; }
+  k.retired = true;
+  s->active.erase(std::find(s->active.begin(), s->active.end(), idx));
+  s->map_dirty = true;
+  return 0;
+}
+
+// issue up to n steps for the admitted rows; calls whose last step has been issued leave (result copy + `done` event) on the way
+static int sched_run(oavsr_scheduler* s, int n) {
+  static const bool graphs_on = [] { const char* e = getenv("OAVSR_DECODE_GRAPH"); return !(e && e[0] == '0'); }();
+  while (n > 0 && !s->active.empty()) {
+    const int k = std::min(n, sched_min_remaining(s));
+    OAVSR_TRY(sched_sync_membership(s));
+    const SchedCall& head = s->ring[s->active[0]];
+    const int task = head.task, banned = head.banned, R = s->cur_R;
+    int done = 0;
+    if (graphs_on && !g_prof.on) {
+      const DecodeGraphKey key{R, task, 0, banned};
+      hipGraphExec_t exec = nullptr;
+      for (auto& e : s->graphs) if (e.first == key) exec = e.second;
+      if (!exec) {
+        OAVSR_TRY(sched_one_step(s, R, task, banned));     // eager once: sets the per-kernel attributes outside of the capture
+        done = 1;
+        hipGraph_t graph = nullptr;
+        OAVSR_CHECK_HIP(hipStreamBeginCapture(s->st, hipStreamCaptureModeRelaxed));
+        int rc = sched_one_step(s, R, task, banned);
+        hipError_t ce = hipStreamEndCapture(s->st, &graph);
+        OAVSR_REQUIRE(rc == 0 && ce == hipSuccess && graph, "scheduler: hipGraph capture of the step failed (%d / %d)", rc, (int)ce);
+        OAVSR_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        hipGraphDestroy(graph);
+        s->graphs.push_back({key, exec});
+      }
+      for (; done < k; ++done) OAVSR_CHECK_HIP(hipGraphLaunch(exec, s->st));
+    }
+    for (; done < k; ++done) OAVSR_TRY(sched_one_step(s, R, task, banned));
+    s->steps_issued += k; s->row_steps += (uint64_t)k * sched_rows(s);
+    std::vector<int> leaving;
+    for (int i : s->active) { s->ring[i].remaining -= k; if (s->ring[i].remaining <= 0) leaving.push_back(i); }
+    for (int i : leaving) OAVSR_TRY(sched_retire(s, i));
+    n -= k;
+  }
+  return 0;
+}
+
+// B contiguous free slots; of all candidates the block whose most recently freed slot was freed longest ago
+static int sched_alloc(oavsr_scheduler* s, int B) {
+  int best = -1; uint64_t best_score = ~0ull;
+  for (int s0 = 0; s0 + B <= s->n_slots; ++s0) {
+    uint64_t score = 0; bool ok = true;
+    for (int b = 0; b < B && ok; ++b) { if (s->slot_used[s0 + b]) ok = false; else score = std::max(score, s->slot_freed_at[s0 + b]); }
+    if (ok && score < best_score) { best = s0; best_score = score; }
+  }
+  return best;
+}
+
+int oavsr_scheduler_create(const oavsr_model* m, int32_t n_slots, int32_t max_rows, int32_t max_prefix, int32_t max_new, oavsr_scheduler** out) {
+  OAVSR_REQUIRE(m && out, "scheduler_create: null argument");
+  OAVSR_REQUIRE(max_rows >= 1 && max_rows <= 32, "scheduler_create: max_rows=%d (the weight-streaming decode kernels serve up to 32 rows per step)", max_rows);
+  OAVSR_REQUIRE(n_slots >= max_rows && n_slots <= 4096 && max_prefix >= 1 && max_new >= 1, "scheduler_create: bad sizes");
+  const oavsr_config& c = m->cfg;
+  oavsr_scheduler* s = new oavsr_scheduler();
+  s->m = m; s->n_slots = n_slots; s->max_rows = max_rows; s->max_prefix = (max_prefix + 63) / 64 * 64; s->max_new = max_new;
+  const size_t e = m->esz, NS = (size_t)n_slots + 1, R = 32;
+  const int d = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, hd = c.llm_head_dim, I = c.llm_mlp;
+  const size_t nqkv = (size_t)(H + 2 * KV) * hd;
+  oavsr_workspace* w = new oavsr_workspace();
+  s->dws = w;
+  w->m = m; w->max_B = n_slots; w->max_beams = 1; w->max_new = max_new; w->max_prefix = s->max_prefix;
+  w->kpre_layer = NS * KV * (size_t)s->max_prefix * hd * e;
+  w->ktail_layer = NS * KV * (size_t)max_new * hd * e;
+  struct Req { void** p; size_t bytes; };
+  std::vector<Req> reqs;
+#define WANT(ptr, bytes) reqs.push_back({(void**)&(ptr), (size_t)(bytes)})
+  WANT(w->lx, R * d * e); WANT(w->lh, R * d * e); WANT(w->lqkv, R * nqkv * e); WANT(w->lattn, R * (size_t)H * hd * e);
+  WANT(w->lact, R * (size_t)I * e); WANT(w->llora, R * (size_t)std::max(64, c.lora_k2) * e); WANT(w->logits, R * (size_t)c.llm_vocab * 4);
+  WANT(w->kpre, w->kpre_layer * c.llm_layers); WANT(w->vpre, w->kpre_layer * c.llm_layers);
+  WANT(w->ktail, w->ktail_layer * c.llm_layers); WANT(w->vtail, w->ktail_layer * c.llm_layers);
+  WANT(w->prefix_len, NS * 4);
+  WANT(s->logits_pre, (size_t)n_slots * c.llm_vocab * 4); WANT(s->partials, R * 64 * 8); WANT(s->rowmap, 64 * 4);
+  WANT(s->ss.tok, NS * 4); WANT(s->ss.finished, NS * 4); WANT(s->ss.out_ids, NS * (size_t)max_new * 4); WANT(s->ss.out_len, NS * 4);
+  WANT(s->ss.nstep, NS * 4); WANT(s->ss.limit, NS * 4); WANT(s->ss.pos, NS * 4); WANT(s->ss.cpos, NS * 4);
+  WANT(s->ss.rope_cs, NS * (size_t)(hd / 2) * sizeof(float2));
+#undef WANT
+  size_t total = 0;
+  for (auto& r : reqs) total = align_up(total, 256) + std::max<size_t>(r.bytes, 256);
+  total += 4096;
+  if (hipMalloc((void**)&s->arena, total) != hipSuccess) { set_last_error("scheduler_create: hipMalloc(%zu bytes) failed", total); delete w; delete s; return -2; }
+  s->arena_bytes = total;
+  if (hipMemset(s->arena, 0, total) != hipSuccess) { set_last_error("scheduler_create: hipMemset failed"); hipFree(s->arena); delete w; delete s; return -2; }
+  { size_t off = 0; for (auto& r : reqs) { off = align_up(off, 256); *r.p = s->arena + off; off += std::max<size_t>(r.bytes, 256); } }
+  w->rowmap = s->rowmap;
+  s->ss.inv_freq = m->inv_freq; s->ss.rope_half = hd / 2; s->ss.out_ld = max_new; s->ss.scratch_slot = n_slots;
+  s->slot_owner.assign(n_slots, -1); s->slot_used.assign(n_slots, 0); s->slot_freed_at.assign(n_slots, 0);
+  s->ring.resize(oavsr_scheduler::kRing);
+  if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    set_last_error("scheduler_create: stream creation / device synchronisation failed"); hipFree(s->arena); delete w; delete s; return -2;
+  }
+  *out = s;
+  return 0;
+}
+
+void oavsr_scheduler_destroy(oavsr_scheduler* s) {
+  if (!s) return;
+  if (s->st) { hipStreamSynchronize(s->st); }
+  for (auto& e : s->graphs) hipGraphExecDestroy(e.second);
+  for (auto& k : s->ring) { if (k.prefilled) hipEventDestroy(k.prefilled); if (k.done) hipEventDestroy(k.done); }
+  if (s->st) hipStreamDestroy(s->st);
+  if (s->arena) hipFree(s->arena);
+  delete s->dws;
+  delete s;
+}
+uint64_t oavsr_scheduler_bytes(const oavsr_scheduler* s) { return s ? s->arena_bytes : 0; }
+
+int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_workspace* ws, int32_t task, const float* video_dev, const int32_t* Tv_host,
+                          const float* wav_dev, int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host, int32_t B, int32_t rate_audio,
+                          int32_t rate_video, int32_t max_new, int32_t force_len, int32_t* out_ids_dev, int32_t* out_len_dev, oavsr_stream stream,
+                          int64_t* ticket_out) {
+  OAVSR_REQUIRE(m && s && ws && out_ids_dev && out_len_dev && ticket_out, "generate_submit: null argument");
+  OAVSR_REQUIRE(s->m == m && ws->m == m, "generate_submit: scheduler / workspace belong to another model");
+  OAVSR_REQUIRE(task >= 0 && task < 3, "generate_submit: bad task %d", task);
+  OAVSR_REQUIRE(B >= 1 && B <= ws->max_B && B <= s->max_rows, "generate_submit: B=%d exceeds the workspace (%d) or the scheduler's rows per step (%d)", B, ws->max_B, s->max_rows);
+  OAVSR_REQUIRE(max_new >= 1 && max_new <= s->max_new, "generate_submit: max_new=%d exceeds the scheduler's (%d)", max_new, s->max_new);
+  hipStream_t st = (hipStream_t)stream;
+  const oavsr_config& c = m->cfg;
+  std::lock_guard<std::mutex> lk(s->mu);
+  const int ltask = c.lora_task_specific ? task : 0;      // rows of one step share the LoRA adapter set (Llama_LoRA.py:250-259) and the banned token
+  const int banned = force_len ? c.id_eos : -1;
+  if (!s->active.empty() && (s->ring[s->active[0]].task != ltask || s->ring[s->active[0]].banned != banned)) OAVSR_TRY(sched_run(s, sched_max_remaining(s)));
+  // room: rows per step and a block of row slots
+  const uint64_t steps0 = s->steps_issued;
+  while (sched_rows(s) + B > s->max_rows) OAVSR_TRY(sched_run(s, sched_min_remaining(s)));
+  int slot0 = sched_alloc(s, B);
+  while (slot0 < 0 && !s->active.empty()) { OAVSR_TRY(sched_run(s, sched_min_remaining(s))); slot0 = sched_alloc(s, B); }
+  OAVSR_REQUIRE(slot0 >= 0, "generate_submit: no block of %d free row slots (pool of %d)", B, s->n_slots);
+  const int64_t ticket = s->next_ticket;
+  SchedCall& k = s->ring[ticket % oavsr_scheduler::kRing];
+  OAVSR_REQUIRE(k.retired, "generate_submit: %d calls in flight", oavsr_scheduler::kRing);
+  if (!k.prefilled) OAVSR_CHECK_HIP(hipEventCreateWithFlags(&k.prefilled, hipEventDisableTiming));
+  if (!k.done) OAVSR_CHECK_HIP(hipEventCreateWithFlags(&k.done, hipEventDisableTiming));
+  // the slots' previous owners must have left (their last step is already in the scheduler stream's queue) before this call's prefill writes there
+  { int64_t seen = -1;
+    for (int b = 0; b < B; ++b) {
+      const int64_t t = s->slot_owner[slot0 + b];
+      if (t < 0 || t == seen) continue;
+      seen = t;
+      const SchedCall& o = s->ring[t % oavsr_scheduler::kRing];
+      if (o.ticket == t && o.done) OAVSR_CHECK_HIP(hipStreamWaitEvent(st, o.done, 0));
+    } }
+  std::vector<int> S(B);
+  { CallScope cs(ws, st);
+    PrefillDest dest{s->dws->kpre, s->dws->vpre, s->dws->kpre_layer, s->max_prefix, s->logits_pre, s->dws->prefix_len, slot0};
+    OAVSR_TRY(encode_prefill(m, ws, task, video_dev, Tv_host, wav_dev, wav_ld, Ts_host, keep_host, B, B, rate_audio, rate_video, st, &dest, S.data())); }
+  OAVSR_CHECK_HIP(hipEventRecord(k.prefilled, st));
+  for (int b = 0; b < B; ++b) { s->slot_used[slot0 + b] = 1; s->slot_owner[slot0 + b] = ticket; }
+  ++s->next_ticket; ++s->calls;
+  k.ticket = ticket; k.task = ltask; k.B = B; k.slot0 = slot0; k.limit = max_new; k.remaining = max_new - 1; k.banned = banned;
+  k.out_ids = out_ids_dev; k.out_len = out_len_dev; k.retired = false;
+  // pacing: the loop advances 1/k of a hypothesis per admission (k = calls of this size that share a step), beside this call's MFMA-bound phase
+  static const int stride_env = [] { const char* e = getenv("OAVSR_SCHED_STRIDE"); return e ? atoi(e) : 0; }();
+  const int share = std::max(1, s->max_rows / B);
+  const int stride = s->stride > 0 ? s->stride : stride_env > 0 ? stride_env : ceil_div(std::max(1, max_new - 1), share);
+  const int issued = (int)(s->steps_issued - steps0);
+  if (stride > issued) OAVSR_TRY(sched_run(s, stride - issued));
+  // admission: after the call's prefill; first token from the prefill's logits (step 0 of the row's own counter)
+  OAVSR_CHECK_HIP(hipStreamWaitEvent(s->st, k.prefilled, 0));
+  IntPack32 Sp;
+  for (int b = 0; b < B; ++b) Sp.v[b] = S[b];
+  OAVSR_TRY(launch_sched_init_slots(s->ss, slot0, B, Sp, max_new, c.id_pad, s->st));
+  OAVSR_TRY(launch_argmax_partial(s->logits_pre + (size_t)slot0 * c.llm_vocab, c.llm_vocab, B, c.llm_vocab, banned, s->partials, s->st));
+  OAVSR_TRY(launch_sched_tail(s->partials, s->ss, nullptr, slot0, B, c.id_eos, c.id_pad, m->dtype, m->embed, c.llm_hidden, nullptr, 0, c.llm_hidden, s->st));
+  s->active.push_back((int)(ticket % oavsr_scheduler::kRing));
+  s->map_dirty = true;
+  if (k.remaining <= 0) OAVSR_TRY(sched_retire(s, (int)(ticket % oavsr_scheduler::kRing)));
+  *ticket_out = ticket;
+  return 0;
+}
+
+int oavsr_generate_wait(oavsr_scheduler* s, int64_t ticket, oavsr_stream stream) {
+  OAVSR_REQUIRE(s, "generate_wait: null scheduler");
+  std::lock_guard<std::mutex> lk(s->mu);
+  OAVSR_REQUIRE(ticket >= 0 && ticket < s->next_ticket, "generate_wait: unknown ticket %lld", (long long)ticket);
+  SchedCall& k = s->ring[ticket % oavsr_scheduler::kRing];
+  OAVSR_REQUIRE(k.ticket == ticket, "generate_wait: ticket %lld has expired (more than %d calls submitted since)", (long long)ticket, oavsr_scheduler::kRing);
+  while (!k.retired) OAVSR_TRY(sched_run(s, k.remaining));
+  OAVSR_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, k.done, 0));
+  return 0;
+}
+
+int oavsr_scheduler_flush(oavsr_scheduler* s) {
+  OAVSR_REQUIRE(s, "scheduler_flush: null scheduler");
+  std::lock_guard<std::mutex> lk(s->mu);
+  while (!s->active.empty()) OAVSR_TRY(sched_run(s, sched_max_remaining(s)));
+  return 0;
+}
+
+int oavsr_scheduler_set_stride(oavsr_scheduler* s, int32_t steps) {
+  OAVSR_REQUIRE(s && steps >= 0, "scheduler_set_stride: bad argument");
+  std::lock_guard<std::mutex> lk(s->mu);
+  s->stride = steps;
+  return 0;
+}
+
+int oavsr_scheduler_stats(const oavsr_scheduler* s, uint64_t* out4) {
+  OAVSR_REQUIRE(s && out4, "scheduler_stats: null argument");
+  out4[0] = s->steps_issued; out4[1] = s->row_steps; out4[2] = s->calls; out4[3] = s->graphs.size();
+  return 0;
 }
 
 int oavsr_profile_enable(int32_t on) { g_prof.on = on != 0; return 0; }

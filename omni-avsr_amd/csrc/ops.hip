@@ -421,6 +421,91 @@ __global__ void greedy_update_kernel(const int* __restrict__ amax, GreedyState s
   }
 }
 
+// ---- decode scheduler (kernels.h: SchedState) ------------------------------------------------------------------------------
+__global__ void set_ints_kernel(int* __restrict__ dst, IntPack32 v, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = v.v[threadIdx.x];
+}
+
+__global__ void sched_init_slots_kernel(SchedState s, int slot0, int B, IntPack32 S, int limit, int pad) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const int slot = slot0 + b;
+  if (threadIdx.x == 0) {
+    s.pos[slot] = S.v[b] - 1; s.cpos[slot] = -1; s.nstep[slot] = 0; s.finished[slot] = 0; s.out_len[slot] = 0; s.limit[slot] = limit; s.tok[slot] = pad;
+  }
+  for (int i = threadIdx.x; i < s.out_ld; i += blockDim.x) s.out_ids[(int64_t)slot * s.out_ld + i] = pad;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void sched_tail_kernel(const float2* __restrict__ partials, SchedState s, const int* __restrict__ rowmap, int slot0,
+                                                              int eos, int pad, const T* __restrict__ embed, int64_t ldt, T* __restrict__ lx, int64_t ldx, int D) {
+  __shared__ int sh_tok, sh_pos;
+  const int r = blockIdx.x;
+  const int slot = rowmap ? rowmap[r] : slot0 + r;
+  const bool live = slot != s.scratch_slot;
+  if (threadIdx.x < 64) {                               // argmax_final_kernel's combine, then greedy_update_kernel's bookkeeping
+    float2 p = partials[r * kArgChunks + threadIdx.x];
+    float best = p.x;
+    int bi = __float_as_int(p.y);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      float ov = __shfl_xor(best, o, 64);
+      int oi = __shfl_xor(bi, o, 64);
+      argmax_combine(best, bi, ov, oi);
+    }
+    if (threadIdx.x == 0) {
+      int tok = bi == 0x7fffffff ? 0 : bi;
+      int pos = 0;
+      if (live) {
+        const int step = s.nstep[slot];
+        if (s.finished[slot]) tok = pad;
+        else {
+          s.out_len[slot] = step + 1;
+          if (tok == eos) s.finished[slot] = 1;
+        }
+        if (step < s.limit[slot]) s.out_ids[(int64_t)slot * s.out_ld + step] = tok;
+        s.tok[slot] = tok;
+        pos = s.pos[slot] + 1;
+        s.pos[slot] = pos;
+        s.cpos[slot] += 1;
+        s.nstep[slot] = step + 1;
+      } else {
+        tok = s.tok[slot];
+      }
+      sh_tok = tok; sh_pos = pos;
+    }
+  }
+  __syncthreads();
+  if (live)                                             // same expression as greedy_update_kernel / the attention kernel's inline path
+    for (int d = threadIdx.x; d < s.rope_half; d += kThreads) {
+      float sn, cs;
+      sincosf((float)sh_pos * s.inv_freq[d], &sn, &cs);
+      s.rope_cs[(int64_t)slot * s.rope_half + d] = make_float2(cs, sn);
+    }
+  if (lx) {
+    constexpr int VEC = TypeInfo<T>::kVec;
+    const T* src = embed + (int64_t)sh_tok * ldt;
+    T* dst = lx + (int64_t)r * ldx;
+    for (int i = threadIdx.x; i < D / VEC; i += kThreads) *reinterpret_cast<Chunk16*>(dst + i * VEC) = *reinterpret_cast<const Chunk16*>(src + i * VEC);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void sched_embed_kernel(const int* __restrict__ tok, const int* __restrict__ rowmap, const T* __restrict__ embed,
+                                                               int64_t ldt, T* __restrict__ lx, int64_t ldx, int D) {
+  constexpr int VEC = TypeInfo<T>::kVec;
+  const int r = blockIdx.x;
+  const T* src = embed + (int64_t)tok[rowmap[r]] * ldt;
+  T* dst = lx + (int64_t)r * ldx;
+  for (int i = threadIdx.x; i < D / VEC; i += kThreads) *reinterpret_cast<Chunk16*>(dst + i * VEC) = *reinterpret_cast<const Chunk16*>(src + i * VEC);
+}
+
+__global__ void sched_retire_kernel(SchedState s, int slot0, int max_new, int* __restrict__ out_ids, int* __restrict__ out_len) {
+  const int b = blockIdx.x, slot = slot0 + b;
+  for (int i = threadIdx.x; i < max_new; i += blockDim.x) out_ids[(int64_t)b * max_new + i] = s.out_ids[(int64_t)slot * s.out_ld + i];
+  if (threadIdx.x == 0) out_len[b] = s.out_len[slot];
+}
+
 __global__ void rowinfo_kernel(const int* __restrict__ cu_out, const int* __restrict__ cu_in, int n_seqs, int stride, int4* __restrict__ ri, int rows) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= rows) return;
@@ -530,6 +615,58 @@ int launch_argmax(const float* logits, int64_t ld, int rows, int V, int banned, 
   } else {
     hipLaunchKernelGGL(argmax_kernel, dim3(1, rows), dim3(kThreads), 0, st, logits, ld, V, banned, out, (float2*)nullptr);
   }
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_argmax_partial(const float* logits, int64_t ld, int rows, int V, int banned, void* partials, hipStream_t st) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(argmax_kernel, dim3(kArgChunks, rows), dim3(kThreads), 0, st, logits, ld, V, banned, (int*)nullptr, (float2*)partials);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_set_ints(int* dst, const IntPack32& v, int n, hipStream_t st) {
+  OAVSR_REQUIRE(n >= 0 && n <= 32, "set_ints: n=%d", n);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(set_ints_kernel, dim3(1), dim3(64), 0, st, dst, v, n);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_sched_init_slots(const SchedState& s, int slot0, int B, const IntPack32& S, int limit, int pad, hipStream_t st) {
+  OAVSR_REQUIRE(B >= 1 && B <= 32, "sched_init_slots: B=%d", B);
+  hipLaunchKernelGGL(sched_init_slots_kernel, dim3(B), dim3(64), 0, st, s, slot0, B, S, limit, pad);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_sched_tail(const void* partials, const SchedState& s, const int* rowmap, int slot0, int rows, int eos, int pad, int dtype,
+                      const void* embed, int64_t ldt, void* lx, int64_t ldx, int D, hipStream_t st) {
+  if (rows <= 0) return 0;
+  const int vec = dtype == DT_F32 ? 4 : 8;
+  OAVSR_REQUIRE(!lx || (D % vec == 0 && ldt % vec == 0 && ldx % vec == 0), "sched_tail: D=%d", D);
+  if (dtype == DT_F32) hipLaunchKernelGGL(sched_tail_kernel<float>, dim3(rows), dim3(kThreads), 0, st, (const float2*)partials, s, rowmap, slot0, eos, pad, (const float*)embed, ldt, (float*)lx, ldx, D);
+  else hipLaunchKernelGGL(sched_tail_kernel<bf16_t>, dim3(rows), dim3(kThreads), 0, st, (const float2*)partials, s, rowmap, slot0, eos, pad, (const bf16_t*)embed, ldt, (bf16_t*)lx, ldx, D);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_sched_embed(const SchedState& s, const int* rowmap, int rows, int dtype, const void* embed, int64_t ldt, void* lx, int64_t ldx, int D,
+                       hipStream_t st) {
+  if (rows <= 0) return 0;
+  const int vec = dtype == DT_F32 ? 4 : 8;
+  OAVSR_REQUIRE(D % vec == 0 && ldt % vec == 0 && ldx % vec == 0, "sched_embed: D=%d", D);
+  if (dtype == DT_F32) hipLaunchKernelGGL(sched_embed_kernel<float>, dim3(rows), dim3(kThreads), 0, st, s.tok, rowmap, (const float*)embed, ldt, (float*)lx, ldx, D);
+  else hipLaunchKernelGGL(sched_embed_kernel<bf16_t>, dim3(rows), dim3(kThreads), 0, st, s.tok, rowmap, (const bf16_t*)embed, ldt, (bf16_t*)lx, ldx, D);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_sched_retire(const SchedState& s, int slot0, int B, int max_new, int* out_ids, int* out_len, hipStream_t st) {
+  if (B <= 0) return 0;
+  OAVSR_REQUIRE(max_new <= s.out_ld, "sched_retire: max_new=%d exceeds the pool's row (%d)", max_new, s.out_ld);
+  hipLaunchKernelGGL(sched_retire_kernel, dim3(B), dim3(64), 0, st, s, slot0, max_new, out_ids, out_len);
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;
 }

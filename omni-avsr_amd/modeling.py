@@ -44,6 +44,11 @@ class OmniEngine:
         self._ws = C.c_void_p(None)
         self._ws_key = None
         self._slots = {}            # extra workspaces (one per concurrent stream): slot -> (ptr, key)
+        self._sched = C.c_void_p(None)   # decode scheduler (continuous batching of the greedy decode across calls); created on first submit
+        self._sched_key = None
+        self._sched_gen = 0              # tickets carry the generation of the pool they belong to (a pool that had to grow is rebuilt)
+        self.sched_rows, self.sched_slots = 32, 64      # rows per decode step (<= 32) / row slots of the pool
+        self.sched_stride = 0                           # steps per admission (0: automatic; oavsr_scheduler_set_stride)
         self._blob = None
         self._names = None
 
@@ -155,6 +160,10 @@ class OmniEngine:
         return self
 
     def close(self):
+        if self._sched:
+            self.lib.oavsr_scheduler_destroy(self._sched)
+            self._sched = C.c_void_p(None)
+            self._sched_key = None
         for ptr, _ in self._slots.values():
             if ptr:
                 self.lib.oavsr_workspace_destroy(ptr)
@@ -280,6 +289,88 @@ class OmniEngine:
         self._keepalive[slot] = (flat, a)
         return ids, lens
 
+    # ---- decode scheduler: calls of any size keep arriving one at a time, their decode rows share the weight passes ----------
+    def prompt_rows(self, task: str, Tv, lengths, rate_a: int, rate_v: int) -> int:
+        """Longest prompt (rows) of a call: [BOS] <audio> A </audio> <video> V </video> prompt (modeling_OmniAVSR.py:434-437,452-455)."""
+        use_a, use_v = task in ("audio", "audiovisual"), task in ("video", "audiovisual")
+        n = len(Tv) if use_v else len(lengths)
+        bos = 1 if self.spec.llm.family == "llama" else 0
+        P = self.spec.prompt_len[task]
+        return max(bos + (whisper_keep_tokens(int(lengths[b])) // rate_a + 2 if use_a else 0) + (int(Tv[b]) // rate_v + 2 if use_v else 0) + P for b in range(n))
+
+    def ensure_scheduler(self, max_prefix: int, max_new: int):
+        key = self._sched_key
+        if key is not None and key[0] >= max_prefix and key[1] >= max_new and key[2:] == (self.sched_rows, self.sched_slots):
+            return
+        if self._sched:                                  # grow: finish what is in flight, then rebuild the pool
+            L.check(self.lib.oavsr_scheduler_flush(self._sched))
+            torch.cuda.synchronize(self.device)
+            self.lib.oavsr_scheduler_destroy(self._sched)
+            self._sched = C.c_void_p(None)
+            max_prefix, max_new = max(max_prefix, key[0]), max(max_new, key[1])
+        max_prefix = (max_prefix + 63) // 64 * 64
+        L.check(self.lib.oavsr_scheduler_create(self._model, self.sched_slots, self.sched_rows, max_prefix, max_new, C.byref(self._sched)))
+        self._sched_key = (max_prefix, max_new, self.sched_rows, self.sched_slots)
+        self._sched_gen += 1
+        self._stride_set = 0
+
+    def submit(self, task: str, video, Tv, audio, lengths, rate_a: int, rate_v: int, max_new: Optional[int] = None, force_len: bool = False,
+               video_is_flat: bool = False, slot: int = 0):
+        """`generate(beams=1)` through the decode scheduler: encoders + prefill are queued on the current stream (workspace `slot`), the
+        rows then join the engine's shared decode loop.  Returns (ids, lens, ticket); ids / lens are valid after `wait(ticket)`."""
+        max_new = max_new or self.spec.max_dec_tokens
+        use_a, use_v = task in ("audio", "audiovisual"), task in ("video", "audiovisual")
+        B = len(Tv) if use_v else len(lengths)
+        flat = a = keep = None
+        if use_v:
+            flat = video if video_is_flat else self._flat_video(video, Tv)
+            if flat.device != self.device or flat.dtype != torch.float32 or not flat.is_contiguous():
+                flat = flat.to(self.device, torch.float32, non_blocking=flat.is_pinned()).contiguous()
+        if use_a:
+            a = audio if audio.dim() == 2 else audio[..., 0]
+            if a.device != self.device or a.dtype != torch.float32 or not a.is_contiguous():
+                a = a.to(self.device, torch.float32, non_blocking=a.is_pinned()).contiguous()
+            keep = [whisper_keep_tokens(int(n)) for n in lengths]
+        ws = self._slot_workspace(slot, B, max(Tv) if use_v else 1, int(max(lengths)) if use_a else 16000, 1, max_new)
+        self.ensure_scheduler(self.prompt_rows(task, Tv, lengths, int(rate_a or 1), int(rate_v or 1)), max_new)
+        if self.sched_stride != self._stride_set:
+            L.check(self.lib.oavsr_scheduler_set_stride(self._sched, int(self.sched_stride)))
+            self._stride_set = self.sched_stride
+        ids = torch.empty(B, max_new, dtype=torch.int32, device=self.device)
+        lens = torch.empty(B, dtype=torch.int32, device=self.device)
+        ticket = C.c_int64(-1)
+        L.check(self.lib.oavsr_generate_submit(
+            self._model, self._sched, ws, L.TASK_ID[task],
+            C.c_void_p(flat.data_ptr()) if use_v else None, _i32arr(Tv) if use_v else None,
+            C.c_void_p(a.data_ptr()) if use_a else None, a.stride(0) if use_a else 0,
+            _i32arr(lengths) if use_a else None, _i32arr(keep) if use_a else None,
+            B, int(rate_a or 1), int(rate_v or 1), max_new, int(force_len),
+            C.c_void_p(ids.data_ptr()), C.c_void_p(lens.data_ptr()), self._stream(), C.byref(ticket)))
+        self._keepalive = getattr(self, "_keepalive", {})
+        self._keepalive[("s", slot)] = (flat, a)
+        self._inflight = getattr(self, "_inflight", {})
+        tk = (self._sched_gen, ticket.value)
+        self._inflight[tk] = (ids, lens)                 # the scheduler writes them when the call's last step has run
+        return ids, lens, tk
+
+    def wait(self, ticket):
+        """Issue the steps the call still needs and make the CURRENT stream wait for its results (no host synchronisation)."""
+        gen, t = ticket
+        if gen == self._sched_gen and self._sched:       # (a pool of an earlier generation was flushed and synchronised before it was rebuilt)
+            L.check(self.lib.oavsr_generate_wait(self._sched, int(t), self._stream()))
+        getattr(self, "_inflight", {}).pop(ticket, None)
+
+    def flush(self):
+        if self._sched:
+            L.check(self.lib.oavsr_scheduler_flush(self._sched))
+
+    def scheduler_stats(self) -> dict:
+        out = (C.c_uint64 * 4)()
+        if not self._sched:
+            return dict(steps=0, row_steps=0, calls=0, graphs=0)
+        L.check(self.lib.oavsr_scheduler_stats(self._sched, out))
+        return dict(steps=int(out[0]), row_steps=int(out[1]), calls=int(out[2]), graphs=int(out[3]), rows_per_step=round(out[1] / max(1, out[0]), 2))
+
     # ---- profiling (bench.py roofline) ------------------------------------------------------------------
     def profile(self, on: bool):
         self.lib.oavsr_profile_enable(int(on))
@@ -296,15 +387,27 @@ class PendingIds:
     """Result of `AVSR_LLMs.forward(..., sync=False)`: the call has been queued on the caller's current HIP stream; `result()` waits for it
     and returns what the synchronous forward returns (ids [B, n] int64 on the device, n = longest hypothesis)."""
 
-    def __init__(self, ids: torch.Tensor, lens: torch.Tensor, stream: "torch.cuda.Stream"):
+    def __init__(self, ids: torch.Tensor, lens: torch.Tensor, stream: "torch.cuda.Stream", engine: "OmniEngine" = None, ticket=None):
         self._ids, self._lens, self._stream = ids, lens, stream
-        self._event = torch.cuda.Event()
-        self._event.record(stream)
+        self._engine, self._ticket = engine, ticket          # ticket: the call's decode rows are in the engine's shared decode loop
+        self._event = None
+        if ticket is None:
+            self._event = torch.cuda.Event()
+            self._event.record(stream)
+
+    def _settle(self):
+        if self._event is None:                              # first query: have the remaining steps issued, then mark the stream
+            with torch.cuda.stream(self._stream):
+                self._engine.wait(self._ticket)
+            self._event = torch.cuda.Event()
+            self._event.record(self._stream)
 
     def done(self) -> bool:
+        self._settle()
         return self._event.query()
 
     def result(self) -> torch.Tensor:
+        self._settle()
         self._event.synchronize()
         with torch.cuda.stream(self._stream):                # the tensors belong to that stream's allocator pool
             n = int(self._lens.cpu().max())
@@ -419,6 +522,14 @@ class AVSR_LLMs:
                 lengths = [int(max(inputs["lengths"]))]                                   # modeling_OmniAVSR.py:399
             else:
                 lengths = [int(x) for x in inputs["lengths"]]
+        nrows = len(Tv) if use_v else len(lengths)
+        if (not sync and self.num_beams == 1 and getattr(self, "decode_scheduler", True) and nrows <= self.engine.sched_rows
+                and getattr(self, "encoder_chunk", None) is None):
+            # asynchronous greedy calls share the engine's decode loop (continuous batching inside the engine: the rows of every call in
+            # flight ride the same weight passes; ids identical to a call on its own).  `model.decode_scheduler = False` opts out.
+            ids, lens, ticket = self.engine.submit(task, video, Tv, audio, lengths, ra, rv, self.max_dec_tokens, force_len,
+                                                   video_is_flat=video_is_flat, slot=slot)
+            return PendingIds(ids, lens, torch.cuda.current_stream(self.engine.device), self.engine, ticket)
         # `model.encoder_chunk = 8` (not a reference attribute): large evaluation batches run their encoders / prefill in chunks of
         # that many utterances and share one decode loop (oavsr_generate_chunked; identical ids)
         ids, lens = self.engine.generate(task, video, Tv, audio, lengths, ra, rv, self.num_beams, self.max_dec_tokens, force_len,

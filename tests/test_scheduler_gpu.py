@@ -1,0 +1,154 @@
+"""-m gpu: the decode scheduler (continuous batching of the greedy decode inside the engine: oavsr_generate_submit / _wait).
+
+The reference decodes one utterance per forward() (eval_OmniAVSR.py:18-24, datamodule/data_module.py:238-242), so what has to hold is
+the per-utterance result: a call's ids must be BIT-IDENTICAL to the same call decoded on its own (oavsr_generate, itself pinned to the
+oracle in tests/test_stages_gpu.py), whatever shares its decode steps, wherever its rows sit in a step, whenever it joined -- in f32
+and in bf16."""
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from omni_avsr_amd.config import tiny_spec  # noqa: E402
+from omni_avsr_amd.modeling import AVSR_LLMs, OmniEngine  # noqa: E402
+from omni_avsr_amd.synth import synth_state_dict  # noqa: E402
+from oracle import torch_oracle as O  # noqa: E402
+
+
+def clips(B, seed):
+    g = torch.Generator().manual_seed(seed)
+    Tv = [int(x) for x in torch.randint(5, 13, (B,), generator=g)]
+    Ts = [640 * t for t in Tv]
+    video = torch.randn(B, 12, 1, 88, 88, generator=g)
+    audio = torch.randn(B, 7680, 1, generator=g)
+    for b in range(B):
+        video[b, Tv[b]:] = 0
+        audio[b, Ts[b]:] = 0
+    return video, audio, Tv, Ts
+
+
+def alone(eng, c, max_new, force_len, task="audiovisual"):
+    video, audio, Tv, Ts = c
+    ids, lens = eng.generate(task, video if task != "audio" else None, Tv if task != "audio" else None, audio if task != "video" else None,
+                             Ts if task != "video" else None, 4, 2, beams=1, max_new=max_new, force_len=force_len)
+    torch.cuda.synchronize()
+    return ids.cpu().tolist(), lens.cpu().tolist()
+
+
+def submit(eng, c, max_new, force_len, slot, stream, task="audiovisual"):
+    video, audio, Tv, Ts = c
+    with torch.cuda.stream(stream):
+        return eng.submit(task, video if task != "audio" else None, Tv if task != "audio" else None, audio if task != "video" else None,
+                          Ts if task != "video" else None, 4, 2, max_new=max_new, force_len=force_len, slot=slot)
+
+
+def collect(eng, pend, stream):
+    ids, lens, ticket = pend
+    with torch.cuda.stream(stream):
+        eng.wait(ticket)
+    stream.synchronize()
+    return ids.cpu().tolist(), lens.cpu().tolist()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("stride", [0, 1, 3])
+def test_three_staggered_calls_equal_isolated_calls(dtype, stride):
+    spec = tiny_spec(family="llama", task_specific=True, shared=True)
+    eng = OmniEngine(spec, dtype=dtype).load_state_dict(synth_state_dict(spec, seed=1234))
+    eng.sched_stride = stride
+    mn = spec.max_dec_tokens
+    calls = [clips(8, 1), clips(3, 2), clips(8, 3)]
+    ref = [alone(eng, c, mn, True) for c in calls]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    pend = []
+    for i, c in enumerate(calls):                       # staggered: every call joins `stride` steps (or 1/k of a hypothesis) after the previous one
+        pend.append(submit(eng, c, mn, True, i, streams[i]))
+        time.sleep(0.02 * i)
+    got = [collect(eng, pend[i], streams[i]) for i in (2, 0, 1)]          # results asked for out of order
+    assert got[1] == ref[0] and got[2] == ref[1] and got[0] == ref[2], f"{dtype}: ids of calls that shared decode steps differ from isolated calls"
+    st = eng.scheduler_stats()
+    assert st["calls"] == 3 and st["rows_per_step"] > 8.0, f"the calls did not share steps: {st}"
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_eos_lengths_and_different_max_new(dtype):
+    """no EOS suppression: rows finish at their own EOS (pad afterwards, lens as HF greedy), calls with different max_new leave at different steps"""
+    spec = tiny_spec(family="qwen2", head_dim=128)
+    eng = OmniEngine(spec, dtype=dtype).load_state_dict(synth_state_dict(spec, seed=77))
+    calls = [(clips(5, 11), 6), (clips(8, 12), spec.max_dec_tokens), (clips(2, 13), 1), (clips(7, 14), 3)]
+    ref = [alone(eng, c, mn, False) for c, mn in calls]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    pend = [submit(eng, c, mn, False, i % 2, streams[i % 2]) for i, (c, mn) in enumerate(calls)]
+    got = [collect(eng, pend[i], streams[i % 2]) for i in range(len(calls))]
+    assert got == ref
+
+
+def test_more_calls_than_rows_per_step_and_oracle_f32():
+    """7 calls of 8 rows against a 32-row step: the host issues the steps that make room; ids equal the CPU oracle's (f32)"""
+    spec = tiny_spec(family="llama", task_specific=True, shared=True)
+    sd = synth_state_dict(spec, seed=1234)
+    eng = OmniEngine(spec, dtype="f32").load_state_dict(sd)
+    orc = O.OmniOracle(sd, spec.oracle_cfg())
+    mn = spec.max_dec_tokens
+    calls = [clips(8, 20 + i) for i in range(7)]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    pend = [submit(eng, c, mn, False, i % 3, streams[i % 3]) for i, c in enumerate(calls)]
+    eng.flush()
+    got = [collect(eng, pend[i], streams[i % 3]) for i in range(7)]
+    st = eng.scheduler_stats()
+    assert st["rows_per_step"] > 16.0, st
+    for i in (0, 3, 6):
+        video, audio, Tv, Ts = calls[i]
+        with torch.no_grad():
+            want = orc.forward(dict(video=video, audio=audio, lengths=torch.tensor(Ts), video_lens=torch.tensor(Tv), tokens=torch.full((8, 1), spec.ids["bos"])),
+                               "audiovisual", 4, 2, num_beams=1)
+        ids, lens = got[i]
+        assert [ids[b][: lens[b]] for b in range(8)] == want, f"call {i}: scheduler ids differ from the oracle"
+
+
+def test_task_switch_drains_the_loop_and_pool_growth():
+    """task-specific LoRA: rows of one step share the adapter set -> a call of another task waits for the loop to drain; a longer prompt
+    than the pool was built for rebuilds the pool (tickets of the old one stay valid)"""
+    spec = tiny_spec(family="llama", task_specific=True, shared=True)
+    eng = OmniEngine(spec, dtype="bf16").load_state_dict(synth_state_dict(spec, seed=5))
+    mn = spec.max_dec_tokens
+    a, v, av = clips(4, 31), clips(6, 32), clips(8, 33)
+    ref = [alone(eng, a, mn, True, "audio"), alone(eng, v, mn, True, "video"), alone(eng, av, mn, True, "audiovisual")]
+    s = torch.cuda.Stream()
+    p0 = submit(eng, a, mn, True, 0, s, "audio")          # pool sized for the audio-only prompt
+    p1 = submit(eng, v, mn, True, 0, s, "video")
+    gen0 = eng._sched_gen
+    p2 = submit(eng, av, mn, True, 0, s, "audiovisual")   # longer prompt: the pool grows
+    assert eng._sched_gen >= gen0
+    got = [collect(eng, p, s) for p in (p0, p1, p2)]
+    assert got == ref
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_forward_sync_false_goes_through_the_scheduler(dtype):
+    spec = tiny_spec(family="llama", task_specific=True, shared=True, matryoshka=True)
+    eng = OmniEngine(spec, dtype=dtype).load_state_dict(synth_state_dict(spec, seed=1234))
+    model = AVSR_LLMs.__new__(AVSR_LLMs)
+    model.modality, model.max_dec_tokens, model.num_beams = "audiovisual", spec.max_dec_tokens, 1
+    model.is_matryoshka, model.is_task_specific, model.spec, model.engine = True, True, spec, eng
+    model.downsample_ratio_audio, model.downsample_ratio_video = spec.downsample_ratio_audio, spec.downsample_ratio_video
+    batches = []
+    for i in range(4):
+        video, audio, Tv, Ts = clips(8 if i % 2 == 0 else 5, 40 + i)
+        batches.append(dict(video=video, audio=audio, lengths=torch.tensor(Ts), video_lengths=torch.tensor(Tv)))
+    want = [model(b, is_trainval=False, modality="audiovisual", test_ratio_matry_audio=4, test_ratio_matry_video=2).cpu() for b in batches]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    pend = []
+    for i, b in enumerate(batches):
+        with torch.cuda.stream(streams[i % 2]):
+            pend.append(model(b, is_trainval=False, modality="audiovisual", test_ratio_matry_audio=4, test_ratio_matry_video=2, slot=i % 2, sync=False))
+    assert model.engine.scheduler_stats()["calls"] == 4
+    got = [p.result().cpu() for p in reversed(pend)][::-1]
+    for w, g in zip(want, got):
+        assert torch.equal(w, g)
+    model.decode_scheduler = False                        # opt-out: the per-call decode loop, same ids
+    with torch.cuda.stream(streams[0]):
+        p = model(batches[0], is_trainval=False, modality="audiovisual", test_ratio_matry_audio=4, test_ratio_matry_video=2, slot=0, sync=False)
+    assert torch.equal(p.result().cpu(), want[0]) and model.engine.scheduler_stats()["calls"] == 4
