@@ -172,8 +172,9 @@ def parse_args():
                     help="round-2 mode: every call runs its own decode loop on its own stream (default: the engine's decode scheduler merges the "
                          "decode rows of the calls in flight; greedy only)")
     ap.add_argument("--sched-rows", type=int, default=32, help="rows per decode step of the engine's scheduler (<= 32)")
-    ap.add_argument("--sched-slots", type=int, default=64, help="row slots of the scheduler's pool")
+    ap.add_argument("--sched-slots", type=int, default=192, help="row slots of the scheduler's pool")
     ap.add_argument("--sched-stride", type=int, default=0, help="steps per admission (0 = automatic)")
+    ap.add_argument("--sched-lanes", type=int, default=3, help="independent step loops of the scheduler")
     ap.add_argument("--no-stagger", action="store_true", help="let the encoder phases of in-flight batches share the chip (default: chained)")
     ap.add_argument("--streams", type=int, default=3, help="batches in flight (one HIP stream + workspace each); 1 = strictly sequential calls")
     return ap.parse_args()
@@ -280,14 +281,16 @@ def main():
     # loop of one batch overlaps the MFMA-bound encoders / prefill of the next.  Every call still is one complete pass.
     nstream = max(1, args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstream)]
-    if nstream > 1 and not args.no_stagger:
-        eng.serialize_encoders(True)
     results = [None] * nstream
     # The decode scheduler (default): every call is still one batch of B utterances submitted on its own stream; the engine merges the
     # decode rows of the calls in flight into one step loop (oavsr_generate_submit).  Caller-side nothing is grouped (decode_group 1).
     use_sched = not args.no_scheduler and args.beams == 1 and G == 1 and B <= args.sched_rows
-    eng.sched_rows, eng.sched_slots, eng.sched_stride = args.sched_rows, args.sched_slots, args.sched_stride
+    eng.sched_rows, eng.sched_slots, eng.sched_stride, eng.sched_lanes = args.sched_rows, args.sched_slots, args.sched_stride, args.sched_lanes
     pending = []
+    # Without the scheduler the encoder + prefill phases of the calls in flight are chained (only the decode loops overlap them); with it
+    # the callers' streams carry nothing but those phases, and letting the tail of one overlap the head of the next is worth 5 %.
+    if nstream > 1 and not args.no_stagger and not use_sched:
+        eng.serialize_encoders(True)
 
     def call(i):
         s = i % nstream
@@ -298,7 +301,7 @@ def main():
                 ids_, lens_, ticket = eng.submit(task, video, Tvs, audio if use_a else None, Ts if use_a else None, ra, rv, max_new=args.max_new,
                                                  force_len=True, video_is_flat=True, slot=s)
                 pending.append((s, ticket))
-                if len(pending) > 2 * nstream + 8:            # every step of that call was issued long ago: a stream-side wait, no host sync
+                if len(pending) > 2 * nstream + 8 * args.sched_lanes:            # every step of that call was issued long ago: a stream-side wait, no host sync
                     s0, t0_ = pending.pop(0)
                     with torch.cuda.stream(streams[s0]):
                         eng.wait(t0_)
@@ -405,7 +408,7 @@ def main():
                        "batch_per_call": B, "calls_per_step": calls, "ms_per_call": round(elapsed / (args.steps * calls) * 1e3, 3),
                        "global_batch": world * B * calls, "input_sets": nsets, "timed_s": round(elapsed, 2),
                        "parallelism": f"utterance-sharded dp{world}", "streams_per_gpu": nstream, "decode_group": G, "setup_s": round(setup_s, 1),
-                       "decode_scheduler": (dict(rows_per_step_cap=args.sched_rows, slots=args.sched_slots, **eng.scheduler_stats()) if use_sched else None)},
+                       "decode_scheduler": (dict(rows_per_step_cap=args.sched_rows, slots=args.sched_slots, lanes=args.sched_lanes, **eng.scheduler_stats()) if use_sched else None)},
             "roofline": roofline, "cpu_baseline": cpu, "decode_group3": grouped, "stages": stages,
         }
         print(json.dumps(line), flush=True)

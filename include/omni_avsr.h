@@ -144,9 +144,11 @@ int oavsr_generate_chunked(const oavsr_model* m, oavsr_workspace* ws, int32_t ta
  * their own max_new tokens.  The schedule is fixed by the host at submission time in units of steps -- no host thread, no host
  * synchronisation, no device-side queue -- and the ids of an utterance are bit-identical to oavsr_generate on that utterance alone.
  * Greedy decode only (beam search keeps its own per-call loop: oavsr_generate). */
-/* n_slots: row slots of the pool (>= max_rows; extra blocks let the prefill of later calls run ahead of the step loop);
+/* n_slots: row slots of the pool (>= max_rows; max_rows x lanes fills every lane, extra blocks let the prefill of later calls run ahead of the step loops);
+ * lanes: independent step loops (own stream each) sharing the pool -- a step is a chain of ~100 dependent launches, so one loop serves a
+ * bounded number of utterances per second however wide its steps are; calls go to the lane with the fewest rows;
  * max_prefix: longest prompt (rows) a slot can hold; max_new: longest hypothesis. */
-int oavsr_scheduler_create(const oavsr_model* m, int32_t n_slots, int32_t max_rows, int32_t max_prefix, int32_t max_new,
+int oavsr_scheduler_create(const oavsr_model* m, int32_t n_slots, int32_t max_rows, int32_t lanes, int32_t max_prefix, int32_t max_new,
                            oavsr_scheduler** out);
 void oavsr_scheduler_destroy(oavsr_scheduler* s);
 uint64_t oavsr_scheduler_bytes(const oavsr_scheduler* s);
@@ -162,7 +164,7 @@ int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_worksp
 int oavsr_generate_wait(oavsr_scheduler* s, int64_t ticket, oavsr_stream stream);
 /* Issues the remaining steps of every admitted call. */
 int oavsr_scheduler_flush(oavsr_scheduler* s);
-/* Pacing: steps the loop advances per admission before it waits for the new call's prefill.  0 (default) = ceil((max_new - 1) / k) with
+/* Pacing: steps the loop advances per admission before it waits for the new call's prefill.  0 (default) = (max_new - 1) / k with
  * k = max_rows / B calls sharing a step in the steady state; 1 = lowest latency (rows join as early as possible, fewer rows per weight
  * pass); larger = fewer, fuller steps.  Scheduling only: results never depend on it. */
 int oavsr_scheduler_set_stride(oavsr_scheduler* s, int32_t steps);

@@ -258,7 +258,7 @@ struct oavsr_workspace {
 // The schedule is decided by the host at submission time, in units of steps (no device-side queues, no host thread, no host sync):
 //   submit(call i):  [stream of the call]  wait(slots free) -> encoders -> prefill into the slots -> record E_i
 //                    [scheduler stream]    n steps for the rows already admitted -> wait(E_i) -> admit(i)
-// with n = ceil((max_new - 1) / k), k = row capacity / rows of the call: the loop advances by 1/k of a hypothesis per admission, so in the
+// with n = (max_new - 1) / k, k = row capacity / rows of the call (plus whatever steps make room for the call's rows): the loop advances by 1/k of a hypothesis per admission, so in the
 // steady state k calls share every weight pass and the n steps run beside the next call's MFMA-bound phase.  Steps not yet issued when
 // the caller asks for a result are issued then (oavsr_generate_wait / oavsr_scheduler_flush).
 // Results do not depend on the schedule: the <= 32-row decode kernels give a row the same bits wherever it sits and whatever shares the
@@ -266,35 +266,44 @@ struct oavsr_workspace {
 // ------------------------------------------------------------------------------------------------
 struct SchedCall {
   int64_t ticket = -1;
-  int task = 0, B = 0, slot0 = 0, limit = 0, remaining = 0, banned = -1;
+  int task = 0, B = 0, slot0 = 0, limit = 0, remaining = 0, banned = -1, lane = 0;
   int32_t *out_ids = nullptr, *out_len = nullptr;
   hipEvent_t prefilled = nullptr, done = nullptr;
   bool retired = true;
 };
 
+// One step loop: its own stream, activation scratch, row map and step graphs.  Several lanes (each up to max_rows rows per step) share the
+// pool: a decode step is a chain of ~100 dependent launches, and beside the MFMA-bound phases of other calls a chain advances at ~2.7 ms
+// per step whatever its width, i.e. one chain serves ~380 utterances/s (31/32 of a step per utterance).  A second chain doubles that
+// without costing weight passes per utterance -- every lane still fills its steps -- at the price of twice the calls in flight.
+struct SchedLane {
+  hipStream_t st = nullptr;
+  oavsr_workspace* dws = nullptr;              // activation scratch of a step (lx ... logits) + the pool's pointers (shared by all lanes)
+  int* rowmap = nullptr;                       // device [32]
+  void* partials = nullptr;                    // [32][64] float2 arg-max partials
+  std::vector<int> active;                     // ring indices in admission order
+  bool map_dirty = true;                       // membership changed since the last step: rowmap + input rows must be rebuilt
+  int cur_R = 0;
+  std::vector<std::pair<DecodeGraphKey, hipGraphExec_t>> graphs;
+};
+
 struct oavsr_scheduler {
   const oavsr_model* m = nullptr;
-  hipStream_t st = nullptr;                    // the step loop's stream
-  oavsr_workspace* dws = nullptr;              // activation scratch of a step + the pool (kpre / vpre / ktail / vtail, prefix_len), indexed by row slot
+  std::vector<SchedLane> lanes;
+  oavsr_workspace* pool = nullptr;             // kpre / vpre / ktail / vtail, prefix_len: indexed by row slot
   char* arena = nullptr; size_t arena_bytes = 0;
   int n_slots = 0, max_rows = 0, max_prefix = 0, max_new = 0;
   SchedState ss;
-  int* rowmap = nullptr;                       // device [32]
   float* logits_pre = nullptr;                 // [n_slots][vocab] last-prompt-position logits, written by the calls' prefills
-  void* partials = nullptr;                    // [32][64] float2 arg-max partials
   std::vector<int64_t> slot_owner;             // ticket that last owned the slot (-1: never used)
   std::vector<char> slot_used;
   std::vector<uint64_t> slot_freed_at;         // allocation prefers the block freed longest ago (its owner's last step is furthest back in the queue)
   uint64_t free_seq = 0;
   static constexpr int kRing = 1024;
   std::vector<SchedCall> ring;
-  std::vector<int> active;                     // ring indices in admission order
   int64_t next_ticket = 0;
-  bool map_dirty = true;                       // membership changed since the last step: rowmap + input rows must be rebuilt
-  int cur_R = 0;
-  std::vector<std::pair<DecodeGraphKey, hipGraphExec_t>> graphs;
   uint64_t steps_issued = 0, row_steps = 0, calls = 0;     // statistics (oavsr_scheduler_stats)
-  int stride = 0;                              // steps issued per admission; 0 = ceil((max_new - 1) / (max_rows / B)) (oavsr_scheduler_set_stride)
+  int stride = 0;                              // steps issued per admission; 0 = (max_new - 1) / (max_rows / B) (oavsr_scheduler_set_stride)
   std::mutex mu;
 };
 
@@ -1448,81 +1457,81 @@ int oavsr_generate_chunked(const oavsr_model* m, oavsr_workspace* ws, int32_t ta
 }
 
 // ---- decode scheduler (struct oavsr_scheduler, above) --------------------------------------------------------------------------------
-static int sched_rows(const oavsr_scheduler* s) { int r = 0; for (int i : s->active) r += s->ring[i].B; return r; }
-static int sched_min_remaining(const oavsr_scheduler* s) { int r = 1 << 30; for (int i : s->active) r = std::min(r, s->ring[i].remaining); return s->active.empty() ? 0 : r; }
-static int sched_max_remaining(const oavsr_scheduler* s) { int r = 0; for (int i : s->active) r = std::max(r, s->ring[i].remaining); return r; }
+static int lane_rows(const oavsr_scheduler* s, const SchedLane& l) { int r = 0; for (int i : l.active) r += s->ring[i].B; return r; }
+static int lane_min_remaining(const oavsr_scheduler* s, const SchedLane& l) { int r = 1 << 30; for (int i : l.active) r = std::min(r, s->ring[i].remaining); return l.active.empty() ? 0 : r; }
+static int lane_max_remaining(const oavsr_scheduler* s, const SchedLane& l) { int r = 0; for (int i : l.active) r = std::max(r, s->ring[i].remaining); return r; }
 
-// one decode step over the R compact rows of the current membership (every launch on the scheduler's stream; hipGraph-capturable)
-static int sched_one_step(oavsr_scheduler* s, int R, int task, int banned) {
-  const oavsr_model* m = s->m; const oavsr_config& c = m->cfg; oavsr_workspace* w = s->dws;
-  OAVSR_TRY(llm_layers(m, w, task, R, true, R, 1, s->max_prefix + s->max_new, s->ss.pos, s->ss.cpos, nullptr, nullptr, s->st, s->ss.rope_cs));
-  OAVSR_TRY(lm_head_rows(m, w, w->lx, R, w->logits, s->st));
-  { ProfScope ps("argmax_partial", 0, (double)R * c.llm_vocab * 4, s->st);
-    OAVSR_TRY(launch_argmax_partial(w->logits, c.llm_vocab, R, c.llm_vocab, banned, s->partials, s->st)); }
-  ProfScope ps("sched_tail", 0, 2.0 * R * c.llm_hidden * m->esz, s->st);
-  return launch_sched_tail(s->partials, s->ss, s->rowmap, 0, R, c.id_eos, c.id_pad, m->dtype, m->embed, c.llm_hidden, w->lx, c.llm_hidden, c.llm_hidden, s->st);
+// one decode step over the R compact rows of the lane's current membership (every launch on the lane's stream; hipGraph-capturable)
+static int sched_one_step(oavsr_scheduler* s, SchedLane& l, int R, int task, int banned) {
+  const oavsr_model* m = s->m; const oavsr_config& c = m->cfg; oavsr_workspace* w = l.dws;
+  OAVSR_TRY(llm_layers(m, w, task, R, true, R, 1, s->max_prefix + s->max_new, s->ss.pos, s->ss.cpos, nullptr, nullptr, l.st, s->ss.rope_cs));
+  OAVSR_TRY(lm_head_rows(m, w, w->lx, R, w->logits, l.st));
+  { ProfScope ps("argmax_partial", 0, (double)R * c.llm_vocab * 4, l.st);
+    OAVSR_TRY(launch_argmax_partial(w->logits, c.llm_vocab, R, c.llm_vocab, banned, l.partials, l.st)); }
+  ProfScope ps("sched_tail", 0, 2.0 * R * c.llm_hidden * m->esz, l.st);
+  return launch_sched_tail(l.partials, s->ss, l.rowmap, 0, R, c.id_eos, c.id_pad, m->dtype, m->embed, c.llm_hidden, w->lx, c.llm_hidden, c.llm_hidden, l.st);
 }
 
 // membership changed (a call joined or left): new row map (padding rows -> the scratch slot), input rows regathered in the new order
-static int sched_sync_membership(oavsr_scheduler* s) {
-  if (!s->map_dirty) return 0;
+static int sched_sync_membership(oavsr_scheduler* s, SchedLane& l) {
+  if (!l.map_dirty) return 0;
   const oavsr_config& c = s->m->cfg;
   IntPack32 map;
   int r = 0;
-  for (int i : s->active) { const SchedCall& k = s->ring[i]; for (int b = 0; b < k.B; ++b) map.v[r++] = k.slot0 + b; }
+  for (int i : l.active) { const SchedCall& k = s->ring[i]; for (int b = 0; b < k.B; ++b) map.v[r++] = k.slot0 + b; }
   const int R = std::max(8, (r + 7) / 8 * 8);
   OAVSR_REQUIRE(R <= 32, "scheduler: %d rows in the step", r);
   for (; r < R; ++r) map.v[r] = s->n_slots;
-  OAVSR_TRY(launch_set_ints(s->rowmap, map, R, s->st));
-  OAVSR_TRY(launch_sched_embed(s->ss, s->rowmap, R, s->m->dtype, s->m->embed, c.llm_hidden, s->dws->lx, c.llm_hidden, c.llm_hidden, s->st));
-  s->cur_R = R; s->map_dirty = false;
+  OAVSR_TRY(launch_set_ints(l.rowmap, map, R, l.st));
+  OAVSR_TRY(launch_sched_embed(s->ss, l.rowmap, R, s->m->dtype, s->m->embed, c.llm_hidden, l.dws->lx, c.llm_hidden, c.llm_hidden, l.st));
+  l.cur_R = R; l.map_dirty = false;
   return 0;
 }
 
-static int sched_retire(oavsr_scheduler* s, int idx) {
+static int sched_retire(oavsr_scheduler* s, SchedLane& l, int idx) {
   SchedCall& k = s->ring[idx];
-  OAVSR_TRY(launch_sched_retire(s->ss, k.slot0, k.B, k.limit, k.out_ids, k.out_len, s->st));
-  OAVSR_CHECK_HIP(hipEventRecord(k.done, s->st));
+  OAVSR_TRY(launch_sched_retire(s->ss, k.slot0, k.B, k.limit, k.out_ids, k.out_len, l.st));
+  OAVSR_CHECK_HIP(hipEventRecord(k.done, l.st));
   ++s->free_seq;
   for (int b = 0; b < k.B; ++b) { s->slot_used[k.slot0 + b] = 0; s->slot_freed_at[k.slot0 + b] = s->free_seq; }
   k.retired = true;
-  s->active.erase(std::find(s->active.begin(), s->active.end(), idx));
-  s->map_dirty = true;
+  l.active.erase(std::find(l.active.begin(), l.active.end(), idx));
+  l.map_dirty = true;
   return 0;
 }
 
-// issue up to n steps for the admitted rows; calls whose last step has been issued leave (result copy + `done` event) on the way
-static int sched_run(oavsr_scheduler* s, int n) {
+// issue up to n steps for the rows admitted to the lane; calls whose last step has been issued leave (result copy + `done` event) on the way
+static int sched_run(oavsr_scheduler* s, SchedLane& l, int n) {
   static const bool graphs_on = [] { const char* e = getenv("OAVSR_DECODE_GRAPH"); return !(e && e[0] == '0'); }();
-  while (n > 0 && !s->active.empty()) {
-    const int k = std::min(n, sched_min_remaining(s));
-    OAVSR_TRY(sched_sync_membership(s));
-    const SchedCall& head = s->ring[s->active[0]];
-    const int task = head.task, banned = head.banned, R = s->cur_R;
+  while (n > 0 && !l.active.empty()) {
+    const int k = std::min(n, lane_min_remaining(s, l));
+    OAVSR_TRY(sched_sync_membership(s, l));
+    const SchedCall& head = s->ring[l.active[0]];
+    const int task = head.task, banned = head.banned, R = l.cur_R;
     int done = 0;
     if (graphs_on && !g_prof.on) {
       const DecodeGraphKey key{R, task, 0, banned};
       hipGraphExec_t exec = nullptr;
-      for (auto& e : s->graphs) if (e.first == key) exec = e.second;
+      for (auto& e : l.graphs) if (e.first == key) exec = e.second;
       if (!exec) {
-        OAVSR_TRY(sched_one_step(s, R, task, banned));     // eager once: sets the per-kernel attributes outside of the capture
+        OAVSR_TRY(sched_one_step(s, l, R, task, banned));     // eager once: sets the per-kernel attributes outside of the capture
         done = 1;
         hipGraph_t graph = nullptr;
-        OAVSR_CHECK_HIP(hipStreamBeginCapture(s->st, hipStreamCaptureModeRelaxed));
-        int rc = sched_one_step(s, R, task, banned);
-        hipError_t ce = hipStreamEndCapture(s->st, &graph);
+        OAVSR_CHECK_HIP(hipStreamBeginCapture(l.st, hipStreamCaptureModeRelaxed));
+        int rc = sched_one_step(s, l, R, task, banned);
+        hipError_t ce = hipStreamEndCapture(l.st, &graph);
         OAVSR_REQUIRE(rc == 0 && ce == hipSuccess && graph, "scheduler: hipGraph capture of the step failed (%d / %d)", rc, (int)ce);
         OAVSR_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
         hipGraphDestroy(graph);
-        s->graphs.push_back({key, exec});
+        l.graphs.push_back({key, exec});
       }
-      for (; done < k; ++done) OAVSR_CHECK_HIP(hipGraphLaunch(exec, s->st));
+      for (; done < k; ++done) OAVSR_CHECK_HIP(hipGraphLaunch(exec, l.st));
     }
-    for (; done < k; ++done) OAVSR_TRY(sched_one_step(s, R, task, banned));
-    s->steps_issued += k; s->row_steps += (uint64_t)k * sched_rows(s);
+    for (; done < k; ++done) OAVSR_TRY(sched_one_step(s, l, R, task, banned));
+    s->steps_issued += k; s->row_steps += (uint64_t)k * lane_rows(s, l);
     std::vector<int> leaving;
-    for (int i : s->active) { s->ring[i].remaining -= k; if (s->ring[i].remaining <= 0) leaving.push_back(i); }
-    for (int i : leaving) OAVSR_TRY(sched_retire(s, i));
+    for (int i : l.active) { s->ring[i].remaining -= k; if (s->ring[i].remaining <= 0) leaving.push_back(i); }
+    for (int i : leaving) OAVSR_TRY(sched_retire(s, l, i));
     n -= k;
   }
   return 0;
@@ -1539,60 +1548,86 @@ static int sched_alloc(oavsr_scheduler* s, int B) {
   return best;
 }
 
-int oavsr_scheduler_create(const oavsr_model* m, int32_t n_slots, int32_t max_rows, int32_t max_prefix, int32_t max_new, oavsr_scheduler** out) {
+int oavsr_scheduler_create(const oavsr_model* m, int32_t n_slots, int32_t max_rows, int32_t lanes, int32_t max_prefix, int32_t max_new,
+                           oavsr_scheduler** out) {
   OAVSR_REQUIRE(m && out, "scheduler_create: null argument");
   OAVSR_REQUIRE(max_rows >= 1 && max_rows <= 32, "scheduler_create: max_rows=%d (the weight-streaming decode kernels serve up to 32 rows per step)", max_rows);
-  OAVSR_REQUIRE(n_slots >= max_rows && n_slots <= 4096 && max_prefix >= 1 && max_new >= 1, "scheduler_create: bad sizes");
+  OAVSR_REQUIRE(lanes >= 1 && lanes <= 8, "scheduler_create: lanes=%d", lanes);
+  OAVSR_REQUIRE(n_slots >= max_rows && n_slots <= 4096 && max_prefix >= 1 && max_new >= 1, "scheduler_create: bad sizes (n_slots >= max_rows)");
   const oavsr_config& c = m->cfg;
   oavsr_scheduler* s = new oavsr_scheduler();
   s->m = m; s->n_slots = n_slots; s->max_rows = max_rows; s->max_prefix = (max_prefix + 63) / 64 * 64; s->max_new = max_new;
+  s->lanes.resize(lanes);
   const size_t e = m->esz, NS = (size_t)n_slots + 1, R = 32;
   const int d = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, hd = c.llm_head_dim, I = c.llm_mlp;
   const size_t nqkv = (size_t)(H + 2 * KV) * hd;
   oavsr_workspace* w = new oavsr_workspace();
-  s->dws = w;
+  s->pool = w;
   w->m = m; w->max_B = n_slots; w->max_beams = 1; w->max_new = max_new; w->max_prefix = s->max_prefix;
   w->kpre_layer = NS * KV * (size_t)s->max_prefix * hd * e;
   w->ktail_layer = NS * KV * (size_t)max_new * hd * e;
   struct Req { void** p; size_t bytes; };
   std::vector<Req> reqs;
 #define WANT(ptr, bytes) reqs.push_back({(void**)&(ptr), (size_t)(bytes)})
-  WANT(w->lx, R * d * e); WANT(w->lh, R * d * e); WANT(w->lqkv, R * nqkv * e); WANT(w->lattn, R * (size_t)H * hd * e);
-  WANT(w->lact, R * (size_t)I * e); WANT(w->llora, R * (size_t)std::max(64, c.lora_k2) * e); WANT(w->logits, R * (size_t)c.llm_vocab * 4);
   WANT(w->kpre, w->kpre_layer * c.llm_layers); WANT(w->vpre, w->kpre_layer * c.llm_layers);
   WANT(w->ktail, w->ktail_layer * c.llm_layers); WANT(w->vtail, w->ktail_layer * c.llm_layers);
   WANT(w->prefix_len, NS * 4);
-  WANT(s->logits_pre, (size_t)n_slots * c.llm_vocab * 4); WANT(s->partials, R * 64 * 8); WANT(s->rowmap, 64 * 4);
+  WANT(s->logits_pre, (size_t)n_slots * c.llm_vocab * 4);
   WANT(s->ss.tok, NS * 4); WANT(s->ss.finished, NS * 4); WANT(s->ss.out_ids, NS * (size_t)max_new * 4); WANT(s->ss.out_len, NS * 4);
   WANT(s->ss.nstep, NS * 4); WANT(s->ss.limit, NS * 4); WANT(s->ss.pos, NS * 4); WANT(s->ss.cpos, NS * 4);
   WANT(s->ss.rope_cs, NS * (size_t)(hd / 2) * sizeof(float2));
+  for (auto& l : s->lanes) {
+    l.dws = new oavsr_workspace();
+    oavsr_workspace* lw = l.dws;
+    WANT(lw->lx, R * d * e); WANT(lw->lh, R * d * e); WANT(lw->lqkv, R * nqkv * e); WANT(lw->lattn, R * (size_t)H * hd * e);
+    WANT(lw->lact, R * (size_t)I * e); WANT(lw->llora, R * (size_t)std::max(64, c.lora_k2) * e); WANT(lw->logits, R * (size_t)c.llm_vocab * 4);
+    WANT(l.partials, R * 64 * 8); WANT(l.rowmap, 64 * 4);
+  }
 #undef WANT
   size_t total = 0;
   for (auto& r : reqs) total = align_up(total, 256) + std::max<size_t>(r.bytes, 256);
   total += 4096;
-  if (hipMalloc((void**)&s->arena, total) != hipSuccess) { set_last_error("scheduler_create: hipMalloc(%zu bytes) failed", total); delete w; delete s; return -2; }
+  auto fail = [&](const char* what) {
+    set_last_error("scheduler_create: %s", what);
+    for (auto& l : s->lanes) { if (l.st) hipStreamDestroy(l.st); delete l.dws; }
+    if (s->arena) hipFree(s->arena);
+    delete w; delete s;
+    return -2;
+  };
+  if (hipMalloc((void**)&s->arena, total) != hipSuccess) { s->arena = nullptr; return fail("hipMalloc failed"); }
   s->arena_bytes = total;
-  if (hipMemset(s->arena, 0, total) != hipSuccess) { set_last_error("scheduler_create: hipMemset failed"); hipFree(s->arena); delete w; delete s; return -2; }
+  if (hipMemset(s->arena, 0, total) != hipSuccess) return fail("hipMemset failed");
   { size_t off = 0; for (auto& r : reqs) { off = align_up(off, 256); *r.p = s->arena + off; off += std::max<size_t>(r.bytes, 256); } }
-  w->rowmap = s->rowmap;
   s->ss.inv_freq = m->inv_freq; s->ss.rope_half = hd / 2; s->ss.out_ld = max_new; s->ss.scratch_slot = n_slots;
   s->slot_owner.assign(n_slots, -1); s->slot_used.assign(n_slots, 0); s->slot_freed_at.assign(n_slots, 0);
   s->ring.resize(oavsr_scheduler::kRing);
-  if (hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-    set_last_error("scheduler_create: stream creation / device synchronisation failed"); hipFree(s->arena); delete w; delete s; return -2;
+  static const int prio = [] { const char* e2 = getenv("OAVSR_SCHED_PRIORITY"); return e2 ? atoi(e2) : 0; }();     // developer switch: < 0 = above the callers' streams
+  for (auto& l : s->lanes) {
+    oavsr_workspace* lw = l.dws;      // the lane's view: its own scratch, the shared pool
+    lw->m = m; lw->max_B = n_slots; lw->max_beams = 1; lw->max_new = max_new; lw->max_prefix = s->max_prefix;
+    lw->kpre = w->kpre; lw->vpre = w->vpre; lw->ktail = w->ktail; lw->vtail = w->vtail; lw->kpre_layer = w->kpre_layer; lw->ktail_layer = w->ktail_layer;
+    lw->prefix_len = w->prefix_len; lw->rowmap = l.rowmap;
+    if ((prio ? hipStreamCreateWithPriority(&l.st, hipStreamNonBlocking, prio) : hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking)) != hipSuccess) {
+      l.st = nullptr;
+      return fail("stream creation failed");
+    }
   }
+  if (hipDeviceSynchronize() != hipSuccess) return fail("device synchronisation failed");
   *out = s;
   return 0;
 }
 
 void oavsr_scheduler_destroy(oavsr_scheduler* s) {
   if (!s) return;
-  if (s->st) { hipStreamSynchronize(s->st); }
-  for (auto& e : s->graphs) hipGraphExecDestroy(e.second);
+  for (auto& l : s->lanes) {
+    if (l.st) hipStreamSynchronize(l.st);
+    for (auto& e : l.graphs) hipGraphExecDestroy(e.second);
+    if (l.st) hipStreamDestroy(l.st);
+    delete l.dws;
+  }
   for (auto& k : s->ring) { if (k.prefilled) hipEventDestroy(k.prefilled); if (k.done) hipEventDestroy(k.done); }
-  if (s->st) hipStreamDestroy(s->st);
   if (s->arena) hipFree(s->arena);
-  delete s->dws;
+  delete s->pool;
   delete s;
 }
 uint64_t oavsr_scheduler_bytes(const oavsr_scheduler* s) { return s ? s->arena_bytes : 0; }
@@ -1611,19 +1646,30 @@ int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_worksp
   std::lock_guard<std::mutex> lk(s->mu);
   const int ltask = c.lora_task_specific ? task : 0;      // rows of one step share the LoRA adapter set (Llama_LoRA.py:250-259) and the banned token
   const int banned = force_len ? c.id_eos : -1;
-  if (!s->active.empty() && (s->ring[s->active[0]].task != ltask || s->ring[s->active[0]].banned != banned)) OAVSR_TRY(sched_run(s, sched_max_remaining(s)));
-  // room: rows per step and a block of row slots
-  const uint64_t steps0 = s->steps_issued;
-  while (sched_rows(s) + B > s->max_rows) OAVSR_TRY(sched_run(s, sched_min_remaining(s)));
-  int slot0 = sched_alloc(s, B);
-  while (slot0 < 0 && !s->active.empty()) { OAVSR_TRY(sched_run(s, sched_min_remaining(s))); slot0 = sched_alloc(s, B); }
-  OAVSR_REQUIRE(slot0 >= 0, "generate_submit: no block of %d free row slots (pool of %d)", B, s->n_slots);
+  // the lane with the fewest rows (ties: round robin by ticket)
   const int64_t ticket = s->next_ticket;
+  const int nl = (int)s->lanes.size();
+  int li = (int)(ticket % nl);
+  for (int i = 0; i < nl; ++i) if (lane_rows(s, s->lanes[i]) < lane_rows(s, s->lanes[li])) li = i;
+  SchedLane& l = s->lanes[li];
+  if (!l.active.empty() && (s->ring[l.active[0]].task != ltask || s->ring[l.active[0]].banned != banned)) OAVSR_TRY(sched_run(s, l, lane_max_remaining(s, l)));
+  // room: rows per step of the lane and a block of row slots
+  const uint64_t steps0 = s->steps_issued;
+  while (lane_rows(s, l) + B > s->max_rows) OAVSR_TRY(sched_run(s, l, lane_min_remaining(s, l)));
+  int slot0 = sched_alloc(s, B);
+  while (slot0 < 0) {      // no block: let the lane that holds the call closest to its end advance
+    SchedLane* v = nullptr;
+    for (auto& x : s->lanes) if (!x.active.empty() && (!v || lane_min_remaining(s, x) < lane_min_remaining(s, *v))) v = &x;
+    if (!v) break;
+    OAVSR_TRY(sched_run(s, *v, lane_min_remaining(s, *v)));
+    slot0 = sched_alloc(s, B);
+  }
+  OAVSR_REQUIRE(slot0 >= 0, "generate_submit: no block of %d free row slots (pool of %d)", B, s->n_slots);
   SchedCall& k = s->ring[ticket % oavsr_scheduler::kRing];
   OAVSR_REQUIRE(k.retired, "generate_submit: %d calls in flight", oavsr_scheduler::kRing);
   if (!k.prefilled) OAVSR_CHECK_HIP(hipEventCreateWithFlags(&k.prefilled, hipEventDisableTiming));
   if (!k.done) OAVSR_CHECK_HIP(hipEventCreateWithFlags(&k.done, hipEventDisableTiming));
-  // the slots' previous owners must have left (their last step is already in the scheduler stream's queue) before this call's prefill writes there
+  // the slots' previous owners must have left (their last step is already in their lane's queue) before this call's prefill writes there
   { int64_t seen = -1;
     for (int b = 0; b < B; ++b) {
       const int64_t t = s->slot_owner[slot0 + b];
@@ -1634,29 +1680,29 @@ int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_worksp
     } }
   std::vector<int> S(B);
   { CallScope cs(ws, st);
-    PrefillDest dest{s->dws->kpre, s->dws->vpre, s->dws->kpre_layer, s->max_prefix, s->logits_pre, s->dws->prefix_len, slot0};
+    PrefillDest dest{s->pool->kpre, s->pool->vpre, s->pool->kpre_layer, s->max_prefix, s->logits_pre, s->pool->prefix_len, slot0};
     OAVSR_TRY(encode_prefill(m, ws, task, video_dev, Tv_host, wav_dev, wav_ld, Ts_host, keep_host, B, B, rate_audio, rate_video, st, &dest, S.data())); }
   OAVSR_CHECK_HIP(hipEventRecord(k.prefilled, st));
   for (int b = 0; b < B; ++b) { s->slot_used[slot0 + b] = 1; s->slot_owner[slot0 + b] = ticket; }
   ++s->next_ticket; ++s->calls;
-  k.ticket = ticket; k.task = ltask; k.B = B; k.slot0 = slot0; k.limit = max_new; k.remaining = max_new - 1; k.banned = banned;
+  k.ticket = ticket; k.task = ltask; k.B = B; k.slot0 = slot0; k.limit = max_new; k.remaining = max_new - 1; k.banned = banned; k.lane = li;
   k.out_ids = out_ids_dev; k.out_len = out_len_dev; k.retired = false;
-  // pacing: the loop advances 1/k of a hypothesis per admission (k = calls of this size that share a step), beside this call's MFMA-bound phase
+  // pacing: the lane advances 1/k of a hypothesis per admission (k = calls of this size that share a step), beside this call's MFMA-bound phase
   static const int stride_env = [] { const char* e = getenv("OAVSR_SCHED_STRIDE"); return e ? atoi(e) : 0; }();
   const int share = std::max(1, s->max_rows / B);
-  const int stride = s->stride > 0 ? s->stride : stride_env > 0 ? stride_env : ceil_div(std::max(1, max_new - 1), share);
+  const int stride = s->stride > 0 ? s->stride : stride_env > 0 ? stride_env : std::max(1, (max_new - 1) / share);
   const int issued = (int)(s->steps_issued - steps0);
-  if (stride > issued) OAVSR_TRY(sched_run(s, stride - issued));
+  if (stride > issued) OAVSR_TRY(sched_run(s, l, stride - issued));
   // admission: after the call's prefill; first token from the prefill's logits (step 0 of the row's own counter)
-  OAVSR_CHECK_HIP(hipStreamWaitEvent(s->st, k.prefilled, 0));
+  OAVSR_CHECK_HIP(hipStreamWaitEvent(l.st, k.prefilled, 0));
   IntPack32 Sp;
   for (int b = 0; b < B; ++b) Sp.v[b] = S[b];
-  OAVSR_TRY(launch_sched_init_slots(s->ss, slot0, B, Sp, max_new, c.id_pad, s->st));
-  OAVSR_TRY(launch_argmax_partial(s->logits_pre + (size_t)slot0 * c.llm_vocab, c.llm_vocab, B, c.llm_vocab, banned, s->partials, s->st));
-  OAVSR_TRY(launch_sched_tail(s->partials, s->ss, nullptr, slot0, B, c.id_eos, c.id_pad, m->dtype, m->embed, c.llm_hidden, nullptr, 0, c.llm_hidden, s->st));
-  s->active.push_back((int)(ticket % oavsr_scheduler::kRing));
-  s->map_dirty = true;
-  if (k.remaining <= 0) OAVSR_TRY(sched_retire(s, (int)(ticket % oavsr_scheduler::kRing)));
+  OAVSR_TRY(launch_sched_init_slots(s->ss, slot0, B, Sp, max_new, c.id_pad, l.st));
+  OAVSR_TRY(launch_argmax_partial(s->logits_pre + (size_t)slot0 * c.llm_vocab, c.llm_vocab, B, c.llm_vocab, banned, l.partials, l.st));
+  OAVSR_TRY(launch_sched_tail(l.partials, s->ss, nullptr, slot0, B, c.id_eos, c.id_pad, m->dtype, m->embed, c.llm_hidden, nullptr, 0, c.llm_hidden, l.st));
+  l.active.push_back((int)(ticket % oavsr_scheduler::kRing));
+  l.map_dirty = true;
+  if (k.remaining <= 0) OAVSR_TRY(sched_retire(s, l, (int)(ticket % oavsr_scheduler::kRing)));
   *ticket_out = ticket;
   return 0;
 }
@@ -1667,7 +1713,7 @@ int oavsr_generate_wait(oavsr_scheduler* s, int64_t ticket, oavsr_stream stream)
   OAVSR_REQUIRE(ticket >= 0 && ticket < s->next_ticket, "generate_wait: unknown ticket %lld", (long long)ticket);
   SchedCall& k = s->ring[ticket % oavsr_scheduler::kRing];
   OAVSR_REQUIRE(k.ticket == ticket, "generate_wait: ticket %lld has expired (more than %d calls submitted since)", (long long)ticket, oavsr_scheduler::kRing);
-  while (!k.retired) OAVSR_TRY(sched_run(s, k.remaining));
+  while (!k.retired) OAVSR_TRY(sched_run(s, s->lanes[k.lane], k.remaining));
   OAVSR_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, k.done, 0));
   return 0;
 }
@@ -1675,7 +1721,7 @@ int oavsr_generate_wait(oavsr_scheduler* s, int64_t ticket, oavsr_stream stream)
 int oavsr_scheduler_flush(oavsr_scheduler* s) {
   OAVSR_REQUIRE(s, "scheduler_flush: null scheduler");
   std::lock_guard<std::mutex> lk(s->mu);
-  while (!s->active.empty()) OAVSR_TRY(sched_run(s, sched_max_remaining(s)));
+  for (auto& l : s->lanes) while (!l.active.empty()) OAVSR_TRY(sched_run(s, l, lane_max_remaining(s, l)));
   return 0;
 }
 
@@ -1688,7 +1734,9 @@ int oavsr_scheduler_set_stride(oavsr_scheduler* s, int32_t steps) {
 
 int oavsr_scheduler_stats(const oavsr_scheduler* s, uint64_t* out4) {
   OAVSR_REQUIRE(s && out4, "scheduler_stats: null argument");
-  out4[0] = s->steps_issued; out4[1] = s->row_steps; out4[2] = s->calls; out4[3] = s->graphs.size();
+  uint64_t g = 0;
+  for (auto& l : s->lanes) g += l.graphs.size();
+  out4[0] = s->steps_issued; out4[1] = s->row_steps; out4[2] = s->calls; out4[3] = g;
   return 0;
 }
 

@@ -47,7 +47,8 @@ class OmniEngine:
         self._sched = C.c_void_p(None)   # decode scheduler (continuous batching of the greedy decode across calls); created on first submit
         self._sched_key = None
         self._sched_gen = 0              # tickets carry the generation of the pool they belong to (a pool that had to grow is rebuilt)
-        self.sched_rows, self.sched_slots = 32, 64      # rows per decode step (<= 32) / row slots of the pool
+        self.sched_rows, self.sched_slots = 32, 192     # rows per decode step (<= 32) / row slots of the pool
+        self.sched_lanes = 3                            # independent step loops sharing the pool (one loop serves ~380 utt/s)
         self.sched_stride = 0                           # steps per admission (0: automatic; oavsr_scheduler_set_stride)
         self._blob = None
         self._names = None
@@ -300,7 +301,7 @@ class OmniEngine:
 
     def ensure_scheduler(self, max_prefix: int, max_new: int):
         key = self._sched_key
-        if key is not None and key[0] >= max_prefix and key[1] >= max_new and key[2:] == (self.sched_rows, self.sched_slots):
+        if key is not None and key[0] >= max_prefix and key[1] >= max_new and key[2:] == (self.sched_rows, self.sched_slots, self.sched_lanes):
             return
         if self._sched:                                  # grow: finish what is in flight, then rebuild the pool
             L.check(self.lib.oavsr_scheduler_flush(self._sched))
@@ -309,8 +310,8 @@ class OmniEngine:
             self._sched = C.c_void_p(None)
             max_prefix, max_new = max(max_prefix, key[0]), max(max_new, key[1])
         max_prefix = (max_prefix + 63) // 64 * 64
-        L.check(self.lib.oavsr_scheduler_create(self._model, self.sched_slots, self.sched_rows, max_prefix, max_new, C.byref(self._sched)))
-        self._sched_key = (max_prefix, max_new, self.sched_rows, self.sched_slots)
+        L.check(self.lib.oavsr_scheduler_create(self._model, self.sched_slots, self.sched_rows, self.sched_lanes, max_prefix, max_new, C.byref(self._sched)))
+        self._sched_key = (max_prefix, max_new, self.sched_rows, self.sched_slots, self.sched_lanes)
         self._sched_gen += 1
         self._stride_set = 0
 

@@ -108,6 +108,22 @@ def test_more_calls_than_rows_per_step_and_oracle_f32():
         assert [ids[b][: lens[b]] for b in range(8)] == want, f"call {i}: scheduler ids differ from the oracle"
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_two_lanes_share_the_pool(dtype):
+    """two step loops (own streams) over one pool of row slots: calls alternate between them; same ids as isolated calls"""
+    spec = tiny_spec(family="llama", task_specific=True, shared=True)
+    eng = OmniEngine(spec, dtype=dtype).load_state_dict(synth_state_dict(spec, seed=1234))
+    eng.sched_lanes, eng.sched_slots = 2, 40             # a small pool: later calls wait for blocks of the earlier ones
+    mn = spec.max_dec_tokens
+    calls = [clips(8 if i % 3 else 6, 60 + i) for i in range(9)]
+    ref = [alone(eng, c, mn, False) for c in calls]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    pend = [submit(eng, c, mn, False, i % 3, streams[i % 3]) for i, c in enumerate(calls)]
+    got = [collect(eng, pend[i], streams[i % 3]) for i in range(9)]
+    assert got == ref
+    assert eng.scheduler_stats()["graphs"] >= 2
+
+
 def test_task_switch_drains_the_loop_and_pool_growth():
     """task-specific LoRA: rows of one step share the adapter set -> a call of another task waits for the loop to drain; a longer prompt
     than the pool was built for rebuilds the pool (tickets of the old one stay valid)"""

@@ -1,5 +1,8 @@
+#!/bin/bash
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+mkdir -p "$R/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/beam_trace -- python3 $R/bench.py --beams 15 --streams 1 --steps 1 --warmup 1 --calls-per-step 2 --no-cpu-baseline --no-roofline > $R/gpurun_out/beam_trace.log 2>&1
 python3 - $R/gpurun_out/beam_trace <<'PY'
 import csv, glob, sys

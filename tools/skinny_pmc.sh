@@ -1,8 +1,10 @@
 #!/bin/bash
+set -u
 # three counter passes (FETCH_SIZE | WRITE_SIZE | SQ_*) over the decode GEMVs (tools/skinny_mix.py), aggregated per kernel family into
 # profiles/<tag>_pmc_traffic_<family>.json by tools/pmc_round.py.   usage: skinny_pmc.sh [tag]   (default r02_skinny)
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+mkdir -p "$R/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 TAG=${1:-r02_skinny}
 i=0
 for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
