@@ -162,7 +162,7 @@ def parse_args():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-grouped", action="store_true", help="skip the extra decode-group-3 leg (N=1, greedy only; reported as `decode_group3`)")
+    ap.add_argument("--no-grouped", action="store_true", help="skip the extra leg with the decode scheduler off (N=1, headline preset only; reported as `per_call_decode`)")
     ap.add_argument("--beams", type=int, default=1, help="1 = greedy (north-star decode); 15 = the reference's default HF beam search")
     ap.add_argument("--llm", default=None, help="override the preset's LLM architecture (random-init)")
     ap.add_argument("--decode-group", type=int, default=1,
@@ -180,32 +180,31 @@ def parse_args():
     return ap.parse_args()
 
 
-def grouped_leg(eng, args, pre, task, use_a, B, Tv, dev, streams, nstream, G=3):
-    """Throughput with the decode loops of G consecutive calls merged (what `--decode-group G` measures), on fresh inputs."""
-    sets = []
-    for s in range(2):
-        Tvs = [Tv] * (B * G)
-        video, audio = make_inputs(Tvs, 900 + s, dev)
-        sets.append((video, audio, Tvs, [640 * t for t in Tvs]))
-    ra, rv = pre["rates"][0]
+def per_call_leg(eng, args, pre, task, use_a, B, sets, streams, nstream):
+    """The same job with the decode scheduler off (round-2 mode): every call runs its own decode loop on its own stream, the encoder +
+    prefill phases of the calls in flight chained.  Reported next to the headline as `per_call_decode`, never as `value`."""
+    eng.serialize_encoders(True)
+    nsets = len(sets)
 
     def call(i):
-        video, audio, Tvs, Ts = sets[i % 2]
+        video, audio, Tvs, Ts = sets[i % nsets]
+        ra, rv = pre["rates"][i % len(pre["rates"])]
         with torch.cuda.stream(streams[i % nstream]):
             return eng.generate(task, video, Tvs, audio if use_a else None, Ts if use_a else None, ra, rv, beams=1, max_new=args.max_new,
-                                force_len=True, video_is_flat=True, slot=i % nstream, chunk=B)
+                                force_len=True, video_is_flat=True, slot=i % nstream)
     n = 0
     for _ in range(nstream + 1):
         call(n); n += 1
     torch.cuda.synchronize()
-    ncall = max(nstream, (args.steps * max(1, args.calls_per_step)) // (2 * G))     # about half the utterances of the main leg
+    ncall = max(2 * nstream, (args.steps * max(1, args.calls_per_step)) // 4)      # a quarter of the main leg's calls
     t0 = time.perf_counter()
     for _ in range(ncall):
         call(n); n += 1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"value": round(ncall * G * B / dt, 3), "unit": "utterances/s", "ms_per_batch": round(dt / (ncall * G) * 1e3, 3), "calls": ncall,
-            "note": f"decode loops of {G} consecutive batches of {B} merged (one weight stream per {G * B} rows); opt-in mode, not `value`"}
+    eng.serialize_encoders(False)
+    return {"value": round(ncall * B / dt, 3), "unit": "utterances/s", "ms_per_call": round(dt / ncall * 1e3, 3), "calls": ncall,
+            "note": "decode scheduler off: one decode loop per call of the same batches (the round-2 configuration); not `value`"}
 
 
 def launch_ranks(args):
@@ -345,25 +344,36 @@ def main():
     assert len(hyp) == world * n_last
     assert args.beams > 1 or int(lens.min()) == args.max_new
 
+    dsched = eng.scheduler_stats() if use_sched else None      # the timed region's (the passes below run more calls)
     roofline = None
     stages = None
+    sides = None
     if rank == 0 and not args.no_roofline:
         torch.cuda.synchronize()
+        # (1) per-kernel-family HIP-event brackets, one call at a time (a bracket times whatever shares the chip with its kernel, so the
+        # calls of this pass do not overlap): what each encoder / projector / prefill kernel costs.  Decode families: pass (3).
+        nprof = max(2, len(pre["rates"]))
         eng.profile(True)
-        for _ in range(len(pre["rates"])):
+        for _ in range(nprof):
             call(ncall)
             ncall += 1
-        drain()
+            drain()
         ents = eng.profile_read()
         eng.profile(False)
         tot_ms = sum(e["ms"] for e in ents) or 1.0
-        stages = {e["name"]: dict(ms=round(e["ms"], 3), launches=e["launches"],
-                                   tflops=round(e["flops"] / e["ms"] / 1e9, 1) if e["ms"] > 0 and e["flops"] > 0 else None,
-                                   gbs=round(e["bytes"] / e["ms"] / 1e6, 1) if e["ms"] > 0 else None) for e in sorted(ents, key=lambda e: -e["ms"])}
-        dom = max(ents, key=lambda e: e["ms"])
+        stages = {}
+        for e in sorted(ents, key=lambda e: -e["ms"]):
+            avg_us = e["ms"] / max(1, e["launches"]) * 1e3
+            stages[e["name"]] = dict(ms_per_call=round(e["ms"] / nprof, 3), launches_per_call=round(e["launches"] / nprof, 1), avg_us=round(avg_us, 1),
+                                     tflops=round(e["flops"] / e["ms"] / 1e9, 1) if e["ms"] > 0 and e["flops"] > 0 else None,
+                                     gbs=round(e["bytes"] / e["ms"] / 1e6, 1) if e["ms"] > 0 else None)
+            if avg_us < 20.0:      # an event bracket resolves a launch to about +-2 us: rates of these families are indicative only
+                stages[e["name"]]["short"] = True
+        is_dec = lambda n: n.startswith(("skinny", "decode_attention", "argmax", "sched_", "beam_"))          # noqa: E731
+        is_mfma = lambda e: e["flops"] > 0 and not is_dec(e["name"]) and "logmel" not in e["name"]           # noqa: E731
+        dom = max((e for e in ents if not is_dec(e["name"])), key=lambda e: e["ms"], default=None) or max(ents, key=lambda e: e["ms"])
         traffic = pmc_traffic(dom["name"])
-        is_mfma = dom["flops"] > 0 and (("gemm" in dom["name"] and "skinny" not in dom["name"] and "splitk" not in dom["name"]) or dom["name"].startswith("attention_"))
-        if is_mfma:
+        if is_mfma(dom):
             ach = dom["flops"] / dom["ms"] / 1e9
             peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
             roofline = dict(bound="mfma", kernel=dom["name"], achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
@@ -374,13 +384,70 @@ def main():
             roofline = dict(bound="hbm", kernel=dom["name"], achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
                             traffic=traffic, avg_launch_ms=round(dom["ms"] / dom["launches"], 4), launches=dom["launches"],
                             share_of_step=round(dom["ms"] / tot_ms, 3))
+        # (2) the two sides of the job.  MFMA side: every encoder / projector / prefill kernel that does flops (long kernels: the brackets are
+        # accurate), algorithmic flops / their summed time.  Decode side: what a weight pass costs is measured on the real thing -- the
+        # scheduler's step loop replayed from its hipGraph with nothing else on the chip -- algorithmic bytes per step / wall time per step.
+        peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
+        mf = [e for e in ents if is_mfma(e)]
+        mfma_ms = sum(e["ms"] for e in mf) / nprof
+        mfma_fl = sum(e["flops"] for e in mf) / nprof
+        other_ms = sum(e["ms"] for e in ents if not is_mfma(e) and not is_dec(e["name"])) / nprof
+        sides = dict(mfma_ms_per_call=round(mfma_ms, 3), mfma_tflop_per_call=round(mfma_fl / 1e12, 3), mfma_frac=round(mfma_fl / mfma_ms / 1e9 / peak, 4) if mfma_ms > 0 else None,
+                     other_ms_per_call=round(other_ms, 3))
+        if use_sched:
+            l = spec.llm
+            esz = 2 if args.dtype == "bf16" else 4
+            nqkv = (l.heads + 2 * l.kv_heads) * l.head_dim
+            from omni_avsr_amd.weights import lora_k2
+            k2 = lora_k2(spec)
+            w_layer = nqkv * (l.hidden + k2) + k2 * l.hidden + l.hidden * l.heads * l.head_dim + 3 * l.mlp * l.hidden
+            step_bytes = esz * (l.layers * w_layer + l.vocab * l.hidden)             # weights streamed once per step (KV and activations: < 3 %)
+            k = max(1, args.sched_rows // B)
+            eng.sched_lanes, eng.sched_stride = 1, 1                                 # ONE step loop, filled as fast as the calls arrive
 
-    # Extra, reported next to the headline and never as `value`: the same job with the decode loops of 3 consecutive calls merged
-    # (`--decode-group 3`: encoders / prefill still per batch of B, one decode loop over 3 B rows; ids identical, tests/test_invariance_gpu.py)
+            def fill():
+                for j in range(k):
+                    call(ncall + j)
+                torch.cuda.synchronize()
+                return eng.scheduler_stats()
+            # (2) wall time of the real step loop: hipGraph replays of the steps the k admitted calls still need, nothing else on the chip
+            st1 = fill()
+            t1 = time.perf_counter()
+            drain()
+            dt = time.perf_counter() - t1
+            st2 = eng.scheduler_stats()
+            nst = st2["steps"] - st1["steps"]
+            if nst > 0:
+                step_ms = dt * 1e3 / nst
+                sides.update(decode_step_ms=round(step_ms, 4), decode_rows_per_step=round((st2["row_steps"] - st1["row_steps"]) / nst, 1),
+                             decode_gb_per_step=round(step_bytes / 1e9, 3), decode_hbm_frac=round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             decode_steps_per_call=round(dsched["steps"] / max(1, dsched["calls"]), 2),
+                             decode_note=f"{nst} hipGraph-replayed steps of one step loop ({k} calls admitted), nothing else on the chip; hbm_frac = weight "
+                                         f"bytes per step / step time / {HBM_PEAK_GBS:.0f} GB/s; steps_per_call: the timed region's")
+            # (3) the same steps eagerly with brackets: the decode kernel families at the row count they run at under the scheduler
+            st3 = fill()
+            eng.profile(True)
+            drain()
+            dents = eng.profile_read()
+            eng.profile(False)
+            for name in [n for n in stages if is_dec(n)]:
+                del stages[name]
+            nsteps = max(1, eng.scheduler_stats()["steps"] - st3["steps"])
+            for e in sorted(dents, key=lambda e: -e["ms"]):
+                if not is_dec(e["name"]) or e["launches"] == 0:
+                    continue
+                avg_us = e["ms"] / e["launches"] * 1e3
+                stages[e["name"]] = dict(ms_per_step=round(e["ms"] / nsteps, 4), launches_per_step=round(e["launches"] / nsteps, 1), avg_us=round(avg_us, 1),
+                                         gbs=round(e["bytes"] / e["ms"] / 1e6, 1) if e["ms"] > 0 else None)
+                if avg_us < 20.0:
+                    stages[e["name"]]["short"] = True
+            eng.sched_lanes, eng.sched_stride = args.sched_lanes, args.sched_stride
+
+    # Extra, reported next to the headline and never as `value`: the same job with the engine's decode scheduler switched off
     grouped = None
-    if rank == 0 and world == 1 and G == 1 and args.beams == 1 and not args.no_grouped and not pre["varlen"] and args.preset == "c1" and not args.llm:
+    if rank == 0 and world == 1 and use_sched and not args.no_grouped and args.preset == "c1" and not args.llm:
         try:
-            grouped = grouped_leg(eng, args, pre, task, use_a, B, Tv, dev, streams, nstream)
+            grouped = per_call_leg(eng, args, pre, task, use_a, B, sets, streams, nstream)
         except Exception as e:                               # the headline line must not depend on this leg
             grouped = {"error": f"{type(e).__name__}: {e}"[:200]}
 
@@ -407,9 +474,10 @@ def main():
                                    + f", BASELINE.json configs[{pre['idx']}]" + ("" if args.preset == "c1" and not args.llm else " (NOT the headline configuration)"),
                        "batch_per_call": B, "calls_per_step": calls, "ms_per_call": round(elapsed / (args.steps * calls) * 1e3, 3),
                        "global_batch": world * B * calls, "input_sets": nsets, "timed_s": round(elapsed, 2),
-                       "parallelism": f"utterance-sharded dp{world}", "streams_per_gpu": nstream, "decode_group": G, "setup_s": round(setup_s, 1),
-                       "decode_scheduler": (dict(rows_per_step_cap=args.sched_rows, slots=args.sched_slots, lanes=args.sched_lanes, **eng.scheduler_stats()) if use_sched else None)},
-            "roofline": roofline, "cpu_baseline": cpu, "decode_group3": grouped, "stages": stages,
+                       "parallelism": f"utterance-sharded dp{world}", "gathered_hypotheses": len(hyp), "dist_backend": (dist.get_backend() if use_dist else None),
+                       "streams_per_gpu": nstream, "decode_group": G, "setup_s": round(setup_s, 1),
+                       "decode_scheduler": (dict(rows_per_step_cap=args.sched_rows, slots=args.sched_slots, lanes=args.sched_lanes, **dsched) if use_sched else None)},
+            "roofline": roofline, "roofline_sides": sides, "cpu_baseline": cpu, "per_call_decode": grouped, "stages": stages,
         }
         print(json.dumps(line), flush=True)
     if use_dist:

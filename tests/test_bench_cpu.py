@@ -19,8 +19,9 @@ def _run(args, **env):
 
 
 def test_gpus_flag_fails_loudly_without_enough_devices():
-    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
-    assert r.returncode == 2 and "needs 2 GPUs" in r.stderr and r.stdout.strip() == ""
+    # more GPUs than any node has: the answer must not depend on the host this CPU test runs on
+    r = _run(["--gpus", "1024", "--steps", "1", "--warmup", "0"])
+    assert r.returncode == 2 and "needs 1024 GPUs" in r.stderr and r.stdout.strip() == ""
 
 
 def test_gpus_flag_builds_a_torchrun_child_command(monkeypatch):
