@@ -20,7 +20,7 @@ __device__ __forceinline__ unsigned float_key(float f) { const unsigned u = __fl
 __device__ __forceinline__ float key_float(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 __global__ __launch_bounds__(256) void stft_mel_kernel(const float* __restrict__ wav, int64_t ld, const int* __restrict__ lens,
                                                         const double* __restrict__ tw, const float* __restrict__ melfb,
-                                                        float* __restrict__ mel_ws, unsigned* __restrict__ max_key) {
+                                                        float* __restrict__ mel_ws, unsigned* __restrict__ max_key, int round_bf16) {
   __shared__ __attribute__((aligned(16))) double sx[kNfft][kFR];   // windowed samples, already widened: [n][frame] -> broadcast 16-byte reads
   __shared__ float spow[kFR][kBins + 7];
   __shared__ float smax[4];
@@ -43,6 +43,9 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float* __restrict__
     if (j < 0) j = -j;
     if (j >= kSamples) j = 2 * (kSamples - 1) - j;
     float v = j < len ? wav[(int64_t)b * ld + j] : 0.f;
+    // bf16 mode = the reference's `bf16-true` evaluation: Lightning's HalfPrecision.convert_input hands forward() the WAVEFORM in bf16
+    // (hence `audio.to(torch.float32)` at modeling_OmniAVSR.py:530); the front end itself then runs in fp32 / fp64 as there
+    if (round_bf16) v = to_f32(from_f32<bf16_t>(v));
     // periodic Hann: 0.5 - 0.5 cos(2 pi n / 400) = 0.5 - 0.5 * tw[n].cos
     float w = (float)(0.5 - 0.5 * tw[2 * n]);
     sx[n][fr] = (double)(v * w);
@@ -107,7 +110,7 @@ int launch_logmel(int dtype, const float* wav, int64_t ld, const int* lens, int 
   static_assert(kFrames % kFR == 0, "frames per workgroup");
   unsigned* max_key = reinterpret_cast<unsigned*>(max_ws);
   OAVSR_CHECK_HIP(hipMemsetAsync(max_key, 0, sizeof(unsigned) * B, st));
-  hipLaunchKernelGGL(stft_mel_kernel, dim3(kFrames / kFR, B), dim3(256), 0, st, wav, ld, lens, twiddle, melfb, mel_ws, max_key);
+  hipLaunchKernelGGL(stft_mel_kernel, dim3(kFrames / kFR, B), dim3(256), 0, st, wav, ld, lens, twiddle, melfb, mel_ws, max_key, dtype == DT_BF16 ? 1 : 0);
   if (dtype == DT_F32) hipLaunchKernelGGL(mel_finalize_kernel<float>, dim3(2048), dim3(256), 0, st, mel_ws, max_key, (float*)out, ldo, B);
   else hipLaunchKernelGGL(mel_finalize_kernel<bf16_t>, dim3(2048), dim3(256), 0, st, mel_ws, max_key, (bf16_t*)out, ldo, B);
   OAVSR_CHECK_HIP(hipGetLastError());

@@ -684,7 +684,8 @@ class OmniOracle:
     def encode_audio(self, audio: Tensor, max_len: int, rate: int, return_stages=False, mel_bf16: bool = False):
         """`mel_bf16`: the reference casts the log-mel features to bf16 whatever the precision plugin (`.to(torch.bfloat16)`, :534);
         the engine's f32 parity mode keeps them in fp32, its bf16 mode stores them in bf16 (= the emulation's `_q`)."""
-        mel = whisper_log_mel(audio.squeeze(-1).float())
+        # emulation: bf16-true hands forward() the waveform in bf16 (Lightning's HalfPrecision.convert_input; `audio.to(torch.float32)`, :530)
+        mel = whisper_log_mel(_q(audio.squeeze(-1).float()))
         if mel_bf16:
             mel = mel.bfloat16().float()
         enc = whisper_encoder(self.sd, "audio_encoder.", mel, self.cfg["whisper"]["layers"], self.cfg["whisper"]["heads"])

@@ -116,3 +116,38 @@ def test_decoder_layer_against_executed_reference(family):
         _, h1 = llm.forward(x1, S, cache, "audiovisual", return_hidden=True)
     assert np.abs(h[0][0].numpy() - g[f"{family}_prefill"]).max() < 2e-5
     assert np.abs(h1[0][0].numpy() - g[f"{family}_step"]).max() < 2e-5
+
+
+@pytest.mark.parametrize("name,kw", [("llama", dict(family="llama", task_specific=True, shared=True, matryoshka=True)),
+                                     ("qwen", dict(family="qwen2", head_dim=128, matryoshka=True, single_projector=True))])
+def test_oracle_and_its_bf16_emulation_against_the_references_bf16_run(name, kw):
+    """tests/golden/ref_bf16.npz (oracle/gen_golden_bf16.py): the reference's classes executed in torch.bfloat16 as `bf16-true` runs them.
+    The fp32 oracle must sit at bf16 distance from them (not at fp32 distance: that would mean the fixture is not a bf16 run; not far: that
+    would mean different mathematics), and the bf16-EMULATING oracle -- the model of this engine's rounding points -- must be no further
+    from the fp32 oracle than the reference's bf16 run is (the same bar tests/test_bf16_reference_gpu.py applies to the engine itself)."""
+    z = np.load(os.path.join(GOLD, "ref_bf16.npz"))
+    spec = tiny_spec(**kw)
+    sd = synth_state_dict(spec, seed=int(z["seed"]))
+    Tv, ra, rv = int(z[f"{name}_Tv"]), int(z[f"{name}_ra"]), int(z[f"{name}_rv"])
+    g = torch.Generator().manual_seed(int(z["input_seed"]))
+    video = torch.randn(1, Tv, 1, 88, 88, generator=g).bfloat16().float()
+    audio = torch.randn(1, 640 * Tv, 1, generator=g).bfloat16().float()
+    tokens = torch.full((1, 1), spec.ids["bos"]) if spec.llm.family == "llama" else torch.zeros(1, 0, dtype=torch.long)
+    inp = dict(video=video, audio=audio, lengths=torch.tensor([640 * Tv]), tokens=tokens)
+    orc = O.OmniOracle(sd, spec.oracle_cfg())
+    mod = "audiovisual" if spec.is_task_specific else None
+
+    def run():
+        with torch.no_grad():
+            e = orc.prepare_inputs(inp, "audiovisual", ra, rv, mel_bf16=True)
+            return e[0], orc.llm.forward(e, 0, [None] * spec.llm.layers, mod)[0, -1]
+    e32, lg32 = run()
+    with O.bf16_emulation():
+        e16, lg16 = run()
+    for what, truth, emu, ref in (("inputs_embeds", e32, e16, z[f"{name}_embeds"]), ("prefill logits", lg32, lg16, z[f"{name}_logits"])):
+        d_ref = np.abs(ref - truth.numpy())
+        d_emu = (emu - truth).abs().numpy()
+        scale = float(truth.abs().mean())
+        assert 2e-4 * scale < d_ref.mean() < 0.05 * scale, f"{name} {what}: the reference's bf16 run is {d_ref.mean():.2e} from the fp32 oracle (scale {scale:.2e})"
+        assert d_emu.mean() <= 1.5 * d_ref.mean(), f"{name} {what}: emulation {d_emu.mean():.2e} vs reference bf16 {d_ref.mean():.2e}"
+    assert int(lg32.argmax()) == int(z[f"{name}_token"])
