@@ -78,9 +78,11 @@ def failed_record(utt_ids: Sequence[int], width: int, device="cpu") -> torch.Ten
     return rec
 
 
-def reduce_wer_counters(edits: int, words: int, device="cpu", group=None) -> Tuple[int, int]:
-    """all_reduce(sum) of {edits, words} when WER is computed distributed (lightning_OmniAVSR.py:206-219 semantics)."""
-    t = torch.tensor([edits, words], dtype=torch.int64, device=device)
+def reduce_wer_counters(edits: int, words: int, device="cpu", group=None, failed: int = None):
+    """all_reduce(sum) of {edits, words} when WER is computed distributed (lightning_OmniAVSR.py:206-219 semantics).  With `failed`
+    (utterances this rank could not decode, harness.WerMeter.failed) the sum of those travels too and (edits, words, failed) comes back:
+    a WER over fewer utterances than the test set holds must be reported as such."""
+    t = torch.tensor([edits, words, 0 if failed is None else failed], dtype=torch.int64, device=device)
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(t, group=group)
-    return int(t[0]), int(t[1])
+    return (int(t[0]), int(t[1])) if failed is None else (int(t[0]), int(t[1]), int(t[2]))

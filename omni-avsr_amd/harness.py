@@ -220,18 +220,30 @@ class WerMeter:
     def wer(self) -> float:
         return self.total_edit_distance / max(self.total_length, 1)
 
+    def summary(self) -> Dict[str, float]:
+        """What a caller should print / log: a WER over fewer utterances than were asked for must say so."""
+        return dict(wer=self.wer, edits=self.total_edit_distance, words=self.total_length, utterances=len(self.per_utt), failed=len(self.failed))
+
 
 def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], modality: str, to_text: Callable[[torch.Tensor], List[str]],
              batch_size: int = 8, bos_id: Optional[int] = None, rank: int = 0, world: int = 1, in_flight: int = 1, decode_group: int = 1,
-             **forward_kw) -> WerMeter:
+             allow_failures: bool = False, allow_regime_change: bool = False, **forward_kw) -> WerMeter:
     """Evaluation loop of eval_OmniAVSR.py:273-357 for one (task, rates) cell, utterance-sharded over `world` ranks
      and batched (the reference runs batch 1).  `samples`: [(transformed sample dict, gold text)].
     `in_flight` > 1 keeps that many batches in flight on their own HIP streams / workspaces (the encoders of one overlap the decode loop
     of the others; same ids, same counters, ~1.4x the throughput on MI355X) -- needs the HIP-backed model (`model.engine`).
     `decode_group` = G > 1 (HIP-backed model): a call takes G x batch_size utterances, runs encoders / prefill in chunks of batch_size and
     ONE decode loop over all rows (`model.encoder_chunk`): the LLM weights are streamed once per step for G batches; keep G x batch_size x
-    num_beams <= 32 rows for ids that are bit-identical to the ungrouped loop (invariance contract).
+    num_beams <= 32 rows for ids that are bit-identical to the ungrouped loop (invariance contract) -- a larger group is
+    refused unless `allow_regime_change` (the > 32-row decode kernels sum in another order: bf16 ids may differ from the ungrouped run).
+    With the HIP-backed model and greedy decode, `in_flight` > 1 alone already shares the decode steps between the batches in flight
+    (the engine's decode scheduler); `decode_group` remains for beam search.
+    Failures: like the reference (whose loop simply crashes), the first batch that raises ends the evaluation -- unless
+    `allow_failures`: then a batch whose INPUTS the engine refused (RuntimeError / ValueError) is recorded in `meter.failed` and skipped;
+    device errors (lib.DeviceError) always propagate, and so does anything raised while results are collected.  `meter.failed` is part
+    of the summary (`meter.summary()`), and dist.reduce_wer_counters can carry its count.
     Returns this rank's WerMeter; combine with dist.reduce_wer_counters."""
+    from .lib import DeviceError
     from .dist import make_batches, shard_utterances
     dur = [float((s.get("video") if "video" in s else s["audio"]).shape[0]) / (1.0 if "video" in s else 640.0) for s, _ in samples]
     owned = shard_utterances(dur, world, rank)
@@ -240,9 +252,20 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
     kw_mod = modality if getattr(model, "is_task_specific", False) else None
     chunk_prev = getattr(model, "encoder_chunk", None)
     if decode_group > 1:
+        rows = batch_size * decode_group * int(getattr(model, "num_beams", 1) or 1)
+        if rows > 32 and not allow_regime_change:
+            raise ValueError(f"decode_group={decode_group} x batch_size={batch_size} x num_beams={getattr(model, 'num_beams', 1)} = {rows} decode rows: "
+                             "above 32 rows the decode GEMMs switch kernel family and bf16 ids may differ from the ungrouped evaluation "
+                             "(pass allow_regime_change=True to accept that)")
         model.encoder_chunk = batch_size
         batch_size = batch_size * decode_group
     batches = list(make_batches(owned, batch_size))
+
+    def skip(idxs, e):
+        if not allow_failures or isinstance(e, DeviceError):
+            raise e
+        meter.failed.extend(idxs)
+        print(f"evaluate: batch {idxs} failed: {e}")
 
     def score(idxs, ids):
         for i, t in zip(idxs, to_text(ids)):
@@ -253,9 +276,8 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
             batch = collate_test([samples[i][0] for i in idxs], modality, bos_id)
             try:
                 ids = model(batch, is_trainval=False, modality=kw_mod, **forward_kw)
-            except (RuntimeError, ValueError) as e:           # a bad clip must not lose the evaluation: report its batch, go on
-                meter.failed.extend(idxs)
-                print(f"evaluate: batch {idxs} failed: {e}")
+            except (RuntimeError, ValueError) as e:
+                skip(idxs, e)
                 continue
             score(idxs, ids)
         if decode_group > 1:
@@ -274,7 +296,8 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
     from concurrent.futures import ThreadPoolExecutor
     limit = 2 * in_flight                                     # calls queued at most: a slot's stream orders its own calls, so the host may run one round ahead
     nset = limit + 1
-    collators = [FlatCollator(batch_size, tv_max, ts_max) for _ in range(nset)]
+    bmax = max(len(b) for b in batches)                       # the largest batch actually owned (pinned memory: nset x bmax clips)
+    collators = [FlatCollator(bmax, tv_max, ts_max) for _ in range(nset)]
     pool = ThreadPoolExecutor(1)
     collate = lambda n: collators[n % nset]([samples[i][0] for i in batches[n]], modality, bos_id)      # noqa: E731
     eng.serialize_encoders(True)
@@ -293,8 +316,7 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
                 with torch.cuda.stream(streams[slot]):
                     p = model(batch, is_trainval=False, modality=kw_mod, slot=slot, sync=False, **forward_kw)
             except (RuntimeError, ValueError) as e:
-                meter.failed.extend(idxs)
-                print(f"evaluate: batch {idxs} failed: {e}")
+                skip(idxs, e)
                 torch.cuda.synchronize(dev)                   # whatever was queued from the staging set must be done before it is refilled
                 continue
             pending.append((slot, idxs, p))

@@ -110,21 +110,33 @@ def load_hf_safetensors(model_dir: str, prefix: str = "") -> Dict[str, torch.Ten
     return sd
 
 
-def resize_token_embeddings(sd: Dict[str, torch.Tensor], new_rows: int, added: Optional[torch.Tensor] = None, prefix: str = "llm.") -> Dict[str, torch.Tensor]:
+def resize_token_embeddings(sd: Dict[str, torch.Tensor], new_rows: int, added=None, prefix: str = "llm.") -> Dict[str, torch.Tensor]:
     """`self.llm.resize_token_embeddings(len(self.tokenizer))` (modeling_OmniAVSR.py:214) on a plain state dict: embed_tokens and lm_head
     grow to `new_rows` (+5 rows for Llama: <pad> and the four audio / video tags, +4 for Qwen; lightning_OmniAVSR.py:83-88).
-    The added rows are `added` [n_new, hidden] when given -- the trained values every `model_avg_N.pth` already carries -- else the
-    mean of the existing rows (HF draws them at random; a mean keeps an untrained model's logits finite and the result deterministic)."""
+    The added rows are `added` when given -- the trained values every `model_avg_N.pth` already carries -- else the mean of the existing
+    rows (HF draws them at random; a mean keeps an untrained model's logits finite and the result deterministic).  `added`: one tensor
+    [n_new, hidden] for tied embeddings; for UNTIED checkpoints (Llama-3.1-8B, Qwen2.5-7B: lm_head is a tensor of its own and its trained
+    rows for <pad> / the tags differ from the embedding's) a pair / dict {"embed": ..., "lm_head": ...} -- a single tensor is refused
+    there, because copying embedding rows into lm_head would give the added tokens wrong logits (beam search could then emit them)."""
     out = dict(sd)
     ek, hk = prefix + "model.embed_tokens.weight", prefix + "lm_head.weight"
     tied = hk not in sd or sd[hk].data_ptr() == sd[ek].data_ptr()
+    if isinstance(added, dict):
+        per_key = {ek: added.get("embed"), hk: added.get("lm_head")}
+    elif isinstance(added, (tuple, list)):
+        per_key = {ek: added[0], hk: added[1]}
+    else:
+        if added is not None and not tied and new_rows > sd[hk].shape[0]:
+            raise ValueError("untied embeddings: `added` must carry separate rows for embed_tokens and lm_head ({'embed': ..., 'lm_head': ...})")
+        per_key = {ek: added, hk: added}
     for k in ((ek,) if tied else (ek, hk)):
         w = sd[k]
         n_new = new_rows - w.shape[0]
         if n_new < 0:
             raise ValueError(f"{k} has {w.shape[0]} rows, more than the tokenizer's {new_rows}")
         if n_new:
-            extra = added.to(w.dtype) if added is not None else w.float().mean(0, keepdim=True).expand(n_new, -1).to(w.dtype)
+            rows = per_key[k]
+            extra = rows.to(w.dtype) if rows is not None else w.float().mean(0, keepdim=True).expand(n_new, -1).to(w.dtype)
             if extra.shape != (n_new, w.shape[1]):
                 raise ValueError(f"added rows have shape {tuple(extra.shape)}, expected {(n_new, w.shape[1])}")
             out[k] = torch.cat([w, extra], 0)
@@ -137,7 +149,8 @@ def assemble_state_dict(avhubert_pt: Optional[str] = None, whisper_dir: Optional
                         adapter_pth: Optional[str] = None, vocab_rows: Optional[int] = None) -> Dict[str, torch.Tensor]:
     """Builds the `AVSR_LLMs.state_dict()` layout from the separate artefacts the reference's constructor pulls in
     (modeling_OmniAVSR.py:59-60,118-147,200-214): the AV-HuBERT fairseq `.pt`, the Whisper / LLM HF directories, and a checkpoint with
-    whatever training produced (projectors, LoRA factors, prompt buffers, the added embedding rows under `llm.added_rows`)."""
+    whatever training produced (projectors, LoRA factors, prompt buffers, the added embedding rows under `llm.added_rows`, or
+    `llm.added_rows.embed` + `llm.added_rows.lm_head` for models with an untied lm_head)."""
     sd: Dict[str, torch.Tensor] = {}
     if avhubert_pt:
         sd.update(load_fairseq_avhubert(avhubert_pt))
@@ -153,6 +166,8 @@ def assemble_state_dict(avhubert_pt: Optional[str] = None, whisper_dir: Optional
     if adapter_pth:
         ad = load_omni_checkpoint(adapter_pth)
         added = ad.pop("llm.added_rows", None)
+        if "llm.added_rows.embed" in ad or "llm.added_rows.lm_head" in ad:      # untied models: the two tensors' rows are stored separately
+            added = {"embed": ad.pop("llm.added_rows.embed", None), "lm_head": ad.pop("llm.added_rows.lm_head", None)}
         sd.update(ad)
     if vocab_rows is not None and llm_dir:
         sd = resize_token_embeddings(sd, vocab_rows, added)

@@ -156,9 +156,16 @@ def last_error() -> str:
     return load().oavsr_last_error().decode("utf-8", "replace")
 
 
+class DeviceError(RuntimeError):
+    """A HIP call inside the library failed (OAVSR_CHECK_HIP): the device / stream state is suspect, later calls will most likely fail
+    the same way -- unlike an argument the library refused, which only concerns the call that carried it."""
+
+
 def check(rc: int):
     if rc != 0:
         msg = last_error()
         if msg.startswith("KeyError"):
             raise KeyError(msg[len("KeyError: "):])
+        if " HIP error " in msg or rc == -2:
+            raise DeviceError(f"libomniavsr_hip: {msg} (rc={rc})")
         raise RuntimeError(f"libomniavsr_hip: {msg} (rc={rc})")

@@ -89,3 +89,48 @@ def test_fullsize_4s_clip_bf16_engine_matches_bf16_emulation():
                            prompt_len={"audio": 8, "video": 8, "audiovisual": 8}, max_dec_tokens=32, num_beams=1)
     sd = synth_state_dict(spec, seed=1234, device="cuda:0")
     run_case(spec, sd, 100, 64000, 4, 4, seed=5, max_new=32)
+
+
+def hyp_score(orc, emb, toks, mod):
+    """HF beam-search score of a finished hypothesis under the (emulating) oracle, teacher-forced along its tokens:
+    sum of log-probabilities / length ** length_penalty (BeamHypotheses.add, length_penalty = 1.0)."""
+    lp = torch.log_softmax(orc.llm.score_path(emb, toks, mod).double(), dim=-1)
+    return float(sum(lp[t, toks[t]] for t in range(len(toks))) / len(toks))
+
+
+def run_beam_case(spec, sd, Tv, Ts, rate_a, rate_v, seed, K=15):
+    """The reference's default decode (eval_OmniAVSR.py:215-226: 15 beams) in bf16: the engine's best hypothesis, scored by the emulating
+    oracle, must be within LOGIT_TOL (per token) of the hypothesis the emulating oracle's own beam search returns -- equal ids wherever
+    no near-tie sits on the way, and never a hypothesis the reference's arithmetic would rank visibly lower."""
+    eng = OmniEngine(spec, dtype="bf16").load_state_dict(sd)
+    sd_cpu = {k: v.cpu().float() for k, v in sd.items()}
+    orc = O.OmniOracle(sd_cpu, spec.oracle_cfg())
+    g = torch.Generator().manual_seed(seed)
+    video = torch.randn(1, Tv, 1, 88, 88, generator=g)
+    audio = torch.nn.functional.layer_norm(torch.randn(1, Ts, generator=g), (Ts,)).unsqueeze(-1)
+    ids, lens = eng.generate("audiovisual", video, [Tv], audio, [Ts], rate_a, rate_v, beams=K, max_new=spec.max_dec_tokens)
+    got = ids[0, : int(lens[0])].cpu().tolist()
+    tokens = torch.full((1, 1), spec.ids["bos"]) if spec.llm.family == "llama" else torch.zeros(1, 0, dtype=torch.long)
+    mod = "audiovisual" if spec.is_task_specific else None
+    with torch.no_grad(), O.bf16_emulation():
+        emb = orc.prepare_inputs(dict(video=video, audio=audio, lengths=torch.tensor([Ts]), tokens=tokens), "audiovisual", rate_a, rate_v)
+        want = orc.llm.generate_beam(emb, spec.max_dec_tokens, K, spec.ids["eos"], spec.ids["pad"], mod)
+        s_got, s_want = hyp_score(orc, emb, got, mod), hyp_score(orc, emb, want, mod)
+    same = sum(int(a == b) for a, b in zip(got, want))
+    print(f"bf16 beam-{K}: engine hypothesis scores {s_got:.4f}, the emulating oracle's {s_want:.4f} (per token); {same}/{max(len(got), len(want))} ids equal")
+    assert s_got >= s_want - LOGIT_TOL, f"the engine's beam-{K} hypothesis scores {s_want - s_got:.3e} per token below the emulating oracle's"
+
+
+@pytest.mark.parametrize("family,hd", [("llama", 64), ("qwen2", 128)])
+def test_tiny_bf16_beam15_hypothesis_is_as_good_as_the_emulations(family, hd):
+    spec = tiny_spec(family=family, head_dim=hd, task_specific=True, shared=True)
+    run_beam_case(spec, synth_state_dict(spec, seed=1234), 12, 7680, 4, 2, seed=3)
+
+
+def test_fullsize_4s_clip_bf16_beam15():
+    spec = spec_from_names("meta-llama/Llama-3.2-1B", "openai/whisper-medium.en", "large_vox_iter5", use_lora_avhubert=True,
+                           intermediate_size=2048, compression_mode="avg-pooling", downsample_ratio_audio=[4, 16], downsample_ratio_video=[2, 4, 5],
+                           is_matryoshka=True, lora_rank=32, lora_alpha=4, is_task_specific=True, shared_lora=True,
+                           prompt_len={"audio": 8, "video": 8, "audiovisual": 8}, max_dec_tokens=32, num_beams=15)
+    sd = synth_state_dict(spec, seed=1234, device="cuda:0")
+    run_beam_case(spec, sd, 100, 64000, 4, 4, seed=5)

@@ -98,9 +98,13 @@ def test_resize_token_embeddings_and_assemble(tmp_path):
     assert out["llm.model.embed_tokens.weight"].shape == (6, 3) and out["llm.lm_head.weight"].data_ptr() == out["llm.model.embed_tokens.weight"].data_ptr()
     assert torch.allclose(out["llm.model.embed_tokens.weight"][4:], emb.mean(0, keepdim=True).expand(2, 3))
     added = torch.ones(2, 3) * 7
-    out2 = ingest.resize_token_embeddings({"llm.model.embed_tokens.weight": emb, "llm.lm_head.weight": emb + 1}, 6, added)
-    assert torch.equal(out2["llm.model.embed_tokens.weight"][4:], added) and torch.equal(out2["llm.lm_head.weight"][:4], emb + 1)
     import pytest
+    untied = {"llm.model.embed_tokens.weight": emb, "llm.lm_head.weight": emb + 1}
+    with pytest.raises(ValueError, match="untied"):          # one tensor cannot serve two different matrices
+        ingest.resize_token_embeddings(untied, 6, added)
+    out2 = ingest.resize_token_embeddings(untied, 6, {"embed": added, "lm_head": added * 2})
+    assert torch.equal(out2["llm.model.embed_tokens.weight"][4:], added) and torch.equal(out2["llm.lm_head.weight"][:4], emb + 1)
+    assert torch.equal(out2["llm.lm_head.weight"][4:], added * 2)
     with pytest.raises(ValueError):
         ingest.resize_token_embeddings(sd, 3)
 
@@ -114,9 +118,29 @@ def test_evaluate_reports_failed_batches():
                 raise RuntimeError("bad clip")
             return torch.tensor([[1, 2]] * batch["video"].shape[0])
 
+    import pytest
+    from omni_avsr_amd.lib import DeviceError
     samples = [({"video": torch.zeros(t, 1, 88, 88)}, "w1 w2") for t in (5, 7, 5, 5)]
-    m = H.evaluate(Boom(), samples, "video", lambda ids: ["w1 w2"] * ids.shape[0], batch_size=1)
+    # default: like the reference's loop, the first failing batch ends the evaluation
+    with pytest.raises(RuntimeError, match="bad clip"):
+        H.evaluate(Boom(), samples, "video", lambda ids: ["w1 w2"] * ids.shape[0], batch_size=1)
+    # opt-in tolerance: the batch is reported, left out of the counters, and shows up in the summary
+    m = H.evaluate(Boom(), samples, "video", lambda ids: ["w1 w2"] * ids.shape[0], batch_size=1, allow_failures=True)
     assert m.failed == [1] and m.total_length == 6 and m.total_edit_distance == 0
+    assert m.summary() == dict(wer=0.0, edits=0, words=6, utterances=3, failed=1)
+
+    class Sticky(Boom):
+        def __call__(self, batch, **kw):
+            raise DeviceError("HIP error 719")
+    with pytest.raises(DeviceError):      # a device fault is never "one bad clip": every later batch would fail the same way
+        H.evaluate(Sticky(), samples, "video", lambda ids: ["w1 w2"] * ids.shape[0], batch_size=1, allow_failures=True)
+    with pytest.raises(ValueError, match="decode rows"):
+        H.evaluate(Boom(), samples, "video", lambda ids: ["w1 w2"] * ids.shape[0], batch_size=8, decode_group=5)
+
+
+def test_reduce_wer_counters_carries_the_failed_count():
+    from omni_avsr_amd.dist import reduce_wer_counters
+    assert reduce_wer_counters(3, 10) == (3, 10) and reduce_wer_counters(3, 10, failed=2) == (3, 10, 2)
 
 
 def test_flat_collator_matches_collate_test():
