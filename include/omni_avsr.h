@@ -84,13 +84,20 @@ int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, 
                            int32_t max_new, oavsr_workspace** out);
 void oavsr_workspace_destroy(oavsr_workspace* ws);
 uint64_t oavsr_workspace_bytes(const oavsr_workspace* ws);
+/* What `video_dev` holds in the calls that follow on this workspace.  channels = 0 (default): f32 [sum(Tv)][88][88], the frames after the
+ * dataset's test-time transform (datamodule/transforms.py:93-99), as the reference's forward() receives them.  channels = 1 / 3: the
+ * DECODED frames, uint8 [sum(Tv)][channels][height][width] (av_dataset.py: load_video(...).permute(0, 3, 1, 2)); x / 255, CenterCrop(88),
+ * Grayscale and Normalize(0.421, 0.165) then run inside the fused stem kernel's window gather with the host code's fp32 operations in
+ * the host code's order (same bits), so a 16 s clip is uploaded as 3.7 MB (gray) / 11 MB (RGB 96 x 96) instead of 12.4 MB of floats and
+ * the host does no per-pixel work. */
+int oavsr_workspace_set_video_format(oavsr_workspace* ws, int32_t channels, int32_t height, int32_t width);
 
 /* ---- stage entry points (each replaces the reference function cited) ------------------------------------ */
 
 /* encode_video (modeling_OmniAVSR.py:461-483) = AVHubertModel.extract_finetune (hubert.py:695-755) + compressor.
- * video_dev: f32 [sum(Tv)][88][88] (frames of all utterances back to back); out_dev: [sum(Tv/rate)][D or D*rate];
+ * video_dev: f32 [sum(Tv)][88][88] (frames of all utterances back to back; or uint8 frames, oavsr_workspace_set_video_format); out_dev: [sum(Tv/rate)][D or D*rate];
  * enc_dev (optional): uncompressed encoder output [sum(Tv)][D]. */
-int oavsr_encode_video(const oavsr_model* m, oavsr_workspace* ws, const float* video_dev, const int32_t* Tv_host, int32_t B,
+int oavsr_encode_video(const oavsr_model* m, oavsr_workspace* ws, const void* video_dev, const int32_t* Tv_host, int32_t B,
                        int32_t rate, void* out_dev, void* enc_dev, oavsr_stream stream);
 
 /* encode_audio (modeling_OmniAVSR.py:528-558) = log-mel + WhisperEncoder + truncation (:537) + compressor.
@@ -122,7 +129,7 @@ int oavsr_decode(const oavsr_model* m, oavsr_workspace* ws, int32_t task, int32_
                  int32_t force_len, int32_t* out_ids_dev, int32_t* out_len_dev, oavsr_stream stream);
 
 /* AVSR_LLMs.forward(inputs, is_trainval=False) end to end (modeling_OmniAVSR.py:308-323). */
-int oavsr_generate(const oavsr_model* m, oavsr_workspace* ws, int32_t task, const float* video_dev, const int32_t* Tv_host,
+int oavsr_generate(const oavsr_model* m, oavsr_workspace* ws, int32_t task, const void* video_dev, const int32_t* Tv_host,
                    const float* wav_dev, int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host, int32_t B,
                    int32_t rate_audio, int32_t rate_video, int32_t beams, int32_t max_new, int32_t force_len,
                    int32_t* out_ids_dev, int32_t* out_len_dev, oavsr_stream stream);
@@ -130,7 +137,7 @@ int oavsr_generate(const oavsr_model* m, oavsr_workspace* ws, int32_t task, cons
  * chunks of chunk_B utterances (the launch shapes of a batch-of-chunk_B request), every chunk's prefix KV and last-token logits
  * land in their own slots, and ONE decode loop then serves all B rows, so the LLM weights are streamed once per step for the
  * whole group (continuous batching of the decode phase).  chunk_B == B is oavsr_generate. */
-int oavsr_generate_chunked(const oavsr_model* m, oavsr_workspace* ws, int32_t task, const float* video_dev, const int32_t* Tv_host,
+int oavsr_generate_chunked(const oavsr_model* m, oavsr_workspace* ws, int32_t task, const void* video_dev, const int32_t* Tv_host,
                            const float* wav_dev, int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host, int32_t B, int32_t chunk_B,
                            int32_t rate_audio, int32_t rate_video, int32_t beams, int32_t max_new, int32_t force_len, int32_t* out_ids_dev,
                            int32_t* out_len_dev, oavsr_stream stream);
@@ -155,7 +162,7 @@ uint64_t oavsr_scheduler_bytes(const oavsr_scheduler* s);
 /* oavsr_generate(beams = 1) split in two: submit queues encoders + prefill on `stream` (workspace ws, as oavsr_generate) and the
  * admission of the B rows on the scheduler's stream; it returns a ticket.  out_ids_dev / out_len_dev ([B][max_new] / [B] int32) are
  * written by the scheduler's stream when the call's last step has run and must stay valid until oavsr_generate_wait. */
-int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_workspace* ws, int32_t task, const float* video_dev,
+int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_workspace* ws, int32_t task, const void* video_dev,
                           const int32_t* Tv_host, const float* wav_dev, int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host,
                           int32_t B, int32_t rate_audio, int32_t rate_video, int32_t max_new, int32_t force_len, int32_t* out_ids_dev,
                           int32_t* out_len_dev, oavsr_stream stream, int64_t* ticket_out);
@@ -246,10 +253,12 @@ int oavsr_op_decode_attention(const oavsr_decode_attn_desc* d, oavsr_stream stre
 int oavsr_op_norm(int32_t mode, int32_t dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, const float* b,
                   int32_t rows, int32_t D, float eps, oavsr_stream stream);
 /* Fused visual stem: Conv3d(1->64, k (5,7,7), s (1,2,2), p (2,3,3)) + folded BN + PReLU + MaxPool3d((1,3,3), s (1,2,2), p (0,1,1))
- * (reference resnet.py:137-141).  video f32 [F][88][88]; frameinfo int32 pairs {t, len} per frame; w [64][256] in the model
+ * (reference resnet.py:137-141).  video: f32 [F][88][88] (channels = 0) or uint8 [F][channels][height][width] with the test-time
+ * transform fused (oavsr_workspace_set_video_format); frameinfo int32 pairs {t, len} per frame; w [64][256] in the model
  * dtype with k = dt*49 + ky*7 + kx (245 valid); wp_scratch: 64*288 elements of the model dtype; out [F][22][22][64]. */
-int oavsr_op_stem_pool(int32_t dtype, const float* video, const int32_t* frameinfo_dev, int32_t F, const void* w, void* wp_scratch,
-                       const float* scale, const float* shift, const float* slope, void* out, oavsr_stream stream);
+int oavsr_op_stem_pool(int32_t dtype, const void* video, int32_t channels, int32_t height, int32_t width, const int32_t* frameinfo_dev,
+                       int32_t F, const void* w, void* wp_scratch, const float* scale, const float* shift, const float* slope, void* out,
+                       oavsr_stream stream);
 /* Image-resident 3x3 / stride 1 / pad 1 convolution, 64 -> 64 channels, NHWC bf16, H*W <= 512 (ResNet trunk layer1,
  * resnet.py:61-74): out = prelu(scale * conv(x, w) + shift + residual); w [64][3*3*64] tap-major; slope NULL = no activation;
  * residual may alias out. */

@@ -146,8 +146,20 @@ int launch_rmsnorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, 
 // Fused visual stem (stem.hip): Conv3d(1->64, 5x7x7, s (1,2,2)) + BN + PReLU + MaxPool(3x3, s2) on f32 video [F][88][88];
 // frameinfo[f] = {t, len}; wp = weights repacked by launch_stem_repack ([64][256] -> [64][288]); out [F][22][22][64].
 int launch_stem_repack(int dtype, const void* w, void* wp, hipStream_t st);
-int launch_stem_pool(int dtype, const float* video, const int2* frameinfo, int F, const void* wp, const float* scale, const float* shift,
-                     const float* slope, void* out, hipStream_t st);
+// Pixel source of the stem.  C == 0: f32 [frame][88][88] (already transformed).  C == 1 / 3: the decoded frames, uint8 [frame][C][H][W];
+// the test-time transform (datamodule/transforms.py:93-99: / 255, CenterCrop(88) at (top, left), Grayscale, Normalize(0.421, 0.165)) runs in
+// the kernel's window gather with the host code's fp32 operations in the host code's order.
+struct StemSrc {
+  int C = 0, H = 88, W = 88, top = 0, left = 0;
+  static StemSrc u8(int C_, int H_, int W_) {          // torchvision CenterCrop: int(round((H - 88) / 2.0)) (Python round: half to even)
+    StemSrc s; s.C = C_; s.H = H_; s.W = W_;
+    auto off = [](int n) { const int d = n - 88; return (d % 2 == 0) ? d / 2 : ((d / 2) % 2 == 0 ? d / 2 : d / 2 + 1); };
+    s.top = off(H_); s.left = off(W_);
+    return s;
+  }
+};
+int launch_stem_pool(int dtype, const void* video, const int2* frameinfo, int F, const void* wp, const float* scale, const float* shift,
+                     const float* slope, void* out, hipStream_t st, const StemSrc& src = StemSrc());
 // Image-resident 3x3 / stride 1 / pad 1 convolution, 64 -> 64 channels, NHWC bf16 (conv.hip): folded BN + residual + PReLU
 // (slope == nullptr: no activation).  Bit-identical to the implicit-GEMM path.
 bool conv3x3_c64_eligible(int dtype, int H, int W, int Cin, int Cout, int ks, int stride);

@@ -231,6 +231,7 @@ struct oavsr_workspace {
   // the row slots of a decode scheduler's pool (set by prefill_impl for the duration of the call)
   void *pf_k = nullptr, *pf_v = nullptr; size_t pf_layer = 0; int pf_max_prefix = 0;
   const int* rowmap = nullptr;                 // decode scheduler only: activation row -> row slot (DecodeAttnArgs::rowmap)
+  StemSrc vsrc;                                // what `video_dev` of the calls on this workspace holds (oavsr_workspace_set_video_format)
 
   void* take(size_t bytes) {
     size_t off = align_up(used, 256);
@@ -593,7 +594,7 @@ static int time_compress(const oavsr_model* m, oavsr_workspace* ws, const void* 
 // ------------------------------------------------------------------------------------------------
 // encode_video
 // ------------------------------------------------------------------------------------------------
-static int encode_video_impl(const oavsr_model* m, oavsr_workspace* ws, const float* video, const int32_t* Tv, int B, int rate,
+static int encode_video_impl(const oavsr_model* m, oavsr_workspace* ws, const void* video, const int32_t* Tv, int B, int rate,
                              void* out_dev, void* enc_dev, int* n_out_host, hipStream_t st) {
   OAVSR_REQUIRE(m->has_video, "model has no video encoder");
   OAVSR_REQUIRE(B >= 1 && B <= ws->max_B, "encode_video: B=%d exceeds workspace (%d)", B, ws->max_B);
@@ -608,8 +609,9 @@ static int encode_video_impl(const oavsr_model* m, oavsr_workspace* ws, const fl
   OAVSR_TRY(h2d(ws->frameinfo, fi, sizeof(int2) * F, st));
   OAVSR_TRY(h2d(ws->cu_a, cu, sizeof(int) * (B + 1), st));
   // K1: stem conv3d + BN + PReLU + MaxPool3d (resnet.py:137-141), one fused kernel (stem.hip)
-  { ProfScope ps(dt == DT_F32 ? "stem_conv_pool_f32" : "stem_conv_pool_bf16", 2.0 * F * 1936 * 245 * 64, (double)F * (7744 * 4 + 484 * 64 * m->esz), st);
-    OAVSR_TRY(launch_stem_pool(dt, video, ws->frameinfo, F, m->stem_wp, m->stem.scale, m->stem.shift, m->stem.slope, ws->pool_out, st)); }
+  { const double in_bytes = ws->vsrc.C ? (double)ws->vsrc.C * ws->vsrc.H * ws->vsrc.W : 7744.0 * 4;
+    ProfScope ps(dt == DT_F32 ? "stem_conv_pool_f32" : "stem_conv_pool_bf16", 2.0 * F * 1936 * 245 * 64, (double)F * (in_bytes + 484 * 64 * m->esz), st);
+    OAVSR_TRY(launch_stem_pool(dt, video, ws->frameinfo, F, m->stem_wp, m->stem.scale, m->stem.shift, m->stem.slope, ws->pool_out, st, ws->vsrc)); }
   GemmArgs g;
   // K2: ResNet-18 trunk (resnet.py:61-74, 121-126)
   // x lives in pool_out and is updated in place: conv2's epilogue reads residual[m][n] and writes C[m][n] from the
@@ -783,6 +785,10 @@ static int build_prompt_impl(const oavsr_model* m, oavsr_workspace* ws, int task
 // Split-K factor of the 33+-row decode GEMMs (128 x 64 weight-streaming tiles, gemm2.hip): enough k-slices that N / 64 column
 // tiles x slices fill the 256 CUs.  A function of N and K ONLY (one M-tile's worth of column tiles), never of the row count, so
 // a row's fp32 summation order does not depend on how many other rows share the launch.
+// rows up to which decode GEMMs run on the weight-streaming kernels (mode 1); above: tiled split-K (mode 2).  (Round 3: the 16-column
+// weight-streaming kernels at 33..128 rows were measured on the beam-15 path -- 120 rows -- and lose: 59 vs 82 utt/s sequentially.)
+static constexpr int skinny_max_rows() { return 32; }
+
 static int decode_split(int N, int Ktot, int esz) {
   const int ktiles = Ktot / (128 / esz);
   int ks = 256 / std::max(1, ceil_div(N, 64));
@@ -822,7 +828,7 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
   const int dt = m->dtype, d = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, hd = c.llm_head_dim, I = c.llm_mlp;
   const int nq = H * hd, nqkv = (H + 2 * KV) * hd;
   const int tl = c.lora_task_specific ? task : 0;
-  const int mode = !decode ? 0 : (rows <= 32 ? 1 : 2);
+  const int mode = !decode ? 0 : (rows <= skinny_max_rows() ? 1 : 2);
   const bool fused_norm = mode == 1;       // RMSNorm folded into the skinny GEMMs (gain on the A fragments, rstd in the epilogue)
   static const bool prune_on = [] { const char* e = getenv("OAVSR_PREFILL_PRUNE"); return !(e && e[0] == '0'); }();
   const bool can_prune = prune_on && !decode && last_rows && cu_last;
@@ -954,7 +960,7 @@ static int lm_head_rows(const oavsr_model* m, oavsr_workspace* ws, const void* x
   const int d = c.llm_hidden;
   GemmArgs g; g.dtype = m->dtype; g.M = rows; g.N = c.llm_vocab; g.K = d; g.W = m->lm_head; g.ldw = d;
   g.C = logits; g.ldc = c.llm_vocab; g.out_f32 = 1;
-  if (rows <= 32 || chunk > 0) {          // final RMSNorm fused into the weight-streaming kernel
+  if (rows <= skinny_max_rows() || chunk > 0) {          // final RMSNorm fused into the weight-streaming kernel
     const int step = chunk > 0 ? chunk : rows;
     for (int r0 = 0; r0 < rows; r0 += step) {
       g.M = std::min(step, rows - r0);
@@ -1115,7 +1121,7 @@ static int decode_beam(const oavsr_model* m, oavsr_workspace* ws, int task, int 
     OAVSR_TRY(launch_embed(m->dtype, m->embed, c.llm_hidden, ws->gs.tok, ws->lx, c.llm_hidden, R, c.llm_hidden, st));
     bool fnorm = false;
     OAVSR_TRY(llm_layers(m, ws, task, R, true, B, K, maxS + max_new, ws->gs.pos, ws->gs.cpos, anc[cur], ws->gs.step, st, nullptr, nullptr, nullptr, nullptr,
-                         R > 32 ? &fnorm : nullptr));
+                         R > skinny_max_rows() ? &fnorm : nullptr));
     OAVSR_TRY(lm_head_rows(m, ws, ws->lx, R, ws->logits, st, 0, fnorm));
     ProfScope ps("beam_search", 0, (double)R * c.llm_vocab * 16, st);
     OAVSR_TRY(launch_beam_topk(ws->logits, c.llm_vocab, R, c.llm_vocab, K, ws->beam_scores, ws->cand_val, ws->cand_tok, ws->topk_flag, st));
@@ -1336,7 +1342,16 @@ void oavsr_workspace_destroy(oavsr_workspace* ws) {
 }
 uint64_t oavsr_workspace_bytes(const oavsr_workspace* ws) { return ws ? ws->arena_bytes : 0; }
 
-int oavsr_encode_video(const oavsr_model* m, oavsr_workspace* ws, const float* video_dev, const int32_t* Tv_host, int32_t B, int32_t rate,
+int oavsr_workspace_set_video_format(oavsr_workspace* ws, int32_t channels, int32_t height, int32_t width) {
+  OAVSR_REQUIRE(ws, "workspace_set_video_format: null workspace");
+  if (channels == 0) { ws->vsrc = StemSrc(); return 0; }
+  OAVSR_REQUIRE((channels == 1 || channels == 3) && height >= 88 && width >= 88 && height <= 4096 && width <= 4096,
+                "workspace_set_video_format: uint8 frames must be [1 or 3][H >= 88][W >= 88], got [%d][%d][%d]", channels, height, width);
+  ws->vsrc = StemSrc::u8(channels, height, width);
+  return 0;
+}
+
+int oavsr_encode_video(const oavsr_model* m, oavsr_workspace* ws, const void* video_dev, const int32_t* Tv_host, int32_t B, int32_t rate,
                        void* out_dev, void* enc_dev, oavsr_stream stream) {
   OAVSR_REQUIRE(m && ws && video_dev && Tv_host, "encode_video: null argument");
   CallScope cs(ws, (hipStream_t)stream);
@@ -1385,7 +1400,7 @@ int oavsr_decode(const oavsr_model* m, oavsr_workspace* ws, int32_t task, int32_
 // Everything of a generate() call up to and including the prefill: encoders + projector + prompt + prefill per chunk of chunk_B
 // utterances (the launch shapes of a batch-of-chunk_B request); each chunk's prefix KV / last-token logits land in its own slots of the
 // workspace -- or (dest) in the row slots of a decode scheduler's pool.  S_out (optional): prompt rows per utterance.
-static int encode_prefill(const oavsr_model* m, oavsr_workspace* ws, int32_t task, const float* video_dev, const int32_t* Tv_host, const float* wav_dev,
+static int encode_prefill(const oavsr_model* m, oavsr_workspace* ws, int32_t task, const void* video_dev, const int32_t* Tv_host, const float* wav_dev,
                           int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host, int32_t B, int32_t chunk_B, int32_t rate_audio,
                           int32_t rate_video, hipStream_t st, const PrefillDest* dest, int* S_out) {
   // Concurrent generate() calls on different streams: the MFMA-bound encoder + prefill phases gain nothing from sharing
@@ -1408,7 +1423,8 @@ static int encode_prefill(const oavsr_model* m, oavsr_workspace* ws, int32_t tas
       OAVSR_TRY(project_impl(m, ws, 0, rate_audio, ws->comp_a, tot_a, ws->tok_a, st));
     }
     if (use_v) {
-      OAVSR_TRY(encode_video_impl(m, ws, video_dev + frames_before * 7744, Tv_host + b0, Bc, rate_video, nullptr, nullptr, nv.data(), st));
+      const int64_t frame_bytes = ws->vsrc.C ? (int64_t)ws->vsrc.C * ws->vsrc.H * ws->vsrc.W : (int64_t)7744 * 4;
+      OAVSR_TRY(encode_video_impl(m, ws, (const char*)video_dev + frames_before * frame_bytes, Tv_host + b0, Bc, rate_video, nullptr, nullptr, nv.data(), st));
       for (int b = 0; b < Bc; ++b) { tot_v += nv[b]; frames_before += Tv_host[b0 + b]; }
       OAVSR_TRY(project_impl(m, ws, 1, rate_video, ws->comp_v, tot_v, ws->tok_v, st));
     }
@@ -1426,7 +1442,7 @@ static int encode_prefill(const oavsr_model* m, oavsr_workspace* ws, int32_t tas
   return 0;
 }
 
-static int generate_impl(const oavsr_model* m, oavsr_workspace* ws, int32_t task, const float* video_dev, const int32_t* Tv_host, const float* wav_dev,
+static int generate_impl(const oavsr_model* m, oavsr_workspace* ws, int32_t task, const void* video_dev, const int32_t* Tv_host, const float* wav_dev,
                          int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host, int32_t B, int32_t chunk_B, int32_t rate_audio,
                          int32_t rate_video, int32_t beams, int32_t max_new, int32_t force_len, int32_t* out_ids_dev, int32_t* out_len_dev,
                          hipStream_t st) {
@@ -1441,14 +1457,14 @@ static int generate_impl(const oavsr_model* m, oavsr_workspace* ws, int32_t task
   return decode_greedy(m, ws, task, B, max_new, force_len, out_ids_dev, out_len_dev, st);
 }
 
-int oavsr_generate(const oavsr_model* m, oavsr_workspace* ws, int32_t task, const float* video_dev, const int32_t* Tv_host, const float* wav_dev,
+int oavsr_generate(const oavsr_model* m, oavsr_workspace* ws, int32_t task, const void* video_dev, const int32_t* Tv_host, const float* wav_dev,
                    int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host, int32_t B, int32_t rate_audio, int32_t rate_video,
                    int32_t beams, int32_t max_new, int32_t force_len, int32_t* out_ids_dev, int32_t* out_len_dev, oavsr_stream stream) {
   return generate_impl(m, ws, task, video_dev, Tv_host, wav_dev, wav_ld, Ts_host, keep_host, B, B, rate_audio, rate_video, beams, max_new, force_len,
                        out_ids_dev, out_len_dev, (hipStream_t)stream);
 }
 
-int oavsr_generate_chunked(const oavsr_model* m, oavsr_workspace* ws, int32_t task, const float* video_dev, const int32_t* Tv_host,
+int oavsr_generate_chunked(const oavsr_model* m, oavsr_workspace* ws, int32_t task, const void* video_dev, const int32_t* Tv_host,
                            const float* wav_dev, int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host, int32_t B, int32_t chunk_B,
                            int32_t rate_audio, int32_t rate_video, int32_t beams, int32_t max_new, int32_t force_len, int32_t* out_ids_dev,
                            int32_t* out_len_dev, oavsr_stream stream) {
@@ -1632,7 +1648,7 @@ void oavsr_scheduler_destroy(oavsr_scheduler* s) {
 }
 uint64_t oavsr_scheduler_bytes(const oavsr_scheduler* s) { return s ? s->arena_bytes : 0; }
 
-int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_workspace* ws, int32_t task, const float* video_dev, const int32_t* Tv_host,
+int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_workspace* ws, int32_t task, const void* video_dev, const int32_t* Tv_host,
                           const float* wav_dev, int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host, int32_t B, int32_t rate_audio,
                           int32_t rate_video, int32_t max_new, int32_t force_len, int32_t* out_ids_dev, int32_t* out_len_dev, oavsr_stream stream,
                           int64_t* ticket_out) {
@@ -1785,11 +1801,12 @@ int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream) {
   return d->skinny ? launch_gemm_skinny(g, (hipStream_t)stream) : launch_gemm(g, (hipStream_t)stream);
 }
 
-int oavsr_op_stem_pool(int32_t dtype, const float* video, const int32_t* frameinfo_dev, int32_t F, const void* w, void* wp_scratch,
-                       const float* scale, const float* shift, const float* slope, void* out, oavsr_stream stream) {
+int oavsr_op_stem_pool(int32_t dtype, const void* video, int32_t channels, int32_t height, int32_t width, const int32_t* frameinfo_dev, int32_t F,
+                       const void* w, void* wp_scratch, const float* scale, const float* shift, const float* slope, void* out, oavsr_stream stream) {
   OAVSR_REQUIRE(w && wp_scratch, "op_stem_pool: null weights");
   OAVSR_TRY(launch_stem_repack(dtype, w, wp_scratch, (hipStream_t)stream));
-  return launch_stem_pool(dtype, video, (const int2*)frameinfo_dev, F, wp_scratch, scale, shift, slope, out, (hipStream_t)stream);
+  return launch_stem_pool(dtype, video, (const int2*)frameinfo_dev, F, wp_scratch, scale, shift, slope, out, (hipStream_t)stream,
+                          channels ? StemSrc::u8(channels, height, width) : StemSrc());
 }
 
 int oavsr_op_conv3x3_c64(const void* x, int32_t imgs, int32_t H, int32_t W, const void* w, const float* scale, const float* shift,

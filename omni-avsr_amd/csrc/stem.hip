@@ -13,6 +13,12 @@
 //   3. BN (one fmaf, same formula as every GEMM epilogue) + PReLU, rounded to T, into a 5-row LDS ring of conv rows;
 //   4. the two pooled rows that became complete are reduced (3x3 max, -inf padding) and stored as 16-byte vectors.
 // The 44 x 44 x 64 conv activation never touches HBM (it was 793 MB written + read per 8 x 16 s batch).
+//
+// Pixel source (template SRC): 0 = f32 [frame][88][88], what the reference's dataset hands over after its test-time transform;
+// 1 / 3 = the DECODED frames themselves, uint8 [frame][C][H][W] with C = 1 / 3 channels (H, W >= 88): the transform of
+// datamodule/transforms.py:93-99 -- x / 255, CenterCrop(88), Grayscale (0.2989 R + 0.587 G + 0.114 B), Normalize(0.421, 0.165) --
+// then happens in the window gather, with the same fp32 operations in the same order as the host code (explicitly rounded, no
+// FMA contraction; the per-channel products come from 256-entry tables built in LDS), so the window holds the same bits either way.
 #include "kernels.h"
 
 namespace oavsr {
@@ -46,11 +52,11 @@ __global__ void stem_repack_kernel(const T* w, T* wp) {
   wp[i] = (krow < kKRows && kx < 7) ? w[n * 256 + krow * 7 + kx] : from_f32<T>(0.f);
 }
 
-template <typename T>
-__global__ __launch_bounds__(kStemThreads) void stem_pool_kernel(const float* __restrict__ vid, const int2* __restrict__ frameinfo,
+template <typename T, int SRC>
+__global__ __launch_bounds__(kStemThreads) void stem_pool_kernel(const void* __restrict__ vid_, const int2* __restrict__ frameinfo,
                                                                  const T* __restrict__ wp, const float* __restrict__ scale,
                                                                  const float* __restrict__ shift, const float* __restrict__ slope,
-                                                                 T* __restrict__ out) {
+                                                                 T* __restrict__ out, StemSrc src_fmt) {
   constexpr int VEC = TypeInfo<T>::kVec;
   constexpr int NKS = kKPacked / (4 * VEC);            // k steps: 9 (bf16, 32 deep) / 18 (f32, 16 deep)
   constexpr bool kWRegs = sizeof(T) == 2;              // bf16: the whole packed weight stays in registers (144 VGPRs)
@@ -58,6 +64,7 @@ __global__ __launch_bounds__(kStemThreads) void stem_pool_kernel(const float* __
   T* swin = reinterpret_cast<T*>(smem);                // [5][13][96]
   T* sconv = swin + 5 * kWinRows * kWinCols;           // [5 ring][44][64]
   float* spar = reinterpret_cast<float*>(sconv + kRing * 44 * 64);   // scale[64] shift[64] slope[64]
+  float* slut = spar + 192;                            // SRC != 0: [SRC][256] per-channel tables of the pixel transform
 
   const int f = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -65,6 +72,13 @@ __global__ __launch_bounds__(kStemThreads) void stem_pool_kernel(const float* __
   const int2 fi = frameinfo[f];
 
   if (tid < 64) { spar[tid] = scale[tid]; spar[64 + tid] = shift[tid]; spar[128 + tid] = slope[tid]; }
+  if constexpr (SRC != 0) {
+    // v / 255 (true division), times the grayscale weight for RGB -- or the whole transform for single-channel frames
+    const float x = __fdiv_rn((float)tid, 255.0f);
+    if constexpr (SRC == 1) slut[tid] = __fdiv_rn(__fsub_rn(x, 0.421f), 0.165f);
+    else { slut[tid] = __fmul_rn(0.2989f, x); slut[256 + tid] = __fmul_rn(0.587f, x); slut[512 + tid] = __fmul_rn(0.114f, x); }
+    __syncthreads();
+  }
 
   Chunk16 wreg[kWRegs ? NKS : 1][kWRegs ? 4 : 1];
   if constexpr (kWRegs) {
@@ -84,17 +98,22 @@ __global__ __launch_bounds__(kStemThreads) void stem_pool_kernel(const float* __
     return (dt * kWinRows + ky) * kWinCols + kx0;
   };
 
+  const float* vid = reinterpret_cast<const float*>(vid_);
   const float* vbase = vid + (int64_t)f * 7744;
+  const int plane = src_fmt.H * src_fmt.W;             // SRC != 0: bytes per channel plane; frame = SRC planes
+  const unsigned char* ubase = reinterpret_cast<const unsigned char*>(vid_) + (int64_t)f * SRC * plane + src_fmt.top * src_fmt.W + src_fmt.left;
   for (int it = 0; it < 11; ++it) {
     // ---- 1. input window: rows 8*it-3 .. 8*it+9, columns -3 .. 92, frames t-2 .. t+2 ----
     // fully unrolled with unconditional loads (clamped address + select): all 26 loads of a thread are in flight together and
     // the step pays the global latency once, not once per loop trip
     constexpr int NQ = 5 * kWinRows * (kWinCols / 2);
     constexpr int kFill = (NQ + kStemThreads - 1) / kStemThreads;
-    constexpr int kGrp = 7;                                // loads in flight per thread: 2 * kGrp (register budget: two workgroups per CU)
+    constexpr int kGrp = SRC == 3 ? 4 : 7;                 // loads in flight per thread: 2 * kGrp (x 3 channel bytes); register budget: two workgroups per CU
 #pragma unroll 1
     for (int k0 = 0; k0 < kFill; k0 += kGrp) {
       float pv0[kGrp], pv1[kGrp];
+      unsigned char rb0[SRC ? kGrp : 1][SRC ? SRC : 1], rb1[SRC ? kGrp : 1][SRC ? SRC : 1];
+      bool okk0[kGrp], okk1[kGrp];
 #pragma unroll
       for (int k = 0; k < kGrp; ++k) {
         const int q = tid + (k0 + k) * kStemThreads, qq = q < NQ ? q : 0;
@@ -102,10 +121,32 @@ __global__ __launch_bounds__(kStemThreads) void stem_pool_kernel(const float* __
         const int wr = rem / (kWinCols / 2), cp = rem - wr * (kWinCols / 2);
         const int iy = 8 * it - 3 + wr, ix = 2 * cp - 3;
         const bool row = (unsigned)(fi.x + dt - 2) < (unsigned)fi.y && (unsigned)iy < 88u;
-        const float* src = vbase + (int64_t)(dt - 2) * 7744 + iy * 88;
         const bool ok0 = row && (unsigned)ix < 88u, ok1 = row && (unsigned)(ix + 1) < 88u;
-        const float a = *(ok0 ? src + ix : vbase), b = *(ok1 ? src + ix + 1 : vbase);
-        pv0[k] = ok0 ? a : 0.f; pv1[k] = ok1 ? b : 0.f;
+        okk0[k] = ok0; okk1[k] = ok1;
+        if constexpr (SRC == 0) {
+          const float* src = vbase + (int64_t)(dt - 2) * 7744 + iy * 88;
+          const float a = *(ok0 ? src + ix : vbase), b = *(ok1 ? src + ix + 1 : vbase);
+          pv0[k] = ok0 ? a : 0.f; pv1[k] = ok1 ? b : 0.f;
+        } else {
+          const unsigned char* src = ubase + (int64_t)(dt - 2) * SRC * plane + iy * src_fmt.W;
+#pragma unroll
+          for (int c = 0; c < SRC; ++c) {
+            rb0[k][c] = *(ok0 ? src + c * plane + ix : ubase);
+            rb1[k][c] = *(ok1 ? src + c * plane + ix + 1 : ubase);
+          }
+        }
+      }
+      if constexpr (SRC != 0) {
+#pragma unroll
+        for (int k = 0; k < kGrp; ++k) {
+          float a, b;
+          if constexpr (SRC == 1) { a = slut[rb0[k][0]]; b = slut[rb1[k][0]]; }
+          else {
+            a = __fdiv_rn(__fsub_rn(__fadd_rn(__fadd_rn(slut[rb0[k][0]], slut[256 + rb0[k][1]]), slut[512 + rb0[k][2]]), 0.421f), 0.165f);
+            b = __fdiv_rn(__fsub_rn(__fadd_rn(__fadd_rn(slut[rb1[k][0]], slut[256 + rb1[k][1]]), slut[512 + rb1[k][2]]), 0.421f), 0.165f);
+          }
+          pv0[k] = okk0[k] ? a : 0.f; pv1[k] = okk1[k] ? b : 0.f;
+        }
       }
 #pragma unroll
       for (int k = 0; k < kGrp; ++k) {
@@ -201,19 +242,19 @@ __global__ __launch_bounds__(kStemThreads) void stem_pool_kernel(const float* __
   }
 }
 
-template <typename T>
-int launch_stem_t(const float* video, const int2* frameinfo, int F, const void* wp, const float* scale, const float* shift, const float* slope,
-                  void* out, hipStream_t st) {
-  constexpr size_t smem = (5 * kWinRows * kWinCols + kRing * 44 * 64) * sizeof(T) + 192 * sizeof(float);
+template <typename T, int SRC>
+int launch_stem_t(const void* video, const int2* frameinfo, int F, const void* wp, const float* scale, const float* shift, const float* slope,
+                  void* out, const StemSrc& src, hipStream_t st) {
+  constexpr size_t smem = (5 * kWinRows * kWinCols + kRing * 44 * 64) * sizeof(T) + (192 + SRC * 256) * sizeof(float);
   static_assert(smem <= 160 * 1024, "LDS");
-  auto kern = stem_pool_kernel<T>;
+  auto kern = stem_pool_kernel<T, SRC>;
   static bool attr = false;
   if (!attr && smem > 48 * 1024) {
     OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     attr = true;
   }
   hipLaunchKernelGGL(kern, dim3(F), dim3(kStemThreads), smem, st, video, frameinfo, reinterpret_cast<const T*>(wp), scale, shift, slope,
-                     reinterpret_cast<T*>(out));
+                     reinterpret_cast<T*>(out), src);
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -228,12 +269,17 @@ int launch_stem_repack(int dtype, const void* w, void* wp, hipStream_t st) {
   return 0;
 }
 
-int launch_stem_pool(int dtype, const float* video, const int2* frameinfo, int F, const void* wp, const float* scale, const float* shift,
-                     const float* slope, void* out, hipStream_t st) {
+int launch_stem_pool(int dtype, const void* video, const int2* frameinfo, int F, const void* wp, const float* scale, const float* shift,
+                     const float* slope, void* out, hipStream_t st, const StemSrc& src) {
   if (F <= 0) return 0;
   OAVSR_REQUIRE(video && frameinfo && wp && scale && shift && slope && out, "stem: null argument");
-  return dtype == DT_F32 ? launch_stem_t<float>(video, frameinfo, F, wp, scale, shift, slope, out, st)
-                         : launch_stem_t<bf16_t>(video, frameinfo, F, wp, scale, shift, slope, out, st);
+  OAVSR_REQUIRE(src.C == 0 || ((src.C == 1 || src.C == 3) && src.H >= 88 && src.W >= 88 && src.top >= 0 && src.left >= 0 && src.top + 88 <= src.H &&
+                               src.left + 88 <= src.W), "stem: uint8 frames must be [C = 1 or 3][H >= 88][W >= 88] (got C=%d, %d x %d)", src.C, src.H, src.W);
+#define STEM_GO(T) (src.C == 0 ? launch_stem_t<T, 0>(video, frameinfo, F, wp, scale, shift, slope, out, src, st) \
+                    : src.C == 1 ? launch_stem_t<T, 1>(video, frameinfo, F, wp, scale, shift, slope, out, src, st) \
+                                 : launch_stem_t<T, 3>(video, frameinfo, F, wp, scale, shift, slope, out, src, st))
+  return dtype == DT_F32 ? STEM_GO(float) : STEM_GO(bf16_t);
+#undef STEM_GO
 }
 
 }  // namespace oavsr

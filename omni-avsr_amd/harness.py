@@ -67,11 +67,17 @@ def audio_test_transform(wave: torch.Tensor, snr_target: Optional[float] = None,
 
 
 def make_sample(frames: Optional[torch.Tensor], wave: Optional[torch.Tensor], modality: str, rate_ratio: int = 640,
-                snr_target: Optional[float] = None, noise: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
-    """AVDataset_LLM.__getitem__ (av_dataset.py:85-114) on already decoded media."""
+                snr_target: Optional[float] = None, noise: Optional[torch.Tensor] = None, device_transform: bool = False) -> Dict[str, torch.Tensor]:
+    """AVDataset_LLM.__getitem__ (av_dataset.py:85-114) on already decoded media.  `device_transform` (HIP-backed model only): the uint8
+    frames [T, C, H, W] are kept as they are ("video_u8") and `video_test_transform` runs inside the engine's stem kernel (same bits)."""
     out: Dict[str, torch.Tensor] = {}
     if modality in ("video", "audiovisual"):
-        out["video"] = video_test_transform(frames)
+        if device_transform:
+            if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[1] not in (1, 3):
+                raise ValueError("device_transform needs uint8 frames [T, C, H, W] with C = 1 or 3")
+            out["video_u8"] = frames.contiguous()
+        else:
+            out["video"] = video_test_transform(frames)
     if modality in ("audio", "audiovisual"):
         if modality == "audiovisual":
             wave = cut_or_pad(wave, frames.shape[0] * rate_ratio)               # :107
@@ -101,9 +107,11 @@ class FlatCollator:
     pad_sequence writes and the engine would immediately re-pack).  One collator per in-flight slot: its buffers are reused by every batch
     of that slot, so the previous batch of the slot must have been consumed (evaluate() drains a slot before it refills it)."""
 
-    def __init__(self, batch_size: int, tv_max: int, ts_max: int, pin: bool = True):
+    def __init__(self, batch_size: int, tv_max: int, ts_max: int, pin: bool = True, u8_shape: Optional[Tuple[int, int, int]] = None):
         pin = pin and torch.cuda.is_available()
-        self.video = torch.empty(batch_size * max(tv_max, 1), 88, 88, dtype=torch.float32, pin_memory=pin)
+        # u8_shape = (C, H, W): samples carry the decoded frames ("video_u8", make_sample(device_transform=True)) -> "video_u8_flat"
+        self.video = (torch.empty(batch_size * max(tv_max, 1), *u8_shape, dtype=torch.uint8, pin_memory=pin) if u8_shape else
+                      torch.empty(batch_size * max(tv_max, 1), 88, 88, dtype=torch.float32, pin_memory=pin))
         self.audio = torch.empty(batch_size * max(ts_max, 1), dtype=torch.float32, pin_memory=pin)      # carved into a CONTIGUOUS [B, longest] per batch
 
     def __call__(self, samples: Sequence[Dict[str, torch.Tensor]], modality: str, bos_id: Optional[int]) -> Dict[str, torch.Tensor]:
@@ -118,12 +126,13 @@ class FlatCollator:
                 a[b, : lens[b]].copy_(s["audio"][:, 0] if s["audio"].dim() == 2 else s["audio"])
             batch["lengths"], batch["audio"] = torch.tensor(lens), a
         if modality in ("video", "audiovisual"):
-            tv = [int(s["video"].shape[0]) for s in samples]
+            u8 = "video_u8" in samples[0]
+            tv = [int(s["video_u8" if u8 else "video"].shape[0]) for s in samples]
             o = 0
             for s, t in zip(samples, tv):
-                self.video[o:o + t].copy_(s["video"][:, 0])
+                self.video[o:o + t].copy_(s["video_u8"] if u8 else s["video"][:, 0])
                 o += t
-            batch["video_lengths"], batch["video_flat"] = torch.tensor(tv), self.video[:o]
+            batch["video_lengths"], batch["video_u8_flat" if u8 else "video_flat"] = torch.tensor(tv), self.video[:o]
         return batch
 
 
@@ -245,7 +254,8 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
     Returns this rank's WerMeter; combine with dist.reduce_wer_counters."""
     from .lib import DeviceError
     from .dist import make_batches, shard_utterances
-    dur = [float((s.get("video") if "video" in s else s["audio"]).shape[0]) / (1.0 if "video" in s else 640.0) for s, _ in samples]
+    vkey = lambda s: "video_u8" if "video_u8" in s else "video"      # noqa: E731   (make_sample(device_transform=True): decoded uint8 frames)
+    dur = [float(s[vkey(s)].shape[0]) if vkey(s) in s else float(s["audio"].shape[0]) / 640.0 for s, _ in samples]
     owned = shard_utterances(dur, world, rank)
     meter = WerMeter()
     model.modality = modality
@@ -272,8 +282,13 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
             meter.update(samples[i][1], t)
 
     if in_flight <= 1 or not batches:
+        raw = bool(batches) and "video_u8" in samples[batches[0][0]][0]
+        if raw:      # decoded uint8 frames: no reference-format (padded float) batch exists for them; the flat collator carries them as they are
+            flat = FlatCollator(max(len(b) for b in batches), max(int(samples[i][0]["video_u8"].shape[0]) for i in owned),
+                                max([int(samples[i][0]["audio"].shape[0]) for i in owned if "audio" in samples[i][0]] or [1]),
+                                u8_shape=tuple(samples[owned[0]][0]["video_u8"].shape[1:]))
         for idxs in batches:
-            batch = collate_test([samples[i][0] for i in idxs], modality, bos_id)
+            batch = flat([samples[i][0] for i in idxs], modality, bos_id) if raw else collate_test([samples[i][0] for i in idxs], modality, bos_id)
             try:
                 ids = model(batch, is_trainval=False, modality=kw_mod, **forward_kw)
             except (RuntimeError, ValueError) as e:
@@ -288,7 +303,8 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
     dev = eng.device
     streams = [torch.cuda.Stream(device=dev) for _ in range(in_flight)]
     # one workspace per slot, sized for the longest owned clip: nothing is re-created while other slots are busy
-    tv_max = max([int(samples[i][0]["video"].shape[0]) for i in owned if "video" in samples[i][0]] or [1])
+    tv_max = max([int(samples[i][0][vkey(samples[i][0])].shape[0]) for i in owned if vkey(samples[i][0]) in samples[i][0]] or [1])
+    u8_shape = tuple(samples[owned[0]][0]["video_u8"].shape[1:]) if owned and "video_u8" in samples[owned[0]][0] else None
     ts_max = max([int(samples[i][0]["audio"].shape[0]) for i in owned if "audio" in samples[i][0]] or [16000])
     eng.reserve(in_flight, batch_size, tv_max, ts_max, getattr(model, "num_beams", 1), getattr(model, "max_dec_tokens", None))
     # 2 x in_flight + 1 staging sets: while the main thread launches batch n and waits for the oldest one, a helper thread collates batch
@@ -297,7 +313,7 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
     limit = 2 * in_flight                                     # calls queued at most: a slot's stream orders its own calls, so the host may run one round ahead
     nset = limit + 1
     bmax = max(len(b) for b in batches)                       # the largest batch actually owned (pinned memory: nset x bmax clips)
-    collators = [FlatCollator(bmax, tv_max, ts_max) for _ in range(nset)]
+    collators = [FlatCollator(bmax, tv_max, ts_max, u8_shape=u8_shape) for _ in range(nset)]
     pool = ThreadPoolExecutor(1)
     collate = lambda n: collators[n % nset]([samples[i][0] for i in batches[n]], modality, bos_id)      # noqa: E731
     eng.serialize_encoders(True)

@@ -93,6 +93,7 @@ SYMBOLS = {
     "oavsr_workspace_create": (C.c_int, [_P, _I, _I, _I, _I, _I, C.POINTER(_P)]),
     "oavsr_workspace_destroy": (None, [_P]),
     "oavsr_workspace_bytes": (C.c_uint64, [_P]),
+    "oavsr_workspace_set_video_format": (C.c_int, [_P, _I, _I, _I]),
     "oavsr_encode_video": (C.c_int, [_P, _P, _P, C.POINTER(_I), _I, _I, _P, _P, _P]),
     "oavsr_encode_audio": (C.c_int, [_P, _P, _P, _L, C.POINTER(_I), C.POINTER(_I), _I, _I, _P, _P, _P, _P]),
     "oavsr_project": (C.c_int, [_P, _P, _I, _I, _P, _I, _P, _P]),
@@ -116,7 +117,7 @@ SYMBOLS = {
     "oavsr_op_attention": (C.c_int, [C.POINTER(AttnDesc), _P]),
     "oavsr_op_decode_attention": (C.c_int, [C.POINTER(DecodeAttnDesc), _P]),
     "oavsr_op_norm": (C.c_int, [_I, _I, _P, _L, _P, _L, _P, _P, _I, _I, _F, _P]),
-    "oavsr_op_stem_pool": (C.c_int, [_I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "oavsr_op_stem_pool": (C.c_int, [_I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "oavsr_op_conv3x3_c64": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "oavsr_op_beam_topk": (C.c_int, [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P]),
     "oavsr_op_maxpool3x3s2": (C.c_int, [_I, _P, _P, _I, _I, _I, _I, _P]),

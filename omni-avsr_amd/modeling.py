@@ -186,6 +186,22 @@ class OmniEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _device_video(self, ws, video: torch.Tensor, Tv: Sequence[int], video_is_flat: bool) -> torch.Tensor:
+        """The video operand of a call on workspace `ws`.  float frames (after the dataset's test-time transform): f32 [sum T, 88, 88].
+        uint8 frames (DECODED media, `video_is_flat` only: [sum T, C, H, W], C = 1 or 3): uploaded as they are, the transform runs inside
+        the stem kernel (oavsr_workspace_set_video_format)."""
+        if video.dtype == torch.uint8:
+            if not video_is_flat or video.dim() != 4:
+                raise ValueError("uint8 video must be the flat [sum T, C, H, W] frames of the batch (harness.FlatCollator: 'video_u8_flat')")
+            flat = video if video.device == self.device and video.is_contiguous() else video.to(self.device, non_blocking=video.is_pinned()).contiguous()
+            L.check(self.lib.oavsr_workspace_set_video_format(ws, int(flat.shape[1]), int(flat.shape[2]), int(flat.shape[3])))
+            return flat
+        flat = video if video_is_flat else self._flat_video(video, Tv)
+        if flat.device != self.device or flat.dtype != torch.float32 or not flat.is_contiguous():
+            flat = flat.to(self.device, torch.float32, non_blocking=flat.is_pinned()).contiguous()     # pinned staging buffers copy asynchronously
+        L.check(self.lib.oavsr_workspace_set_video_format(ws, 0, 88, 88))
+        return flat
+
     # ---- stage wrappers (parity tests call these) ----------------------------------------------------
     def _flat_video(self, video: torch.Tensor, Tv: Sequence[int]) -> torch.Tensor:
         """[B,T,1,88,88] (padded) -> contiguous f32 [sum(Tv),88,88]"""
@@ -195,7 +211,7 @@ class OmniEngine:
     def encode_video(self, video: torch.Tensor, Tv: Sequence[int], rate: int, return_enc: bool = False):
         B = len(Tv)
         self.ensure_workspace(max(B, self._ws_key[0] if self._ws_key else 0), max(max(Tv), self._ws_key[1] if self._ws_key else 0), self._ws_key[2] if self._ws_key else 16000)
-        flat = self._flat_video(video, Tv)
+        flat = self._device_video(self._ws, video, Tv, video.dtype == torch.uint8)
         D = self.spec.avhubert.dim
         n_out = [t // rate for t in Tv]
         Dout = D * rate if self.spec.compression_mode == "stack" else D
@@ -267,16 +283,14 @@ class OmniEngine:
         B = len(Tv) if use_v else len(lengths)
         flat = a = None
         keep = None
+        ws = self._slot_workspace(slot, B, max(Tv) if use_v else 1, int(max(lengths)) if use_a else 16000, beams, max_new)
         if use_v:
-            flat = video if video_is_flat else self._flat_video(video, Tv)
-            if flat.device != self.device or flat.dtype != torch.float32 or not flat.is_contiguous():
-                flat = flat.to(self.device, torch.float32, non_blocking=flat.is_pinned()).contiguous()     # pinned staging buffers copy asynchronously
+            flat = self._device_video(ws, video, Tv, video_is_flat)
         if use_a:
             a = audio if audio.dim() == 2 else audio[..., 0]
             if a.device != self.device or a.dtype != torch.float32 or not a.is_contiguous():
                 a = a.to(self.device, torch.float32, non_blocking=a.is_pinned()).contiguous()
             keep = [whisper_keep_tokens(int(n)) for n in lengths]
-        ws = self._slot_workspace(slot, B, max(Tv) if use_v else 1, int(max(lengths)) if use_a else 16000, beams, max_new)
         ids = torch.empty(B, max_new, dtype=torch.int32, device=self.device)
         lens = torch.empty(B, dtype=torch.int32, device=self.device)
         L.check(self.lib.oavsr_generate_chunked(
@@ -323,16 +337,14 @@ class OmniEngine:
         use_a, use_v = task in ("audio", "audiovisual"), task in ("video", "audiovisual")
         B = len(Tv) if use_v else len(lengths)
         flat = a = keep = None
+        ws = self._slot_workspace(slot, B, max(Tv) if use_v else 1, int(max(lengths)) if use_a else 16000, 1, max_new)
         if use_v:
-            flat = video if video_is_flat else self._flat_video(video, Tv)
-            if flat.device != self.device or flat.dtype != torch.float32 or not flat.is_contiguous():
-                flat = flat.to(self.device, torch.float32, non_blocking=flat.is_pinned()).contiguous()
+            flat = self._device_video(ws, video, Tv, video_is_flat)
         if use_a:
             a = audio if audio.dim() == 2 else audio[..., 0]
             if a.device != self.device or a.dtype != torch.float32 or not a.is_contiguous():
                 a = a.to(self.device, torch.float32, non_blocking=a.is_pinned()).contiguous()
             keep = [whisper_keep_tokens(int(n)) for n in lengths]
-        ws = self._slot_workspace(slot, B, max(Tv) if use_v else 1, int(max(lengths)) if use_a else 16000, 1, max_new)
         self.ensure_scheduler(self.prompt_rows(task, Tv, lengths, int(rate_a or 1), int(rate_v or 1)), max_new)
         if self.sched_stride != self._stride_set:
             L.check(self.lib.oavsr_scheduler_set_stride(self._sched, int(self.sched_stride)))
@@ -507,8 +519,10 @@ class AVSR_LLMs:
             raise KeyError(rv)
         # "video_flat" (not a reference key; harness.collate_flat): the valid frames of all utterances back to back, [sum T, 88, 88] f32 --
         # what the engine consumes, without the padded [B, T, 1, 88, 88] detour; needs "video_lengths"
-        video_is_flat = use_v and "video_flat" in inputs
-        video = (inputs["video_flat"] if video_is_flat else inputs.get("video")) if use_v else None
+        # "video_u8_flat" (harness.FlatCollator on raw samples): the DECODED uint8 frames [sum T, C, H, W]; the test-time transform then runs
+        # inside the engine's stem kernel instead of on the host
+        video_is_flat = use_v and ("video_flat" in inputs or "video_u8_flat" in inputs)
+        video = (inputs["video_u8_flat"] if "video_u8_flat" in inputs else inputs["video_flat"] if video_is_flat else inputs.get("video")) if use_v else None
         audio = inputs.get("audio") if use_a else None
         Tv = lengths = None
         if use_v:

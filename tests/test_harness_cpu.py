@@ -158,3 +158,22 @@ def test_flat_collator_matches_collate_test():
         assert torch.equal(got["audio"], ref["audio"][..., 0])
         flat = torch.cat([ref["video"][b, :n, 0] for b, n in enumerate(frames)], 0)
         assert torch.equal(got["video_flat"], flat)
+
+
+def test_raw_uint8_samples_and_flat_collation():
+    """make_sample(device_transform=True) keeps the decoded uint8 frames; FlatCollator carries them back to back ("video_u8_flat")"""
+    import torch
+    from omni_avsr_amd import harness as H
+    g = torch.Generator().manual_seed(1)
+    clips = [torch.randint(0, 256, (n, 3, 96, 96), generator=g, dtype=torch.uint8) for n in (6, 4)]
+    waves = [torch.randn(n * 640 + 17, 1, generator=g) for n in (6, 4)]
+    samples = [H.make_sample(c, w, "audiovisual", device_transform=True) for c, w in zip(clips, waves)]
+    assert all(s["video_u8"].dtype == torch.uint8 and s["audio"].shape[0] == 640 * n for s, n in zip(samples, (6, 4)))
+    col = H.FlatCollator(2, 6, 6 * 640, pin=False, u8_shape=(3, 96, 96))
+    b = col(samples, "audiovisual", 5)
+    assert b["video_u8_flat"].shape == (10, 3, 96, 96) and torch.equal(b["video_u8_flat"], torch.cat(clips)) and b["video_lengths"].tolist() == [6, 4]
+    ref = torch.cat([H.video_test_transform(c) for c in clips])           # what the host path would have uploaded instead
+    assert ref.shape == (10, 1, 88, 88)
+    import pytest
+    with pytest.raises(ValueError):
+        H.make_sample(clips[0].float(), waves[0], "audiovisual", device_transform=True)

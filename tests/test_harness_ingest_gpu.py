@@ -89,6 +89,18 @@ def test_manifest_to_wer_through_the_engine(tmp_path):
         assert sorted(mp.per_utt) == sorted(meter.per_utt), f"in_flight={k}, decode_group={grp}: hypotheses differ from the sequential loop"
         assert (mp.total_edit_distance, mp.total_length, mp.failed) == (meter.total_edit_distance, meter.total_length, [])
     assert getattr(model, "encoder_chunk", None) is None
+    # the decoded uint8 frames themselves as samples (make_sample(device_transform=True)): the test-time transform runs inside the stem kernel,
+    # the host uploads [sum T, 3, 96, 96] bytes -- same hypotheses and counters, sequential and with batches in flight (f32 AND bf16 engines)
+    pairs_u8 = [(H.make_sample(clip, wave, "audiovisual", device_transform=True), t) for (clip, wave), t in zip(raw, gold)]
+    assert pairs_u8[0][0]["video_u8"].dtype == torch.uint8 and "video" not in pairs_u8[0][0]
+    for k in (1, 3):
+        mu = H.evaluate(model, pairs_u8, "audiovisual", to_text, batch_size=2, bos_id=spec.ids["bos"], in_flight=k, test_ratio_matry_audio=4, test_ratio_matry_video=2)
+        assert sorted(mu.per_utt) == sorted(meter.per_utt), f"uint8 ingest (in_flight={k}): hypotheses differ from the host-transform path"
+    eng16 = OmniEngine(spec, dtype="bf16").load_state_dict(sd)
+    m16 = _shim(spec, eng16, "audiovisual")
+    a16 = H.evaluate(m16, pairs, "audiovisual", to_text, batch_size=2, bos_id=spec.ids["bos"], in_flight=2, test_ratio_matry_audio=4, test_ratio_matry_video=2)
+    b16 = H.evaluate(m16, pairs_u8, "audiovisual", to_text, batch_size=2, bos_id=spec.ids["bos"], in_flight=2, test_ratio_matry_audio=4, test_ratio_matry_video=2)
+    assert sorted(a16.per_utt) == sorted(b16.per_utt), "bf16: uint8 ingest decodes differently from the host-transform path"
 
 
 def _decode(eng, spec, seed=5):

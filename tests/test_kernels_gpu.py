@@ -417,7 +417,7 @@ def test_stem_conv_pool_fused(dtype, lens):
     scratch = torch.empty(64 * 288, dtype=tdt(dtype), device=DEV)
     out = torch.empty(Fr, 22, 22, 64, dtype=tdt(dtype), device=DEV)
     sc, sh, sl = scale.to(DEV), shift.to(DEV), slope.to(DEV)
-    L.check(L.load().oavsr_op_stem_pool(dcode(dtype), P(vd), P(fi), Fr, P(wd), P(scratch), P(sc), P(sh), P(sl), P(out), stream()))
+    L.check(L.load().oavsr_op_stem_pool(dcode(dtype), P(vd), 0, 88, 88, P(fi), Fr, P(wd), P(scratch), P(sc), P(sh), P(sl), P(out), stream()))
     refs = []
     o = 0
     vq = vid.to(tdt(dtype)).float()
@@ -430,6 +430,34 @@ def test_stem_conv_pool_fused(dtype, lens):
         refs.append(y[0].permute(1, 2, 3, 0))
         o += n
     close(out.reshape(Fr * 484, 64), torch.cat(refs).reshape(Fr * 484, 64), tol(dtype) * 2, what="fused stem")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,H,W", [(3, 96, 96), (1, 96, 96), (3, 97, 101), (1, 88, 88)])
+def test_stem_uint8_frames_with_fused_test_transform(dtype, C, H, W):
+    """uint8 frame source of the fused stem: x / 255, CenterCrop(88), Grayscale, Normalize(0.421, 0.165) (datamodule/transforms.py:93-99)
+    inside the window gather.  Bar: the SAME BITS as the host transform (harness.video_test_transform, fp32 torch ops) followed by the
+    f32-source kernel -- the pixel arithmetic is replayed operation by operation, so nothing may differ."""
+    from omni_avsr_amd.harness import video_test_transform
+    lens = [5, 3]
+    Fr = sum(lens)
+    g = torch.Generator().manual_seed(C * 1000 + H)
+    frames = torch.randint(0, 256, (Fr, C, H, W), generator=g, dtype=torch.uint8)
+    w = rnd(64, 1, 5, 7, 7, seed=2) / math.sqrt(245)
+    wp = torch.zeros(64, 256)
+    wp[:, :245] = w.reshape(64, 245)
+    wd, _ = q(wp, dtype)
+    sc, sh, sl = (rnd(64, seed=3) * 0.1 + 1).to(DEV), (rnd(64, seed=4) * 0.1).to(DEV), (rnd(64, seed=5) * 0.05 + 0.25).to(DEV)
+    fi = torch.tensor([[t, n] for n in lens for t in range(n)], dtype=torch.int32, device=DEV)
+    scratch = torch.empty(64 * 288, dtype=tdt(dtype), device=DEV)
+    outs = []
+    host = video_test_transform(frames)[:, 0].contiguous()          # [F, 88, 88] f32, what the reference's dataset hands to forward()
+    for src, fmt in ((host.to(DEV), (0, 88, 88)), (frames.to(DEV), (C, H, W))):
+        out = torch.empty(Fr, 22, 22, 64, dtype=tdt(dtype), device=DEV)
+        L.check(L.load().oavsr_op_stem_pool(dcode(dtype), P(src), *fmt, P(fi), Fr, P(wd), P(scratch), P(sc), P(sh), P(sl), P(out), stream()))
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]), f"uint8 source differs from host transform + f32 source: max |d| = {(outs[0].float() - outs[1].float()).abs().max().item():.3e}"
 
 
 # ------------------------------------------------------------------------------------------------ attention

@@ -57,7 +57,7 @@ def collect(eng, pend, stream):
 def test_three_staggered_calls_equal_isolated_calls(dtype, stride):
     spec = tiny_spec(family="llama", task_specific=True, shared=True)
     eng = OmniEngine(spec, dtype=dtype).load_state_dict(synth_state_dict(spec, seed=1234))
-    eng.sched_stride = stride
+    eng.sched_stride, eng.sched_lanes = stride, 1            # ONE step loop: the three calls must share its steps
     mn = spec.max_dec_tokens
     calls = [clips(8, 1), clips(3, 2), clips(8, 3)]
     ref = [alone(eng, c, mn, True) for c in calls]
@@ -90,6 +90,7 @@ def test_more_calls_than_rows_per_step_and_oracle_f32():
     spec = tiny_spec(family="llama", task_specific=True, shared=True)
     sd = synth_state_dict(spec, seed=1234)
     eng = OmniEngine(spec, dtype="f32").load_state_dict(sd)
+    eng.sched_lanes, eng.sched_slots = 1, 64
     orc = O.OmniOracle(sd, spec.oracle_cfg())
     mn = spec.max_dec_tokens
     calls = [clips(8, 20 + i) for i in range(7)]

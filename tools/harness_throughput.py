@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """harness.evaluate on the headline model with HOST inputs (collate + host-to-device copies inside the timed loop: the PCIe-inclusive rate
-of the caller-side loop), sequential vs batches in flight.  Synthetic 16 s clips, random-init weights, greedy, 32 tokens (EOS is not
-suppressed here, so hypotheses may be shorter)."""
+of the caller-side loop), sequential vs batches in flight, float samples (host transform done beforehand, as the reference's dataset
+does it in its workers) vs the decoded uint8 frames (transform inside the stem kernel).  Synthetic 16 s clips, random-init weights,
+greedy, 32 tokens (EOS is not suppressed here, so hypotheses may be shorter)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -25,20 +26,21 @@ m.is_matryoshka, m.is_task_specific, m.spec, m.engine = True, True, spec, eng
 m.downsample_ratio_audio, m.downsample_ratio_video = spec.downsample_ratio_audio, spec.downsample_ratio_video
 n_utt = int(sys.argv[1]) if len(sys.argv) > 1 else 96
 g = torch.Generator().manual_seed(0)
-samples = []
+samples, samples_u8 = [], []
 for i in range(n_utt):
-    v = torch.randn(400, 1, 88, 88, generator=g)
-    a = torch.nn.functional.layer_norm(torch.randn(256000, generator=g), (256000,))[:, None]
-    samples.append(({"video": v, "audio": a}, "gold"))
+    clip = torch.randint(0, 256, (400, 3, 96, 96), generator=g, dtype=torch.uint8)          # decoded mouth ROI, RGB
+    wave = torch.randn(256000, 1, generator=g) * 0.1
+    samples.append((H.make_sample(clip, wave, "audiovisual"), "gold"))
+    samples_u8.append((H.make_sample(clip, wave, "audiovisual", device_transform=True), "gold"))
 to_text = lambda ids: [" ".join(str(int(t)) for t in row) for row in ids.cpu()]      # noqa: E731
 out = {}
-for k, grp in ((1, 1), (3, 1), (3, 3), (3, 1), (3, 3)):
+for name, smp, k in (("float samples, sequential", samples, 1), ("float samples, 3 in flight", samples, 3), ("uint8 frames, 3 in flight", samples_u8, 3),
+                     ("float samples, 3 in flight", samples, 3), ("uint8 frames, 3 in flight", samples_u8, 3), ("uint8 frames, 4 in flight", samples_u8, 4)):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    meter = H.evaluate(m, samples, "audiovisual", to_text, batch_size=8, bos_id=spec.ids["bos"], in_flight=k, decode_group=grp,
-                       test_ratio_matry_audio=4, test_ratio_matry_video=4)
+    meter = H.evaluate(m, smp, "audiovisual", to_text, batch_size=8, bos_id=spec.ids["bos"], in_flight=k, test_ratio_matry_audio=4, test_ratio_matry_video=4)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     hyp = sorted(h for _, h, _, _ in meter.per_utt)
     assert out.setdefault("hyp", hyp) == hyp, "hypotheses differ between the modes"
-    print(f"in_flight={k} decode_group={grp}: {n_utt / dt:7.1f} utt/s  ({dt / (n_utt / 8) * 1e3:.1f} ms per batch of 8, host inputs)", flush=True)
+    print(f"{name:28s}: {n_utt / dt:7.1f} utt/s  ({dt / (n_utt / 8) * 1e3:.1f} ms per batch of 8, host inputs; scheduler {eng.scheduler_stats()})", flush=True)
