@@ -169,6 +169,9 @@ int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_worksp
 /* Issues whatever steps the call still needs (other admitted rows ride along) and makes `stream` wait for its results: work queued on
  * `stream` afterwards sees out_ids_dev / out_len_dev.  No host synchronisation. */
 int oavsr_generate_wait(oavsr_scheduler* s, int64_t ticket, oavsr_stream stream);
+/* 1: the call's results are final (its last step has been issued by later submissions / waits AND has run); 0: not yet.  Never issues
+ * steps and never blocks: a caller that only collects what is ready lets the scheduler keep its steps full.  < 0: error. */
+int oavsr_generate_poll(oavsr_scheduler* s, int64_t ticket);
 /* Issues the remaining steps of every admitted call. */
 int oavsr_scheduler_flush(oavsr_scheduler* s);
 /* Pacing: steps the loop advances per admission before it waits for the new call's prefill.  0 (default) = (max_new - 1) / k with

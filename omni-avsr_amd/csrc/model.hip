@@ -1734,6 +1734,20 @@ int oavsr_generate_wait(oavsr_scheduler* s, int64_t ticket, oavsr_stream stream)
   return 0;
 }
 
+int oavsr_generate_poll(oavsr_scheduler* s, int64_t ticket) {
+  OAVSR_REQUIRE(s, "generate_poll: null scheduler");
+  std::lock_guard<std::mutex> lk(s->mu);
+  OAVSR_REQUIRE(ticket >= 0 && ticket < s->next_ticket, "generate_poll: unknown ticket %lld", (long long)ticket);
+  const SchedCall& k = s->ring[ticket % oavsr_scheduler::kRing];
+  OAVSR_REQUIRE(k.ticket == ticket, "generate_poll: ticket %lld has expired", (long long)ticket);
+  if (!k.retired) return 0;                              // steps still to be issued: nothing is forced here
+  const hipError_t e = hipEventQuery(k.done);
+  if (e == hipSuccess) return 1;
+  if (e == hipErrorNotReady) return 0;
+  set_last_error("generate_poll: HIP error %d (%s)", (int)e, hipGetErrorString(e));
+  return -2;
+}
+
 int oavsr_scheduler_flush(oavsr_scheduler* s) {
   OAVSR_REQUIRE(s, "scheduler_flush: null scheduler");
   std::lock_guard<std::mutex> lk(s->mu);

@@ -307,37 +307,73 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
     u8_shape = tuple(samples[owned[0]][0]["video_u8"].shape[1:]) if owned and "video_u8" in samples[owned[0]][0] else None
     ts_max = max([int(samples[i][0]["audio"].shape[0]) for i in owned if "audio" in samples[i][0]] or [16000])
     eng.reserve(in_flight, batch_size, tv_max, ts_max, getattr(model, "num_beams", 1), getattr(model, "max_dec_tokens", None))
-    # 2 x in_flight + 1 staging sets: while the main thread launches batch n and waits for the oldest one, a helper thread collates batch
-    # n + 1 into the set that the batch drained last released (the reference gets the same overlap from its DataLoader workers)
+    # Greedy calls go through the engine's decode scheduler (forward(sync=False)): a slot's stream then carries only the encoder + prefill
+    # phase, so (a) a staging set is free again as soon as that phase has read it -- an event on the slot's stream, not the call's result --
+    # and (b) results are collected when they are READY (PendingIds.ready(): never forces steps), so that the scheduler's step loops stay
+    # full; only when more than `max_pending` calls are uncollected is the oldest one waited for.  Beam search (per-call decode loop on
+    # the slot's stream): the event is the end of the call and at most 2 x in_flight calls are queued, as before.
+    sched = getattr(model, "num_beams", 1) == 1 and getattr(model, "decode_scheduler", True) and decode_group == 1 and batch_size <= eng.sched_rows
+    max_pending = (2 * eng.sched_lanes * max(1, eng.sched_rows // batch_size) + in_flight) if sched else 2 * in_flight
+    # 2 x in_flight + 1 staging sets: while the main thread launches batch n, a helper thread collates batch n + 1 into the set whose last
+    # reader finished longest ago (the reference gets the same overlap from its DataLoader workers)
     from concurrent.futures import ThreadPoolExecutor
-    limit = 2 * in_flight                                     # calls queued at most: a slot's stream orders its own calls, so the host may run one round ahead
-    nset = limit + 1
+    depth = 2                                                 # batches collated ahead, each by its own helper thread
+    nset = 2 * in_flight + depth
     bmax = max(len(b) for b in batches)                       # the largest batch actually owned (pinned memory: nset x bmax clips)
-    collators = [FlatCollator(bmax, tv_max, ts_max, u8_shape=u8_shape) for _ in range(nset)]
-    pool = ThreadPoolExecutor(1)
-    collate = lambda n: collators[n % nset]([samples[i][0] for i in batches[n]], modality, bos_id)      # noqa: E731
-    eng.serialize_encoders(True)
-    pending = []                                              # [(slot, idxs, PendingIds)], oldest first
+    # (kept on the engine between evaluate() calls: the first touch of a fresh pinned buffer costs ~0.2 s of page faults per set)
+    cache = eng.__dict__.setdefault("_staging_cache", {})
+    ckey = (nset, bmax, tv_max, ts_max, u8_shape)
+    if ckey not in cache:
+        while len(cache) >= 3:
+            cache.pop(next(iter(cache)))
+        cache[ckey] = [FlatCollator(bmax, tv_max, ts_max, u8_shape=u8_shape) for _ in range(nset)]
+    collators = cache[ckey]
+    consumed = [None] * nset                                  # event after the last call that read staging set k
+    pool = ThreadPoolExecutor(depth)
+
+    def collate(n):
+        k = n % nset
+        if consumed[k] is not None:
+            consumed[k].synchronize()
+        return collators[k]([samples[i][0] for i in batches[n]], modality, bos_id)
+    if not sched:
+        eng.serialize_encoders(True)
+    pending = []                                              # [(idxs, PendingIds)], oldest first
+
+    def collect(force: bool):
+        while pending and (force or len(pending) > max_pending or pending[0][1].ready()):
+            done_idxs, p = pending.pop(0)
+            score(done_idxs, p.result())
+    import time as _time
+    tm = eng.__dict__.setdefault("_eval_timing", {"wait_collate": 0.0, "submit": 0.0, "collect": 0.0, "batches": 0})      # host seconds per phase (diagnostics)
     try:
-        fut = pool.submit(collate, 0)
+        futs = [pool.submit(collate, j) for j in range(min(depth, len(batches)))]
         for n, idxs in enumerate(batches):
             slot = n % in_flight
-            while len(pending) >= limit:                      # frees the staging set batch n + 1 is about to be collated into
-                _, done_idxs, p = pending.pop(0)
-                score(done_idxs, p.result())
-            batch = fut.result()
-            if n + 1 < len(batches):
-                fut = pool.submit(collate, n + 1)
+            t0 = _time.perf_counter()
+            batch = futs.pop(0).result()
+            t1 = _time.perf_counter()
+            tm["wait_collate"] += t1 - t0
+            tm["batches"] += 1
+            if n + depth < len(batches):
+                futs.append(pool.submit(collate, n + depth))
             try:
                 with torch.cuda.stream(streams[slot]):
                     p = model(batch, is_trainval=False, modality=kw_mod, slot=slot, sync=False, **forward_kw)
+                    ev = torch.cuda.Event()
+                    ev.record(streams[slot])
+                    consumed[n % nset] = ev
+                tm["submit"] += _time.perf_counter() - t1
             except (RuntimeError, ValueError) as e:
                 skip(idxs, e)
                 torch.cuda.synchronize(dev)                   # whatever was queued from the staging set must be done before it is refilled
-                continue
-            pending.append((slot, idxs, p))
-        for _, done_idxs, p in pending:
-            score(done_idxs, p.result())
+                p = None
+            if p is not None:
+                pending.append((idxs, p))
+            t2 = _time.perf_counter()
+            collect(False)
+            tm["collect"] += _time.perf_counter() - t2
+        collect(True)
     finally:
         pool.shutdown(wait=True)
         torch.cuda.synchronize(dev)

@@ -373,6 +373,22 @@ class OmniEngine:
             L.check(self.lib.oavsr_generate_wait(self._sched, int(t), self._stream()))
         getattr(self, "_inflight", {}).pop(ticket, None)
 
+    def result_stream(self) -> "torch.cuda.Stream":
+        """Side stream on which results of scheduled calls are awaited and copied to the host (PendingIds)."""
+        if getattr(self, "_result_stream", None) is None:
+            self._result_stream = torch.cuda.Stream(device=self.device)
+        return self._result_stream
+
+    def poll(self, ticket) -> bool:
+        """True once the call's results are final; never issues steps, never blocks (oavsr_generate_poll)."""
+        gen, t = ticket
+        if gen != self._sched_gen or not self._sched:
+            return True
+        rc = self.lib.oavsr_generate_poll(self._sched, int(t))
+        if rc < 0:
+            L.check(rc)
+        return rc == 1
+
     def flush(self):
         if self._sched:
             L.check(self.lib.oavsr_scheduler_flush(self._sched))
@@ -409,15 +425,28 @@ class PendingIds:
             self._event.record(stream)
 
     def _settle(self):
-        if self._event is None:                              # first query: have the remaining steps issued, then mark the stream
+        if self._event is None:                              # first query: have the remaining steps issued, then mark a stream
+            # NOT the call's own stream: later calls of the same slot have queued their encoder phases there, and the device-to-host
+            # copy of the result would wait behind them (the host would fall back into lock step with the GPU).  The engine's result
+            # stream carries nothing but these waits and copies.
+            self._stream = self._engine.result_stream()
             with torch.cuda.stream(self._stream):
                 self._engine.wait(self._ticket)
+            self._ids.record_stream(self._stream)
+            self._lens.record_stream(self._stream)
             self._event = torch.cuda.Event()
             self._event.record(self._stream)
 
     def done(self) -> bool:
         self._settle()
         return self._event.query()
+
+    def ready(self) -> bool:
+        """Like done(), but never makes the engine issue decode steps on this call's behalf: True only once the steps that later
+        submissions (or waits) issued have completed it.  Collecting only what is ready keeps the scheduler's steps full."""
+        if self._event is None and not self._engine.poll(self._ticket):
+            return False
+        return self.done()
 
     def result(self) -> torch.Tensor:
         self._settle()
