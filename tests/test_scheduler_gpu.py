@@ -169,3 +169,40 @@ def test_forward_sync_false_goes_through_the_scheduler(dtype):
     with torch.cuda.stream(streams[0]):
         p = model(batches[0], is_trainval=False, modality="audiovisual", test_ratio_matry_audio=4, test_ratio_matry_video=2, slot=0, sync=False)
     assert torch.equal(p.result().cpu(), want[0]) and model.engine.scheduler_stats()["calls"] == 4
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_schedules_never_change_a_result(seed):
+    """Seeded stress: 14 calls with random sizes (1..12 utterances), tasks, max_new, EOS suppression, pacing, lane count and pool size,
+    submitted in bursts with results collected in random order and at random moments (some early, forcing steps; some only after the
+    final flush) -- every call must return the ids of the same call decoded alone."""
+    import random
+    rng = random.Random(1000 + seed)
+    spec = tiny_spec(family="llama" if seed != 1 else "qwen2", head_dim=64 if seed != 1 else 128, task_specific=(seed != 1), shared=(seed != 1))
+    dtype = "bf16" if seed != 2 else "f32"
+    eng = OmniEngine(spec, dtype=dtype).load_state_dict(synth_state_dict(spec, seed=99 + seed))
+    eng.sched_lanes, eng.sched_slots, eng.sched_rows = rng.choice([1, 2, 3]), rng.choice([32, 48, 96]), rng.choice([16, 24, 32])
+    tasks = ["audiovisual", "audiovisual", "audiovisual", "audio", "video"]
+    calls = []
+    for i in range(14):
+        B = rng.randint(1, min(12, eng.sched_rows))
+        calls.append(dict(c=clips(B, 500 + 31 * seed + i), mn=rng.choice([1, 2, 5, spec.max_dec_tokens, spec.max_dec_tokens]), force=rng.random() < 0.5,
+                          task=rng.choice(tasks) if spec.is_task_specific else "audiovisual"))
+    ref = [alone(eng, k["c"], k["mn"], k["force"], k["task"]) for k in calls]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    pend, got = {}, {}
+    for i, k in enumerate(calls):
+        eng.sched_stride = rng.choice([0, 0, 1, 2, 5])
+        pend[i] = (submit(eng, k["c"], k["mn"], k["force"], i % 3, streams[i % 3], k["task"]), streams[i % 3])
+        if rng.random() < 0.3:                                 # collect something now, out of order
+            j = rng.choice(sorted(pend))
+            p, s = pend.pop(j)
+            got[j] = collect(eng, p, s)
+        if rng.random() < 0.2:
+            time.sleep(0.01)
+    eng.flush()
+    for j in rng.sample(sorted(pend), len(pend)):
+        p, s = pend.pop(j)
+        got[j] = collect(eng, p, s)
+    for i in range(len(calls)):
+        assert got[i] == ref[i], f"seed {seed}: call {i} ({calls[i]['task']}, B={len(calls[i]['c'][2])}, max_new={calls[i]['mn']}) differs from the isolated call"

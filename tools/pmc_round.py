@@ -33,6 +33,13 @@ FAMILY = [  # rocprof kernel-name pattern -> bench.py family name
 
 
 def fam(name):
+    # round 3: the 9..32-row decode kernels (what the decode scheduler's 32-row steps run): family from the template arguments
+    m = re.search(r"skinny_(persist_)?r16_kernel(?:IDF16b|<[^,]*,)\s*(?:Li)?(\d)E?,?\s*(?:Li)?(\d)?E?,?\s*(?:Lb)?(\d|true|false)?", name)
+    if m:
+        persist, a, b, c = m.group(1), m.group(2), m.group(3), m.group(4)
+        if persist:
+            return f"skinny_persist_r16_mt{a}_bf16"
+        return f"skinny_r16_mt{a}_nt{b}{'_norm' if c in ('1', 'true') else ''}_bf16"
     for pat, f in FAMILY:
         if re.search(pat, name):
             return f
@@ -73,7 +80,7 @@ for f in sorted(set(fa) | set(sa)):
     write = wa[f].get("WRITE_SIZE", 0.0) / max(wc[f].get("WRITE_SIZE", 0), 1)
     ns = max(sc[f].get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0), 1)
     mops = sa[f].get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) / ns
-    what = "tools/skinny_mix.py 8" if "skinny" in tag else "tools/gemm_mix.py" if "gemm" in tag else \
+    what = "tools/skinny_mix.py 32" if "skinny32" in tag else "tools/skinny_mix.py 8" if "skinny" in tag else "tools/gemm_mix.py" if "gemm" in tag else \
         "bench.py --streams 1 --steps 1 --warmup 1 --calls-per-step 2 --no-cpu-baseline --no-roofline"
     d = dict(note="rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*; separate runs, each with --kernel-trace) over `" + what + "`; traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B (gfx950 read-side "
                   "correction; the counters sit on the L2's memory side, Infinity-Cache hits included); mfma flops = SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512; "
