@@ -207,6 +207,55 @@ def per_call_leg(eng, args, pre, task, use_a, B, sets, streams, nstream):
             "note": "decode scheduler off: one decode loop per call of the same batches (the round-2 configuration); not `value`"}
 
 
+def schedule_summary(recs, skip_calls):
+    """Occupancy summary of a scheduler trace (OmniEngine.scheduler_trace_read): when were encoder + prefill phases running, when were decode
+    steps running, and how fast do steps go beside the phases.  Everything is clipped to the steady window that starts with call
+    `skip_calls` (the lanes are full from there on) and ends with the last phase."""
+    phases = [r for r in recs if r["kind"] == 0 and r["t1"] >= 0]
+    bursts = [r for r in recs if r["kind"] == 1 and r["t1"] >= 0]
+    if len(phases) <= skip_calls + 2 or not bursts:
+        return None
+    w0, w1 = phases[skip_calls]["t0"], max(r["t1"] for r in phases)
+    clip = lambda iv: [(max(a, w0), min(b, w1)) for a, b in iv if min(b, w1) > max(a, w0)]      # noqa: E731
+
+    def union(iv):
+        tot, end = 0.0, None
+        for a, b in sorted(iv):
+            if end is None or a > end:
+                tot += b - a
+                end = b
+            elif b > end:
+                tot += b - end
+                end = b
+        return tot
+
+    def both(iv1, iv2):                    # measure of (union iv1) intersected with (union iv2), by sweeping the boundaries
+        pts = sorted([(a, 1, 0) for a, _ in iv1] + [(b, -1, 0) for _, b in iv1] + [(a, 0, 1) for a, _ in iv2] + [(b, 0, -1) for _, b in iv2])
+        c1 = c2 = 0
+        last, tot = None, 0.0
+        for t, d1, d2 in pts:
+            if last is not None and c1 > 0 and c2 > 0:
+                tot += t - last
+            c1 += d1
+            c2 += d2
+            last = t
+        return tot
+    pi, bi = clip([(r["t0"], r["t1"]) for r in phases]), clip([(r["t0"], r["t1"]) for r in bursts])
+    win = w1 - w0
+    inside = [r for r in bursts if r["t0"] >= w0 and r["t1"] <= w1]
+    steps = sum(r["steps"] for r in inside)
+    n_ph = len([r for r in phases[skip_calls:]])
+    return dict(window_ms=round(win, 2), calls=n_ph, period_ms_per_call=round(win / max(1, n_ph), 3),
+                phase_active_frac=round(union(pi) / win, 4), phases_in_flight_avg=round(sum(b - a for a, b in pi) / win, 3),
+                phase_ms_mean=round(sum(r["t1"] - r["t0"] for r in phases[skip_calls:]) / max(1, n_ph), 3),
+                decode_active_frac=round(union(bi) / win, 4), lanes_active_avg=round(sum(b - a for a, b in bi) / win, 3),
+                both_active_frac=round(both(pi, bi) / win, 4),
+                step_ms_beside_phases=round(sum(r["t1"] - r["t0"] for r in inside) / max(1, steps), 4) if steps else None,
+                rows_per_step=round(sum(r["rows"] * r["steps"] for r in inside) / max(1, steps), 2) if steps else None,
+                note="HIP timing events around every call's encoder + prefill phase (caller streams) and every burst of decode steps (scheduler "
+                     "lanes), un-profiled run; fractions of the steady window; step_ms_beside_phases = burst time / steps of one lane")
+
+
 def launch_ranks(args):
     """Parent of a multi-GPU run: never touches the GPU (device_count() does not initialise it), starts the ranks as a child
     process and hands their return code back."""
@@ -345,6 +394,17 @@ def main():
     assert args.beams > 1 or int(lens.min()) == args.max_new
 
     dsched = eng.scheduler_stats() if use_sched else None      # the timed region's (the passes below run more calls)
+    schedule = None
+    if rank == 0 and use_sched and not args.no_roofline:
+        # the same loop for 32 more calls with the scheduler's trace on: what overlaps what (a kernel trace cannot show it: the profiler
+        # takes the hardware queues in turn)
+        eng.scheduler_trace(True)
+        for _ in range(32):
+            call(ncall)
+            ncall += 1
+        drain()
+        schedule = schedule_summary(eng.scheduler_trace_read(), skip_calls=4 * args.sched_lanes)
+        eng.scheduler_trace(False)
     roofline = None
     stages = None
     sides = None
@@ -477,7 +537,7 @@ def main():
                        "parallelism": f"utterance-sharded dp{world}", "gathered_hypotheses": len(hyp), "dist_backend": (dist.get_backend() if use_dist else None),
                        "streams_per_gpu": nstream, "decode_group": G, "setup_s": round(setup_s, 1),
                        "decode_scheduler": (dict(rows_per_step_cap=args.sched_rows, slots=args.sched_slots, lanes=args.sched_lanes, **dsched) if use_sched else None)},
-            "roofline": roofline, "roofline_sides": sides, "cpu_baseline": cpu, "per_call_decode": grouped, "stages": stages,
+            "roofline": roofline, "roofline_sides": sides, "schedule": schedule, "cpu_baseline": cpu, "per_call_decode": grouped, "stages": stages,
         }
         print(json.dumps(line), flush=True)
     if use_dist:

@@ -178,6 +178,16 @@ int oavsr_scheduler_flush(oavsr_scheduler* s);
  * k = max_rows / B calls sharing a step in the steady state; 1 = lowest latency (rows join as early as possible, fewer rows per weight
  * pass); larger = fewer, fuller steps.  Scheduling only: results never depend on it. */
 int oavsr_scheduler_set_stride(oavsr_scheduler* s, int32_t steps);
+/* Schedule trace: while on, every submitted call's encoder + prefill phase (on the caller's stream) and every burst of steps a lane issues
+ * are bracketed by timing events; _read waits for the device and returns the records in issue order, times in ms relative to the first
+ * record's start.  kind 0: a call's phase (id = ticket, rows = B); kind 1: a burst (id = lane, steps, rows = live rows).  Diagnostics
+ * (bench.py's `schedule` object): a kernel trace cannot show this overlap because rocprofv3 takes the hardware queues in turn. */
+typedef struct oavsr_trace_rec {
+  int32_t kind, id, steps, rows;
+  float t0_ms, t1_ms;
+} oavsr_trace_rec;
+int oavsr_scheduler_trace(oavsr_scheduler* s, int32_t on);
+int oavsr_scheduler_trace_read(oavsr_scheduler* s, oavsr_trace_rec* out, int32_t max_recs);
 /* out4 = {steps issued, sum over steps of live rows, calls submitted, step graphs instantiated} */
 int oavsr_scheduler_stats(const oavsr_scheduler* s, uint64_t* out4);
 

@@ -305,6 +305,16 @@ struct oavsr_scheduler {
   int64_t next_ticket = 0;
   uint64_t steps_issued = 0, row_steps = 0, calls = 0;     // statistics (oavsr_scheduler_stats)
   int stride = 0;                              // steps issued per admission; 0 = (max_new - 1) / (max_rows / B) (oavsr_scheduler_set_stride)
+  // schedule trace (oavsr_scheduler_trace): timing events around every call's encoder + prefill phase (on the caller's stream) and around every
+  // burst of steps a lane issues -- the only way to SEE the overlap (rocprofv3's kernel trace takes the queues in turn)
+  struct TraceRec { int kind, id, steps, rows; hipEvent_t e0, e1; };
+  bool trace = false;
+  std::vector<TraceRec> trace_recs;
+  std::vector<hipEvent_t> trace_pool;
+  hipEvent_t trace_event() {
+    if (!trace_pool.empty()) { hipEvent_t e = trace_pool.back(); trace_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr; hipEventCreate(&e); return e;
+  }
   std::mutex mu;
 };
 
@@ -1525,6 +1535,8 @@ static int sched_run(oavsr_scheduler* s, SchedLane& l, int n) {
     const SchedCall& head = s->ring[l.active[0]];
     const int task = head.task, banned = head.banned, R = l.cur_R;
     int done = 0;
+    hipEvent_t tr0 = nullptr;
+    if (s->trace) { tr0 = s->trace_event(); hipEventRecord(tr0, l.st); }
     if (graphs_on && !g_prof.on) {
       const DecodeGraphKey key{R, task, 0, banned};
       hipGraphExec_t exec = nullptr;
@@ -1544,6 +1556,11 @@ static int sched_run(oavsr_scheduler* s, SchedLane& l, int n) {
       for (; done < k; ++done) OAVSR_CHECK_HIP(hipGraphLaunch(exec, l.st));
     }
     for (; done < k; ++done) OAVSR_TRY(sched_one_step(s, l, R, task, banned));
+    if (tr0) {
+      hipEvent_t tr1 = s->trace_event();
+      hipEventRecord(tr1, l.st);
+      s->trace_recs.push_back({1, (int)(&l - s->lanes.data()), k, lane_rows(s, l), tr0, tr1});
+    }
     s->steps_issued += k; s->row_steps += (uint64_t)k * lane_rows(s, l);
     std::vector<int> leaving;
     for (int i : l.active) { s->ring[i].remaining -= k; if (s->ring[i].remaining <= 0) leaving.push_back(i); }
@@ -1642,6 +1659,8 @@ void oavsr_scheduler_destroy(oavsr_scheduler* s) {
     delete l.dws;
   }
   for (auto& k : s->ring) { if (k.prefilled) hipEventDestroy(k.prefilled); if (k.done) hipEventDestroy(k.done); }
+  for (auto& r : s->trace_recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  for (auto e : s->trace_pool) hipEventDestroy(e);
   if (s->arena) hipFree(s->arena);
   delete s->pool;
   delete s;
@@ -1695,10 +1714,17 @@ int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_worksp
       if (o.ticket == t && o.done) OAVSR_CHECK_HIP(hipStreamWaitEvent(st, o.done, 0));
     } }
   std::vector<int> S(B);
+  hipEvent_t tr0 = nullptr;
+  if (s->trace) { tr0 = s->trace_event(); hipEventRecord(tr0, st); }
   { CallScope cs(ws, st);
     PrefillDest dest{s->pool->kpre, s->pool->vpre, s->pool->kpre_layer, s->max_prefix, s->logits_pre, s->pool->prefix_len, slot0};
     OAVSR_TRY(encode_prefill(m, ws, task, video_dev, Tv_host, wav_dev, wav_ld, Ts_host, keep_host, B, B, rate_audio, rate_video, st, &dest, S.data())); }
   OAVSR_CHECK_HIP(hipEventRecord(k.prefilled, st));
+  if (tr0) {
+    hipEvent_t tr1 = s->trace_event();
+    hipEventRecord(tr1, st);
+    s->trace_recs.push_back({0, (int)(ticket & 0x7fffffff), 0, B, tr0, tr1});
+  }
   for (int b = 0; b < B; ++b) { s->slot_used[slot0 + b] = 1; s->slot_owner[slot0 + b] = ticket; }
   ++s->next_ticket; ++s->calls;
   k.ticket = ticket; k.task = ltask; k.B = B; k.slot0 = slot0; k.limit = max_new; k.remaining = max_new - 1; k.banned = banned; k.lane = li;
@@ -1760,6 +1786,34 @@ int oavsr_scheduler_set_stride(oavsr_scheduler* s, int32_t steps) {
   std::lock_guard<std::mutex> lk(s->mu);
   s->stride = steps;
   return 0;
+}
+
+int oavsr_scheduler_trace(oavsr_scheduler* s, int32_t on) {
+  OAVSR_REQUIRE(s, "scheduler_trace: null scheduler");
+  std::lock_guard<std::mutex> lk(s->mu);
+  if (on && !s->trace) {
+    OAVSR_CHECK_HIP(hipDeviceSynchronize());
+    for (auto& r : s->trace_recs) { s->trace_pool.push_back(r.e0); s->trace_pool.push_back(r.e1); }
+    s->trace_recs.clear();
+  }
+  s->trace = on != 0;
+  return 0;
+}
+
+int oavsr_scheduler_trace_read(oavsr_scheduler* s, oavsr_trace_rec* out, int32_t max_recs) {
+  OAVSR_REQUIRE(s && (out || max_recs == 0), "scheduler_trace_read: null argument");
+  std::lock_guard<std::mutex> lk(s->mu);
+  OAVSR_CHECK_HIP(hipDeviceSynchronize());
+  const int n = std::min<int>((int)s->trace_recs.size(), max_recs);
+  if (n == 0) return 0;
+  const hipEvent_t base = s->trace_recs[0].e0;           // the first record's start: every time below is relative to it
+  for (int i = 0; i < n; ++i) {
+    const auto& r = s->trace_recs[i];
+    float t0 = 0.f, t1 = 0.f;
+    if (hipEventElapsedTime(&t0, base, r.e0) != hipSuccess || hipEventElapsedTime(&t1, base, r.e1) != hipSuccess) { t0 = t1 = -1.f; }
+    out[i].kind = r.kind; out[i].id = r.id; out[i].steps = r.steps; out[i].rows = r.rows; out[i].t0_ms = t0; out[i].t1_ms = t1;
+  }
+  return n;
 }
 
 int oavsr_scheduler_stats(const oavsr_scheduler* s, uint64_t* out4) {

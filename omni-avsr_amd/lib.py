@@ -43,6 +43,10 @@ class OavsrProfEntry(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint64), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
 
 
+class OavsrTraceRec(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("id", C.c_int32), ("steps", C.c_int32), ("rows", C.c_int32), ("t0_ms", C.c_float), ("t1_ms", C.c_float)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [
         ("dtype", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("K2", C.c_int32),
@@ -110,6 +114,8 @@ SYMBOLS = {
     "oavsr_generate_poll": (C.c_int, [_P, _L]),
     "oavsr_scheduler_flush": (C.c_int, [_P]),
     "oavsr_scheduler_set_stride": (C.c_int, [_P, _I]),
+    "oavsr_scheduler_trace": (C.c_int, [_P, _I]),
+    "oavsr_scheduler_trace_read": (C.c_int, [_P, C.POINTER(OavsrTraceRec), _I]),
     "oavsr_scheduler_stats": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "oavsr_profile_enable": (C.c_int, [_I]),
     "oavsr_profile_reset": (C.c_int, []),

@@ -393,6 +393,21 @@ class OmniEngine:
         if self._sched:
             L.check(self.lib.oavsr_scheduler_flush(self._sched))
 
+    def scheduler_trace(self, on: bool):
+        """Bracket every call's encoder + prefill phase and every burst of decode steps with timing events (oavsr_scheduler_trace)."""
+        if self._sched:
+            L.check(self.lib.oavsr_scheduler_trace(self._sched, int(on)))
+
+    def scheduler_trace_read(self, max_recs: int = 65536) -> List[dict]:
+        if not self._sched:
+            return []
+        arr = (L.OavsrTraceRec * max_recs)()
+        n = self.lib.oavsr_scheduler_trace_read(self._sched, arr, max_recs)
+        if n < 0:
+            L.check(n)
+        return [dict(kind=int(arr[i].kind), id=int(arr[i].id), steps=int(arr[i].steps), rows=int(arr[i].rows), t0=float(arr[i].t0_ms), t1=float(arr[i].t1_ms))
+                for i in range(n)]
+
     def scheduler_stats(self) -> dict:
         out = (C.c_uint64 * 4)()
         if not self._sched:
