@@ -18,6 +18,15 @@ Whisper-medium.en + Llama-3.2-1B (Omni-LoRA task-specific + shared, rank 32 / al
 headline).  Weights are seeded random tensors of the real architecture (no checkpoints offline).  dtype: bf16 storage /
 fp32 accumulate (the reference evaluates in bf16-true, eval_OmniAVSR.py:19).
 
+Every call is one batch of B utterances, submitted on one of `--streams` caller streams (`oavsr_generate_submit`: encoders +
+prefill there); the ENGINE's decode scheduler serves the decode rows of the calls in flight from its own step loops (up to 32 rows
+per weight pass, `--sched-*`), nothing is grouped on the caller's side.  The timed region ends with the scheduler's flush and a device
+synchronisation: every hypothesis of every timed call is complete inside it.  `--no-scheduler`: one decode loop per call (round 2).
+
+Besides the contract's fields the line carries `roofline` (dominant MFMA-side kernel family, HIP events, one call at a time),
+`roofline_sides` (MFMA side: flops / summed kernel time; decode side: the real step loop replayed alone), `schedule` (event trace
+of the scheduler: what overlaps what), `cpu_baseline`, `per_call_decode` (the same job with the scheduler off) and `stages`.
+
 Multi-GPU: the path shards by utterance with no data-path collective: every rank runs its own batches ("weak"
 scaling); the only exchange is one all_gather of the last call's hypotheses (omni_avsr_amd.dist.gather_hypotheses), inside the
 timed region before the closing barrier.
