@@ -64,6 +64,8 @@ def test_encode_audio(dtype):
     refs_out = []
     for b in range(2):
         a = audio[b:b + 1, :Ts[b]]
+        if dtype == "bf16":      # bf16 mode = the reference's bf16-true run, where Lightning hands forward() the WAVEFORM in bf16:
+            a = a.bfloat16().float()                       # same input for the fp32 oracle, so that the bound below is about arithmetic
         o, st = orc.encode_audio(a, Ts[b], 4, return_stages=True)
         em = maxerr(mel[b].transpose(0, 1), st["mel"][0])
         ee = maxerr(enc[b], st["enc"][0])
