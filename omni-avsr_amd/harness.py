@@ -313,7 +313,7 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
     # full; only when more than `max_pending` calls are uncollected is the oldest one waited for.  Beam search (per-call decode loop on
     # the slot's stream): the event is the end of the call and at most 2 x in_flight calls are queued, as before.
     sched = getattr(model, "num_beams", 1) == 1 and getattr(model, "decode_scheduler", True) and decode_group == 1 and batch_size <= eng.sched_rows
-    max_pending = (2 * eng.sched_lanes * max(1, eng.sched_rows // batch_size) + in_flight) if sched else 2 * in_flight
+    max_pending = (4 * eng.sched_lanes * max(1, eng.sched_rows // batch_size) + in_flight) if sched else 2 * in_flight
     # 2 x in_flight + 1 staging sets: while the main thread launches batch n, a helper thread collates batch n + 1 into the set whose last
     # reader finished longest ago (the reference gets the same overlap from its DataLoader workers)
     from concurrent.futures import ThreadPoolExecutor
