@@ -800,8 +800,6 @@ static int build_prompt_impl(const oavsr_model* m, oavsr_workspace* ws, int task
 static constexpr int skinny_max_rows() { return 32; }
 
 static int decode_split(int N, int Ktot, int esz) {
-  static const int nosplit_n = [] { const char* e = getenv("OAVSR_BEAM_NOSPLIT_N"); return e ? atoi(e) : 0; }();      // experiment: N <= this -> one k range per column tile
-  if (N <= nosplit_n) return 1;
   const int ktiles = Ktot / (128 / esz);
   int ks = 256 / std::max(1, ceil_div(N, 64));
   ks = std::min(ks, std::max(1, ktiles / 2));
