@@ -147,3 +147,36 @@ torch.save(outs[0], sys.argv[1])
         got.append(torch.load(f))
     for a, b in zip(got[0], got[1]):
         assert torch.equal(a, b), "fused launches decode different ids than separate launches"
+
+
+def test_fullsize_scheduler_equals_separate_calls():
+    """The headline configuration's own mechanism at the full model size: three calls of 8 utterances (ragged lengths) submitted one after another
+    through the decode scheduler -- encoders / prefill per call on three streams, decode rows sharing the 32-row steps of one lane -- decode the
+    ids of the same calls run on their own (bf16, EOS suppressed and free-running)."""
+    spec = full_spec()
+    sd = synth_state_dict(spec, seed=1234, device="cuda:0", dtype=torch.bfloat16)
+    eng = OmniEngine(spec, dtype="bf16").load_state_dict(sd)
+    del sd
+    torch.cuda.empty_cache()
+    g = torch.Generator().manual_seed(31)
+    calls = []
+    for c in range(3):
+        Tv = [int(x) for x in torch.randint(30, 101, (8,), generator=g)]
+        video, audio, Ts = clips(Tv, seed=40 + c)
+        calls.append((video, audio, Tv, Ts))
+    for force in (True, False):
+        ref = []
+        for video, audio, Tv, Ts in calls:
+            ids, lens = eng.generate("audiovisual", video, Tv, audio, Ts, 4, 4, beams=1, max_new=32, force_len=force)
+            ref.append((ids.cpu(), lens.cpu()))
+        eng.sched_lanes = 1
+        streams = [torch.cuda.Stream() for _ in range(3)]
+        pend = []
+        for i, (video, audio, Tv, Ts) in enumerate(calls):
+            with torch.cuda.stream(streams[i]):
+                pend.append(eng.submit("audiovisual", video, Tv, audio, Ts, 4, 4, max_new=32, force_len=force, slot=i))
+        eng.flush()
+        torch.cuda.synchronize()
+        for i, (ids, lens, _) in enumerate(pend):
+            assert torch.equal(lens.cpu(), ref[i][1]) and torch.equal(ids.cpu(), ref[i][0]), f"call {i} (force_len={force}) decodes differently inside the shared decode loop"
+    assert eng.scheduler_stats()["rows_per_step"] > 12
