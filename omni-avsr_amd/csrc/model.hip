@@ -285,6 +285,7 @@ struct SchedLane {
   std::vector<int> active;                     // ring indices in admission order
   bool map_dirty = true;                       // membership changed since the last step: rowmap + input rows must be rebuilt
   int cur_R = 0;
+  uint64_t steps = 0;                          // steps issued on this lane
   std::vector<std::pair<DecodeGraphKey, hipGraphExec_t>> graphs;
 };
 
@@ -1561,7 +1562,7 @@ static int sched_run(oavsr_scheduler* s, SchedLane& l, int n) {
       hipEventRecord(tr1, l.st);
       s->trace_recs.push_back({1, (int)(&l - s->lanes.data()), k, lane_rows(s, l), tr0, tr1});
     }
-    s->steps_issued += k; s->row_steps += (uint64_t)k * lane_rows(s, l);
+    s->steps_issued += k; l.steps += k; s->row_steps += (uint64_t)k * lane_rows(s, l);
     std::vector<int> leaving;
     for (int i : l.active) { s->ring[i].remaining -= k; if (s->ring[i].remaining <= 0) leaving.push_back(i); }
     for (int i : leaving) OAVSR_TRY(sched_retire(s, l, i));
@@ -1689,7 +1690,7 @@ int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_worksp
   SchedLane& l = s->lanes[li];
   if (!l.active.empty() && (s->ring[l.active[0]].task != ltask || s->ring[l.active[0]].banned != banned)) OAVSR_TRY(sched_run(s, l, lane_max_remaining(s, l)));
   // room: rows per step of the lane and a block of row slots
-  const uint64_t steps0 = s->steps_issued;
+  const uint64_t steps0 = l.steps;
   while (lane_rows(s, l) + B > s->max_rows) OAVSR_TRY(sched_run(s, l, lane_min_remaining(s, l)));
   int slot0 = sched_alloc(s, B);
   while (slot0 < 0) {      // no block: let the lane that holds the call closest to its end advance
@@ -1718,7 +1719,11 @@ int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_worksp
   if (s->trace) { tr0 = s->trace_event(); hipEventRecord(tr0, st); }
   { CallScope cs(ws, st);
     PrefillDest dest{s->pool->kpre, s->pool->vpre, s->pool->kpre_layer, s->max_prefix, s->logits_pre, s->pool->prefix_len, slot0};
-    OAVSR_TRY(encode_prefill(m, ws, task, video_dev, Tv_host, wav_dev, wav_ld, Ts_host, keep_host, B, B, rate_audio, rate_video, st, &dest, S.data())); }
+    const int rc = encode_prefill(m, ws, task, video_dev, Tv_host, wav_dev, wav_ld, Ts_host, keep_host, B, B, rate_audio, rate_video, st, &dest, S.data());
+    if (rc != 0) {                                   // refused inputs: nothing of the call has reached a lane, its slots were never taken
+      if (tr0) s->trace_pool.push_back(tr0);
+      return rc;
+    } }
   OAVSR_CHECK_HIP(hipEventRecord(k.prefilled, st));
   if (tr0) {
     hipEvent_t tr1 = s->trace_event();
@@ -1733,7 +1738,7 @@ int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_worksp
   static const int stride_env = [] { const char* e = getenv("OAVSR_SCHED_STRIDE"); return e ? atoi(e) : 0; }();
   const int share = std::max(1, s->max_rows / B);
   const int stride = s->stride > 0 ? s->stride : stride_env > 0 ? stride_env : std::max(1, (max_new - 1) / share);
-  const int issued = (int)(s->steps_issued - steps0);
+  const int issued = (int)(l.steps - steps0);                 // what making room already cost this lane
   if (stride > issued) OAVSR_TRY(sched_run(s, l, stride - issued));
   // admission: after the call's prefill; first token from the prefill's logits (step 0 of the row's own counter)
   OAVSR_CHECK_HIP(hipStreamWaitEvent(l.st, k.prefilled, 0));
