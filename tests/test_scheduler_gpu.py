@@ -206,3 +206,23 @@ def test_random_schedules_never_change_a_result(seed):
         got[j] = collect(eng, p, s)
     for i in range(len(calls)):
         assert got[i] == ref[i], f"seed {seed}: call {i} ({calls[i]['task']}, B={len(calls[i]['c'][2])}, max_new={calls[i]['mn']}) differs from the isolated call"
+
+
+def test_a_refused_call_leaves_the_scheduler_consistent():
+    """a call the engine refuses half way (unknown compression rate: KeyError like the reference's matry_map lookup, modeling_OmniAVSR.py:429) has
+    taken no slots and joined no lane; calls before and after it decode as if it had never been submitted"""
+    spec = tiny_spec(family="llama", task_specific=True, shared=True)
+    eng = OmniEngine(spec, dtype="bf16").load_state_dict(synth_state_dict(spec, seed=1234))
+    eng.sched_lanes = 1
+    mn = spec.max_dec_tokens
+    a, b = clips(8, 71), clips(6, 72)
+    ref = [alone(eng, a, mn, True), alone(eng, b, mn, True)]
+    s = torch.cuda.Stream()
+    p0 = submit(eng, a, mn, True, 0, s)
+    video, audio, Tv, Ts = clips(4, 73)
+    with pytest.raises(KeyError):
+        with torch.cuda.stream(s):
+            eng.submit("audiovisual", video, Tv, audio, Ts, 3, 2, max_new=mn, force_len=True, slot=0)       # rate 3 is not configured
+    p1 = submit(eng, b, mn, True, 0, s)
+    assert eng.scheduler_stats()["calls"] == 2
+    assert [collect(eng, p0, s), collect(eng, p1, s)] == ref
