@@ -185,7 +185,9 @@ def parse_args():
     ap.add_argument("--sched-stride", type=int, default=0, help="steps per admission (0 = automatic)")
     ap.add_argument("--sched-lanes", type=int, default=3, help="independent step loops of the scheduler")
     ap.add_argument("--no-stagger", action="store_true", help="let the encoder phases of in-flight batches share the chip (default: chained)")
-    ap.add_argument("--streams", type=int, default=3, help="batches in flight (one HIP stream + workspace each); 1 = strictly sequential calls")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="caller streams = batches whose encoder phases (and, without the scheduler, decode loops) may be in flight; default 3, "
+                         "4 for beam search; 1 = strictly sequential calls")
     return ap.parse_args()
 
 
@@ -287,6 +289,12 @@ def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
+    if args.streams is None:
+        args.streams = 4 if args.beams > 1 else 3
+    if args.beams > 1:
+        # beam search runs one decode chain per call on the call's own stream: four chains in flight need more than ROCm's default four
+        # hardware queues to advance independently (120.6 -> 133.6 utt/s with 8; the greedy scheduler path is best at the default)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -477,7 +477,14 @@ int launch_dma_mode(const GemmArgs& a, hipStream_t st) {
     static const int wide = [] { const char* e = getenv("OAVSR_GEMM_M128_WIDE"); return e ? atoi(e) : 1; }();
     if (wide && a.N >= 256 * 256 && a.ksplit <= 1) return launch_dma<T, A_DENSE, 128, 256, 3, 2, 8>(a, st);   // 8 waves (2 x 4) of 64 x 64: 0.5 B of A per byte of W
     if (a.N >= 256 * 128 && a.ksplit <= 1) return launch_dma<T, A_DENSE, 128, 128, 3, 2, 4>(a, st);   // 4 waves (2 x 2) of 64 x 64
-    return launch_dma<T, A_DENSE, 128, 64, 4, 4, 4>(a, st);     // 4 waves (4 x 1) of 32 x 64, 4 stages of 24 KiB
+    // 4 waves (4 x 1) of 32 x 64.  LDS stages of 24 KiB: 3 by default (72 KiB: two workgroups share a CU) -- with the whole k range of a
+    // split-K slice resident (4 stages, 96 KiB, one workgroup per CU) a launch is 8 % faster alone, but beam search keeps several decode
+    // chains in flight and what counts there is how many of their workgroups fit beside each other: 120.6 -> 125.1 utt/s (round 3).
+    // Same k order, same bits.  OAVSR_M128_STAGES=2|4 for A/B runs.
+    static const int m128_stages = [] { const char* e = getenv("OAVSR_M128_STAGES"); return e ? atoi(e) : 3; }();
+    if (m128_stages == 2) return launch_dma<T, A_DENSE, 128, 64, 2, 4, 4>(a, st);
+    if (m128_stages == 4) return launch_dma<T, A_DENSE, 128, 64, 4, 4, 4>(a, st);
+    return launch_dma<T, A_DENSE, 128, 64, 3, 4, 4>(a, st);
   }
   switch (a.amode) {
     case A_DENSE: return launch_dma<T, A_DENSE, 256, 128, 3, 4, 8>(a, st);
