@@ -43,6 +43,11 @@ struct GemmArgs {
   int swiglu_pairs = 0;
   // classic kernel only: split-K over blockIdx.y with fp32 partial slabs [ksplit][M][N] + deterministic reduce/epilogue kernel
   int ksplit = 1; float* partial = nullptr;
+  // Weight-streaming decode kernels at 17..32 rows: 1 = the launch shares the chip with other streams' MFMA-bound kernels (the decode
+  // scheduler's steps): fewer, wider workgroups -- 64-column tiles for the narrow projections, half as many persistent workgroups -- which
+  // fetch the activation rows less often and block fewer CUs.  Slower alone (step 1.55 -> 2.1 ms), faster beside the encoders (+3..4 % on the
+  // headline); never changes a bit (a column's k order and cross-wave sums do not depend on how many columns its workgroup owns).
+  int shared_chip = 0;
   // LDS-DMA kernels: order in which an XCD's contiguous range of workgroups walks the output tiles.  0: row-major (or column-major when
   // M < N); 1: blocks of 8 M-tiles x 4 N-tiles, so the 32 tiles an XCD's CUs work on at one time share 8 A panels and 4 W panels in
   // its L2 (12 panel fetches per k-step for 64 panel reads).  Speed only, never results.  Set by the launcher.

@@ -92,7 +92,8 @@ static const char* gemm_family(const GemmArgs& a, bool skinny) {
     const int mt = ceil_div(a.M, 16) <= 1 ? 1 : ceil_div(a.M, 16) <= 2 ? 2 : ceil_div(a.M, 16) <= 4 ? 4 : 8;
     const bool wide = a.N >= 8192;
     const int nt = a.swiglu_pairs ? (wide ? 4 : 2) : (mt <= 2 && wide ? 4 : 1);
-    if (skinny_uses_r16(a)) snprintf(buf, sizeof(buf), "skinny_r16_mt%d_nt%d%s%s_%s", mt, wide ? 4 : 2, a.norm_gain ? "_norm" : "", a.swiglu_pairs ? "_swiglu" : "", dt);
+    const int r16_nt = wide ? 4 : (a.shared_chip && mt == 2 && a.N >= 512) ? ((a.norm_gain || a.N < 1024) ? 4 : 8) : 2;      // launch_sk_t's choice
+    if (skinny_uses_r16(a)) snprintf(buf, sizeof(buf), "skinny_r16_mt%d_nt%d%s%s_%s", mt, r16_nt, a.norm_gain ? "_norm" : "", a.swiglu_pairs ? "_swiglu" : "", dt);
     else snprintf(buf, sizeof(buf), "skinny_mt%d_nt%d%s%s_%s", mt, nt, a.norm_gain ? "_norm" : "", a.swiglu_pairs ? "_swiglu" : "", dt);
     return buf;
   }
@@ -121,7 +122,11 @@ static int video_narrow_split() {
 }
 static void set_split(GemmArgs& g, const oavsr_workspace* ws, int ks);
 
-static int run_gemm(const GemmArgs& a, hipStream_t st, bool skinny = false) {
+static thread_local int g_shared_chip = 0;      // set by the decode scheduler around its steps: GemmArgs::shared_chip of the launches below
+
+static int run_gemm(const GemmArgs& a_, hipStream_t st, bool skinny = false) {
+  GemmArgs a = a_;
+  a.shared_chip = skinny ? g_shared_chip : 0;
   const double esz = a.dtype == DT_F32 ? 4 : 2;
   const double kk = (double)a.K + a.K2;
   const double flops = 2.0 * a.M * a.N * kk * a.groups;
@@ -1491,6 +1496,7 @@ static int lane_max_remaining(const oavsr_scheduler* s, const SchedLane& l) { in
 // one decode step over the R compact rows of the lane's current membership (every launch on the lane's stream; hipGraph-capturable)
 static int sched_one_step(oavsr_scheduler* s, SchedLane& l, int R, int task, int banned) {
   const oavsr_model* m = s->m; const oavsr_config& c = m->cfg; oavsr_workspace* w = l.dws;
+  struct Shared { Shared() { g_shared_chip = 1; } ~Shared() { g_shared_chip = 0; } } shared_chip_scope;      // the step runs beside other calls' encoder phases
   OAVSR_TRY(llm_layers(m, w, task, R, true, R, 1, s->max_prefix + s->max_new, s->ss.pos, s->ss.cpos, nullptr, nullptr, l.st, s->ss.rope_cs));
   OAVSR_TRY(lm_head_rows(m, w, w->lx, R, w->logits, l.st));
   { ProfScope ps("argmax_partial", 0, (double)R * c.llm_vocab * 4, l.st);

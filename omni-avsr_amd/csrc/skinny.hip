@@ -895,7 +895,11 @@ int launch_persist_r16(const GemmArgs& a, hipStream_t st) {
     const int load = c * ceil_div(ntiles, c * ncu);
     if (load < best) { best = load; per_cu = c; }
   }
-  const int grid = ntiles < per_cu * ncu ? ntiles : per_cu * ncu;
+  // shared chip (decode scheduler): half as many persistent workgroups; OAVSR_PERSIST_GRID_DIV overrides the divisor (A/B runs)
+  static const int grid_div = [] { const char* e = getenv("OAVSR_PERSIST_GRID_DIV"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : v; }();
+  int grid = ntiles < per_cu * ncu ? ntiles : per_cu * ncu;
+  const int div = grid_div > 0 ? grid_div : (a.shared_chip ? 2 : 1);
+  if (div > 1) grid = std::max(1, grid / div);
   auto kern = nsteps <= W * AS0 ? skinny_persist_r16_kernel<T, MT, NORM, AS0, W, SWIGLU> : skinny_persist_r16_kernel<T, MT, NORM, 2 * AS0, W, SWIGLU>;
   if (smem > 64 * 1024) {
     static bool attr_set[2] = {false, false};
@@ -1083,7 +1087,15 @@ int launch_sk_t(const GemmArgs& a, hipStream_t st) {
     }
     // narrow N: two 8-column tiles per workgroup (N / 16 workgroups, as many as the 16-column kernel launched, and the activation rows --
     // 2 - 4 x the weight bytes of a tile at these row counts -- are fetched once per 16 columns); each tile sums exactly as above
-    if (!a.swiglu_pairs && a.N >= 64 && a.N / 16 < 384) return mt <= 1 ? launch_r16<T, 1, 2, NORM, 4>(a, st) : launch_r16<T, 2, 2, NORM, 2>(a, st);
+    if (!a.swiglu_pairs && a.N >= 64 && a.N / 16 < 384) {
+      // shared chip (decode scheduler), 17..32 rows: eight (o_proj, down_proj) / four (QKV, with the fused norm's second LDS image) 8-column
+      // tiles per workgroup instead of two.  OAVSR_R16_NARROW_NT=2|4|8 forces a width (A/B runs).
+      static const int nt_force = [] { const char* e = getenv("OAVSR_R16_NARROW_NT"); return e ? atoi(e) : 0; }();
+      const int want = nt_force ? nt_force : (a.shared_chip ? 8 : 2);
+      if constexpr (!NORM) { if (want >= 8 && mt == 2 && a.N >= 1024) return launch_r16<T, 2, 8, NORM, 1>(a, st); }
+      if (want >= 4 && mt == 2 && a.N >= 512) return launch_r16<T, 2, 4, NORM, 2>(a, st);
+      return mt <= 1 ? launch_r16<T, 1, 2, NORM, 4>(a, st) : launch_r16<T, 2, 2, NORM, 2>(a, st);
+    }
   }
   if (a.swiglu_pairs) {
     OAVSR_REQUIRE(mt <= 2 && a.N % 32 == 0, "skinny gemm: fused SwiGLU needs M <= 32 and N %% 32 == 0");
