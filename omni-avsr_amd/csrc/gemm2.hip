@@ -420,12 +420,24 @@ int launch_dma(const GemmArgs& a, hipStream_t st) {
   return 0;
 }
 
+static bool small_tile_rule(const GemmArgs& a) {
+  static const int on = [] { const char* e = getenv("OAVSR_GEMM_SMALL"); return e ? atoi(e) : 1; }();
+  static const int force = [] { const char* e = getenv("OAVSR_GEMM_TILE"); return e ? atoi(e) : -1; }();
+  if (!on || force >= 0 || a.amode != A_DENSE || a.groups != 1 || a.ksplit > 1 || a.swiglu_pairs || a.N < 64 || a.M <= 128) return false;
+  return (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 128) < 144;
+}
+
 static int dma_tile_choice(const GemmArgs& a) {
   // 0: not eligible, 1: 256x128, 2: 256x256
   static const int force = [] { const char* e = getenv("OAVSR_GEMM_TILE"); return e ? atoi(e) : -1; }();
   // <= 128 rows (beam-search decode, tiny prefills): 128 x 64 tiles stream the weights with 4 x more workgroups per N
   if (a.amode == A_DENSE && a.groups == 1 && a.M <= 128 && a.M > 32 && a.N >= 64 && force < 0) return 4;
   if (a.ksplit > 1) return (a.amode == A_DENSE && a.groups == 1 && a.N >= 64) ? 1 : 0;   // independent of M on purpose
+  // Small dense GEMMs -- fewer than 144 tiles of 256 x 128: the LoRA down projections (N = 128 / 256), AV-HuBERT's out-projection, the
+  // projector layers -- on the 128 x 64 tile (4 waves, 3 LDS stages = 72 KiB: two workgroups per CU) WITHOUT split-K: 2-8 x the workgroups
+  // of the big tiles, no fp32 slabs, no reduce launch.  Round 2 ran them as 256 x 128 tiles with a static split (20-33 us at 40-200 TFLOP/s).
+  // The tile shape never changes a bit (same k order, same epilogue expressions); OAVSR_GEMM_SMALL=0 restores the old dispatch.
+  if (small_tile_rule(a)) return 4;
   if (a.amode == A_STEM || a.N < 128) return 0;
   const int64_t n128 = (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 128) * a.groups;
   const int64_t n256 = (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 256) * a.groups;
@@ -497,6 +509,7 @@ int launch_dma_mode(const GemmArgs& a, hipStream_t st) {
 }  // namespace
 
 bool gemm_dma_eligible(const GemmArgs& a) { return dma_tile_choice(a) != 0; }
+bool gemm_small_tile(const GemmArgs& a) { return small_tile_rule(a); }
 // fused SwiGLU epilogue (gate / up rows interleaved by 16): LDS-DMA kernels only, whole 32-row blocks, plain epilogue, 16-byte rows
 bool gemm_dma_swiglu_ok(const GemmArgs& a) {
   const int vec = a.dtype == DT_F32 ? 4 : 8;

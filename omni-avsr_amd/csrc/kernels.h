@@ -71,6 +71,7 @@ __host__ __device__ inline void blocked_tile(int bid, int ntm, int ntn, int& mt,
 int launch_gemm(const GemmArgs& a, hipStream_t st);
 // LDS-DMA pipelined 256x128 variant (gemm2.hip); launch_gemm dispatches to it when the grid fills the chip
 bool gemm_dma_eligible(const GemmArgs& a);
+bool gemm_small_tile(const GemmArgs& a);       // small dense GEMM: 128 x 64 tiles, no split-K (the caller then sets no split either)
 bool gemm_dma_swiglu_ok(const GemmArgs& a);
 const char* gemm_dma_variant(const GemmArgs& a);
 int launch_gemm_dma(const GemmArgs& a, hipStream_t st);

@@ -121,6 +121,7 @@ static int video_narrow_split() {
   return v;
 }
 static void set_split(GemmArgs& g, const oavsr_workspace* ws, int ks);
+static bool split_small_call_sites();
 
 static thread_local int g_shared_chip = 0;      // set by the decode scheduler around its steps: GemmArgs::shared_chip of the launches below
 
@@ -531,6 +532,13 @@ static int resolve_model(oavsr_model* m) {
 static void set_split(GemmArgs& g, const oavsr_workspace* ws, int ks) {
   if (ks > 1 && ws->partial && (size_t)ks * g.M * g.N * 4 <= ws->partial_bytes) { g.ksplit = ks; g.partial = ws->partial; }
 }
+// Round 3: the LoRA down projections and AV-HuBERT's out-projection are never split any more (a static property of the call site, like the
+// split factors: an utterance's bits must not depend on its batch) -- un-split they run on the 128 x 64 small-GEMM tile (gemm2.hip:
+// gemm_small_tile; the TILE may follow M, it never changes a bit).  OAVSR_GEMM_SMALL=0: the round-2 forms (split + 256 x 128 tiles).
+static bool split_small_call_sites() {
+  static const bool on = [] { const char* e = getenv("OAVSR_GEMM_SMALL"); return e && e[0] == '0'; }();
+  return on;
+}
 
 static int run_encoder_layers(const oavsr_model* m, oavsr_workspace* ws, const std::vector<EncLayer>& layers, int rows, int D,
                               int heads, int ffn, int lora_k2, const int* cu_dev, int n_seqs, int max_len, int narrow_split, hipStream_t st) {
@@ -543,7 +551,7 @@ static int run_encoder_layers(const oavsr_model* m, oavsr_workspace* ws, const s
     if (lora_k2 > 0) {   // t = h . [A_q; A_v]^T
       g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = lora_k2; g.K = D; g.A = ws->enc_h; g.lda = D; g.W = L.lora_dn; g.ldw = D;
       g.C = ws->enc_lora; g.ldc = lora_k2;
-      set_split(g, ws, lora_dn_split(D, (int)m->esz));
+      if (split_small_call_sites()) set_split(g, ws, lora_dn_split(D, (int)m->esz));
       OAVSR_TRY(run_gemm(g, st));
     }
     g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 3 * D; g.K = D; g.A = ws->enc_h; g.lda = D; g.W = L.qkvw; g.ldw = D;
@@ -559,7 +567,7 @@ static int run_encoder_layers(const oavsr_model* m, oavsr_workspace* ws, const s
       OAVSR_TRY(launch_attention(a, st)); }
     g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = D; g.K = D; g.A = ws->enc_attn; g.lda = D; g.W = L.ow; g.ldw = D; g.col_bias = L.ob;
     g.residual = ws->enc_x; g.ldr = D; g.C = ws->enc_x; g.ldc = D;
-    set_split(g, ws, narrow_split);
+    if (split_small_call_sites()) set_split(g, ws, narrow_split);
     OAVSR_TRY(run_gemm(g, st));
     { ProfScope ps("layernorm", 0, 2.0 * rows * D * m->esz, st);
       OAVSR_TRY(launch_layernorm(dt, ws->enc_x, D, ws->enc_h, D, L.ln2w, L.ln2b, rows, D, 1e-5f, st)); }
@@ -866,7 +874,7 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
       gl = GemmArgs(); gl.dtype = dt; gl.M = rows; gl.N = c.lora_k2; gl.K = d; gl.A = hin; gl.lda = d; gl.W = L.lora_dn[tl]; gl.ldw = d;
       gl.C = ws->llora; gl.ldc = c.lora_k2;
       if (fused_norm) { gl.norm_gain = L.ln1w; gl.norm_eps = c.llm_rms_eps; }
-      if (mode == 0) set_split(gl, ws, lora_dn_split(d, (int)m->esz));
+      if (mode == 0 && split_small_call_sites()) set_split(gl, ws, lora_dn_split(d, (int)m->esz));
     }
     g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = nqkv; g.K = d; g.A = hin; g.lda = d; g.W = L.qkvw; g.ldw = d; g.col_bias = L.qkvb;
     if (c.lora_k2 > 0) { g.A2 = ws->llora; g.lda2 = c.lora_k2; g.W2 = L.lora_up[tl]; g.ldw2 = c.lora_k2; g.K2 = c.lora_k2; }
