@@ -108,7 +108,7 @@ static const char* gemm_family(const GemmArgs& a, bool skinny) {
 // Split-K factors are STATIC per call site (functions of the layer's N and K, never of the row count), so that an utterance
 // gets the same bits whether it runs alone or inside a batch: the k-slices are summed in a fixed order by the reduce kernel.
 constexpr int kPrefillTailChunk = 8;    // rows per launch of the pruned last prefill layer / first lm_head (batch-independent kernels)
-constexpr int kVideoNarrowSplit = 2;   // AV-HuBERT out-proj / fc2: N = D leaves ~100 tiles for a batch of 8 x 400 frames
+constexpr int kVideoNarrowSplit = 2;   // AV-HuBERT fc2 under OAVSR_GEMM_SMALL=0 (round 2: N = D leaves ~100 tiles of 256 x 128 for a batch of 8 x 400 frames)
 constexpr int kLoraDnSplitMax = 8;     // LoRA down projections: N = k*r is one or two column tiles
 static int lora_dn_split(int K, int esz) {
   const int ktiles = K / (128 / esz);
@@ -576,7 +576,7 @@ static int run_encoder_layers(const oavsr_model* m, oavsr_workspace* ws, const s
     OAVSR_TRY(run_gemm(g, st));
     g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = D; g.K = ffn; g.A = ws->enc_ffn; g.lda = ffn; g.W = L.fc2w; g.ldw = ffn; g.col_bias = L.fc2b;
     g.residual = ws->enc_x; g.ldr = D; g.C = ws->enc_x; g.ldc = D;
-    set_split(g, ws, narrow_split);
+    if (split_small_call_sites()) set_split(g, ws, narrow_split);      // round 3: never split (small-GEMM tile while the grid is small, the big tiles beyond)
     OAVSR_TRY(run_gemm(g, st));
   }
   return 0;
