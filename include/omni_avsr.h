@@ -161,11 +161,15 @@ void oavsr_scheduler_destroy(oavsr_scheduler* s);
 uint64_t oavsr_scheduler_bytes(const oavsr_scheduler* s);
 /* oavsr_generate(beams = 1) split in two: submit queues encoders + prefill on `stream` (workspace ws, as oavsr_generate) and the
  * admission of the B rows on the scheduler's stream; it returns a ticket.  out_ids_dev / out_len_dev ([B][max_new] / [B] int32) are
- * written by the scheduler's stream when the call's last step has run and must stay valid until oavsr_generate_wait. */
+ * written by the scheduler's stream when the call's last step has run and must stay valid until oavsr_generate_wait.
+ * out_ids_host / out_len_host (optional, PINNED host memory of the same shapes): filled on the scheduler's stream right after the device
+ * buffers, before the call counts as done -- once oavsr_generate_poll returns 1 the host can read them without touching any stream (a caller
+ * loop that fetches every result through a stream of its own pays for it: on ROCm the enqueue can block the host behind another stream that
+ * shares the hardware queue). */
 int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_workspace* ws, int32_t task, const void* video_dev,
                           const int32_t* Tv_host, const float* wav_dev, int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host,
                           int32_t B, int32_t rate_audio, int32_t rate_video, int32_t max_new, int32_t force_len, int32_t* out_ids_dev,
-                          int32_t* out_len_dev, oavsr_stream stream, int64_t* ticket_out);
+                          int32_t* out_len_dev, int32_t* out_ids_host, int32_t* out_len_host, oavsr_stream stream, int64_t* ticket_out);
 /* Issues whatever steps the call still needs (other admitted rows ride along) and makes `stream` wait for its results: work queued on
  * `stream` afterwards sees out_ids_dev / out_len_dev.  No host synchronisation. */
 int oavsr_generate_wait(oavsr_scheduler* s, int64_t ticket, oavsr_stream stream);

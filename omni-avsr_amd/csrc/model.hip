@@ -275,6 +275,7 @@ struct SchedCall {
   int64_t ticket = -1;
   int task = 0, B = 0, slot0 = 0, limit = 0, remaining = 0, banned = -1, lane = 0;
   int32_t *out_ids = nullptr, *out_len = nullptr;
+  int32_t *host_ids = nullptr, *host_len = nullptr;     // optional pinned host copies, filled on the lane's stream right after the device ones
   hipEvent_t prefilled = nullptr, done = nullptr;
   bool retired = true;
 };
@@ -1532,6 +1533,8 @@ static int sched_sync_membership(oavsr_scheduler* s, SchedLane& l) {
 static int sched_retire(oavsr_scheduler* s, SchedLane& l, int idx) {
   SchedCall& k = s->ring[idx];
   OAVSR_TRY(launch_sched_retire(s->ss, k.slot0, k.B, k.limit, k.out_ids, k.out_len, l.st));
+  if (k.host_ids) OAVSR_CHECK_HIP(hipMemcpyAsync(k.host_ids, k.out_ids, sizeof(int32_t) * k.B * k.limit, hipMemcpyDeviceToHost, l.st));
+  if (k.host_len) OAVSR_CHECK_HIP(hipMemcpyAsync(k.host_len, k.out_len, sizeof(int32_t) * k.B, hipMemcpyDeviceToHost, l.st));
   OAVSR_CHECK_HIP(hipEventRecord(k.done, l.st));
   ++s->free_seq;
   for (int b = 0; b < k.B; ++b) { s->slot_used[k.slot0 + b] = 0; s->slot_freed_at[k.slot0 + b] = s->free_seq; }
@@ -1684,8 +1687,8 @@ uint64_t oavsr_scheduler_bytes(const oavsr_scheduler* s) { return s ? s->arena_b
 
 int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_workspace* ws, int32_t task, const void* video_dev, const int32_t* Tv_host,
                           const float* wav_dev, int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host, int32_t B, int32_t rate_audio,
-                          int32_t rate_video, int32_t max_new, int32_t force_len, int32_t* out_ids_dev, int32_t* out_len_dev, oavsr_stream stream,
-                          int64_t* ticket_out) {
+                          int32_t rate_video, int32_t max_new, int32_t force_len, int32_t* out_ids_dev, int32_t* out_len_dev, int32_t* out_ids_host,
+                          int32_t* out_len_host, oavsr_stream stream, int64_t* ticket_out) {
   OAVSR_REQUIRE(m && s && ws && out_ids_dev && out_len_dev && ticket_out, "generate_submit: null argument");
   OAVSR_REQUIRE(s->m == m && ws->m == m, "generate_submit: scheduler / workspace belong to another model");
   OAVSR_REQUIRE(task >= 0 && task < 3, "generate_submit: bad task %d", task);
@@ -1747,7 +1750,7 @@ int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_worksp
   for (int b = 0; b < B; ++b) { s->slot_used[slot0 + b] = 1; s->slot_owner[slot0 + b] = ticket; }
   ++s->next_ticket; ++s->calls;
   k.ticket = ticket; k.task = ltask; k.B = B; k.slot0 = slot0; k.limit = max_new; k.remaining = max_new - 1; k.banned = banned; k.lane = li;
-  k.out_ids = out_ids_dev; k.out_len = out_len_dev; k.retired = false;
+  k.out_ids = out_ids_dev; k.out_len = out_len_dev; k.host_ids = out_ids_host; k.host_len = out_len_host; k.retired = false;
   // pacing: the lane advances 1/k of a hypothesis per admission (k = calls of this size that share a step), beside this call's MFMA-bound phase
   static const int stride_env = [] { const char* e = getenv("OAVSR_SCHED_STRIDE"); return e ? atoi(e) : 0; }();
   const int share = std::max(1, s->max_rows / B);

@@ -109,7 +109,7 @@ SYMBOLS = {
     "oavsr_scheduler_create": (C.c_int, [_P, _I, _I, _I, _I, _I, C.POINTER(_P)]),
     "oavsr_scheduler_destroy": (None, [_P]),
     "oavsr_scheduler_bytes": (C.c_uint64, [_P]),
-    "oavsr_generate_submit": (C.c_int, [_P, _P, _P, _I, _P, C.POINTER(_I), _P, _L, C.POINTER(_I), C.POINTER(_I), _I, _I, _I, _I, _I, _P, _P, _P, C.POINTER(_L)]),
+    "oavsr_generate_submit": (C.c_int, [_P, _P, _P, _I, _P, C.POINTER(_I), _P, _L, C.POINTER(_I), C.POINTER(_I), _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, C.POINTER(_L)]),
     "oavsr_generate_wait": (C.c_int, [_P, _L, _P]),
     "oavsr_generate_poll": (C.c_int, [_P, _L]),
     "oavsr_scheduler_flush": (C.c_int, [_P]),

@@ -351,6 +351,7 @@ class OmniEngine:
             self._stride_set = self.sched_stride
         ids = torch.empty(B, max_new, dtype=torch.int32, device=self.device)
         lens = torch.empty(B, dtype=torch.int32, device=self.device)
+        host = torch.empty(B * (max_new + 1), dtype=torch.int32, pin_memory=True)      # [ids | lens], filled by the scheduler's stream when the call leaves
         ticket = C.c_int64(-1)
         L.check(self.lib.oavsr_generate_submit(
             self._model, self._sched, ws, L.TASK_ID[task],
@@ -358,12 +359,13 @@ class OmniEngine:
             C.c_void_p(a.data_ptr()) if use_a else None, a.stride(0) if use_a else 0,
             _i32arr(lengths) if use_a else None, _i32arr(keep) if use_a else None,
             B, int(rate_a or 1), int(rate_v or 1), max_new, int(force_len),
-            C.c_void_p(ids.data_ptr()), C.c_void_p(lens.data_ptr()), self._stream(), C.byref(ticket)))
+            C.c_void_p(ids.data_ptr()), C.c_void_p(lens.data_ptr()), C.c_void_p(host.data_ptr()), C.c_void_p(host.data_ptr() + 4 * B * max_new),
+            self._stream(), C.byref(ticket)))
         self._keepalive = getattr(self, "_keepalive", {})
         self._keepalive[("s", slot)] = (flat, a)
         self._inflight = getattr(self, "_inflight", {})
         tk = (self._sched_gen, ticket.value)
-        self._inflight[tk] = (ids, lens)                 # the scheduler writes them when the call's last step has run
+        self._inflight[tk] = (ids, lens, host)           # the scheduler writes them when the call's last step has run
         return ids, lens, tk
 
     def wait(self, ticket):
@@ -372,6 +374,11 @@ class OmniEngine:
         if gen == self._sched_gen and self._sched:       # (a pool of an earlier generation was flushed and synchronised before it was rebuilt)
             L.check(self.lib.oavsr_generate_wait(self._sched, int(t), self._stream()))
         getattr(self, "_inflight", {}).pop(ticket, None)
+
+    def host_result(self, ticket):
+        """The pinned host copy [B, max_new + 1] view material of a submitted call (ids then lens), valid once `poll(ticket)` is True."""
+        ent = getattr(self, "_inflight", {}).get(ticket)
+        return ent[2] if ent is not None and len(ent) > 2 else None
 
     def result_stream(self) -> "torch.cuda.Stream":
         """Side stream on which results of scheduled calls are awaited and copied to the host (PendingIds)."""
@@ -459,8 +466,8 @@ class PendingIds:
     def ready(self) -> bool:
         """Like done(), but never makes the engine issue decode steps on this call's behalf: True only once the steps that later
         submissions (or waits) issued have completed it.  Collecting only what is ready keeps the scheduler's steps full."""
-        if self._event is None and not self._engine.poll(self._ticket):
-            return False
+        if self._event is None and self._ticket is not None:
+            return self._engine.poll(self._ticket)           # complete incl. the pinned host copy: result(host=True) touches no stream
         return self.done()
 
     def result(self, host: bool = False) -> torch.Tensor:
@@ -468,9 +475,17 @@ class PendingIds:
         (`host=True`: what `tokenizer.batch_decode` needs anyway).  Both go through ONE small copy into pinned memory: a device-to-host copy
         into pageable memory takes ~10 ms on this platform while other streams are busy copying and computing (measured: two `.cpu()` calls
         per batch were 21 of the caller loop's 36 ms)."""
+        B, W = self._ids.shape
+        if host and self._ticket is not None and self._event is None and self._engine.poll(self._ticket):
+            # the scheduler's stream has already put ids and lengths into the call's pinned host buffer: no stream is touched at all
+            flat = self._engine.host_result(self._ticket)
+            if flat is not None:
+                n = int(flat[B * W:].max())
+                out = flat[: B * W].view(B, W)[:, :n].to(torch.long)
+                self._engine._inflight.pop(self._ticket, None)
+                return out
         self._settle()
         self._event.synchronize()
-        B, W = self._ids.shape
         buf = torch.empty(B, W + 1, dtype=torch.int32, pin_memory=True)
         with torch.cuda.stream(self._stream):                # the tensors belong to that stream's allocator pool
             buf[:, :W].copy_(self._ids, non_blocking=True)
