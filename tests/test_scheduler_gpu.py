@@ -226,3 +226,36 @@ def test_a_refused_call_leaves_the_scheduler_consistent():
     p1 = submit(eng, b, mn, True, 0, s)
     assert eng.scheduler_stats()["calls"] == 2
     assert [collect(eng, p0, s), collect(eng, p1, s)] == ref
+
+
+def test_poll_never_forces_and_pinned_host_results_and_trace():
+    """oavsr_generate_poll: 0 while steps are still to be issued (it issues none), 1 once later submissions / a flush have completed the call --
+    and then the PINNED host buffers the scheduler's stream filled hold exactly the device results.  oavsr_scheduler_trace: one record per
+    call phase and per burst of steps, times ordered and non-negative."""
+    spec = tiny_spec(family="llama", task_specific=True, shared=True)
+    eng = OmniEngine(spec, dtype="bf16").load_state_dict(synth_state_dict(spec, seed=1234))
+    eng.sched_lanes = 1
+    mn = spec.max_dec_tokens
+    s = torch.cuda.Stream()
+    c0 = clips(8, 81)
+    p0 = submit(eng, c0, mn, True, 0, s)
+    torch.cuda.synchronize()
+    assert eng.poll(p0[2]) is False, "a call alone in its lane cannot be complete: nobody has issued its steps yet"
+    steps_before = eng.scheduler_stats()["steps"]
+    assert eng.poll(p0[2]) is False and eng.scheduler_stats()["steps"] == steps_before, "poll must not issue steps"
+    eng.scheduler_trace(True)
+    pend = [submit(eng, clips(8, 82 + i), mn, True, 0, s) for i in range(4)]        # their admissions issue p0's remaining steps
+    eng.flush()
+    torch.cuda.synchronize()
+    assert eng.poll(p0[2]) is True
+    host = eng.host_result(p0[2])
+    ids, lens = p0[0].cpu(), p0[1].cpu()
+    assert torch.equal(host[: 8 * mn].view(8, mn), ids) and torch.equal(host[8 * mn:], lens)
+    assert (ids.tolist(), lens.tolist()) == alone(eng, c0, mn, True)
+    recs = eng.scheduler_trace_read()
+    eng.scheduler_trace(False)
+    phases, bursts = [r for r in recs if r["kind"] == 0], [r for r in recs if r["kind"] == 1]
+    assert len(phases) == 4 and len(bursts) >= 2 and sum(r["steps"] for r in bursts) >= mn - 1
+    assert all(0 <= r["t0"] <= r["t1"] for r in recs), recs
+    for p in pend:
+        collect(eng, p, s)
