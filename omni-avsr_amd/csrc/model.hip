@@ -92,7 +92,7 @@ static const char* gemm_family(const GemmArgs& a, bool skinny) {
     const int mt = ceil_div(a.M, 16) <= 1 ? 1 : ceil_div(a.M, 16) <= 2 ? 2 : ceil_div(a.M, 16) <= 4 ? 4 : 8;
     const bool wide = a.N >= 8192;
     const int nt = a.swiglu_pairs ? (wide ? 4 : 2) : (mt <= 2 && wide ? 4 : 1);
-    const int r16_nt = wide ? 4 : (a.shared_chip && mt == 2 && a.N >= 512) ? ((a.norm_gain || a.N < 1024) ? 4 : 8) : 2;      // launch_sk_t's choice
+    const int r16_nt = wide ? 4 : (a.shared_chip && mt == 2 && a.N >= (a.norm_gain ? 2048 : 512)) ? ((a.norm_gain || a.N < 1024) ? 4 : 8) : 2;      // launch_sk_t's choice
     if (skinny_uses_r16(a)) snprintf(buf, sizeof(buf), "skinny_r16_mt%d_nt%d%s%s_%s", mt, r16_nt, a.norm_gain ? "_norm" : "", a.swiglu_pairs ? "_swiglu" : "", dt);
     else snprintf(buf, sizeof(buf), "skinny_mt%d_nt%d%s%s_%s", mt, nt, a.norm_gain ? "_norm" : "", a.swiglu_pairs ? "_swiglu" : "", dt);
     return buf;

@@ -1093,7 +1093,7 @@ int launch_sk_t(const GemmArgs& a, hipStream_t st) {
       static const int nt_force = [] { const char* e = getenv("OAVSR_R16_NARROW_NT"); return e ? atoi(e) : 0; }();
       const int want = nt_force ? nt_force : (a.shared_chip ? 8 : 2);
       if constexpr (!NORM) { if (want >= 8 && mt == 2 && a.N >= 1024) return launch_r16<T, 2, 8, NORM, 1>(a, st); }
-      if (want >= 4 && mt == 2 && a.N >= 512) return launch_r16<T, 2, 4, NORM, 2>(a, st);
+      if (want >= 4 && mt == 2 && a.N >= (NORM ? 2048 : 512)) return launch_r16<T, 2, 4, NORM, 2>(a, st);      // (the LoRA down projection, N <= 512, keeps its 16 - 32 workgroups)
       return mt <= 1 ? launch_r16<T, 1, 2, NORM, 4>(a, st) : launch_r16<T, 2, 2, NORM, 2>(a, st);
     }
   }
