@@ -392,8 +392,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    host_s = 0.0
     for _ in range(args.steps * (calls // G)):       # one call = G batches of B when --decode-group G
+        th = time.perf_counter()
         ids, lens = call(ncall)
+        host_s += time.perf_counter() - th            # host time inside the call (launches; includes waiting for queue / staging space)
         ncall += 1
     drain()
     n_last = B * G
@@ -551,6 +554,7 @@ def main():
                                    + f", BASELINE.json configs[{pre['idx']}]" + ("" if args.preset == "c1" and not args.llm else " (NOT the headline configuration)"),
                        "batch_per_call": B, "calls_per_step": calls, "ms_per_call": round(elapsed / (args.steps * calls) * 1e3, 3),
                        "global_batch": world * B * calls, "input_sets": nsets, "timed_s": round(elapsed, 2),
+                       "host_ms_per_call": round(host_s / (args.steps * (calls // G)) * 1e3, 3),
                        "parallelism": f"utterance-sharded dp{world}", "gathered_hypotheses": len(hyp), "dist_backend": (dist.get_backend() if use_dist else None),
                        "streams_per_gpu": nstream, "decode_group": G, "setup_s": round(setup_s, 1),
                        "decode_scheduler": (dict(rows_per_step_cap=args.sched_rows, slots=args.sched_slots, lanes=args.sched_lanes, **dsched) if use_sched else None)},
