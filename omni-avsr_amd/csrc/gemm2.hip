@@ -424,7 +424,8 @@ static bool small_tile_rule(const GemmArgs& a) {
   static const int on = [] { const char* e = getenv("OAVSR_GEMM_SMALL"); return e ? atoi(e) : 1; }();
   static const int force = [] { const char* e = getenv("OAVSR_GEMM_TILE"); return e ? atoi(e) : -1; }();
   if (!on || force >= 0 || a.amode != A_DENSE || a.groups != 1 || a.ksplit > 1 || a.swiglu_pairs || a.N < 64 || a.M <= 128) return false;
-  return (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 128) < 144;
+  static const int max_tiles = [] { const char* e = getenv("OAVSR_GEMM_SMALL_TILES"); return e ? atoi(e) : 144; }();      // A/B runs
+  return (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 128) < max_tiles;
 }
 
 static int dma_tile_choice(const GemmArgs& a) {
