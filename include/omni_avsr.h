@@ -184,7 +184,7 @@ int oavsr_scheduler_flush(oavsr_scheduler* s);
 int oavsr_scheduler_set_stride(oavsr_scheduler* s, int32_t steps);
 /* Schedule trace: while on, every submitted call's encoder + prefill phase (on the caller's stream) and every burst of steps a lane issues
  * are bracketed by timing events; _read waits for the device and returns the records in issue order, times in ms relative to the first
- * record's start.  kind 0: a call's phase (id = ticket, rows = B); kind 1: a burst (id = lane, steps, rows = live rows).  Diagnostics
+ * record's start (at most 65 536 records per session; later ones are dropped).  kind 0: a call's phase (id = ticket, rows = B); kind 1: a burst (id = lane, steps, rows = live rows).  Diagnostics
  * (bench.py's `schedule` object): a kernel trace cannot show this overlap because rocprofv3 takes the hardware queues in turn. */
 typedef struct oavsr_trace_rec {
   int32_t kind, id, steps, rows;

@@ -323,7 +323,9 @@ struct oavsr_scheduler {
     if (!trace_pool.empty()) { hipEvent_t e = trace_pool.back(); trace_pool.pop_back(); return e; }
     hipEvent_t e = nullptr; hipEventCreate(&e); return e;
   }
-  std::mutex mu;
+  static constexpr size_t kTraceMax = 1 << 16;           // records kept per trace session (two events each); later ones are dropped
+  bool tracing() const { return trace && trace_recs.size() < kTraceMax; }
+  mutable std::mutex mu;
 };
 
 namespace oavsr {
@@ -1554,7 +1556,7 @@ static int sched_run(oavsr_scheduler* s, SchedLane& l, int n) {
     const int task = head.task, banned = head.banned, R = l.cur_R;
     int done = 0;
     hipEvent_t tr0 = nullptr;
-    if (s->trace) { tr0 = s->trace_event(); hipEventRecord(tr0, l.st); }
+    if (s->tracing()) { tr0 = s->trace_event(); hipEventRecord(tr0, l.st); }
     if (graphs_on && !g_prof.on) {
       const DecodeGraphKey key{R, task, 0, banned};
       hipGraphExec_t exec = nullptr;
@@ -1653,12 +1655,23 @@ int oavsr_scheduler_create(const oavsr_model* m, int32_t n_slots, int32_t max_ro
   s->slot_owner.assign(n_slots, -1); s->slot_used.assign(n_slots, 0); s->slot_freed_at.assign(n_slots, 0);
   s->ring.resize(oavsr_scheduler::kRing);
   static const int prio = [] { const char* e2 = getenv("OAVSR_SCHED_PRIORITY"); return e2 ? atoi(e2) : 0; }();     // developer switch: < 0 = above the callers' streams
+  static const int lane_cus = [] { const char* e2 = getenv("OAVSR_SCHED_CUS"); return e2 ? atoi(e2) : 0; }();
+  static const int lane_cu_offset = [] { const char* e2 = getenv("OAVSR_SCHED_CU_OFFSET"); return e2 ? atoi(e2) : 0; }();
   for (auto& l : s->lanes) {
     oavsr_workspace* lw = l.dws;      // the lane's view: its own scratch, the shared pool
     lw->m = m; lw->max_B = n_slots; lw->max_beams = 1; lw->max_new = max_new; lw->max_prefix = s->max_prefix;
     lw->kpre = w->kpre; lw->vpre = w->vpre; lw->ktail = w->ktail; lw->vtail = w->vtail; lw->kpre_layer = w->kpre_layer; lw->ktail_layer = w->ktail_layer;
     lw->prefix_len = w->prefix_len; lw->rowmap = l.rowmap;
-    if ((prio ? hipStreamCreateWithPriority(&l.st, hipStreamNonBlocking, prio) : hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking)) != hipSuccess) {
+    hipError_t se;
+    if (lane_cus > 0) {                // developer switch: the lane's kernels may only occupy `lane_cus` CUs (mask bit i -> XCD i % 8, so a dense range spreads over the XCDs)
+      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      const int first = (int)(&l - s->lanes.data()) * lane_cu_offset;
+      for (int b = 0; b < std::min(lane_cus, 256); ++b) { const int bit = (first + b) % 256; mask[bit / 32] |= 1u << (bit % 32); }
+      se = hipExtStreamCreateWithCUMask(&l.st, 8, mask);
+    } else {
+      se = prio ? hipStreamCreateWithPriority(&l.st, hipStreamNonBlocking, prio) : hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking);
+    }
+    if (se != hipSuccess) {
       l.st = nullptr;
       return fail("stream creation failed");
     }
@@ -1720,6 +1733,7 @@ int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_worksp
   OAVSR_REQUIRE(slot0 >= 0, "generate_submit: no block of %d free row slots (pool of %d)", B, s->n_slots);
   SchedCall& k = s->ring[ticket % oavsr_scheduler::kRing];
   OAVSR_REQUIRE(k.retired, "generate_submit: %d calls in flight", oavsr_scheduler::kRing);
+  if (k.done && k.ticket >= 0) OAVSR_CHECK_HIP(hipEventSynchronize(k.done));      // kRing tickets ago: long complete; makes "ticket expired => its device work is over" exact
   if (!k.prefilled) OAVSR_CHECK_HIP(hipEventCreateWithFlags(&k.prefilled, hipEventDisableTiming));
   if (!k.done) OAVSR_CHECK_HIP(hipEventCreateWithFlags(&k.done, hipEventDisableTiming));
   // the slots' previous owners must have left (their last step is already in their lane's queue) before this call's prefill writes there
@@ -1733,7 +1747,7 @@ int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_worksp
     } }
   std::vector<int> S(B);
   hipEvent_t tr0 = nullptr;
-  if (s->trace) { tr0 = s->trace_event(); hipEventRecord(tr0, st); }
+  if (s->tracing()) { tr0 = s->trace_event(); hipEventRecord(tr0, st); }
   { CallScope cs(ws, st);
     PrefillDest dest{s->pool->kpre, s->pool->vpre, s->pool->kpre_layer, s->max_prefix, s->logits_pre, s->pool->prefix_len, slot0};
     const int rc = encode_prefill(m, ws, task, video_dev, Tv_host, wav_dev, wav_ld, Ts_host, keep_host, B, B, rate_audio, rate_video, st, &dest, S.data());
@@ -1840,6 +1854,7 @@ int oavsr_scheduler_trace_read(oavsr_scheduler* s, oavsr_trace_rec* out, int32_t
 
 int oavsr_scheduler_stats(const oavsr_scheduler* s, uint64_t* out4) {
   OAVSR_REQUIRE(s && out4, "scheduler_stats: null argument");
+  std::lock_guard<std::mutex> lk(s->mu);
   uint64_t g = 0;
   for (auto& l : s->lanes) g += l.graphs.size();
   out4[0] = s->steps_issued; out4[1] = s->row_steps; out4[2] = s->calls; out4[3] = g;
