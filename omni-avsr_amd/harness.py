@@ -301,7 +301,13 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
 
     eng = model.engine
     dev = eng.device
-    streams = [torch.cuda.Stream(device=dev) for _ in range(in_flight)]
+    # The slots' streams and the copy stream are kept on the engine between evaluate() calls: the runtime maps every stream onto one of a few
+    # hardware queues when it is created, and which caller stream shares a queue with which decode lane decides how the encoder phases and
+    # the decode bursts interleave ("Why lanes") -- fresh streams per call made the same loop run at 256 or at 228 utt/s.
+    scache = eng.__dict__.setdefault("_eval_streams", {})
+    if in_flight not in scache:
+        scache[in_flight] = ([torch.cuda.Stream(device=dev) for _ in range(in_flight)], torch.cuda.Stream(device=dev))
+    streams, copy_stream = scache[in_flight]
     # one workspace per slot, sized for the longest owned clip: nothing is re-created while other slots are busy
     tv_max = max([int(samples[i][0][vkey(samples[i][0])].shape[0]) for i in owned if vkey(samples[i][0]) in samples[i][0]] or [1])
     u8_shape = tuple(samples[owned[0]][0]["video_u8"].shape[1:]) if owned and "video_u8" in samples[owned[0]][0] else None
@@ -331,7 +337,7 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
     consumed = [None] * nset                                  # event after the last call that read staging set k
     pool = ThreadPoolExecutor(depth)
 
-    copy_stream = torch.cuda.Stream(device=dev)               # uploads run ahead of the calls, on a stream of their own (issued by the helper threads)
+    # uploads run ahead of the calls, on a stream of their own (copy_stream; issued by the helper threads)
 
     def collate(n):
         k = n % nset
