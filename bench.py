@@ -185,6 +185,8 @@ def parse_args():
     ap.add_argument("--sched-stride", type=int, default=0, help="steps per admission (0 = automatic)")
     ap.add_argument("--sched-lanes", type=int, default=3, help="independent step loops of the scheduler")
     ap.add_argument("--no-stagger", action="store_true", help="let the encoder phases of in-flight batches share the chip (default: chained)")
+    ap.add_argument("--prime-streams", action="store_true",
+                    help="developer switch: run one operation on every caller stream before the first call (binds their hardware queues before the scheduler's lanes get theirs)")
     ap.add_argument("--streams", type=int, default=None,
                     help="caller streams = batches whose encoder phases (and, without the scheduler, decode loops) may be in flight; default 3, "
                          "4 for beam search; 1 = strictly sequential calls")
@@ -382,6 +384,11 @@ def main():
             pending.clear()
         torch.cuda.synchronize()
 
+    if args.prime_streams:
+        for st_ in streams:
+            with torch.cuda.stream(st_):
+                torch.zeros(1, device=dev)
+        torch.cuda.synchronize()
     ncall = 0
     torch.cuda.synchronize()
     for _ in range(max(args.warmup * (calls // G), nstream, nsets * len(pre["rates"]))):

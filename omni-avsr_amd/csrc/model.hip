@@ -317,6 +317,7 @@ struct oavsr_scheduler {
   // burst of steps a lane issues -- the only way to SEE the overlap (rocprofv3's kernel trace takes the queues in turn)
   struct TraceRec { int kind, id, steps, rows; hipEvent_t e0, e1; };
   bool trace = false;
+  std::vector<hipStream_t> placeholders;       // developer switch OAVSR_SCHED_LANE_SKIP
   std::vector<TraceRec> trace_recs;
   std::vector<hipEvent_t> trace_pool;
   hipEvent_t trace_event() {
@@ -1655,6 +1656,12 @@ int oavsr_scheduler_create(const oavsr_model* m, int32_t n_slots, int32_t max_ro
   s->slot_owner.assign(n_slots, -1); s->slot_used.assign(n_slots, 0); s->slot_freed_at.assign(n_slots, 0);
   s->ring.resize(oavsr_scheduler::kRing);
   static const int prio = [] { const char* e2 = getenv("OAVSR_SCHED_PRIORITY"); return e2 ? atoi(e2) : 0; }();     // developer switch: < 0 = above the callers' streams
+  static const int eager_queues = [] { const char* e2 = getenv("OAVSR_SCHED_EAGER_QUEUES"); return e2 ? atoi(e2) : 0; }();
+  auto lane_skip = [](int i) {                    // OAVSR_SCHED_LANE_SKIP="a,b,c": placeholder streams in front of lane 0, 1, 2
+    const char* e2 = getenv("OAVSR_SCHED_LANE_SKIP");
+    for (int k = 0; e2; ++k) { if (k == i) return atoi(e2); e2 = strchr(e2, ','); if (e2) ++e2; }
+    return 0;
+  };
   static const int lane_cus = [] { const char* e2 = getenv("OAVSR_SCHED_CUS"); return e2 ? atoi(e2) : 0; }();
   static const int lane_cu_offset = [] { const char* e2 = getenv("OAVSR_SCHED_CU_OFFSET"); return e2 ? atoi(e2) : 0; }();
   for (auto& l : s->lanes) {
@@ -1663,6 +1670,13 @@ int oavsr_scheduler_create(const oavsr_model* m, int32_t n_slots, int32_t max_ro
     lw->kpre = w->kpre; lw->vpre = w->vpre; lw->ktail = w->ktail; lw->vtail = w->vtail; lw->kpre_layer = w->kpre_layer; lw->ktail_layer = w->ktail_layer;
     lw->prefix_len = w->prefix_len; lw->rowmap = l.rowmap;
     hipError_t se;
+    // developer switch: placeholder streams created (and bound to a hardware queue by a first operation) in front of lane i shift the queue the
+    // lane lands on; OAVSR_SCHED_EAGER_QUEUES=1 binds the lanes' queues here instead of at their first step ("Why lanes")
+    { const int li = (int)(&l - s->lanes.data());
+      for (int j = 0; j < lane_skip(li); ++j) {
+        hipStream_t ph = nullptr;
+        if (hipStreamCreateWithFlags(&ph, hipStreamNonBlocking) == hipSuccess) { (void)hipMemsetAsync(s->arena, 0, 4, ph); (void)hipStreamSynchronize(ph); s->placeholders.push_back(ph); }
+      } }
     if (lane_cus > 0) {                // developer switch: the lane's kernels may only occupy `lane_cus` CUs (mask bit i -> XCD i % 8, so a dense range spreads over the XCDs)
       uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       const int first = (int)(&l - s->lanes.data()) * lane_cu_offset;
@@ -1675,6 +1689,7 @@ int oavsr_scheduler_create(const oavsr_model* m, int32_t n_slots, int32_t max_ro
       l.st = nullptr;
       return fail("stream creation failed");
     }
+    if (eager_queues) { (void)hipMemsetAsync(s->arena, 0, 4, l.st); (void)hipStreamSynchronize(l.st); }
   }
   if (hipDeviceSynchronize() != hipSuccess) return fail("device synchronisation failed");
   *out = s;
@@ -1689,6 +1704,7 @@ void oavsr_scheduler_destroy(oavsr_scheduler* s) {
     if (l.st) hipStreamDestroy(l.st);
     delete l.dws;
   }
+  for (auto ph : s->placeholders) hipStreamDestroy(ph);
   for (auto& k : s->ring) { if (k.prefilled) hipEventDestroy(k.prefilled); if (k.done) hipEventDestroy(k.done); }
   for (auto& r : s->trace_recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   for (auto e : s->trace_pool) hipEventDestroy(e);
