@@ -810,8 +810,10 @@ static int build_prompt_impl(const oavsr_model* m, oavsr_workspace* ws, int task
 // ------------------------------------------------------------------------------------------------
 // GEMM dispatch of the LLM stack: prefill rows -> tiled MFMA GEMM; decode with <= 32 rows -> weight-streaming skinny kernel
 // (RMSNorm / SwiGLU fused); decode with more rows (beam search: B*K) -> 128-row tiles with split-K so every CU streams weights.
-// Split-K factor of the 33+-row decode GEMMs (128 x 64 weight-streaming tiles, gemm2.hip): enough k-slices that N / 64 column
-// tiles x slices fill the 256 CUs.  A function of N and K ONLY (one M-tile's worth of column tiles), never of the row count, so
+// Split-K factor of the 33+-row decode GEMMs (128 x 64 weight-streaming tiles, gemm2.hip): k-slices so that N / 64 column tiles x slices
+// give ~128 workgroups (rounds 1-2: 256, one per CU; beam search keeps four decode chains in flight beside the encoder phases, and there
+// half as many workgroups of twice the k range -- half the fp32 slabs for the reduce pass -- are worth 134 -> 138 utt/s; 64: 137, 512:
+// 125).  A function of N and K ONLY (one M-tile's worth of column tiles), never of the row count, so
 // a row's fp32 summation order does not depend on how many other rows share the launch.
 // rows up to which decode GEMMs run on the weight-streaming kernels (mode 1); above: tiled split-K (mode 2).  (Round 3: the 16-column
 // weight-streaming kernels at 33..128 rows were measured on the beam-15 path -- 120 rows -- and lose: 59 vs 82 utt/s sequentially.)
@@ -819,7 +821,8 @@ static constexpr int skinny_max_rows() { return 32; }
 
 static int decode_split(int N, int Ktot, int esz) {
   const int ktiles = Ktot / (128 / esz);
-  int ks = 256 / std::max(1, ceil_div(N, 64));
+  static const int target = [] { const char* e = getenv("OAVSR_DECODE_SPLIT_TARGET"); return e ? atoi(e) : 128; }();      // developer switch (changes the fp32 summation order)
+  int ks = target / std::max(1, ceil_div(N, 64));
   ks = std::min(ks, std::max(1, ktiles / 2));
   return std::max(1, std::min(ks, 16));
 }
