@@ -457,7 +457,8 @@ def main():
             if avg_us < 20.0:      # an event bracket resolves a launch to about +-2 us: rates of these families are indicative only
                 stages[e["name"]]["short"] = True
         is_dec = lambda n: n.startswith(("skinny", "decode_attention", "argmax", "sched_", "beam_"))          # noqa: E731
-        is_mfma = lambda e: e["flops"] > 0 and not is_dec(e["name"]) and "logmel" not in e["name"]           # noqa: E731
+        # (the 128 x 64 split-K family is the 33..128-row decode GEMM of beam search: weights streamed once per step, HBM-bound like the skinny kernels)
+        is_mfma = lambda e: e["flops"] > 0 and not is_dec(e["name"]) and "logmel" not in e["name"] and "splitk_128x64" not in e["name"]           # noqa: E731
         dom = max((e for e in ents if not is_dec(e["name"])), key=lambda e: e["ms"], default=None) or max(ents, key=lambda e: e["ms"])
         traffic = pmc_traffic(dom["name"])
         if is_mfma(dom):
