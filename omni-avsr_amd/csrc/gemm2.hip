@@ -489,7 +489,8 @@ int launch_dma_mode(const GemmArgs& a, hipStream_t st) {
     // worth it as soon as N / 128 still gives every CU several workgroups (lm_head)
     static const int wide = [] { const char* e = getenv("OAVSR_GEMM_M128_WIDE"); return e ? atoi(e) : 1; }();
     if (wide && a.N >= 256 * 256 && a.ksplit <= 1) return launch_dma<T, A_DENSE, 128, 256, 3, 2, 8>(a, st);   // 8 waves (2 x 4) of 64 x 64: 0.5 B of A per byte of W
-    if (a.N >= 256 * 128 && a.ksplit <= 1) return launch_dma<T, A_DENSE, 128, 128, 3, 2, 4>(a, st);   // 4 waves (2 x 2) of 64 x 64
+    static const int n128_min = [] { const char* e = getenv("OAVSR_GEMM_M128_N128_MIN"); return e ? atoi(e) : 256 * 128; }();      // A/B runs
+    if (a.N >= n128_min && a.ksplit <= 1) return launch_dma<T, A_DENSE, 128, 128, 3, 2, 4>(a, st);   // 4 waves (2 x 2) of 64 x 64
     // 4 waves (4 x 1) of 32 x 64.  LDS stages of 24 KiB: 3 by default (72 KiB: two workgroups share a CU) -- with the whole k range of a
     // split-K slice resident (4 stages, 96 KiB, one workgroup per CU) a launch is 8 % faster alone, but beam search keeps several decode
     // chains in flight and what counts there is how many of their workgroups fit beside each other: 120.6 -> 125.1 utt/s (round 3).
