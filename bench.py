@@ -141,6 +141,18 @@ def cpu_baseline(spec, sd_cpu, Tv, max_new, task, rates):
                 rtf=round((t_enc + t_greedy) / dur, 3))
 
 
+def env_snapshot():
+    """Every environment variable that can steer the library or the runtime under it: the OAVSR_* names (oavsr_env_report: a trailing '?' marks
+    a name the library itself does not read -- none of its own switches changes a result, they pick between bit-identical kernel forms) and
+    the ROCm runtime's knobs that were set for this process."""
+    from omni_avsr_amd import lib as L
+    env = dict(L.env_report())
+    for k, v in os.environ.items():
+        if k.startswith(("GPU_MAX_HW_QUEUES", "HSA_", "HIP_", "AMD_", "ROCR_", "NCCL_", "RCCL_")):
+            env[k] = v
+    return env
+
+
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic_*.json: FETCH_SIZE and
     WRITE_SIZE collected in separate runs, gfx950 read-side correction applied; counters cannot be read from inside this process).
@@ -185,8 +197,6 @@ def parse_args():
     ap.add_argument("--sched-stride", type=int, default=0, help="steps per admission (0 = automatic)")
     ap.add_argument("--sched-lanes", type=int, default=3, help="independent step loops of the scheduler")
     ap.add_argument("--no-stagger", action="store_true", help="let the encoder phases of in-flight batches share the chip (default: chained)")
-    ap.add_argument("--prime-streams", action="store_true",
-                    help="developer switch: run one operation on every caller stream before the first call (binds their hardware queues before the scheduler's lanes get theirs)")
     ap.add_argument("--streams", type=int, default=None,
                     help="caller streams = batches whose encoder phases (and, without the scheduler, decode loops) may be in flight; default 3, "
                          "4 for beam search; 1 = strictly sequential calls")
@@ -347,13 +357,20 @@ def main():
     # Independent batches are pipelined over `--streams` HIP streams (each with its own workspace): the latency-bound decode
     # loop of one batch overlaps the MFMA-bound encoders / prefill of the next.  Every call still is one complete pass.
     nstream = max(1, args.streams)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(nstream)]
     results = [None] * nstream
     # The decode scheduler (default): every call is still one batch of B utterances submitted on its own stream; the engine merges the
     # decode rows of the calls in flight into one step loop (oavsr_generate_submit).  Caller-side nothing is grouped (decode_group 1).
     use_sched = not args.no_scheduler and args.beams == 1 and G == 1 and B <= args.sched_rows
     eng.sched_rows, eng.sched_slots, eng.sched_stride, eng.sched_lanes = args.sched_rows, args.sched_slots, args.sched_stride, args.sched_lanes
+    if use_sched and nstream <= 8:
+        # the ENGINE's caller streams (created before its lanes' streams: the hardware-queue binding order no longer depends on the caller)
+        eng.reserve_scheduler(task, max(max(s[2]) for s in sets), max(max(s[3]) for s in sets),
+                              min(r[0] for r in pre["rates"]), min(r[1] for r in pre["rates"]), args.max_new)
+        streams = [eng.caller_stream(i) for i in range(nstream)]
+    else:
+        streams = [torch.cuda.Stream(device=dev) for _ in range(nstream)]
     pending = []
+    timed = None                                     # inside the timed region: [(call index, ids, lens)] of every call, for the identity check after it
     # Without the scheduler the encoder + prefill phases of the calls in flight are chained (only the decode loops overlap them); with it
     # the callers' streams carry nothing but those phases, and letting the tail of one overlap the head of the next is worth 5 %.
     if nstream > 1 and not args.no_stagger and not use_sched:
@@ -373,9 +390,13 @@ def main():
                     with torch.cuda.stream(streams[s0]):
                         eng.wait(t0_)
                 results[s] = (ids_, lens_)
+                if timed is not None:
+                    timed.append((i, ids_, lens_))
             else:
                 results[s] = eng.generate(task, video, Tvs, audio if use_a else None, Ts if use_a else None, ra, rv, beams=args.beams,
                                           max_new=args.max_new, force_len=(args.beams == 1), video_is_flat=True, slot=s, chunk=B if G > 1 else None)
+                if timed is not None:
+                    timed.append((i, results[s][0], results[s][1]))
         return results[s]
 
     def drain():
@@ -384,11 +405,6 @@ def main():
             pending.clear()
         torch.cuda.synchronize()
 
-    if args.prime_streams:
-        for st_ in streams:
-            with torch.cuda.stream(st_):
-                torch.zeros(1, device=dev)
-        torch.cuda.synchronize()
     ncall = 0
     torch.cuda.synchronize()
     for _ in range(max(args.warmup * (calls // G), nstream, nsets * len(pre["rates"]))):
@@ -398,6 +414,7 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    timed = []
     t0 = time.perf_counter()
     host_s = 0.0
     for _ in range(args.steps * (calls // G)):       # one call = G batches of B when --decode-group G
@@ -419,6 +436,36 @@ def main():
         elapsed = float(t.item())
     assert len(hyp) == world * n_last
     assert args.beams > 1 or int(lens.min()) == args.max_new
+    # ---- identity check (outside the timed region): the input sets and rates rotate, so every timed call must have produced exactly the
+    # ids of ONE ISOLATED oavsr_generate of its (input set, rates) -- nothing else on the chip, no scheduler, default stream.  A mismatch
+    # means the pipelined / scheduled configuration the number was measured in does not compute what a single call computes: no line then.
+    timed_calls, timed = timed, None
+    torch.cuda.synchronize()
+    iso = {}
+    bad = []
+    for i, ids_t, lens_t in timed_calls:
+        key = (i % nsets, i % len(pre["rates"]))
+        if key not in iso:
+            video, audio, Tvs, Ts = sets[key[0]]
+            ra, rv = pre["rates"][key[1]]
+            r_ids, r_lens = eng.generate(task, video, Tvs, audio if use_a else None, Ts if use_a else None, ra, rv, beams=args.beams, max_new=args.max_new,
+                                         force_len=(args.beams == 1), video_is_flat=True, slot=0, chunk=B if G > 1 else None)
+            torch.cuda.synchronize()
+            iso[key] = (r_ids.clone(), r_lens.clone())
+        if not (torch.equal(ids_t, iso[key][0]) and torch.equal(lens_t, iso[key][1])):
+            bad.append(i)
+    ok_t = torch.tensor([0 if bad else 1], device=dev, dtype=torch.int32)
+    if use_dist:
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+    if bad:
+        print(f"bench.py: rank {rank}: {len(bad)} of {len(timed_calls)} timed calls returned ids that differ from an isolated call of the same inputs "
+              f"(first: call {bad[0]})", file=sys.stderr, flush=True)
+    if int(ok_t.item()) != 1:
+        if use_dist:
+            dist.destroy_process_group()
+        sys.exit(3)
+    n_verified = len(timed_calls)
+    del timed_calls, iso
 
     dsched = eng.scheduler_stats() if use_sched else None      # the timed region's (the passes below run more calls)
     schedule = None
@@ -565,6 +612,8 @@ def main():
                        "host_ms_per_call": round(host_s / (args.steps * (calls // G)) * 1e3, 3),
                        "parallelism": f"utterance-sharded dp{world}", "gathered_hypotheses": len(hyp), "dist_backend": (dist.get_backend() if use_dist else None),
                        "streams_per_gpu": nstream, "decode_group": G, "setup_s": round(setup_s, 1),
+                       "ids_verified": True, "ids_verified_calls": n_verified,
+                       "env": env_snapshot(),
                        "decode_scheduler": (dict(rows_per_step_cap=args.sched_rows, slots=args.sched_slots, lanes=args.sched_lanes, **dsched) if use_sched else None)},
             "roofline": roofline, "roofline_sides": sides, "schedule": schedule, "cpu_baseline": cpu, "per_call_decode": grouped, "stages": stages,
         }

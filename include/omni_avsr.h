@@ -20,7 +20,9 @@
 extern "C" {
 #endif
 
-#define OAVSR_ABI_VERSION 1
+/* 2 (round 4): oavsr_op_stem_pool takes the pixel format (three ints after `video`), oavsr_gemm_desc gained `grid`, the decode scheduler entry
+ * points (oavsr_scheduler_*, oavsr_generate_submit / _wait / _poll) and oavsr_trace_rec were added.  A binding built against version 1 must not load. */
+#define OAVSR_ABI_VERSION 2
 #define OAVSR_DT_F32 0  /* parity mode: exact-f32 MFMA */
 #define OAVSR_DT_BF16 1 /* throughput mode: bf16 storage, f32 accumulate (reference: bf16-true, eval_OmniAVSR.py:19) */
 #define OAVSR_MAX_RATES 8
@@ -69,6 +71,10 @@ typedef struct oavsr_tensor {
 
 int oavsr_abi_version(void);
 const char* oavsr_last_error(void);
+/* Every OAVSR_* variable of the process environment, ';'-separated "NAME=value" ("NAME=value?": a name the library does not read) into buf;
+ * returns how many there are.  The library's own switches (csrc/model.hip: kKnobs) only pick between kernel forms that produce the same
+ * bits or turn diagnostics on -- no environment variable changes a result; bench.py records this string in `config.env`. */
+int oavsr_env_report(char* buf, int32_t nbytes);
 
 /* weights: one device blob + manifest (replaces AVSR_LLMs.load_state_dict, lightning_OmniAVSR.py:148-150) */
 int oavsr_model_create(const oavsr_config* cfg, const void* blob_dev, uint64_t blob_bytes, const oavsr_tensor* tensors,
@@ -159,6 +165,13 @@ int oavsr_scheduler_create(const oavsr_model* m, int32_t n_slots, int32_t max_ro
                            oavsr_scheduler** out);
 void oavsr_scheduler_destroy(oavsr_scheduler* s);
 uint64_t oavsr_scheduler_bytes(const oavsr_scheduler* s);
+/* Caller stream i (0 .. 7) of the scheduler: a HIP stream the ENGINE created, before its lanes' streams, for submitting calls on.  ROCm
+ * binds a stream to one of its few hardware queues at creation, and which caller stream shares a queue with which lane decides how encoder
+ * phases and decode bursts take turns: with streams of the caller's own making the same loop ran at 226-229 or at 255-260 utt/s depending
+ * on when they were created (round 3).  Streams handed out here are in the fast order by construction; they belong to the MODEL
+ * (created with its first scheduler, kept when a scheduler is destroyed and re-created, destroyed by oavsr_model_destroy).  Any other stream
+ * still works (speed only, never results).  NULL: index out of range. */
+oavsr_stream oavsr_scheduler_caller_stream(oavsr_scheduler* s, int32_t i);
 /* oavsr_generate(beams = 1) split in two: submit queues encoders + prefill on `stream` (workspace ws, as oavsr_generate) and the
  * admission of the B rows on the scheduler's stream; it returns a ticket.  out_ids_dev / out_len_dev ([B][max_new] / [B] int32) are
  * written by the scheduler's stream when the call's last step has run and must stay valid until oavsr_generate_wait.
@@ -226,7 +239,8 @@ typedef struct oavsr_gemm_desc {
   const int32_t* rowinfo; /* int4 per output row */
   int32_t taps, Kvalid;
   const int32_t* frameinfo; /* int2 per frame */
-  int32_t skinny;           /* 1: decode kernel (M <= 128) */
+  int32_t skinny;           /* kernel selector: 0 dispatcher's choice, 1 decode kernel (M <= 128); parity tests only: 2 ping-pong 256 x 256,
+                               3 persistent ping-pong, 5 16-wave 256 x 256 */
   /* skinny only: fused RMSNorm prologue (y = rstd * ((x*gain) W^T) + seg2) and SwiGLU epilogue (16-row interleaved gate/up) */
   const float* norm_gain;
   float norm_eps;
@@ -240,6 +254,7 @@ typedef struct oavsr_gemm_desc {
   int64_t rn_ld;
   const float* rn_gain;
   float rn_eps;
+  int32_t grid; /* persistent kernel only: workgroups (multiple of 8); 0 = the launcher's rule */
 } oavsr_gemm_desc;
 int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream);
 

@@ -761,13 +761,12 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
   OAVSR_REQUIRE(a.ldq % vec == 0 && a.ldk % vec == 0 && a.ldv % vec == 0 && a.ldo % vec == 0, "attention: rows must be 16-byte aligned");
   OAVSR_REQUIRE((((uintptr_t)a.Q | (uintptr_t)a.K | (uintptr_t)a.V | (uintptr_t)a.O) & 15) == 0, "attention: pointers must be 16-byte aligned");
   if (a.dtype == DT_F32) return a.head_dim == 64 ? launch_attn_t<float, 64>(a, st) : launch_attn_t<float, 128>(a, st);
-  static const int dma = [] { const char* e = getenv("OAVSR_ATTN_DMA"); return e ? atoi(e) : 1; }();
-  if (dma && a.head_dim == 64) {
+  if (a.head_dim == 64) {
     // two query tiles per wave (128-row workgroups) once the sequences are long enough that the ragged last workgroup is cheap
-    if (dma == 2 || (dma == 1 && a.max_q >= 1024)) return launch_attn_dma<2>(a, st);
+    if (a.max_q >= 1024) return launch_attn_dma<2>(a, st);
     return launch_attn_dma<1>(a, st);
   }
-  return a.head_dim == 64 ? launch_attn_t<bf16_t, 64>(a, st) : launch_attn_t<bf16_t, 128>(a, st);
+  return launch_attn_t<bf16_t, 128>(a, st);
 }
 
 int launch_decode_attention(const DecodeAttnArgs& a, hipStream_t st) {
@@ -780,8 +779,7 @@ int launch_decode_attention(const DecodeAttnArgs& a, hipStream_t st) {
   // beam search (B * K x kv heads workgroups, several per CU): 4-wave workgroups with half the LDS pack more of them onto a CU
   // than 8-wave ones.  The choice follows the decode MODE (beams > 1), never the row count: the key -> wave partition and with
   // it the fp32 merge order of a row is then the same whether its utterance is decoded alone or inside a batch.
-  static const int nw4 = [] { const char* e = getenv("OAVSR_DEC_ATTN_NW4"); return e ? atoi(e) : 1; }();
-  if (a.head_dim == 64 && nw4 && a.beams > 1) return launch_dec_t<bf16_t, 64, 4>(a, st);
+  if (a.head_dim == 64 && a.beams > 1) return launch_dec_t<bf16_t, 64, 4>(a, st);
   return a.head_dim == 64 ? launch_dec_t<bf16_t, 64>(a, st) : launch_dec_t<bf16_t, 128>(a, st);
 }
 

@@ -423,7 +423,7 @@ int launch_beam_topk(const float* logits, int64_t ld, int rows, int V, int K, co
                      int* need_exact, hipStream_t st) {
   OAVSR_REQUIRE(K >= 1 && K <= kMaxK, "beam search: num_beams=%d unsupported (max %d)", K, kMaxK);
   if (rows <= 0) return 0;
-  static const bool fast = [] { const char* e = getenv("OAVSR_BEAM_TOPK_FAST"); return !(e && e[0] == '0'); }();
+  const bool fast = true;      // certified register top-2K first; rows it cannot certify fall through to the exact radix select
   if (fast && need_exact)
     hipLaunchKernelGGL(beam_topk_fast_kernel, dim3(rows), dim3(kTopkThreads), 0, st, logits, ld, V, 2 * K, beam_scores, cand_val, cand_tok, need_exact);
   hipLaunchKernelGGL(beam_topk_exact_kernel, dim3(rows), dim3(kTopkThreads), 0, st, logits, ld, V, 2 * K, beam_scores, cand_val, cand_tok,

@@ -109,6 +109,11 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- developer switches ---------------------------------------------------------------------
+// The ONLY place the library reads its environment (model.hip: kKnobs).  Every switch left picks between forms that give the same bits
+// (tests compare them) or turns a diagnostic on: nothing a process environment can set changes a result.  An unregistered name aborts.
+int knob(const char* name);
+
 // ---- host side error plumbing -------------------------------------------------------------
 void set_last_error(const char* fmt, ...);
 #define OAVSR_CHECK_HIP(expr)                                                              \

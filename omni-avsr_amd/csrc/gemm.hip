@@ -426,8 +426,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   OAVSR_REQUIRE(a.act != ACT_PRELU || a.prelu, "gemm: PReLU needs slopes");
   if (a.ksplit > 1) {
     OAVSR_REQUIRE(a.partial && a.groups == 1 && a.amode == A_DENSE, "gemm: split-K needs a partial buffer, dense A, no groups");
-    static const bool dma_sk = [] { const char* e = getenv("OAVSR_GEMM_DMA"); return !(e && e[0] == '0'); }();
-    if (dma_sk && gemm_dma_eligible(a)) OAVSR_TRY(launch_gemm_dma(a, st));   // same k order as the classic kernel
+    if (gemm_dma_eligible(a)) OAVSR_TRY(launch_gemm_dma(a, st));   // same k order as the classic kernel
     else OAVSR_TRY(a.dtype == DT_F32 ? launch_mode<float>(a, st) : launch_mode<bf16_t>(a, st));
     if (a.rn_out) {
       OAVSR_REQUIRE(splitk_rmsnorm_ok(a), "gemm: split-K reduce + RMSNorm needs a plain bf16 / f32 epilogue on 16-byte rows");
@@ -443,9 +442,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     OAVSR_CHECK_HIP(hipGetLastError());
     return 0;
   }
-  static const bool use_dma = [] { const char* e = getenv("OAVSR_GEMM_DMA"); return !(e && e[0] == '0'); }();
-  if (a.swiglu_pairs) OAVSR_REQUIRE(use_dma && gemm_dma_swiglu_ok(a), "gemm: fused SwiGLU epilogue unavailable for this shape (check gemm_dma_swiglu_ok)");
-  if (use_dma && gemm_dma_eligible(a)) return launch_gemm_dma(a, st);
+  if (a.swiglu_pairs) OAVSR_REQUIRE(gemm_dma_swiglu_ok(a), "gemm: fused SwiGLU epilogue unavailable for this shape (check gemm_dma_swiglu_ok)");
+  if (gemm_dma_eligible(a)) return launch_gemm_dma(a, st);
   return a.dtype == DT_F32 ? launch_mode<float>(a, st) : launch_mode<bf16_t>(a, st);
 }
 

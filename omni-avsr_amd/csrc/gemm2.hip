@@ -4,7 +4,7 @@
 // but built around LDS-DMA (`global_load_lds_dwordx4`): tiles go HBM -> LDS without touching VGPRs, one raw `s_barrier` per
 // k-tile, counted `s_waitcnt vmcnt(N)` where more than one k-tile is in flight.  Wave tile 64 x 64 (4 x 4 MFMA 16x16) throughout;
 // tile shapes (launch_dma_mode): 256 x 256 / 16 waves / 2 stages (the workhorse), 256 x 128 / 8 waves / 3 stages (mid-size grids,
-// conv gathers, split-K), 128 x 64 and 128 x 128 / 4 waves (<= 128 rows: beam-search decode), 256 x 192 and 192 x 256 / 12 waves (opt-in).
+// conv gathers, split-K), 128 x 64, 128 x 128 and 128 x 256 / 4-8 waves (<= 128 rows: beam-search decode; small GEMMs).
 //   * the DMA writes LDS linearly (wave-uniform base + lane*16), so the XOR swizzle that makes the ds_read_b128 fragment
 //     reads conflict-free is applied to the per-lane SOURCE address (chunk ^ (row & 7)) and again on the read
 //   * out-of-range rows / conv padding read a 16-byte zero page instead of branching
@@ -411,66 +411,36 @@ int launch_dma(const GemmArgs& a, hipStream_t st) {
   }
   int64_t nblk = (int64_t)ceil_div(a.M, BM) * ceil_div(a.N, BN);
   dim3 grid((unsigned)nblk, a.ksplit > 1 ? a.ksplit : 1, a.groups);
-  // row-major by default: the blocked order only pays on deep-K shapes (fc2 126 -> 118 us), which the ping-pong kernel takes anyway
-  static const int order = [] { const char* e = getenv("OAVSR_GEMM_TILE_ORDER"); return e ? atoi(e) : 0; }();
+  // row-major: the blocked order only pays on deep-K shapes (fc2 126 -> 118 us), which the ping-pong kernels take anyway
   GemmArgs b = a;
-  b.tile_order = order;
+  b.tile_order = 0;
   hipLaunchKernelGGL(kern, grid, dim3(NWAVES * 64), smem, st, b);
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
+// Small dense GEMMs -- fewer than 144 tiles of 256 x 128: the LoRA down projections (N = 128 / 256), AV-HuBERT's out-projection, the
+// projector layers -- run on the 128 x 64 tile (4 waves, 3 LDS stages = 72 KiB: two workgroups per CU) WITHOUT split-K: 2-8 x the
+// workgroups of the big tiles, no fp32 slabs, no reduce launch (round 2 ran them as 256 x 128 tiles with a static split: 20-33 us at
+// 40-200 TFLOP/s).  The tile shape never changes a bit (same k order, same epilogue expressions).
 static bool small_tile_rule(const GemmArgs& a) {
-  static const int on = [] { const char* e = getenv("OAVSR_GEMM_SMALL"); return e ? atoi(e) : 1; }();
-  static const int force = [] { const char* e = getenv("OAVSR_GEMM_TILE"); return e ? atoi(e) : -1; }();
-  if (!on || force >= 0 || a.amode != A_DENSE || a.groups != 1 || a.ksplit > 1 || a.swiglu_pairs || a.N < 64 || a.M <= 128) return false;
-  static const int max_tiles = [] { const char* e = getenv("OAVSR_GEMM_SMALL_TILES"); return e ? atoi(e) : 144; }();      // A/B runs
-  return (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 128) < max_tiles;
+  if (a.amode != A_DENSE || a.groups != 1 || a.ksplit > 1 || a.swiglu_pairs || a.N < 64 || a.M <= 128) return false;
+  return (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 128) < 144;
 }
 
 static int dma_tile_choice(const GemmArgs& a) {
-  // 0: not eligible, 1: 256x128, 2: 256x256
-  static const int force = [] { const char* e = getenv("OAVSR_GEMM_TILE"); return e ? atoi(e) : -1; }();
+  // 0: not eligible, 1: 256x128, 2: 256x256, 4: the <= 128-row / small-GEMM tiles
   // <= 128 rows (beam-search decode, tiny prefills): 128 x 64 tiles stream the weights with 4 x more workgroups per N
-  if (a.amode == A_DENSE && a.groups == 1 && a.M <= 128 && a.M > 32 && a.N >= 64 && force < 0) return 4;
+  if (a.amode == A_DENSE && a.groups == 1 && a.M <= 128 && a.M > 32 && a.N >= 64) return 4;
   if (a.ksplit > 1) return (a.amode == A_DENSE && a.groups == 1 && a.N >= 64) ? 1 : 0;   // independent of M on purpose
-  // Small dense GEMMs -- fewer than 144 tiles of 256 x 128: the LoRA down projections (N = 128 / 256), AV-HuBERT's out-projection, the
-  // projector layers -- on the 128 x 64 tile (4 waves, 3 LDS stages = 72 KiB: two workgroups per CU) WITHOUT split-K: 2-8 x the workgroups
-  // of the big tiles, no fp32 slabs, no reduce launch.  Round 2 ran them as 256 x 128 tiles with a static split (20-33 us at 40-200 TFLOP/s).
-  // The tile shape never changes a bit (same k order, same epilogue expressions); OAVSR_GEMM_SMALL=0 restores the old dispatch.
   if (small_tile_rule(a)) return 4;
   if (a.amode == A_STEM || a.N < 128) return 0;
   const int64_t n128 = (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 128) * a.groups;
   const int64_t n256 = (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 256) * a.groups;
-  if (force == 1) return n128 >= 1 ? 1 : 0;
-  if (force == 2) return (a.N >= 256 && a.amode == A_DENSE) ? 2 : 1;
-  if (force == 5) return (a.N >= 192 && a.amode == A_DENSE) ? 5 : 1;
-  if (force == 6) return (a.N >= 256 && a.amode == A_DENSE) ? 6 : 1;
-  // measured on MI355X (tools/bench_kernels.py): the 256x256 tile wins as soon as ~60 % of the CUs get a tile
-  if (a.amode == A_DENSE && a.N >= 256 && n256 >= 144) {
-    // one workgroup per CU: time ~ rounds x tile size.  N = 3072 (QKV): 12 tiles of 256 columns leave a ragged last round
-    // (M = 12000: 564 tiles = 2.2 rounds); 16 tiles of 192 columns give 752 tiles = 2.94 rounds of 3/4 the work each
-    static const int ncu = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
-    // Off by default: alone on the chip the 3/4-size tiles win (Whisper QKV 112 -> 99 us, fc2 125 -> 106 us, +1.2 % per
-    // sequential batch), but with three batches in flight the mostly empty last round of the 256 x 256 grid is filled by the
-    // other streams' decode kernels anyway and the 12-wave tiles cost 2 % of throughput.  OAVSR_GEMM_BN192=1 for latency mode.
-    static const int t192 = [] { const char* e = getenv("OAVSR_GEMM_BN192"); return e ? atoi(e) : 0; }();
-    if (t192 && a.groups == 1) {
-      // candidates: 256 x 256 (cost 1), 256 x 192 (N % 192 == 0) and 192 x 256, both 3/4 of the work at ~4 % lower efficiency
-      const double c256 = (double)ceil_div((int)n256, ncu);
-      double best = c256; int pick = 2;
-      if (a.N % 192 == 0) {
-        const double c = (double)ceil_div((int)((int64_t)ceil_div(a.M, 256) * (a.N / 192)), ncu) * 0.75 * 1.04;
-        if (c < best) { best = c; pick = 5; }
-      }
-      {
-        const double c = (double)ceil_div((int)((int64_t)ceil_div(a.M, 192) * ceil_div(a.N, 256)), ncu) * 0.75 * 1.04;
-        if (c < best * 0.97) { best = c; pick = 6; }
-      }
-      return pick;
-    }
-    return 2;
-  }
+  // measured on MI355X (tools/bench_kernels.py): the 256x256 tile wins as soon as ~60 % of the CUs get a tile.  (256 x 192 / 192 x 256
+  // tiles against the ragged last round were built in round 1 and dropped in round 4: alone on the chip they won 10 %, with several
+  // calls in flight they cost 2 % -- the persistent kernel now takes the multi-round shapes anyway.)
+  if (a.amode == A_DENSE && a.N >= 256 && n256 >= 144) return 2;
   if (n128 >= 144) return 1;
   return 0;
 }
@@ -478,26 +448,20 @@ static int dma_tile_choice(const GemmArgs& a) {
 template <typename T>
 int launch_dma_mode(const GemmArgs& a, hipStream_t st) {
   // 256x256: 16 waves (4 x 4) of 64 x 64, 2 stages; dense only.  256x128: 8 waves (4 x 2) of 64 x 64, 3 stages.
+  if (a.force_tile == 2 && a.amode == A_DENSE && a.groups == 1 && a.ksplit <= 1 && a.N >= 256) return launch_dma<T, A_DENSE, 256, 256, 2, 4, 16>(a, st);
   if (dma_tile_choice(a) == 2) {
+    if (gemm_8pp_eligible(a)) return launch_gemm_8pp(a, st);      // more tiles than CUs: persistent ping-pong kernel (gemm4.hip), bf16
     if (gemm_8p_eligible(a)) return launch_gemm_8p(a, st);        // 8-wave ping-pong schedule (gemm3.hip), bf16
     return launch_dma<T, A_DENSE, 256, 256, 2, 4, 16>(a, st);
   }
-  if (dma_tile_choice(a) == 5) return launch_dma<T, A_DENSE, 256, 192, 2, 4, 12, 8>(a, st);   // 12 waves (4 x 3) of 64 x 64; 8 of them issue the DMA
-  if (dma_tile_choice(a) == 6) return launch_dma<T, A_DENSE, 192, 256, 2, 3, 12, 8>(a, st);   // 12 waves (3 x 4) of 64 x 64
   if (dma_tile_choice(a) == 4) {
     // every workgroup re-reads the A rows of its k range: 64-column tiles move 2 B of A per byte of W, 128-column tiles 1 B --
     // worth it as soon as N / 128 still gives every CU several workgroups (lm_head)
-    static const int wide = [] { const char* e = getenv("OAVSR_GEMM_M128_WIDE"); return e ? atoi(e) : 1; }();
-    if (wide && a.N >= 256 * 256 && a.ksplit <= 1) return launch_dma<T, A_DENSE, 128, 256, 3, 2, 8>(a, st);   // 8 waves (2 x 4) of 64 x 64: 0.5 B of A per byte of W
-    static const int n128_min = [] { const char* e = getenv("OAVSR_GEMM_M128_N128_MIN"); return e ? atoi(e) : 256 * 128; }();      // A/B runs
-    if (a.N >= n128_min && a.ksplit <= 1) return launch_dma<T, A_DENSE, 128, 128, 3, 2, 4>(a, st);   // 4 waves (2 x 2) of 64 x 64
-    // 4 waves (4 x 1) of 32 x 64.  LDS stages of 24 KiB: 3 by default (72 KiB: two workgroups share a CU) -- with the whole k range of a
-    // split-K slice resident (4 stages, 96 KiB, one workgroup per CU) a launch is 8 % faster alone, but beam search keeps several decode
-    // chains in flight and what counts there is how many of their workgroups fit beside each other: 120.6 -> 125.1 utt/s (round 3).
-    // Same k order, same bits.  OAVSR_M128_STAGES=2|4 for A/B runs.
-    static const int m128_stages = [] { const char* e = getenv("OAVSR_M128_STAGES"); return e ? atoi(e) : 3; }();
-    if (m128_stages == 2) return launch_dma<T, A_DENSE, 128, 64, 2, 4, 4>(a, st);
-    if (m128_stages == 4) return launch_dma<T, A_DENSE, 128, 64, 4, 4, 4>(a, st);
+    if (a.N >= 256 * 256 && a.ksplit <= 1) return launch_dma<T, A_DENSE, 128, 256, 3, 2, 8>(a, st);   // 8 waves (2 x 4) of 64 x 64: 0.5 B of A per byte of W
+    if (a.N >= 256 * 128 && a.ksplit <= 1) return launch_dma<T, A_DENSE, 128, 128, 3, 2, 4>(a, st);   // 4 waves (2 x 2) of 64 x 64
+    // 4 waves (4 x 1) of 32 x 64.  Three LDS stages of 24 KiB (72 KiB: two workgroups share a CU): with the whole k range of a split-K
+    // slice resident (4 stages, one workgroup per CU) a launch is 8 % faster alone, but beam search keeps several decode chains in flight
+    // and what counts there is how many of their workgroups fit beside each other (120.6 -> 125.1 utt/s, round 3).
     return launch_dma<T, A_DENSE, 128, 64, 3, 4, 4>(a, st);
   }
   switch (a.amode) {
@@ -521,8 +485,9 @@ bool gemm_dma_swiglu_ok(const GemmArgs& a) {
 const char* gemm_dma_variant(const GemmArgs& a) {
   const int c = dma_tile_choice(a);
   if (c == 4) return a.ksplit > 1 ? "dma_splitk_128x64" : "dma_128x64";
+  if (c == 2 && gemm_8pp_eligible(a)) return "8pp_256x256";
   if (c == 2 && gemm_8p_eligible(a)) return "8p_256x256";
-  return a.ksplit > 1 ? "dma_splitk_256x128" : c == 2 ? "dma_256x256" : c == 5 ? "dma_256x192" : c == 6 ? "dma_192x256" : "dma_256x128";
+  return a.ksplit > 1 ? "dma_splitk_256x128" : c == 2 ? "dma_256x256" : "dma_256x128";
 }
 
 int launch_gemm_dma(const GemmArgs& a, hipStream_t st) {

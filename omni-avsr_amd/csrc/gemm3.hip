@@ -346,12 +346,8 @@ bool gemm_8p_supported(const GemmArgs& a) {
 // Measured on MI355X (tools/bench_kernels.py, tools/gemm_kscan.py): per k-tile the ping-pong loop is 10-20 % faster than the 16-wave
 // kernel (1.44 vs 1.78 us at 4096 x 4096), but its start-up (six half-tiles of prologue, the half-filled pipeline of the first
 // k-tiles) and its 2-waves-per-SIMD epilogue cost ~4-6 us more per tile: it wins from K = 2048 up (Whisper fc2 126 -> 115 us, LLM
-// down_proj 135 -> 126 us) and loses at K = 1024 (QKV 97 -> 124 us).  OAVSR_GEMM_8P: 0 never, 1 by this rule (default), 2 whenever supported.
-bool gemm_8p_eligible(const GemmArgs& a) {
-  static const int on = [] { const char* e = getenv("OAVSR_GEMM_8P"); return e ? atoi(e) : 1; }();
-  if (!on || !gemm_8p_supported(a)) return false;
-  return on >= 2 || a.K + a.K2 >= 2048;
-}
+// down_proj 135 -> 126 us) and loses at K = 1024 (QKV 97 -> 124 us).  (Tests reach either kernel through oavsr_op_gemm's kernel selector.)
+bool gemm_8p_eligible(const GemmArgs& a) { return gemm_8p_supported(a) && a.K + a.K2 >= 2048; }
 
 int launch_gemm_8p(const GemmArgs& a, hipStream_t st) {
   static bool attr_set = false;
@@ -361,9 +357,8 @@ int launch_gemm_8p(const GemmArgs& a, hipStream_t st) {
   }
   const int64_t nblk = (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 256);
   // 8 x 4 blocks of tiles per XCD (kernels.h): +3..5 % on the deep-K shapes this kernel serves
-  static const int order = [] { const char* e = getenv("OAVSR_GEMM_TILE_ORDER"); return e ? atoi(e) : 1; }();
   GemmArgs b = a;
-  b.tile_order = order;
+  b.tile_order = 1;
   hipLaunchKernelGGL(gemm_8p_kernel, dim3((unsigned)nblk), dim3(512), kSmem8p, st, b);
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;

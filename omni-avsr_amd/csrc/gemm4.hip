@@ -1,0 +1,429 @@
+// PERSISTENT 256 x 256 bf16 GEMM with the 8-wave ping-pong k loop of gemm3.hip:  C[M,N] = epi(A1.W1^T + A2.W2^T), dense operands.
+//
+// What a non-persistent tile pays besides its k loop (profiles/r03: 12 us per tile for the 16-wave kernel, 16-18 us for the ping-pong kernel,
+// against 23-28 us of k loop at K = 1024): dispatch + address set-up, a cold prologue (six half-tiles through an empty pipeline), the
+// transposing epilogue, and -- because every CU of a round reaches its epilogue at the same time -- 128 KiB of C per CU leaving in one
+// chip-wide burst, with the workgroup's successor unable to start before the last store is acknowledged.  Here ONE workgroup per CU walks a
+// list of output tiles (round j: logical tile j*grid + its position; an XCD's workgroups always hold a contiguous range of logical tiles, in
+// the 8 x 4 blocked order of kernels.h) and the k-tile stream simply continues across tiles:
+//   * LDS-DMA never drains: the half-tiles issued in the last two k-tiles of tile i are the first 1.5 k-tiles of tile i+1 (issuing A1 / B1
+//     of its second k-tile as well before the epilogue's stores -- two more phases of slack for them -- was measured: no gain, removed);
+//   * the epilogue's C stores are NOT waited for: vector-memory operations retire in issue order, so the k loop's counted `s_waitcnt
+//     vmcnt(N)` of the next tile's first four phases allow S more outstanding operations -- the tile's stores, a compile-time count on full
+//     tiles (2 x 16-byte stores per 16-row slab: 16 per wave; fused SwiGLU: 8) -- and the stores drain behind ~2 us of MFMA work.  Edge tiles
+//     (ragged M / N: row-guarded stores, unknown count) fall back to the plain counts, i.e. they wait for their stores: slower, never wrong
+//     (assuming FEWER outstanding operations than there are is the safe direction);
+//   * bias + activation (+ SwiGLU: gate and up columns of a pair sit in the same lane) are applied in the MFMA C layout; the transposition
+//     that turns the results into 16-byte row-segment stores goes through 32 KiB of LDS of its own (8 waves x 16 rows x 64 fp32,
+//     XOR-swizzled instead of padded), because the two k-tile buffers already hold the next tile; the bias is fetched once per tile
+//     BEFORE the first store (an ordinary load behind the stores would make the compiler wait for them);
+//   * the two wave groups re-synchronise for the epilogue (waves 4-7 run one barrier behind in the k loop, see gemm3.hip) and re-stagger after.
+// Same accumulation order (k ascending, 32 per MFMA) and the same epilogue expressions as gemm2.hip / gemm3.hip: bit-identical to them
+// (tests/test_kernels_gpu.py).  No residual, no per-column scale / PReLU, bf16 output: what the multi-round launches of this model need
+// (Whisper QKV / fc1, LLM gate / up); everything else stays on gemm2.hip / gemm3.hip.
+#include <stdlib.h>
+#include <type_traits>
+#include "kernels.h"
+
+namespace oavsr {
+namespace {
+
+constexpr int kHalf4 = 16384;                 // one half-tile: 128 rows x 128 B
+constexpr int kBuf4 = 4 * kHalf4;             // A0 | A1 | B0 | B1
+constexpr int kPatch4 = 2 * kBuf4;            // 8 waves x 4 KiB: epilogue patches; also where the dummy DMAs of a workgroup's LAST tile land
+constexpr int kSmem8pp = 2 * kBuf4 + 8 * 4096;   // 160 KiB: the whole LDS of a CU
+
+__device__ __forceinline__ void mma4(const Chunk16& a, const Chunk16& b, f32x4& c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a.v), __builtin_bit_cast(bf16x8, b.v), c, 0, 0, 0);
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+#define PP_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PP_BARRIER() do { PP_FENCE(); __builtin_amdgcn_s_barrier(); PP_FENCE(); } while (0)
+
+// SWIGLU: fused SwiGLU epilogue (gate / up rows interleaved by 16).
+template <bool SWIGLU>
+__global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, const int ntiles) {
+  typedef bf16_t T;
+  constexpr int BKE = 64, VEC = 8;
+  constexpr int S = SWIGLU ? 8 : 16;            // store instructions a wave issues for one FULL tile: 8 slabs x 2 (SwiGLU: 8 slabs x 1)
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int R = wave >> 1, Cw = wave & 1;
+  const bool late = wave >= 4;                  // waves 4-7 run one barrier behind waves 0-3 inside the k loop
+
+  // ---- tile list of this workgroup.  Workgroups are dealt round-robin over the 8 XCDs (private L2s): in every round the workgroups of
+  //      one XCD hold a CONTIGUOUS range of logical tiles (gridDim.x is a multiple of 8; the last, partial round is dealt bijectively).
+  const int ntn = (p.N + 255) / 256, ntm = (p.M + 255) / 256;
+  const int G = gridDim.x, xcd = blockIdx.x & 7, wi = blockIdx.x >> 3;
+  const bool nmajor = p.M < p.N;
+  auto tile_at = [&](int round, int& m0o, int& n0o) -> bool {
+    const int base = round * G, rem = ntiles - base;
+    if (rem <= 0) return false;
+    int pos;
+    if (rem >= G) {
+      pos = xcd * (G >> 3) + wi;
+    } else {
+      const int q = rem >> 3, r = rem & 7;
+      if (wi >= q + (xcd < r ? 1 : 0)) return false;
+      pos = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + wi;
+    }
+    const int L = base + pos;
+    int mt = nmajor ? L % ntm : L / ntn, nt = nmajor ? L / ntm : L - (L / ntn) * ntn;
+    if (p.tile_order == 1) blocked_tile(L, ntm, ntn, mt, nt);
+    m0o = mt * 256; n0o = nt * 256;
+    return true;
+  };
+  int m0 = 0, n0 = 0, m0n = 0, n0n = 0;
+  if (!tile_at(0, m0, n0)) return;              // workgroup-uniform, before any barrier
+  int round = 0;
+  bool has_next = tile_at(1, m0n, n0n);
+
+  // ---- DMA sources.  Half-tile kind h in {A0, A1, B0, B1} = 16 segments of 1 KiB (8 rows x 128 B); this wave fills segments `wave` and
+  //      `wave + 8`.  Lane i lands at physical chunk (i & 7) of row seg*8 + (i >> 3) and fetches logical chunk (i & 7) ^ (i >> 3).  A and W
+  //      are buffer resources that end with their last valid row: a lane's byte offset inside an 8-row segment is ONE constant VGPR per
+  //      operand, everything that moves (tile, half, segment, k-tile) is a scalar offset, and rows past M / N arrive as zeros from the
+  //      hardware range check (they feed accumulators the epilogue never stores).  Every kind walks the k-tiles of a tile in order and moves
+  //      on to the next tile of the list by itself (A0 / B0 in the second-to-last k-tile, A1 / B1 in the last).
+  const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
+  const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)(((int64_t)p.M - 1) * p.lda * 2 + (int64_t)p.K * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, (int)(((int64_t)p.N - 1) * p.ldw * 2 + (int64_t)p.K * 2), 0x00020000);
+  const int avo = (lrow * (int)p.lda + lchunk * VEC) * 2, wvo = (lrow * (int)p.ldw + lchunk * VEC) * 2;
+  const int a64 = 64 * (int)p.lda * 2, w64 = 64 * (int)p.ldw * 2;      // segment `wave + 8` starts 64 rows below segment `wave`
+  int so[4];                                    // scalar byte offset of segment `wave` of the k-tile each kind issues next
+  auto set_src = [&](auto hc, int m0x, int n0x) __attribute__((always_inline)) {
+    constexpr int h = decltype(hc)::value;
+    if (h < 2) so[h] = (m0x + (h & 1) * 128 + wave * 8) * (int)p.lda * 2;
+    else so[h] = (n0x + (h & 1) * 128 + wave * 8) * (int)p.ldw * 2;
+  };
+  const std::integral_constant<int, 0> kA0; const std::integral_constant<int, 1> kA1;
+  const std::integral_constant<int, 2> kB0; const std::integral_constant<int, 3> kB1;
+  set_src(kA0, m0, n0); set_src(kA1, m0, n0); set_src(kB0, m0, n0); set_src(kB1, m0, n0);
+
+  const int nall = p.K / BKE;                   // >= 3 (launcher)
+  int par = 0;                                  // buffer of local k-tile t of the current tile: (t + par) & 1 (the stream never restarts)
+  auto dma2 = [&](auto hc, int soff, char* dst0, char* dst1) __attribute__((always_inline)) {
+    constexpr int h = decltype(hc)::value;
+    if (h < 2) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void*)dst0, 16, avo, soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void*)dst1, 16, avo, soff + a64, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)dst0, 16, wvo, soff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)dst1, 16, wvo, soff + w64, 0, 0);
+    }
+  };
+  // half-tile h of k-tile tt, counted from the start of the tile being COMPUTED (tt >= nall: k-tile tt - nall of the next tile)
+  auto issue = [&](auto hc, int tt) __attribute__((always_inline)) {
+    constexpr int h = decltype(hc)::value;
+    char* dst = smem + ((tt + par) & 1) * kBuf4 + h * kHalf4 + wave * 1024;
+    dma2(hc, so[h], dst, dst + 8192);
+    so[h] += 128;
+  };
+  // k-tile lt (0 / 1) of the NEXT tile of the list; without one, dummies that keep the vmcnt arithmetic uniform: each lane re-reads its
+  // last real chunk -- an L2 hit at an address of its own -- into this wave's patch, which nobody reads before the drain in front of the
+  // workgroup's last epilogue
+  auto issue_next = [&](auto hc, int lt) __attribute__((always_inline)) {
+    constexpr int h = decltype(hc)::value;
+    if (has_next) {
+      if (lt == 0) set_src(hc, m0n, n0n);
+      issue(hc, nall + lt);
+    } else {
+      char* dst = smem + kPatch4 + wave * 4096;
+      dma2(hc, so[h] - 128, dst, dst + 1024);
+    }
+  };
+
+  // fragment read addresses (gemm3.hip): row r of a half-tile lives at r*128 + ((chunk ^ (r & 7)) << 4)
+  const int frow = lane & 15, fg = lane >> 4;
+  const int sw0 = ((fg ^ (frow & 7)) << 4), sw1 = (((4 + fg) ^ (frow & 7)) << 4);
+  const int a_off = (R * 32 + frow) * 128, b_off = 2 * kHalf4 + (Cw * 64 + frow) * 128;
+
+  f32x4 acc[2][2][2][4];                        // [mh][nh][m-tile][n-tile]
+  Chunk16 af0[2][2], af1[2][2], bf[4][2];
+  auto load_a = [&](const char* buf, int mh, Chunk16 (&af)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      af[i][0] = *reinterpret_cast<const Chunk16*>(buf + mh * kHalf4 + a_off + i * 2048 + sw0);
+      af[i][1] = *reinterpret_cast<const Chunk16*>(buf + mh * kHalf4 + a_off + i * 2048 + sw1);
+    }
+  };
+  auto load_b = [&](const char* buf, int nh) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf[j][0] = *reinterpret_cast<const Chunk16*>(buf + nh * kHalf4 + b_off + j * 2048 + sw0);
+      bf[j][1] = *reinterpret_cast<const Chunk16*>(buf + nh * kHalf4 + b_off + j * 2048 + sw1);
+    }
+  };
+  auto quad = [&](f32x4 (&c)[2][4], const Chunk16 (&af)[2][2]) __attribute__((always_inline)) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma4(af[i][kb], bf[j][kb], c[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // counted wait of a tile's first phases: `se` != 0 -> the S stores of the previous (full) tile may still be outstanding
+  auto wait_se = [&](auto cc, int se) __attribute__((always_inline)) {
+    constexpr int C = decltype(cc)::value;
+    if (se) wait_vm<S + C>(); else wait_vm<C>();
+  };
+  const std::integral_constant<int, 8> c8;
+
+  // One k-tile = four phases (gemm3.hip).  KT 0: steady state.  KT 1: first k-tile of a tile -- the queue still holds the previous tile's
+  // stores behind the four half-tiles issued before them, so the counts are larger.  KT 3 / 4: second-to-last / last k-tile -- the
+  // half-tiles issued are the next tile's.  What every wait guarantees is unchanged: p0 -> A1(t), p1 -> B1(t), p2 -> B0(t+1), p3 -> A0(t+1) have landed (this
+  // wave's share).
+  auto ktile = [&](int t, auto ktc, int se) __attribute__((always_inline)) {
+    constexpr int KT = decltype(ktc)::value;
+    const char* buf = smem + ((t + par) & 1) * kBuf4;
+    // p0
+    load_a(buf, 0, af0);
+    load_b(buf, 0);
+    if (KT == 4) issue_next(kA1, 0);
+    else issue(kA1, t + 1);
+    if (KT == 1) wait_se(c8, se); else wait_vm<8>();
+    PP_BARRIER();
+    quad(acc[0][0], af0);
+    PP_BARRIER();
+    // p1
+    load_a(buf, 1, af1);
+    if (KT == 4) issue_next(kB1, 0);
+    else issue(kB1, t + 1);
+    if (KT == 1) wait_se(c8, se); else wait_vm<8>();
+    PP_BARRIER();
+    quad(acc[1][0], af1);
+    PP_BARRIER();
+    // p2
+    load_b(buf, 1);
+    if (KT == 3) issue_next(kB0, 0);
+    else if (KT == 4) issue_next(kB0, 1);
+    else issue(kB0, t + 2);
+    if (KT == 1) wait_se(c8, se); else wait_vm<8>();
+    PP_BARRIER();
+    quad(acc[1][1], af1);
+    PP_BARRIER();
+    // p3
+    if (KT == 3) issue_next(kA0, 0);
+    else if (KT == 4) issue_next(kA0, 1);
+    else issue(kA0, t + 2);
+    if (KT == 1) wait_se(c8, se); else wait_vm<8>();
+    PP_BARRIER();
+    quad(acc[0][1], af0);
+    PP_BARRIER();
+  };
+  const std::integral_constant<int, 0> kt_steady; const std::integral_constant<int, 1> kt_first;
+  const std::integral_constant<int, 3> kt_penult; const std::integral_constant<int, 4> kt_last;
+
+  // ---- prologue of the workgroup's first tile: the half-tiles the periodic schedule would have issued before its first phase
+  issue(kB0, 0); issue(kA0, 0); issue(kA1, 0); issue(kB1, 0); issue(kB0, 1); issue(kA0, 1);
+  wait_vm<8>();                                 // B0(0), A0(0) have landed (this wave's share)
+  PP_BARRIER();
+  if (late) PP_BARRIER();
+
+  // epilogue geometry.  Bias and activation are applied in the MFMA C layout (a lane: rows fg*4 + r, column j*16 + frow); each 16 x 64
+  // (SwiGLU: 16 x 32) slab is then transposed through this wave's fp32 patch (XOR-swizzled, 16 x 64 floats) so that a lane owns 16 (8)
+  // consecutive columns of one row and every store is a 16-byte vector, four lanes per 128-byte (64-byte) row segment.
+  float* sw = reinterpret_cast<float*>(smem + kPatch4 + wave * 4096);
+  const bool c_vec = (p.ldc % VEC) == 0 && ((uintptr_t)p.C & 15) == 0;
+  // patch element (row, col) lives at float index row*64 + (col ^ ((row & 3) << 2)).  A lane writes (row fg*4 + r, column j*16 + frow):
+  // (wr_base ^ (r << 2)) + r*64 + j*16 -- the xor permutes frow's bits 2-3
+  const int wr_base = fg * 4 * 64 + frow;
+
+  int se = 0;                                   // S if the previous tile of this workgroup issued exactly S stores per wave, else 0
+  for (;;) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ktile(0, kt_first, se);
+    for (int t = 1; t < nall - 2; ++t) ktile(t, kt_steady, 0);
+    ktile(nall - 2, kt_penult, 0);
+    ktile(nall - 1, kt_last, 0);
+
+    // ---- tile boundary
+    if (!has_next) wait_vm<0>();                // the dummy DMAs of the last phases land in this wave's patch
+    if (!late) PP_BARRIER();                    // waves 0-3 wait for the last quadrant of waves 4-7: both groups run the epilogue together
+    PP_FENCE();
+
+    const bool full = m0 + 256 <= p.M && n0 + 256 <= p.N && c_vec;
+    // bias of the lane's 2 x 4 columns (C layout), requested before the first store: an ordinary load issued behind the stores would make
+    // the compiler wait for them
+    float cb[2][4];
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + nh * 128 + Cw * 64 + j * 16 + frow;
+        cb[nh][j] = (p.col_bias && n < p.N) ? p.col_bias[n] : 0.f;
+      }
+    auto epi = [&](f32x4 (&cq)[2][4], int mh, int nh) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        // per-element arithmetic: gemm2.hip / gemm3.hip expression for expression with col_scale = 1 and a zero residual (the `+ 0.f` is
+        // theirs too: it turns -0 into +0)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = fmaf(cq[i][j][r], 1.f, cb[nh][j]);
+            if (!p.res_after_act) v[r] += 0.f;
+          }
+          switch (p.act) {                      // one uniform branch per four elements
+            case ACT_GELU:
+              gelu_act4<T>(v);
+              break;
+            case ACT_RELU:
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+              break;
+            case ACT_SILU:
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = silu(v[r]);
+              break;
+            default: break;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cq[i][j][r] = p.res_after_act ? v[r] + 0.f : v[r];
+        }
+        const int rr = SWIGLU ? lane >> 2 : lane >> 2;
+        const int m = m0 + mh * 128 + R * 32 + i * 16 + rr;
+        if (SWIGLU) {
+          // gate / up weight rows are interleaved in blocks of 16: n-tiles 0, 2 hold gate columns, 1, 3 the matching up columns -- in the C
+          // layout both sit in the same lane.  Both are rounded to T first (what the unfused GEMM -> swiglu_kernel sequence reads back).
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float o = silu(to_f32(from_f32<T>(cq[i][2 * jj][r]))) * to_f32(from_f32<T>(cq[i][2 * jj + 1][r]));
+              sw[(wr_base ^ (r << 2)) + r * 64 + jj * 16] = o;
+            }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const int c0 = (lane & 3) * 8;          // 8 of the slab's 32 output columns
+          float y[8];
+#pragma unroll
+          for (int e = 0; e < 8; e += 4) {
+            f32x4 t4 = *reinterpret_cast<const f32x4*>(sw + ((rr * 64 + c0 + e) ^ ((rr & 3) << 2)));
+            y[e] = t4[0]; y[e + 1] = t4[1]; y[e + 2] = t4[2]; y[e + 3] = t4[3];
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const int nb = ((n0 + nh * 128 + Cw * 64) >> 1) + c0;     // output column (N / 2 columns in all)
+          T* Ct = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + nb;
+          if (full) {
+            *reinterpret_cast<Chunk16*>(Ct) = chunk_from_f32<T>(y);
+          } else if (m < p.M && nb + 8 <= (p.N >> 1)) {
+            if (c_vec) *reinterpret_cast<Chunk16*>(Ct) = chunk_from_f32<T>(y);
+            else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) Ct[e] = from_f32<T>(y[e]);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sw[(wr_base ^ (r << 2)) + r * 64 + j * 16] = cq[i][j][r];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const int c0 = (lane & 3) * 16;
+          float y[16];
+#pragma unroll
+          for (int e = 0; e < 16; e += 4) {
+            f32x4 t4 = *reinterpret_cast<const f32x4*>(sw + ((rr * 64 + c0 + e) ^ ((rr & 3) << 2)));
+            y[e] = t4[0]; y[e + 1] = t4[1]; y[e + 2] = t4[2]; y[e + 3] = t4[3];
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const int nb = n0 + nh * 128 + Cw * 64 + c0;          // first of this lane's 16 columns
+          T* Ct = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + nb;
+          if (full) {
+            *reinterpret_cast<Chunk16*>(Ct) = chunk_from_f32<T>(y);
+            *reinterpret_cast<Chunk16*>(Ct + 8) = chunk_from_f32<T>(y + 8);
+          } else if (m < p.M && nb < p.N) {
+            if (c_vec && nb + 16 <= p.N) {
+#pragma unroll
+              for (int e = 0; e < 16; e += VEC) *reinterpret_cast<Chunk16*>(Ct + e) = chunk_from_f32<T>(y + e);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 16; ++e) if (nb + e < p.N) Ct[e] = from_f32<T>(y[e]);
+            }
+          }
+        }
+      }
+    };
+    epi(acc[0][0], 0, 0); epi(acc[0][1], 0, 1); epi(acc[1][0], 1, 0); epi(acc[1][1], 1, 1);
+    PP_FENCE();
+
+    if (!has_next) break;
+    se = full ? S : 0;
+    par = (par + nall) & 1;
+    m0 = m0n; n0 = n0n;
+    ++round;
+    has_next = tile_at(round + 1, m0n, n0n);
+    if (late) PP_BARRIER();                     // re-stagger: waves 4-7 fall one barrier behind again
+  }
+}
+
+int ncu8() {
+  static const int n = [] {
+    int d = 0, c = 256;
+    (void)hipGetDevice(&d);
+    (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d);
+    return c & ~7;
+  }();
+  return n;
+}
+
+}  // namespace
+
+// what the kernel can compute at all: the ping-pong kernel's operands (one K segment, at least four k-tiles), bf16 output on 16-byte rows,
+// bias + GELU / ReLU / SiLU (or the fused SwiGLU)
+bool gemm_8pp_supported(const GemmArgs& a) {
+  const int64_t abytes = ((int64_t)a.M - 1) * a.lda * 2 + (int64_t)a.K * 2, wbytes = ((int64_t)a.N - 1) * a.ldw * 2 + (int64_t)a.K * 2;
+  if (abytes >= (1ll << 31) || wbytes >= (1ll << 31)) return false;      // 32-bit buffer offsets
+  return gemm_8p_supported(a) && a.K2 == 0 && a.K >= 192 && !a.residual && !a.col_scale && a.act != ACT_PRELU && !a.out_f32 && a.ldc % 8 == 0 &&
+         ((uintptr_t)a.C & 15) == 0 && (!a.swiglu_pairs || a.N % 64 == 0);
+}
+// workgroups for `ntiles` tiles: as few rounds as the chip allows, then the smallest multiple of 8 that still needs that many rounds
+// (Whisper QKV: 564 tiles -> 3 rounds -> 192 workgroups; the other 64 CUs stay free for the kernels of other streams)
+int gemm_8pp_grid(int64_t ntiles) {
+  const int cap = ncu8() < 8 ? 8 : ncu8();
+  const int64_t rounds = (ntiles + cap - 1) / cap;
+  int64_t g = (ntiles + rounds - 1) / rounds;
+  g = (g + 7) / 8 * 8;
+  return (int)(g > cap ? cap : g);
+}
+// the dispatcher's rule: more tiles than CUs (a single round gains nothing from persistence)
+bool gemm_8pp_eligible(const GemmArgs& a) {
+  if (!gemm_8pp_supported(a)) return false;
+  const int64_t ntiles = (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 256);
+  return ntiles > ncu8();
+}
+
+int launch_gemm_8pp(const GemmArgs& a, hipStream_t st, int grid) {
+  OAVSR_REQUIRE(gemm_8pp_supported(a), "gemm_8pp: shape / epilogue not supported by the persistent ping-pong kernel");
+  const int64_t ntiles = (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 256);
+  if (grid <= 0) grid = gemm_8pp_grid(ntiles);
+  OAVSR_REQUIRE(grid % 8 == 0 && grid >= 8, "gemm_8pp: the grid must be a multiple of 8 (got %d)", grid);
+  if ((int64_t)grid > ntiles) grid = (int)(ntiles / 8 * 8);
+  OAVSR_REQUIRE(grid >= 8, "gemm_8pp: fewer than 8 tiles");
+  GemmArgs b = a;
+  b.tile_order = 1;
+  auto go = [&](auto kern) -> int {
+    static bool attr_set = false;
+    if (!attr_set) {
+      OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem8pp));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), kSmem8pp, st, b, (int)ntiles);
+    OAVSR_CHECK_HIP(hipGetLastError());
+    return 0;
+  };
+  return a.swiglu_pairs ? go(gemm_8pp_kernel<true>) : go(gemm_8pp_kernel<false>);
+}
+
+}  // namespace oavsr

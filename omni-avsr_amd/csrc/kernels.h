@@ -52,6 +52,8 @@ struct GemmArgs {
   // M < N); 1: blocks of 8 M-tiles x 4 N-tiles, so the 32 tiles an XCD's CUs work on at one time share 8 A panels and 4 W panels in
   // its L2 (12 panel fetches per k-step for 64 panel reads).  Speed only, never results.  Set by the launcher.
   int tile_order = 0;
+  // parity tests / yardsticks (oavsr_op_gemm): 2 = the 16-wave 256 x 256 LDS-DMA kernel whatever the dispatcher would pick.  0 in the product.
+  int force_tile = 0;
 };
 // (mt, nt) of linear tile index bid in the blocked order above; bijective for any ntm x ntn
 __host__ __device__ inline void blocked_tile(int bid, int ntm, int ntn, int& mt, int& nt) {
@@ -79,6 +81,14 @@ int launch_gemm_dma(const GemmArgs& a, hipStream_t st);
 bool gemm_8p_eligible(const GemmArgs& a);      // the dispatcher's rule (deep K)
 bool gemm_8p_supported(const GemmArgs& a);     // what the kernel can compute at all
 int launch_gemm_8p(const GemmArgs& a, hipStream_t st);
+// PERSISTENT ping-pong kernel (gemm4.hip): one workgroup per CU walks a list of 256 x 256 tiles, the LDS-DMA stream continues across
+// tiles and the C stores are not waited for.  bf16, bias + GELU / ReLU / SiLU or fused SwiGLU, no residual; picked by launch_gemm_dma
+// when a launch has more tiles than the chip has CUs.  Bit-identical to the other tile variants.
+bool gemm_8pp_eligible(const GemmArgs& a);     // the dispatcher's rule (supported && multi-round)
+bool gemm_8pp_supported(const GemmArgs& a);
+int gemm_8pp_grid(int64_t ntiles);             // workgroups the launcher uses for `ntiles` tiles
+// grid: workgroups (multiple of 8; 0 = gemm_8pp_grid)
+int launch_gemm_8pp(const GemmArgs& a, hipStream_t st, int grid = 0);
 
 // Skinny (decode) GEMM: M <= 128 rows, weights streamed once.  Same math/epilogue subset.
 int launch_gemm_skinny(const GemmArgs& a, hipStream_t st);

@@ -33,6 +33,27 @@ void set_last_error(const char* fmt, ...) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// developer switches: the one table, the one getenv site (common.h: knob)
+// ------------------------------------------------------------------------------------------------
+struct KnobDef { const char* name; int dflt; const char* what; };
+static const KnobDef kKnobs[] = {
+    {"OAVSR_PROF_SHAPES", 0, "profiling hook: one family per GEMM shape instead of per kernel"},
+    {"OAVSR_DECODE_GRAPH", 1, "0: decode steps are launched eagerly instead of replayed from hipGraphs (same kernels, same bits)"},
+    {"OAVSR_SKINNY_PERSIST", 1, "0: per-tile decode GEMVs instead of the persistent forms (bit-identical, tests compare them)"},
+    {"OAVSR_SKINNY_PERSIST_GU", 1, "0: per-tile gate / up GEMV at <= 8 rows (bit-identical)"},
+    {"OAVSR_SKINNY_CHAIN", 0, "1 / 2 / 3: two dependent decode GEMVs in one launch (bit-identical, measured slower; tests)"},
+};
+int knob(const char* name) {
+  for (const KnobDef& k : kKnobs)
+    if (strcmp(k.name, name) == 0) {
+      const char* e = getenv(name);
+      return e ? atoi(e) : k.dflt;
+    }
+  fprintf(stderr, "libomniavsr_hip: unregistered developer switch %s\n", name);
+  abort();
+}
+
+// ------------------------------------------------------------------------------------------------
 // profiler: optional HIP-event bracket around every launch, aggregated per kernel family
 // ------------------------------------------------------------------------------------------------
 struct Profiler {
@@ -99,7 +120,7 @@ static const char* gemm_family(const GemmArgs& a, bool skinny) {
   }
   const char* mode = a.amode == A_DENSE ? "gemm" : a.amode == A_CONV2D ? "conv2d_gemm" : a.amode == A_CONV1D ? "conv1d_gemm" : "stem_gemm";
   const char* tile = (a.ksplit > 1 && !gemm_dma_eligible(a)) ? "splitk_128x128" : gemm_dma_eligible(a) ? gemm_dma_variant(a) : (a.N <= 64 ? "128x64" : "128x128");
-  static const bool shapes = getenv("OAVSR_PROF_SHAPES") != nullptr;      // developer aid: one family per GEMM shape
+  static const bool shapes = knob("OAVSR_PROF_SHAPES") != 0;      // developer aid: one family per GEMM shape
   if (shapes) { snprintf(buf, sizeof(buf), "%c%s %dx%dx%d", mode[0], tile, a.M, a.N, a.K + a.K2); buf[31] = 0; return buf; }
   snprintf(buf, sizeof(buf), "%s_%s_%s", mode, tile, dt);
   return buf;
@@ -108,20 +129,8 @@ static const char* gemm_family(const GemmArgs& a, bool skinny) {
 // Split-K factors are STATIC per call site (functions of the layer's N and K, never of the row count), so that an utterance
 // gets the same bits whether it runs alone or inside a batch: the k-slices are summed in a fixed order by the reduce kernel.
 constexpr int kPrefillTailChunk = 8;    // rows per launch of the pruned last prefill layer / first lm_head (batch-independent kernels)
-constexpr int kVideoNarrowSplit = 2;   // AV-HuBERT fc2 under OAVSR_GEMM_SMALL=0 (round 2: N = D leaves ~100 tiles of 256 x 128 for a batch of 8 x 400 frames)
-constexpr int kLoraDnSplitMax = 8;     // LoRA down projections: N = k*r is one or two column tiles
-static int lora_dn_split(int K, int esz) {
-  const int ktiles = K / (128 / esz);
-  int ks = ktiles / 4;                 // at least 4 k-tiles per slice
-  static const int cap = [] { const char* e = getenv("OAVSR_LORA_SPLIT_MAX"); int v = e ? atoi(e) : kLoraDnSplitMax; return v < 1 ? 1 : v > kLoraDnSplitMax ? kLoraDnSplitMax : v; }();
-  return ks < 1 ? 1 : ks > cap ? cap : ks;
-}
-static int video_narrow_split() {
-  static const int v = [] { const char* e = getenv("OAVSR_NARROW_SPLIT"); int x = e ? atoi(e) : kVideoNarrowSplit; return x < 1 ? 1 : x > kVideoNarrowSplit ? kVideoNarrowSplit : x; }();
-  return v;
-}
-static void set_split(GemmArgs& g, const oavsr_workspace* ws, int ks);
-static bool split_small_call_sites();
+// (Round 3: the narrow encoder projections and the LoRA down projections are never split any more -- they run un-split on the small-GEMM
+// tile, gemm2.hip -- so the only split-K call sites left are the > 32-row decode GEMMs of beam search, decode_split below.)
 
 static thread_local int g_shared_chip = 0;      // set by the decode scheduler around its steps: GemmArgs::shared_chip of the launches below
 
@@ -193,6 +202,10 @@ struct oavsr_model {
   mutable hipEvent_t enc_done = nullptr;       // recorded after the prefill of the most recent generate()
   mutable hipStream_t enc_last = nullptr;
   mutable bool enc_recorded = false;
+  // caller streams handed out by oavsr_scheduler_caller_stream: created with the model's FIRST scheduler, before that scheduler's lanes
+  // (hardware-queue binding order), kept across pool rebuilds, destroyed with the model
+  static constexpr int kCallerStreams = 8;
+  mutable std::vector<hipStream_t> caller_streams;
 
   const void* ptr(const std::string& n, bool required = true) const {
     auto it = t.find(n);
@@ -317,7 +330,6 @@ struct oavsr_scheduler {
   // burst of steps a lane issues -- the only way to SEE the overlap (rocprofv3's kernel trace takes the queues in turn)
   struct TraceRec { int kind, id, steps, rows; hipEvent_t e0, e1; };
   bool trace = false;
-  std::vector<hipStream_t> placeholders;       // developer switch OAVSR_SCHED_LANE_SKIP
   std::vector<TraceRec> trace_recs;
   std::vector<hipEvent_t> trace_pool;
   hipEvent_t trace_event() {
@@ -533,19 +545,12 @@ static int resolve_model(oavsr_model* m) {
 // ------------------------------------------------------------------------------------------------
 // shared transformer-encoder layer stack (AV-HuBERT wav2vec2.py:977-1006 / WhisperEncoderLayer), pre-LN
 // ------------------------------------------------------------------------------------------------
-static void set_split(GemmArgs& g, const oavsr_workspace* ws, int ks) {
-  if (ks > 1 && ws->partial && (size_t)ks * g.M * g.N * 4 <= ws->partial_bytes) { g.ksplit = ks; g.partial = ws->partial; }
-}
-// Round 3: the LoRA down projections and AV-HuBERT's out-projection are never split any more (a static property of the call site, like the
-// split factors: an utterance's bits must not depend on its batch) -- un-split they run on the 128 x 64 small-GEMM tile (gemm2.hip:
-// gemm_small_tile; the TILE may follow M, it never changes a bit).  OAVSR_GEMM_SMALL=0: the round-2 forms (split + 256 x 128 tiles).
-static bool split_small_call_sites() {
-  static const bool on = [] { const char* e = getenv("OAVSR_GEMM_SMALL"); return e && e[0] == '0'; }();
-  return on;
-}
+// The LoRA down projections and AV-HuBERT's out-projection / fc2 are never split (a static property of the call site: an utterance's bits
+// must not depend on its batch) -- they run on the 128 x 64 small-GEMM tile (gemm2.hip: gemm_small_tile; the TILE may follow M, it never
+// changes a bit).
 
 static int run_encoder_layers(const oavsr_model* m, oavsr_workspace* ws, const std::vector<EncLayer>& layers, int rows, int D,
-                              int heads, int ffn, int lora_k2, const int* cu_dev, int n_seqs, int max_len, int narrow_split, hipStream_t st) {
+                              int heads, int ffn, int lora_k2, const int* cu_dev, int n_seqs, int max_len, hipStream_t st) {
   const int dt = m->dtype;
   const int hd = D / heads;
   for (const EncLayer& L : layers) {
@@ -555,7 +560,6 @@ static int run_encoder_layers(const oavsr_model* m, oavsr_workspace* ws, const s
     if (lora_k2 > 0) {   // t = h . [A_q; A_v]^T
       g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = lora_k2; g.K = D; g.A = ws->enc_h; g.lda = D; g.W = L.lora_dn; g.ldw = D;
       g.C = ws->enc_lora; g.ldc = lora_k2;
-      if (split_small_call_sites()) set_split(g, ws, lora_dn_split(D, (int)m->esz));
       OAVSR_TRY(run_gemm(g, st));
     }
     g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 3 * D; g.K = D; g.A = ws->enc_h; g.lda = D; g.W = L.qkvw; g.ldw = D;
@@ -571,7 +575,6 @@ static int run_encoder_layers(const oavsr_model* m, oavsr_workspace* ws, const s
       OAVSR_TRY(launch_attention(a, st)); }
     g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = D; g.K = D; g.A = ws->enc_attn; g.lda = D; g.W = L.ow; g.ldw = D; g.col_bias = L.ob;
     g.residual = ws->enc_x; g.ldr = D; g.C = ws->enc_x; g.ldc = D;
-    if (split_small_call_sites()) set_split(g, ws, narrow_split);
     OAVSR_TRY(run_gemm(g, st));
     { ProfScope ps("layernorm", 0, 2.0 * rows * D * m->esz, st);
       OAVSR_TRY(launch_layernorm(dt, ws->enc_x, D, ws->enc_h, D, L.ln2w, L.ln2b, rows, D, 1e-5f, st)); }
@@ -580,7 +583,6 @@ static int run_encoder_layers(const oavsr_model* m, oavsr_workspace* ws, const s
     OAVSR_TRY(run_gemm(g, st));
     g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = D; g.K = ffn; g.A = ws->enc_ffn; g.lda = ffn; g.W = L.fc2w; g.ldw = ffn; g.col_bias = L.fc2b;
     g.residual = ws->enc_x; g.ldr = D; g.C = ws->enc_x; g.ldc = D;
-    if (split_small_call_sites()) set_split(g, ws, narrow_split);      // round 3: never split (small-GEMM tile while the grid is small, the big tiles beyond)
     OAVSR_TRY(run_gemm(g, st));
   }
   return 0;
@@ -588,8 +590,7 @@ static int run_encoder_layers(const oavsr_model* m, oavsr_workspace* ws, const s
 
 static int conv2d_gemm(const oavsr_model* m, const void* x, int imgs, int H, int W, int Cin, int Cout, int ks, int stride, const ConvBN& c,
                        const void* residual, bool prelu, void* out, hipStream_t st) {
-  static const bool direct = [] { const char* e = getenv("OAVSR_CONV_DIRECT"); return !(e && e[0] == '0'); }();
-  if (direct && conv3x3_c64_eligible(m->dtype, H, W, Cin, Cout, ks, stride)) {
+  if (conv3x3_c64_eligible(m->dtype, H, W, Cin, Cout, ks, stride)) {
     ProfScope ps("conv3x3_c64_bf16", 2.0 * imgs * H * W * 9.0 * Cin * Cout, 2.0 * imgs * H * W * (Cin + Cout * (residual ? 2 : 1)), st);
     return launch_conv3x3_c64(x, imgs, H, W, c.w, c.scale, c.shift, prelu ? c.slope : nullptr, residual, out, st);
   }
@@ -674,7 +675,7 @@ static int encode_video_impl(const oavsr_model* m, oavsr_workspace* ws, const vo
   g.Cin = Cg; g.A = ws->enc_h; g.lda = D; g.groups = G; g.a_goff = Cg; g.rowinfo = ws->rowinfo; g.W = m->vpos_w; g.ldw = g.K;
   g.col_bias = m->vpos_b; g.act = ACT_GELU; g.residual = ws->enc_h; g.ldr = D; g.res_after_act = 1; g.C = ws->enc_x; g.ldc = D;
   OAVSR_TRY(run_gemm(g, st));
-  OAVSR_TRY(run_encoder_layers(m, ws, m->vlayers, F, D, c.av_heads, c.av_ffn, c.av_lora_k2, ws->cu_a, B, maxT, video_narrow_split(), st));
+  OAVSR_TRY(run_encoder_layers(m, ws, m->vlayers, F, D, c.av_heads, c.av_ffn, c.av_lora_k2, ws->cu_a, B, maxT, st));
   void* enc = ws->enc_out_v;
   { ProfScope ps("layernorm", 0, 2.0 * F * D * m->esz, st);
     OAVSR_TRY(launch_layernorm(dt, ws->enc_x, D, enc, D, m->vlnf_w, m->vlnf_b, F, D, 1e-5f, st)); }
@@ -723,7 +724,7 @@ static int encode_audio_impl(const oavsr_model* m, oavsr_workspace* ws, const fl
   g.A = ws->conv1_out; g.lda = D; g.rowinfo = ws->rowinfo2; g.W = m->aconv2_w; g.ldw = 3 * D; g.col_bias = m->aconv2_b; g.act = ACT_GELU;
   g.residual = ws->pos_rep; g.ldr = D; g.res_after_act = 1; g.C = ws->enc_x; g.ldc = D;
   OAVSR_TRY(run_gemm(g, st));
-  OAVSR_TRY(run_encoder_layers(m, ws, m->alayers, B * 1500, D, c.wh_heads, c.wh_ffn, 0, ws->cu_b, B, 1500, 1, st));
+  OAVSR_TRY(run_encoder_layers(m, ws, m->alayers, B * 1500, D, c.wh_heads, c.wh_ffn, 0, ws->cu_b, B, 1500, st));
   void* enc = ws->enc_out_a;
   { ProfScope ps("layernorm", 0, 2.0 * B * 1500 * D * m->esz, st);
     OAVSR_TRY(launch_layernorm(dt, ws->enc_x, D, enc, D, m->alnf_w, m->alnf_b, B * 1500, D, 1e-5f, st)); }
@@ -821,7 +822,7 @@ static constexpr int skinny_max_rows() { return 32; }
 
 static int decode_split(int N, int Ktot, int esz) {
   const int ktiles = Ktot / (128 / esz);
-  static const int target = [] { const char* e = getenv("OAVSR_DECODE_SPLIT_TARGET"); return e ? atoi(e) : 128; }();      // developer switch (changes the fp32 summation order)
+  constexpr int target = 128;             // workgroups per launch the split is sized for (part of the > 32-row regime's summation order: a constant)
   int ks = target / std::max(1, ceil_div(N, 64));
   ks = std::min(ks, std::max(1, ktiles / 2));
   return std::max(1, std::min(ks, 16));
@@ -838,8 +839,7 @@ static int llm_gemm(const oavsr_model* m, oavsr_workspace* ws, GemmArgs& g, int 
   if (ks > 1) {
     OAVSR_REQUIRE((size_t)ks * g.M * g.N * 4 <= ws->partial_bytes, "decode GEMM: split-K slabs (%d x %d x %d) exceed the workspace", ks, g.M, g.N);
     g.ksplit = ks; g.partial = ws->partial;
-    static const bool fuse_rn = [] { const char* e = getenv("OAVSR_REDUCE_NORM"); return !(e && e[0] == '0'); }();
-    if (fuse_rn && rn_gain && normed) {
+    if (rn_gain && normed) {
       g.rn_out = ws->lh; g.rn_ld = g.N; g.rn_gain = rn_gain; g.rn_eps = m->cfg.llm_rms_eps;
       if (splitk_rmsnorm_ok(g)) *normed = true;
       else { g.rn_out = nullptr; g.rn_gain = nullptr; }
@@ -861,8 +861,7 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
   const int tl = c.lora_task_specific ? task : 0;
   const int mode = !decode ? 0 : (rows <= skinny_max_rows() ? 1 : 2);
   const bool fused_norm = mode == 1;       // RMSNorm folded into the skinny GEMMs (gain on the A fragments, rstd in the epilogue)
-  static const bool prune_on = [] { const char* e = getenv("OAVSR_PREFILL_PRUNE"); return !(e && e[0] == '0'); }();
-  const bool can_prune = prune_on && !decode && last_rows && cu_last;
+  const bool can_prune = !decode && last_rows && cu_last;
   if (pruned) *pruned = false;
   if (final_normed) *final_normed = false;
   bool have_h = false;                     // mode 2: ws->lh already holds ln1(x) of this layer, written by the previous down_proj's reduce pass
@@ -881,7 +880,6 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
       gl = GemmArgs(); gl.dtype = dt; gl.M = rows; gl.N = c.lora_k2; gl.K = d; gl.A = hin; gl.lda = d; gl.W = L.lora_dn[tl]; gl.ldw = d;
       gl.C = ws->llora; gl.ldc = c.lora_k2;
       if (fused_norm) { gl.norm_gain = L.ln1w; gl.norm_eps = c.llm_rms_eps; }
-      if (mode == 0 && split_small_call_sites()) set_split(gl, ws, lora_dn_split(d, (int)m->esz));
     }
     g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = nqkv; g.K = d; g.A = hin; g.lda = d; g.W = L.qkvw; g.ldw = d; g.col_bias = L.qkvb;
     if (c.lora_k2 > 0) { g.A2 = ws->llora; g.lda2 = c.lora_k2; g.W2 = L.lora_up[tl]; g.ldw2 = c.lora_k2; g.K2 = c.lora_k2; }
@@ -954,12 +952,11 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
         if (!h2) { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
           OAVSR_TRY(launch_rmsnorm(dt, ws->lx, d, ws->lh, d, L.ln2w, rows, d, c.llm_rms_eps, st)); }
         g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 2 * I; g.K = d; g.A = ws->lh; g.lda = d; g.W = L.guw; g.ldw = d; g.C = ws->lgu; g.ldc = 2 * I;
-        static const bool fuse_swiglu = [] { const char* e2 = getenv("OAVSR_FUSE_SWIGLU"); return !(e2 && e2[0] == '0'); }();
         GemmArgs gf = g; gf.swiglu_pairs = 1; gf.C = ws->lact; gf.ldc = I;
         // prefill, and beam-search decode (33..128 rows) when the 128 x 64 tiles already fill the chip without split-K:
         // SwiGLU in the GEMM epilogue, the [rows][2I] tensor never exists
         const bool dec_fill = mode == 2 && (int64_t)ceil_div(rows, 128) * ceil_div(2 * I, 64) >= 256;
-        if (fuse_swiglu && (mode == 0 || dec_fill) && gemm_dma_swiglu_ok(gf)) {
+        if ((mode == 0 || dec_fill) && gemm_dma_swiglu_ok(gf)) {
           OAVSR_TRY(run_gemm(gf, st, false));
         } else {
           OAVSR_TRY(llm_gemm(m, ws, g, mode, st));
@@ -1062,7 +1059,7 @@ static int decode_greedy(const oavsr_model* m, oavsr_workspace* ws, int task, in
   for (int b = 0; b < B; ++b) { ipos[b] = ws->S_host[b] - 1; icpos[b] = -1; ifin[b] = 0; ilen[b] = 0; maxS = std::max(maxS, ws->S_host[b]); }
   *istep = 0;
   for (int i = 0; i < B * max_new; ++i) iout[i] = c.id_pad;
-  static const bool graphs_on = [] { const char* e = getenv("OAVSR_DECODE_GRAPH"); return !(e && e[0] == '0'); }();
+  static const bool graphs_on = knob("OAVSR_DECODE_GRAPH") != 0;
   // hipGraph replay needs stable addresses -> results land in workspace buffers and are copied out at the end; the eager
   // path (profiling, legacy default stream which cannot be captured) writes the caller's buffers directly.
   const bool use_graph = graphs_on && !g_prof.on && max_new > 3 && st != nullptr;
@@ -1161,7 +1158,7 @@ static int decode_beam(const oavsr_model* m, oavsr_workspace* ws, int task, int 
   // Every step-dependent value lives in device memory, so a PAIR of steps (side 0 -> 1 -> 0) is one hipGraph, captured once per
   // (B, K, task, max_new) and replayed: one graph launch instead of ~450 kernel launches.  Step 1 always runs eagerly (it also
   // sets the kernels' attributes before the first capture) and leaves the tables on side 0.
-  static const bool graphs_on = [] { const char* e = getenv("OAVSR_DECODE_GRAPH"); return !(e && e[0] == '0'); }();
+  static const bool graphs_on = knob("OAVSR_DECODE_GRAPH") != 0;
   const bool use_graph = graphs_on && !g_prof.on && max_new > 4 && st != nullptr;
   int t = 1, cur = 1;
   if (t < max_new) { OAVSR_TRY(one_step(cur)); cur ^= 1; ++t; }
@@ -1194,6 +1191,27 @@ static int decode_beam(const oavsr_model* m, oavsr_workspace* ws, int task, int 
 extern "C" {
 
 int oavsr_abi_version(void) { return OAVSR_ABI_VERSION; }
+
+extern char** environ;
+int oavsr_env_report(char* buf, int32_t nbytes) {
+  // every OAVSR_* variable of the process: "NAME=value" (the library's own switches) or "NAME=value?" (a name the library does not read --
+  // the Python host's, or a switch that no longer exists), ';'-separated
+  std::string out;
+  int n = 0;
+  for (char** e = environ; e && *e; ++e) {
+    if (strncmp(*e, "OAVSR_", 6) != 0) continue;
+    const char* eq = strchr(*e, '=');
+    const std::string name(*e, eq ? (size_t)(eq - *e) : strlen(*e));
+    bool known = false;
+    for (const KnobDef& k : kKnobs) known = known || name == k.name;
+    if (!out.empty()) out += ';';
+    out += *e;
+    if (!known) out += '?';
+    ++n;
+  }
+  if (buf && nbytes > 0) { strncpy(buf, out.c_str(), (size_t)nbytes - 1); buf[nbytes - 1] = 0; }
+  return n;
+}
 const char* oavsr_last_error(void) { return g_err; }
 
 int oavsr_model_create(const oavsr_config* cfg, const void* blob_dev, uint64_t blob_bytes, const oavsr_tensor* tensors, int32_t n_tensors,
@@ -1238,6 +1256,7 @@ void oavsr_model_destroy(oavsr_model* m) {
   if (m->melfb) hipFree(m->melfb);
   if (m->stem_wp) hipFree(m->stem_wp);
   if (m->enc_done) hipEventDestroy(m->enc_done);
+  for (auto cs : m->caller_streams) { hipStreamSynchronize(cs); hipStreamDestroy(cs); }
   delete m;
 }
 
@@ -1317,16 +1336,13 @@ int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, 
   WANT(sync, ws->sync_bytes);
   WANT(gs.tok, rows_dec * 4); WANT(gs.finished, rows_dec * 4); WANT(gs.out_ids, rows_dec * (size_t)max_new * 4); WANT(gs.out_len, rows_dec * 4);
   WANT(gs.step, 256); WANT(gs.pos, rows_dec * 4); WANT(gs.cpos, rows_dec * 4); WANT(gs.rope_cs, rows_dec * (size_t)(hd / 2) * sizeof(float2));
-  {   // split-K partial slabs: decode GEMMs with > 32 rows, the narrow video-encoder projections, the LoRA down projections
+  {   // split-K partial slabs: decode GEMMs with > 32 rows (beam search)
     size_t pb = 0;
     if (rows_dec > 32) {   // every decode GEMM call site: ks(N, K) x rows x N fp32 (decode_split)
       const int es = (int)e, qkv = (int)nqkv, nq_ = H * hd;
       const int sites[5][2] = {{c.lora_k2, d}, {qkv, d + c.lora_k2}, {d, nq_}, {2 * I, d}, {d, I}};
       for (auto& s2 : sites) if (s2[0] > 0) pb = std::max(pb, (size_t)decode_split(s2[0], s2[1], es) * rows_dec * s2[0] * 4);
     }
-    if (m->has_video) pb = std::max(pb, (size_t)kVideoNarrowSplit * F * Dv * 4);
-    if (m->has_video && c.av_lora_k2 > 0) pb = std::max(pb, (size_t)kLoraDnSplitMax * F * c.av_lora_k2 * 4);
-    if (c.lora_k2 > 0) pb = std::max(pb, (size_t)kLoraDnSplitMax * ST * c.lora_k2 * 4);
     ws->partial_bytes = pb;
     if (pb) WANT(partial, pb);
   }
@@ -1552,7 +1568,7 @@ static int sched_retire(oavsr_scheduler* s, SchedLane& l, int idx) {
 
 // issue up to n steps for the rows admitted to the lane; calls whose last step has been issued leave (result copy + `done` event) on the way
 static int sched_run(oavsr_scheduler* s, SchedLane& l, int n) {
-  static const bool graphs_on = [] { const char* e = getenv("OAVSR_DECODE_GRAPH"); return !(e && e[0] == '0'); }();
+  static const bool graphs_on = knob("OAVSR_DECODE_GRAPH") != 0;
   while (n > 0 && !l.active.empty()) {
     const int k = std::min(n, lane_min_remaining(s, l));
     OAVSR_TRY(sched_sync_membership(s, l));
@@ -1658,41 +1674,26 @@ int oavsr_scheduler_create(const oavsr_model* m, int32_t n_slots, int32_t max_ro
   s->ss.inv_freq = m->inv_freq; s->ss.rope_half = hd / 2; s->ss.out_ld = max_new; s->ss.scratch_slot = n_slots;
   s->slot_owner.assign(n_slots, -1); s->slot_used.assign(n_slots, 0); s->slot_freed_at.assign(n_slots, 0);
   s->ring.resize(oavsr_scheduler::kRing);
-  static const int prio = [] { const char* e2 = getenv("OAVSR_SCHED_PRIORITY"); return e2 ? atoi(e2) : 0; }();     // developer switch: < 0 = above the callers' streams
-  static const int eager_queues = [] { const char* e2 = getenv("OAVSR_SCHED_EAGER_QUEUES"); return e2 ? atoi(e2) : 0; }();
-  auto lane_skip = [](int i) {                    // OAVSR_SCHED_LANE_SKIP="a,b,c": placeholder streams in front of lane 0, 1, 2
-    const char* e2 = getenv("OAVSR_SCHED_LANE_SKIP");
-    for (int k = 0; e2; ++k) { if (k == i) return atoi(e2); e2 = strchr(e2, ','); if (e2) ++e2; }
-    return 0;
-  };
-  static const int lane_cus = [] { const char* e2 = getenv("OAVSR_SCHED_CUS"); return e2 ? atoi(e2) : 0; }();
-  static const int lane_cu_offset = [] { const char* e2 = getenv("OAVSR_SCHED_CU_OFFSET"); return e2 ? atoi(e2) : 0; }();
+  // Stream creation order matters for speed (never for results): ROCm binds a stream to one of its few hardware queues when the stream is
+  // created, and which caller stream shares a queue with which lane decides how encoder phases and decode bursts take turns (DESIGN.md
+  // section 5).  The engine therefore creates the CALLER streams it hands out (oavsr_scheduler_caller_stream) first, then the lanes: the
+  // order the round-3 scan found in the fast regime.  (Priority streams, CU-masked lanes, eagerly bound queues and placeholder streams
+  // were measured in round 3 and removed in round 4: profiles/r03_sched_scan.txt.)
+  // (they belong to the MODEL, so that they survive a pool that has to be rebuilt: created once, with the model's first scheduler)
+  while ((int)m->caller_streams.size() < oavsr_model::kCallerStreams) {
+    hipStream_t cs = nullptr;
+    if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return fail("stream creation failed");
+    m->caller_streams.push_back(cs);
+  }
   for (auto& l : s->lanes) {
     oavsr_workspace* lw = l.dws;      // the lane's view: its own scratch, the shared pool
     lw->m = m; lw->max_B = n_slots; lw->max_beams = 1; lw->max_new = max_new; lw->max_prefix = s->max_prefix;
     lw->kpre = w->kpre; lw->vpre = w->vpre; lw->ktail = w->ktail; lw->vtail = w->vtail; lw->kpre_layer = w->kpre_layer; lw->ktail_layer = w->ktail_layer;
     lw->prefix_len = w->prefix_len; lw->rowmap = l.rowmap;
-    hipError_t se;
-    // developer switch: placeholder streams created (and bound to a hardware queue by a first operation) in front of lane i shift the queue the
-    // lane lands on; OAVSR_SCHED_EAGER_QUEUES=1 binds the lanes' queues here instead of at their first step ("Why lanes")
-    { const int li = (int)(&l - s->lanes.data());
-      for (int j = 0; j < lane_skip(li); ++j) {
-        hipStream_t ph = nullptr;
-        if (hipStreamCreateWithFlags(&ph, hipStreamNonBlocking) == hipSuccess) { (void)hipMemsetAsync(s->arena, 0, 4, ph); (void)hipStreamSynchronize(ph); s->placeholders.push_back(ph); }
-      } }
-    if (lane_cus > 0) {                // developer switch: the lane's kernels may only occupy `lane_cus` CUs (mask bit i -> XCD i % 8, so a dense range spreads over the XCDs)
-      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      const int first = (int)(&l - s->lanes.data()) * lane_cu_offset;
-      for (int b = 0; b < std::min(lane_cus, 256); ++b) { const int bit = (first + b) % 256; mask[bit / 32] |= 1u << (bit % 32); }
-      se = hipExtStreamCreateWithCUMask(&l.st, 8, mask);
-    } else {
-      se = prio ? hipStreamCreateWithPriority(&l.st, hipStreamNonBlocking, prio) : hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking);
-    }
-    if (se != hipSuccess) {
+    if (hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking) != hipSuccess) {
       l.st = nullptr;
       return fail("stream creation failed");
     }
-    if (eager_queues) { (void)hipMemsetAsync(s->arena, 0, 4, l.st); (void)hipStreamSynchronize(l.st); }
   }
   if (hipDeviceSynchronize() != hipSuccess) return fail("device synchronisation failed");
   *out = s;
@@ -1707,7 +1708,6 @@ void oavsr_scheduler_destroy(oavsr_scheduler* s) {
     if (l.st) hipStreamDestroy(l.st);
     delete l.dws;
   }
-  for (auto ph : s->placeholders) hipStreamDestroy(ph);
   for (auto& k : s->ring) { if (k.prefilled) hipEventDestroy(k.prefilled); if (k.done) hipEventDestroy(k.done); }
   for (auto& r : s->trace_recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
   for (auto e : s->trace_pool) hipEventDestroy(e);
@@ -1716,6 +1716,10 @@ void oavsr_scheduler_destroy(oavsr_scheduler* s) {
   delete s;
 }
 uint64_t oavsr_scheduler_bytes(const oavsr_scheduler* s) { return s ? s->arena_bytes : 0; }
+oavsr_stream oavsr_scheduler_caller_stream(oavsr_scheduler* s, int32_t i) {
+  if (!s || i < 0 || i >= (int)s->m->caller_streams.size()) { set_last_error("scheduler_caller_stream: index %d out of range (0..%d)", (int)i, oavsr_model::kCallerStreams - 1); return nullptr; }
+  return (oavsr_stream)s->m->caller_streams[i];
+}
 
 int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_workspace* ws, int32_t task, const void* video_dev, const int32_t* Tv_host,
                           const float* wav_dev, int64_t wav_ld, const int32_t* Ts_host, const int32_t* keep_host, int32_t B, int32_t rate_audio,
@@ -1767,40 +1771,67 @@ int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_worksp
   std::vector<int> S(B);
   hipEvent_t tr0 = nullptr;
   if (s->tracing()) { tr0 = s->trace_event(); hipEventRecord(tr0, st); }
+  const int ridx = (int)(ticket % oavsr_scheduler::kRing);
+  // The call dies after it may have queued work that touches its slots (a refused input half way through the encoders, a failed launch
+  // during admission): the ticket is consumed, the slots go back to the pool, and the ring entry's `done` event is recorded on `where` --
+  // behind everything the call queued -- so the block's next owner (which waits for the previous owner's `done`) is ordered after it.
+  // Nothing stays "in flight": flush() and the ring never see the call.
+  auto abandon = [&](hipStream_t where) {
+    k.ticket = ticket; k.task = ltask; k.B = B; k.slot0 = slot0; k.limit = max_new; k.remaining = 0; k.banned = banned; k.lane = li;
+    k.out_ids = nullptr; k.out_len = nullptr; k.host_ids = nullptr; k.host_len = nullptr; k.retired = true;
+    (void)hipEventRecord(k.done, where);
+    auto it = std::find(l.active.begin(), l.active.end(), ridx);
+    if (it != l.active.end()) { l.active.erase(it); l.map_dirty = true; }
+    ++s->free_seq;
+    for (int b = 0; b < B; ++b) { s->slot_used[slot0 + b] = 0; s->slot_owner[slot0 + b] = ticket; s->slot_freed_at[slot0 + b] = s->free_seq; }
+    ++s->next_ticket;
+  };
   { CallScope cs(ws, st);
     PrefillDest dest{s->pool->kpre, s->pool->vpre, s->pool->kpre_layer, s->max_prefix, s->logits_pre, s->pool->prefix_len, slot0};
     const int rc = encode_prefill(m, ws, task, video_dev, Tv_host, wav_dev, wav_ld, Ts_host, keep_host, B, B, rate_audio, rate_video, st, &dest, S.data());
-    if (rc != 0) {                                   // refused inputs: nothing of the call has reached a lane, its slots were never taken
+    if (rc != 0) {                                   // refused inputs: nothing of the call has reached a lane
       if (tr0) s->trace_pool.push_back(tr0);
+      abandon(st);
       return rc;
     } }
-  OAVSR_CHECK_HIP(hipEventRecord(k.prefilled, st));
-  if (tr0) {
-    hipEvent_t tr1 = s->trace_event();
-    hipEventRecord(tr1, st);
-    s->trace_recs.push_back({0, (int)(ticket & 0x7fffffff), 0, B, tr0, tr1});
+  // admission: everything below either completes or is rolled back (abandon) -- the scheduler's state is committed only with the last step
+  auto admit = [&]() -> int {
+    OAVSR_CHECK_HIP(hipEventRecord(k.prefilled, st));
+    if (tr0) {
+      hipEvent_t tr1 = s->trace_event();
+      hipEventRecord(tr1, st);
+      s->trace_recs.push_back({0, (int)(ticket & 0x7fffffff), 0, B, tr0, tr1});
+    }
+    // pacing: the lane advances 1/k of a hypothesis per admission (k = calls of this size that share a step), beside this call's MFMA-bound phase
+    const int share = std::max(1, s->max_rows / B);
+    const int stride = s->stride > 0 ? s->stride : std::max(1, (max_new - 1) / share);
+    const int issued = (int)(l.steps - steps0);                 // what making room already cost this lane
+    if (stride > issued) OAVSR_TRY(sched_run(s, l, stride - issued));
+    // after the call's prefill; first token from the prefill's logits (step 0 of the row's own counter)
+    OAVSR_CHECK_HIP(hipStreamWaitEvent(l.st, k.prefilled, 0));
+    IntPack32 Sp;
+    for (int b = 0; b < B; ++b) Sp.v[b] = S[b];
+    OAVSR_TRY(launch_sched_init_slots(s->ss, slot0, B, Sp, max_new, c.id_pad, l.st));
+    OAVSR_TRY(launch_argmax_partial(s->logits_pre + (size_t)slot0 * c.llm_vocab, c.llm_vocab, B, c.llm_vocab, banned, l.partials, l.st));
+    OAVSR_TRY(launch_sched_tail(l.partials, s->ss, nullptr, slot0, B, c.id_eos, c.id_pad, m->dtype, m->embed, c.llm_hidden, nullptr, 0, c.llm_hidden, l.st));
+    return 0;
+  };
+  // the slots are taken while the pacing steps run (sched_alloc of nobody else may see them free), the rest of the entry follows the launches
+  for (int b = 0; b < B; ++b) s->slot_used[slot0 + b] = 1;
+  const int arc = admit();
+  if (arc != 0) {
+    (void)hipStreamWaitEvent(l.st, k.prefilled, 0);    // best effort: `done` then also sits behind the encoder phase on the caller's stream
+    abandon(l.st);
+    return arc;
   }
-  for (int b = 0; b < B; ++b) { s->slot_used[slot0 + b] = 1; s->slot_owner[slot0 + b] = ticket; }
+  for (int b = 0; b < B; ++b) s->slot_owner[slot0 + b] = ticket;
   ++s->next_ticket; ++s->calls;
   k.ticket = ticket; k.task = ltask; k.B = B; k.slot0 = slot0; k.limit = max_new; k.remaining = max_new - 1; k.banned = banned; k.lane = li;
   k.out_ids = out_ids_dev; k.out_len = out_len_dev; k.host_ids = out_ids_host; k.host_len = out_len_host; k.retired = false;
-  // pacing: the lane advances 1/k of a hypothesis per admission (k = calls of this size that share a step), beside this call's MFMA-bound phase
-  static const int stride_env = [] { const char* e = getenv("OAVSR_SCHED_STRIDE"); return e ? atoi(e) : 0; }();
-  const int share = std::max(1, s->max_rows / B);
-  const int stride = s->stride > 0 ? s->stride : stride_env > 0 ? stride_env : std::max(1, (max_new - 1) / share);
-  const int issued = (int)(l.steps - steps0);                 // what making room already cost this lane
-  if (stride > issued) OAVSR_TRY(sched_run(s, l, stride - issued));
-  // admission: after the call's prefill; first token from the prefill's logits (step 0 of the row's own counter)
-  OAVSR_CHECK_HIP(hipStreamWaitEvent(l.st, k.prefilled, 0));
-  IntPack32 Sp;
-  for (int b = 0; b < B; ++b) Sp.v[b] = S[b];
-  OAVSR_TRY(launch_sched_init_slots(s->ss, slot0, B, Sp, max_new, c.id_pad, l.st));
-  OAVSR_TRY(launch_argmax_partial(s->logits_pre + (size_t)slot0 * c.llm_vocab, c.llm_vocab, B, c.llm_vocab, banned, l.partials, l.st));
-  OAVSR_TRY(launch_sched_tail(l.partials, s->ss, nullptr, slot0, B, c.id_eos, c.id_pad, m->dtype, m->embed, c.llm_hidden, nullptr, 0, c.llm_hidden, l.st));
-  l.active.push_back((int)(ticket % oavsr_scheduler::kRing));
+  l.active.push_back(ridx);
   l.map_dirty = true;
-  if (k.remaining <= 0) OAVSR_TRY(sched_retire(s, l, (int)(ticket % oavsr_scheduler::kRing)));
   *ticket_out = ticket;
+  if (k.remaining <= 0) OAVSR_TRY(sched_retire(s, l, ridx));      // max_new == 1: the first token is the whole hypothesis (a failure here leaves a consistent, retirable entry)
   return 0;
 }
 
@@ -1921,6 +1952,11 @@ int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream) {
   if (d->skinny == 2) {      // tests: the 8-wave ping-pong 256 x 256 kernel whatever the dispatcher's rule says
     OAVSR_REQUIRE(gemm_8p_supported(g), "op_gemm: shape / layout not supported by the ping-pong kernel");
     return launch_gemm_8p(g, (hipStream_t)stream);
+  }
+  if (d->skinny == 3) return launch_gemm_8pp(g, (hipStream_t)stream, d->grid);      // tests: the persistent ping-pong kernel on d->grid workgroups
+  if (d->skinny == 5) {      // tests / yardsticks: the 16-wave 256 x 256 LDS-DMA kernel whatever the dispatcher's rule says
+    g.force_tile = 2;
+    return launch_gemm(g, (hipStream_t)stream);
   }
   return d->skinny ? launch_gemm_skinny(g, (hipStream_t)stream) : launch_gemm(g, (hipStream_t)stream);
 }

@@ -895,10 +895,9 @@ int launch_persist_r16(const GemmArgs& a, hipStream_t st) {
     const int load = c * ceil_div(ntiles, c * ncu);
     if (load < best) { best = load; per_cu = c; }
   }
-  // shared chip (decode scheduler): half as many persistent workgroups; OAVSR_PERSIST_GRID_DIV overrides the divisor (A/B runs)
-  static const int grid_div = [] { const char* e = getenv("OAVSR_PERSIST_GRID_DIV"); int v = e ? atoi(e) : 0; return v < 0 ? 0 : v; }();
+  // shared chip (decode scheduler): half as many persistent workgroups
   int grid = ntiles < per_cu * ncu ? ntiles : per_cu * ncu;
-  const int div = grid_div > 0 ? grid_div : (a.shared_chip ? 2 : 1);
+  const int div = a.shared_chip ? 2 : 1;
   if (div > 1) grid = std::max(1, grid / div);
   auto kern = nsteps <= W * AS0 ? skinny_persist_r16_kernel<T, MT, NORM, AS0, W, SWIGLU> : skinny_persist_r16_kernel<T, MT, NORM, 2 * AS0, W, SWIGLU>;
   if (smem > 64 * 1024) {
@@ -949,8 +948,7 @@ int launch_persist(const GemmArgs& a, hipStream_t st) {
 // <= 8 rows, 8-wave form: gate / up (SwiGLU epilogue) with at least two tiles per CU (one persistent workgroup per CU walks them: 18.5 ->
 // 17.7 us per launch, +2 % with three batches in flight, neutral alone).  OAVSR_SKINNY_PERSIST_GU=0: the per-tile kernel.
 static bool persist_w8_eligible(const GemmArgs& a) {
-  static const int on = [] { const char* e = getenv("OAVSR_SKINNY_PERSIST"); return e ? atoi(e) : 1; }();
-  static const int gu = [] { const char* e = getenv("OAVSR_SKINNY_PERSIST_GU"); return e ? atoi(e) : 1; }();
+  static const int on = knob("OAVSR_SKINNY_PERSIST"), gu = knob("OAVSR_SKINNY_PERSIST_GU");
   const int esz = a.dtype == DT_F32 ? 4 : 2, kbe = 64 / esz;
   static const int ncu = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
   return on && gu && a.M <= 8 && a.K2 == 0 && a.swiglu_pairs && !a.out_f32 && !a.residual && a.act == ACT_NONE && a.N % 32 == 0 && a.N < 65536 &&
@@ -959,7 +957,7 @@ static bool persist_w8_eligible(const GemmArgs& a) {
 
 // 9..32 rows, 8-wave form: the wide GEMVs below the lm_head class -- gate / up (SwiGLU epilogue) with at least two tiles per CU
 static bool persist_r16_w8_eligible(const GemmArgs& a) {
-  static const int on = [] { const char* e = getenv("OAVSR_SKINNY_PERSIST"); return e ? atoi(e) : 1; }();
+  static const int on = knob("OAVSR_SKINNY_PERSIST");
   const int esz = a.dtype == DT_F32 ? 4 : 2, kbe = 64 / esz;
   static const int ncu = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
   return on && a.M > 8 && a.M <= 32 && a.K2 == 0 && a.swiglu_pairs && !a.out_f32 && !a.residual && a.act == ACT_NONE && a.N % 32 == 0 &&
@@ -968,7 +966,7 @@ static bool persist_r16_w8_eligible(const GemmArgs& a) {
 }
 
 static bool persist_eligible(const GemmArgs& a, int max_rows = 8) {
-  static const int on = [] { const char* e = getenv("OAVSR_SKINNY_PERSIST"); return e ? atoi(e) : 1; }();
+  static const int on = knob("OAVSR_SKINNY_PERSIST");
   const int esz = a.dtype == DT_F32 ? 4 : 2, kbe = 64 / esz;
   if (max_rows > 8 && (a.K / kbe) / 2 > 4 * 8 && a.M > 16) return false;     // 32 rows x 16 steps of resident fragments do not fit the register file
   return on && a.M <= max_rows && a.K2 == 0 && !a.swiglu_pairs && !a.residual && a.act == ACT_NONE && a.N >= 65536 && (a.K / kbe) % 2 == 0 &&
@@ -1036,10 +1034,7 @@ int launch_sk_u(const GemmArgs& a, hipStream_t st) {
   return 0;
 }
 
-static bool half_enabled() {
-  static const int on = [] { const char* e = getenv("OAVSR_SKINNY_HALF"); return e ? atoi(e) : 1; }();
-  return on != 0;
-}
+static bool half_enabled() { return true; }      // (8-column HALF-mode tiles for <= 8 rows: always on since round 1)
 
 template <typename T, int MT, int NT, bool NORM>
 int launch_sk(const GemmArgs& a, hipStream_t st) {
@@ -1074,7 +1069,7 @@ int launch_sk_t(const GemmArgs& a, hipStream_t st) {
   // batches in flight (64 - 96 workgroups per launch: the chain of dependent launches gets longer, which costs more than the CU time saved)
   const bool wide = a.N >= 8192;
   // 9..32 rows: 8-column tiles with 16-row activation operands (skinny_r16_kernel) wherever the <= 8-row path would use its 8-column tiles
-  static const int r16_on = [] { const char* e = getenv("OAVSR_SKINNY_R16"); return e ? atoi(e) : 1; }();
+  constexpr int r16_on = 1;
   constexpr int kbe = 64 / (int)sizeof(T);
   if (r16_on && half_enabled() && a.M > 8 && mt <= 2 && (a.K / kbe) % 2 == 0) {
     if (wide && (!a.swiglu_pairs || a.N % 32 == 0)) {
@@ -1089,9 +1084,8 @@ int launch_sk_t(const GemmArgs& a, hipStream_t st) {
     // 2 - 4 x the weight bytes of a tile at these row counts -- are fetched once per 16 columns); each tile sums exactly as above
     if (!a.swiglu_pairs && a.N >= 64 && a.N / 16 < 384) {
       // shared chip (decode scheduler), 17..32 rows: eight (o_proj, down_proj) / four (QKV, with the fused norm's second LDS image) 8-column
-      // tiles per workgroup instead of two.  OAVSR_R16_NARROW_NT=2|4|8 forces a width (A/B runs).
-      static const int nt_force = [] { const char* e = getenv("OAVSR_R16_NARROW_NT"); return e ? atoi(e) : 0; }();
-      const int want = nt_force ? nt_force : (a.shared_chip ? 8 : 2);
+      // tiles per workgroup instead of two.
+      const int want = a.shared_chip ? 8 : 2;
       if constexpr (!NORM) { if (want >= 8 && mt == 2 && a.N >= 1024) return launch_r16<T, 2, 8, NORM, 1>(a, st); }
       if (want >= 4 && mt == 2 && a.N >= (NORM ? 2048 : 512)) return launch_r16<T, 2, 4, NORM, 2>(a, st);      // (the LoRA down projection, N <= 512, keeps its 16 - 32 workgroups)
       return mt <= 1 ? launch_r16<T, 1, 2, NORM, 4>(a, st) : launch_r16<T, 2, 2, NORM, 2>(a, st);
@@ -1126,7 +1120,7 @@ bool skinny_chain_supported(const GemmArgs& a0, const GemmArgs& a1, int kind) {
   // sc1 activation loads -- costs what the kernel boundary it replaces costs (4-5 us): LoRA down -> QKV +1 % sequential / -2 % with three
   // batches in flight, gate/up -> down -3 % / -5 % (its 256 consumers can only start when the 512 producers have left the CUs).
   // OAVSR_SKINNY_CHAIN: 0 off, 1 both fusions, 2 / 3 only LoRA->QKV / gate-up->down.
-  static const int on = [] { const char* e = getenv("OAVSR_SKINNY_CHAIN"); return e ? atoi(e) : 0; }();
+  static const int on = knob("OAVSR_SKINNY_CHAIN");
   if (!on || (on == 2 && kind != 0) || (on == 3 && kind != 1) || !half_enabled() || a0.dtype != a1.dtype) return false;
   if (kind == 0) return a0.norm_gain && a1.norm_gain && a1.K2 > 0 && chain_stage_ok(a0, 1) && chain_stage_ok(a1, 1);   // LoRA down -> QKV
   return a0.norm_gain && !a1.norm_gain && chain_stage_ok(a0, 4) && chain_stage_ok(a1, 1);                               // gate/up -> down
@@ -1140,7 +1134,7 @@ int launch_gemm_skinny_chain2(const GemmArgs& a0, const GemmArgs& a1, const Skin
 
 // which weight-streaming kernel launch_gemm_skinny picks for 9..32 rows (profiling family names follow the kernel that runs)
 bool skinny_uses_r16(const GemmArgs& a) {
-  static const int r16_on = [] { const char* e = getenv("OAVSR_SKINNY_R16"); return e ? atoi(e) : 1; }();
+  constexpr int r16_on = 1;
   const int esz = a.dtype == DT_F32 ? 4 : 2, kbe = 64 / esz, mt = ceil_div(a.M, 16);
   if (!(r16_on && half_enabled() && a.M > 8 && mt <= 2 && (a.K / kbe) % 2 == 0)) return false;
   if (a.N >= 8192 && (!a.swiglu_pairs || a.N % 32 == 0)) return true;

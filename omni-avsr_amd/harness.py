@@ -301,13 +301,6 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
 
     eng = model.engine
     dev = eng.device
-    # The slots' streams and the copy stream are kept on the engine between evaluate() calls: the runtime maps every stream onto one of a few
-    # hardware queues when it is created, and which caller stream shares a queue with which decode lane decides how the encoder phases and
-    # the decode bursts interleave ("Why lanes") -- fresh streams per call made the same loop run at 256 or at 228 utt/s.
-    scache = eng.__dict__.setdefault("_eval_streams", {})
-    if in_flight not in scache:
-        scache[in_flight] = ([torch.cuda.Stream(device=dev) for _ in range(in_flight)], torch.cuda.Stream(device=dev))
-    streams, copy_stream = scache[in_flight]
     # one workspace per slot, sized for the longest owned clip: nothing is re-created while other slots are busy
     tv_max = max([int(samples[i][0][vkey(samples[i][0])].shape[0]) for i in owned if vkey(samples[i][0]) in samples[i][0]] or [1])
     u8_shape = tuple(samples[owned[0]][0]["video_u8"].shape[1:]) if owned and "video_u8" in samples[owned[0]][0] else None
@@ -320,6 +313,19 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
     # the slot's stream): the event is the end of the call and at most 2 x in_flight calls are queued, as before.
     sched = getattr(model, "num_beams", 1) == 1 and getattr(model, "decode_scheduler", True) and decode_group == 1 and batch_size <= eng.sched_rows
     max_pending = (4 * eng.sched_lanes * max(1, eng.sched_rows // batch_size) + in_flight) if sched else 2 * in_flight
+    if sched:      # the scheduler's pool too is sized once, for the longest owned clip (a pool that grows mid-run drains the whole pipeline)
+        eng.reserve_scheduler(modality, tv_max, ts_max, forward_kw.get("test_ratio_matry_audio"), forward_kw.get("test_ratio_matry_video"),
+                              getattr(model, "max_dec_tokens", None))
+    # Caller streams.  With the scheduler they are the ENGINE's (oavsr_scheduler_caller_stream: created before its lanes' streams, so the
+    # hardware-queue binding that decides how encoder phases and decode bursts take turns is the same on every call -- round 3 ran the same
+    # loop at 256 or at 228 utt/s depending on when evaluate() had created its streams).  Without it (beam search) and for the copy stream,
+    # torch streams kept on the engine between evaluate() calls.
+    scache = eng.__dict__.setdefault("_eval_streams", {})
+    if in_flight not in scache:
+        scache[in_flight] = ([torch.cuda.Stream(device=dev) for _ in range(in_flight)], torch.cuda.Stream(device=dev))
+    streams, copy_stream = scache[in_flight]
+    if sched and in_flight <= 8:
+        streams = [eng.caller_stream(i) for i in range(in_flight)]
     # 2 x in_flight + 1 staging sets: while the main thread launches batch n, a helper thread collates batch n + 1 into the set whose last
     # reader finished longest ago (the reference gets the same overlap from its DataLoader workers)
     from concurrent.futures import ThreadPoolExecutor

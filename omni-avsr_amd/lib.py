@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # OAVSR_LIB points the binding at another build of the same library (A/B timing of kernel variants on one box)
 LIB_PATH = os.environ.get("OAVSR_LIB") or os.path.join(_HERE, "libomniavsr_hip.so")
 
+ABI_VERSION = 2      # OAVSR_ABI_VERSION of include/omni_avsr.h this binding's structures and argument lists follow
 MAX_RATES = 8
 DT_F32, DT_BF16 = 0, 1
 TASK_ID = {"audio": 0, "video": 1, "audiovisual": 2}
@@ -62,6 +63,7 @@ class GemmDesc(C.Structure):
         ("skinny", C.c_int32), ("norm_gain", C.c_void_p), ("norm_eps", C.c_float), ("swiglu_pairs", C.c_int32),
         ("ksplit", C.c_int32), ("partial", C.c_void_p),
         ("rn_out", C.c_void_p), ("rn_ld", C.c_int64), ("rn_gain", C.c_void_p), ("rn_eps", C.c_float),
+        ("grid", C.c_int32),
     ]
 
 
@@ -91,6 +93,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SYMBOLS = {
     "oavsr_abi_version": (C.c_int, []),
     "oavsr_last_error": (C.c_char_p, []),
+    "oavsr_env_report": (C.c_int, [C.c_char_p, _I]),
     "oavsr_model_create": (C.c_int, [C.POINTER(OavsrConfig), _P, C.c_uint64, C.POINTER(OavsrTensor), _I, C.POINTER(_P)]),
     "oavsr_model_destroy": (None, [_P]),
     "oavsr_model_serialize_encoders": (C.c_int, [_P, C.c_int32]),
@@ -109,6 +112,7 @@ SYMBOLS = {
     "oavsr_scheduler_create": (C.c_int, [_P, _I, _I, _I, _I, _I, C.POINTER(_P)]),
     "oavsr_scheduler_destroy": (None, [_P]),
     "oavsr_scheduler_bytes": (C.c_uint64, [_P]),
+    "oavsr_scheduler_caller_stream": (C.c_void_p, [_P, _I]),
     "oavsr_generate_submit": (C.c_int, [_P, _P, _P, _I, _P, C.POINTER(_I), _P, _L, C.POINTER(_I), C.POINTER(_I), _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, C.POINTER(_L)]),
     "oavsr_generate_wait": (C.c_int, [_P, _L, _P]),
     "oavsr_generate_poll": (C.c_int, [_P, _L]),
@@ -154,10 +158,22 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.oavsr_abi_version() != 1:
-        raise RuntimeError("libomniavsr_hip.so ABI version mismatch")
+    if lib.oavsr_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libomniavsr_hip.so ABI version {lib.oavsr_abi_version()} != {ABI_VERSION} of this binding: rebuild the library (make -C omni-avsr_amd/csrc)")
     _lib = lib
     return lib
+
+
+def env_report() -> dict:
+    """OAVSR_* variables of this process: {name: value}; a trailing '?' on the value marks a name the library itself does not read."""
+    buf = C.create_string_buffer(4096)
+    load().oavsr_env_report(buf, len(buf))
+    out = {}
+    for item in buf.value.decode("utf-8", "replace").split(";"):
+        if "=" in item:
+            k, v = item.split("=", 1)
+            out[k] = v
+    return out
 
 
 def last_error() -> str:

@@ -329,6 +329,34 @@ class OmniEngine:
         self._sched_gen += 1
         self._stride_set = 0
 
+    def reserve_scheduler(self, task: str, tv_max: int, ts_max: int, rate_a: Optional[int] = None, rate_v: Optional[int] = None,
+                          max_new: Optional[int] = None):
+        """Size the decode scheduler's pool once for the longest clip of a run (rates default to the smallest configured ones = the longest
+        prompt): a pool that has to grow in the middle of an evaluation drains every lane, synchronises the device and re-captures the step graphs."""
+        use_a, use_v = task in ("audio", "audiovisual"), task in ("video", "audiovisual")
+        ra = int(rate_a or (min(self.spec.rates("audio")) if use_a else 1))
+        rv = int(rate_v or (min(self.spec.rates("video")) if use_v else 1))
+        self.ensure_scheduler(self.prompt_rows(task, [int(tv_max)], [int(ts_max)], ra, rv), max_new or self.spec.max_dec_tokens)
+        return self
+
+    def caller_stream(self, i: int) -> "torch.cuda.Stream":
+        """Caller stream i (0..7) of the decode scheduler, created by the ENGINE before its lanes' streams (oavsr_scheduler_caller_stream):
+        submit calls on these and the loop's throughput no longer depends on when the caller happened to create its streams (ROCm binds a
+        stream to a hardware queue at creation).  Needs the scheduler (reserve_scheduler / a first submit); the
+        streams belong to the model: they survive a pool that has to grow and die with `close()` / a new `load_state_dict`."""
+        if not self._sched:
+            raise RuntimeError("caller_stream: the decode scheduler does not exist yet (call reserve_scheduler first)")
+        cache = self.__dict__.setdefault("_caller_streams", {})
+        key = (self._model.value, int(i))
+        if key not in cache:
+            for k in [k for k in cache if k[0] != self._model.value]:
+                del cache[k]
+            ptr = self.lib.oavsr_scheduler_caller_stream(self._sched, int(i))
+            if not ptr:
+                raise IndexError(L.last_error())
+            cache[key] = torch.cuda.ExternalStream(ptr, device=self.device)
+        return cache[key]
+
     def submit(self, task: str, video, Tv, audio, lengths, rate_a: int, rate_v: int, max_new: Optional[int] = None, force_len: bool = False,
                video_is_flat: bool = False, slot: int = 0):
         """`generate(beams=1)` through the decode scheduler: encoders + prefill are queued on the current stream (workspace `slot`), the
@@ -365,15 +393,35 @@ class OmniEngine:
         self._keepalive[("s", slot)] = (flat, a)
         self._inflight = getattr(self, "_inflight", {})
         tk = (self._sched_gen, ticket.value)
-        self._inflight[tk] = (ids, lens, host)           # the scheduler writes them when the call's last step has run
+        self._reap()
+        self._inflight[tk] = [ids, lens, host, False]    # the scheduler writes them when the call's last step has run; [3]: wait() was called
         return ids, lens, tk
 
     def wait(self, ticket):
-        """Issue the steps the call still needs and make the CURRENT stream wait for its results (no host synchronisation)."""
+        """Issue the steps the call still needs and make the CURRENT stream wait for its results (no host synchronisation).  The call's
+        buffers -- the pinned host copy in particular, which the scheduler's stream fills when the call leaves its lane -- stay referenced
+        until the call's `done` event has completed (`_reap`): PyTorch's pinned-memory allocator knows nothing about the library's lane
+        stream, so a block handed back earlier could be given to the next submit() while the old call's copy into it is still queued."""
         gen, t = ticket
         if gen == self._sched_gen and self._sched:       # (a pool of an earlier generation was flushed and synchronised before it was rebuilt)
             L.check(self.lib.oavsr_generate_wait(self._sched, int(t), self._stream()))
+        ent = getattr(self, "_inflight", {}).get(ticket)
+        if ent is not None:
+            ent[3] = True                                # waited for: released as soon as the device has finished the call
+        self._reap()
+
+    def release(self, ticket):
+        """The caller has synchronised with the call's results (event / stream synchronisation after `wait`): its buffers may go."""
         getattr(self, "_inflight", {}).pop(ticket, None)
+
+    def _reap(self):
+        """Drop the buffers of calls that were waited for AND whose last step, result copy included, has run on the device."""
+        infl = getattr(self, "_inflight", None)
+        if not infl:
+            return
+        for tk in [tk for tk, ent in infl.items() if ent[3]]:
+            if self.poll(tk):
+                del infl[tk]
 
     def host_result(self, ticket):
         """The pinned host copy [B, max_new + 1] view material of a submitted call (ids then lens), valid once `poll(ticket)` is True."""
@@ -482,10 +530,12 @@ class PendingIds:
             if flat is not None:
                 n = int(flat[B * W:].max())
                 out = flat[: B * W].view(B, W)[:, :n].to(torch.long)
-                self._engine._inflight.pop(self._ticket, None)
+                self._engine.release(self._ticket)      # poll() said 1: the lane's copy into the pinned buffer is complete
                 return out
         self._settle()
         self._event.synchronize()
+        if self._ticket is not None:
+            self._engine.release(self._ticket)           # the event sits behind the call's `done` on the result stream: the device is through with it
         buf = torch.empty(B, W + 1, dtype=torch.int32, pin_memory=True)
         with torch.cuda.stream(self._stream):                # the tensors belong to that stream's allocator pool
             buf[:, :W].copy_(self._ids, non_blocking=True)

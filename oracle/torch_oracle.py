@@ -57,12 +57,30 @@ class bf16_emulation:
 
     def __exit__(self, *a):
         _P.emu = self.prev
+        if not _P.emu:
+            _QW.clear()
         return False
 
 
 def _q(x: Tensor) -> Tensor:
     """Storage rounding of the bf16 engine; identity in fp32 mode."""
     return x.bfloat16().float() if _P.emu else x
+
+
+_QW: Dict[int, tuple] = {}
+
+
+def _qw(w: Tensor) -> Tensor:
+    """_q(w.float()) for a WEIGHT of the state dict: in emulation mode the rounded copy is kept for the lifetime of the outermost
+    `bf16_emulation()` block (keyed by the tensor object, which the entry keeps alive), so a decode loop does not re-round 1.2 B
+    parameters on every step.  Same values as _q(w.float())."""
+    if not _P.emu:
+        return w.float()
+    ent = _QW.get(id(w))
+    if ent is None or ent[0] is not w:
+        ent = (w, w.float().bfloat16().float())
+        _QW[id(w)] = ent
+    return ent[1]
 
 
 def _ln(x: Tensor, w: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
@@ -77,7 +95,7 @@ def _gelu(x: Tensor) -> Tensor:
 
 def _linear(x: Tensor, sd: Dict[str, Tensor], key: str) -> Tensor:
     """GEMM operand W in the compute dtype, bias fp32; the caller rounds the result where the engine's fused epilogue ends."""
-    w = _q(sd[key + ".weight"].float())
+    w = _qw(sd[key + ".weight"])
     b = sd.get(key + ".bias")
     return F.linear(x, w, None if b is None else b.float())
 
@@ -113,7 +131,7 @@ def _prelu(x: Tensor, a: Tensor) -> Tensor:
 def resnet_frontend3d(sd, p: str, video: Tensor) -> Tensor:
     """resnet.py:137-141,158: Conv3d(1,64,(5,7,7),(1,2,2),(2,3,3)) -> BN3d -> PReLU -> MaxPool3d.
     video: [B,1,T,88,88] -> [B,64,T,22,22]"""
-    x = F.conv3d(_q(video.float()), _q(sd[p + "frontend3D.0.weight"].float()), None, stride=(1, 2, 2), padding=(2, 3, 3))
+    x = F.conv3d(_q(video.float()), _qw(sd[p + "frontend3D.0.weight"]), None, stride=(1, 2, 2), padding=(2, 3, 3))
     x = _bn_eval(x, sd, p + "frontend3D.1")
     x = _prelu(x, sd[p + "frontend3D.2.weight"])
     x = F.max_pool3d(x, kernel_size=(1, 3, 3), stride=(1, 2, 2), padding=(0, 1, 1))
@@ -123,13 +141,13 @@ def resnet_frontend3d(sd, p: str, video: Tensor) -> Tensor:
 def resnet_basic_block(sd, p: str, x: Tensor, stride: int, has_down: bool) -> Tensor:
     """resnet.py:61-74 BasicBlock.forward with PReLU."""
     residual = x
-    out = F.conv2d(x, _q(sd[p + "conv1.weight"].float()), None, stride=stride, padding=1)
+    out = F.conv2d(x, _qw(sd[p + "conv1.weight"]), None, stride=stride, padding=1)
     out = _bn_eval(out, sd, p + "bn1")
     out = _q(_prelu(out, sd[p + "relu1.weight"]))
-    out = F.conv2d(out, _q(sd[p + "conv2.weight"].float()), None, stride=1, padding=1)
+    out = F.conv2d(out, _qw(sd[p + "conv2.weight"]), None, stride=1, padding=1)
     out = _bn_eval(out, sd, p + "bn2")
     if has_down:  # resnet.py:20-24: 1x1 conv stride s + BN
-        residual = F.conv2d(x, _q(sd[p + "downsample.0.weight"].float()), None, stride=stride)
+        residual = F.conv2d(x, _qw(sd[p + "downsample.0.weight"]), None, stride=stride)
         residual = _q(_bn_eval(residual, sd, p + "downsample.1"))
     out = out + residual
     return _q(_prelu(out, sd[p + "relu2.weight"]))
@@ -180,8 +198,8 @@ def fairseq_mha(sd, p: str, x: Tensor, heads: int, lora: bool, scaling_lora: flo
         q = q + F.linear(F.linear(x, sd[p + "lora_down_Q.weight"].float()), sd[p + "lora_up_Q.weight"].float()) * scaling_lora
         v = v + F.linear(F.linear(x, sd[p + "lora_down_V.weight"].float()), sd[p + "lora_up_V.weight"].float()) * scaling_lora
     elif lora:               # engine: t = x A^T stored in bf16, the scale folded into the stored up-projection, one fp32 accumulator
-        q = q + F.linear(_q(F.linear(x, _q(sd[p + "lora_down_Q.weight"].float()))), _q(sd[p + "lora_up_Q.weight"].float() * scaling_lora))
-        v = v + F.linear(_q(F.linear(x, _q(sd[p + "lora_down_V.weight"].float()))), _q(sd[p + "lora_up_V.weight"].float() * scaling_lora))
+        q = q + F.linear(_q(F.linear(x, _qw(sd[p + "lora_down_Q.weight"]))), _q(sd[p + "lora_up_Q.weight"].float() * scaling_lora))
+        v = v + F.linear(_q(F.linear(x, _qw(sd[p + "lora_down_V.weight"]))), _q(sd[p + "lora_up_V.weight"].float() * scaling_lora))
     q, k, v = _q(q), _q(k), _q(v)
     if not _P.emu:
         q = q * (hd ** -0.5)                                 # :511 (after LoRA)
@@ -300,9 +318,9 @@ def whisper_log_mel(wave: Tensor, n_samples: int = 480000) -> Tensor:
 def whisper_encoder(sd, p: str, mel: Tensor, layers: int, heads: int, return_layers: bool = False):
     """transformers WhisperEncoder.forward: conv1(k3,p1)+GELU, conv2(k3,s2,p1)+GELU, +pos-emb,
     pre-LN layers (k_proj without bias, q scaled by head_dim^-0.5), final LN.  mel: [B,80,3000] -> [B,1500,D]."""
-    x = _q(_gelu(F.conv1d(_q(mel.float()), _q(sd[p + "conv1.weight"].float()), sd[p + "conv1.bias"].float(), padding=1)))
-    x = _gelu(F.conv1d(x, _q(sd[p + "conv2.weight"].float()), sd[p + "conv2.bias"].float(), stride=2, padding=1))
-    x = _q(x.permute(0, 2, 1) + _q(sd[p + "embed_positions.weight"].float())[None])
+    x = _q(_gelu(F.conv1d(_q(mel.float()), _qw(sd[p + "conv1.weight"]), sd[p + "conv1.bias"].float(), padding=1)))
+    x = _gelu(F.conv1d(x, _qw(sd[p + "conv2.weight"]), sd[p + "conv2.bias"].float(), stride=2, padding=1))
+    x = _q(x.permute(0, 2, 1) + _qw(sd[p + "embed_positions.weight"])[None])
     B, T, C = x.shape
     hd = C // heads
     outs = []
@@ -312,7 +330,7 @@ def whisper_encoder(sd, p: str, mel: Tensor, layers: int, heads: int, return_lay
         q = _linear(h, sd, lp + "self_attn.q_proj")
         if not _P.emu:
             q = q * (hd ** -0.5)
-        k = F.linear(h, _q(sd[lp + "self_attn.k_proj.weight"].float()))
+        k = F.linear(h, _qw(sd[lp + "self_attn.k_proj.weight"]))
         v = _linear(h, sd, lp + "self_attn.v_proj")
         q = _q(q).view(B, T, heads, hd).transpose(1, 2)
         k = _q(k).view(B, T, heads, hd).transpose(1, 2)
@@ -425,7 +443,7 @@ class LLMOracle:
         # stored up-projection, all adapters summed in the QKV GEMM's fp32 accumulator
         out = 0
         for d_, u_ in pairs:
-            t = F.linear(x, _q(sd[d_].float()))
+            t = F.linear(x, _qw(sd[d_]))
             if rstd is not None:
                 t = t * rstd
             out = out + F.linear(_q(t), _q(sd[u_].float() * self.scaling))
@@ -467,9 +485,9 @@ class LLMOracle:
             if emu and skinny:
                 h, rstd = fused_norm(x, sd[lp + "input_layernorm.weight"])
                 bias = lambda n: (sd[ap + n + ".bias"].float() if ap + n + ".bias" in sd else 0.0)    # noqa: E731
-                q = F.linear(h, _q(sd[ap + "q_proj.weight"].float())) * rstd + bias("q_proj")
-                k = F.linear(h, _q(sd[ap + "k_proj.weight"].float())) * rstd + bias("k_proj")
-                v = F.linear(h, _q(sd[ap + "v_proj.weight"].float())) * rstd + bias("v_proj")
+                q = F.linear(h, _qw(sd[ap + "q_proj.weight"])) * rstd + bias("q_proj")
+                k = F.linear(h, _qw(sd[ap + "k_proj.weight"])) * rstd + bias("k_proj")
+                v = F.linear(h, _qw(sd[ap + "v_proj.weight"])) * rstd + bias("v_proj")
                 if cfg.get("lora_rank"):
                     q = q + self._lora(ap, "Q", h, modality, rstd)
                     v = v + self._lora(ap, "V", h, modality, rstd)
@@ -505,7 +523,7 @@ class LLMOracle:
             # the engine prunes the LAST prefill layer to each utterance's final row and runs its MLP through the decode kernels
             if emu and (skinny or (last and last_only and S > 1 and few_rows)):
                 h, rstd = fused_norm(x, sd[lp + "post_attention_layernorm.weight"])
-                g = F.silu(F.linear(h, _q(sd[lp + "mlp.gate_proj.weight"].float())) * rstd) * (F.linear(h, _q(sd[lp + "mlp.up_proj.weight"].float())) * rstd)
+                g = F.silu(F.linear(h, _qw(sd[lp + "mlp.gate_proj.weight"])) * rstd) * (F.linear(h, _qw(sd[lp + "mlp.up_proj.weight"])) * rstd)
             else:
                 h = _q(_rms(x, sd[lp + "post_attention_layernorm.weight"], cfg["rms_eps"]))
                 g = F.silu(_q(_linear(h, sd, lp + "mlp.gate_proj"))) * _q(_linear(h, sd, lp + "mlp.up_proj"))
@@ -514,7 +532,7 @@ class LLMOracle:
                 hiddens.append(x)
         if last_only:
             x = x[:, -1:]
-        W = _q(sd[p + "lm_head.weight"].float())
+        W = _qw(sd[p + "lm_head.weight"])
         if emu and few_rows:                                   # lm_head with the final RMSNorm fused (<= 32 rows)
             h, rstd = fused_norm(x, sd[p + "model.norm.weight"])
             logits = (F.linear(h, W) * rstd).float()
@@ -709,13 +727,18 @@ class OmniOracle:
         return f"{which}_proj."
 
     # modeling_OmniAVSR.py:397-458
-    def prepare_inputs(self, inputs: dict, modality: str, rate_a: int, rate_v: int, mel_bf16: bool = False) -> Tensor:
+    def prepare_inputs(self, inputs: dict, modality: str, rate_a: int, rate_v: int, mel_bf16: bool = False, feats=None) -> Tensor:
+        """`feats` = (a_feat, v_feat): compressed encoder outputs the caller already has from encode_audio / encode_video on the same inputs
+        (tests that also compare the encoder stages: the 24-layer encoders then run once, not twice)."""
         c, ids = self.cfg, self.cfg["ids"]
         B = inputs["tokens"].shape[0]
         E = self.llm.embed
-        a_feat = self.encode_audio(inputs["audio"], int(max(inputs["lengths"])), rate_a, mel_bf16=mel_bf16) if modality in ("audio", "audiovisual") else None
-        v_feat = self.encode_video(inputs["video"], rate_v) if modality in ("video", "audiovisual") else None
-        prompt = _q(self.sd[f"prompt_{modality}"].float()).expand(B, -1, -1)
+        if feats is not None:
+            a_feat, v_feat = feats
+        else:
+            a_feat = self.encode_audio(inputs["audio"], int(max(inputs["lengths"])), rate_a, mel_bf16=mel_bf16) if modality in ("audio", "audiovisual") else None
+            v_feat = self.encode_video(inputs["video"], rate_v) if modality in ("video", "audiovisual") else None
+        prompt = _qw(self.sd[f"prompt_{modality}"]).expand(B, -1, -1)
         if c["family"] == "qwen2":
             text = prompt                                      # :417
         else:

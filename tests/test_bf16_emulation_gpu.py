@@ -24,6 +24,9 @@ from omni_avsr_amd.synth import synth_state_dict  # noqa: E402
 from oracle import torch_oracle as O  # noqa: E402
 
 ENC_MAX, ENC_MEAN, LOGIT_TOL = 0.05, 0.004, 0.08
+# the emulating oracle's inputs_embeds of a (weights seed, clip) pair: the two full-size cases below share one 4 s clip, and its 2 x 24
+# encoder layers on the CPU are the bulk of their run time
+_EMB_CACHE = {}
 
 
 def rel(a, b):
@@ -51,19 +54,23 @@ def run_case(spec, sd, Tv, Ts, rate_a, rate_v, seed, max_new, task="audiovisual"
     ids, lens = eng.generate(task, video, [Tv], audio, [Ts], rate_a, rate_v, beams=1, max_new=max_new, force_len=True)
     got = ids[0, : int(lens[0])].cpu().tolist()
     with torch.no_grad(), O.bf16_emulation():
+        a_feat = v_feat = None
         if use_v:
             _, venc, _ = eng.encode_video(video, [Tv], rate_v, return_enc=True)
-            check_enc("video encoder", venc, orc.encode_video(video, rate_v, return_stages=True)[1]["enc"][0])
+            v_feat, vst = orc.encode_video(video, rate_v, return_stages=True)
+            check_enc("video encoder", venc, vst["enc"][0])
         if use_a:
             _, aenc, _, _ = eng.encode_audio(audio, [Ts], rate_a, return_enc=True)
-            check_enc("whisper encoder", aenc[0], orc.encode_audio(audio, Ts, rate_a, return_stages=True)[1]["enc"][0])
+            a_feat, ast_ = orc.encode_audio(audio, Ts, rate_a, return_stages=True)
+            check_enc("whisper encoder", aenc[0], ast_["enc"][0])
         a_out, na = eng.encode_audio(audio, [Ts], rate_a) if use_a else (None, None)
         v_out, nv = eng.encode_video(video, [Tv], rate_v) if use_v else (None, None)
         emb, S = eng.build_prompt(task, 1, na, eng.project("audio", rate_a, a_out) if use_a else None, nv,
                                   eng.project("video", rate_v, v_out) if use_v else None)
         logits = eng.prefill(task, emb, S)
         tokens = torch.full((1, 1), spec.ids["bos"]) if spec.llm.family == "llama" else torch.zeros(1, 0, dtype=torch.long)
-        ref_emb = orc.prepare_inputs(dict(video=video, audio=audio, lengths=torch.tensor([Ts]), tokens=tokens), task, rate_a, rate_v)
+        ref_emb = orc.prepare_inputs(dict(video=video, audio=audio, lengths=torch.tensor([Ts]), tokens=tokens), task, rate_a, rate_v, feats=(a_feat, v_feat))
+        _EMB_CACHE[(spec.llm.hidden, spec.llm.layers, Tv, Ts, rate_a, rate_v, seed, task)] = ref_emb
         check_enc("inputs_embeds", emb, ref_emb[0])
         mod = task if spec.is_task_specific else None
         path = orc.llm.score_path(ref_emb, got, mod)
@@ -113,9 +120,12 @@ def run_beam_case(spec, sd, Tv, Ts, rate_a, rate_v, seed, K=15):
     tokens = torch.full((1, 1), spec.ids["bos"]) if spec.llm.family == "llama" else torch.zeros(1, 0, dtype=torch.long)
     mod = "audiovisual" if spec.is_task_specific else None
     with torch.no_grad(), O.bf16_emulation():
-        emb = orc.prepare_inputs(dict(video=video, audio=audio, lengths=torch.tensor([Ts]), tokens=tokens), "audiovisual", rate_a, rate_v)
+        emb = _EMB_CACHE.get((spec.llm.hidden, spec.llm.layers, Tv, Ts, rate_a, rate_v, seed, "audiovisual"))      # same weights (seed 1234), same clip
+        if emb is None:
+            emb = orc.prepare_inputs(dict(video=video, audio=audio, lengths=torch.tensor([Ts]), tokens=tokens), "audiovisual", rate_a, rate_v)
         want = orc.llm.generate_beam(emb, spec.max_dec_tokens, K, spec.ids["eos"], spec.ids["pad"], mod)
-        s_got, s_want = hyp_score(orc, emb, got, mod), hyp_score(orc, emb, want, mod)
+        s_got = hyp_score(orc, emb, got, mod)
+        s_want = s_got if want == got else hyp_score(orc, emb, want, mod)
     same = sum(int(a == b) for a, b in zip(got, want))
     print(f"bf16 beam-{K}: engine hypothesis scores {s_got:.4f}, the emulating oracle's {s_want:.4f} (per token); {same}/{max(len(got), len(want))} ids equal")
     assert s_got >= s_want - LOGIT_TOL, f"the engine's beam-{K} hypothesis scores {s_want - s_got:.3e} per token below the emulating oracle's"

@@ -33,6 +33,19 @@ def clips(Tv, seed=0):
     return video, audio, [640 * t for t in Tv]
 
 
+@pytest.fixture(scope="module")
+def bf16_engine():
+    """ONE full-size bf16 engine for the cases of this file (1.9 B parameters of seeded weights: building it per test was a third of
+    the file's run time).  Tests that change the scheduler's shape restore the defaults."""
+    spec = full_spec()
+    sd = synth_state_dict(spec, seed=1234, device="cuda:0", dtype=torch.bfloat16)
+    eng = OmniEngine(spec, dtype="bf16").load_state_dict(sd)
+    del sd
+    torch.cuda.empty_cache()
+    yield eng
+    eng.close()
+
+
 def test_fullsize_f32_matches_oracle():
     spec = full_spec()
     sd = synth_state_dict(spec, seed=1234, device="cuda:0")
@@ -58,13 +71,8 @@ def test_fullsize_f32_matches_oracle():
     assert ids[0].cpu().tolist() == ref[0]
 
 
-@pytest.mark.parametrize("dtype", ["bf16"])
-def test_fullsize_batch_invariance_and_determinism(dtype):
-    spec = full_spec()
-    sd = synth_state_dict(spec, seed=1234, device="cuda:0", dtype=torch.bfloat16)
-    eng = OmniEngine(spec, dtype=dtype).load_state_dict(sd)
-    del sd
-    torch.cuda.empty_cache()
+def test_fullsize_batch_invariance_and_determinism(bf16_engine):
+    eng = bf16_engine
     Tv = [400, 250, 100, 61]
     video, audio, Ts = clips(Tv, seed=9)
     ids_b, lens_b = eng.generate("audiovisual", video, Tv, audio, Ts, 4, 4, beams=1, max_new=32, force_len=True)
@@ -88,14 +96,10 @@ def test_fullsize_batch_invariance_and_determinism(dtype):
         assert ids12[b].tolist() == ids_b[b].tolist(), f"utterance {b} decodes differently inside a batch of 12"
 
 
-def test_fullsize_grouped_decode_equals_separate_calls():
+def test_fullsize_grouped_decode_equals_separate_calls(bf16_engine):
     """harness decode_group / bench --decode-group: 24 utterances in one call (encoders / prefill in chunks of 8, ONE decode loop over 24 rows:
     the 32-row forms of the decode kernels, persistent lm_head and gate / up included) decode the ids of three separate calls of 8."""
-    spec = full_spec()
-    sd = synth_state_dict(spec, seed=1234, device="cuda:0", dtype=torch.bfloat16)
-    eng = OmniEngine(spec, dtype="bf16").load_state_dict(sd)
-    del sd
-    torch.cuda.empty_cache()
+    eng = bf16_engine
     g = torch.Generator().manual_seed(21)
     Tv = [int(x) for x in torch.randint(30, 101, (24,), generator=g)]
     video, audio, Ts = clips(Tv, seed=22)
@@ -149,15 +153,12 @@ torch.save(outs[0], sys.argv[1])
         assert torch.equal(a, b), "fused launches decode different ids than separate launches"
 
 
-def test_fullsize_scheduler_equals_separate_calls():
+def test_fullsize_scheduler_equals_separate_calls(bf16_engine):
     """The headline configuration's own mechanism at the full model size: three calls of 8 utterances (ragged lengths) submitted one after another
     through the decode scheduler -- encoders / prefill per call on three streams, decode rows sharing the 32-row steps of one lane -- decode the
     ids of the same calls run on their own (bf16, EOS suppressed and free-running)."""
-    spec = full_spec()
-    sd = synth_state_dict(spec, seed=1234, device="cuda:0", dtype=torch.bfloat16)
-    eng = OmniEngine(spec, dtype="bf16").load_state_dict(sd)
-    del sd
-    torch.cuda.empty_cache()
+    eng = bf16_engine
+    lanes0 = eng.sched_lanes
     g = torch.Generator().manual_seed(31)
     calls = []
     for c in range(3):
@@ -180,3 +181,40 @@ def test_fullsize_scheduler_equals_separate_calls():
         for i, (ids, lens, _) in enumerate(pend):
             assert torch.equal(lens.cpu(), ref[i][1]) and torch.equal(ids.cpu(), ref[i][0]), f"call {i} (force_len={force}) decodes differently inside the shared decode loop"
     assert eng.scheduler_stats()["rows_per_step"] > 12
+    eng.sched_lanes = lanes0
+
+
+def test_headline_configuration_returns_the_ids_of_isolated_calls(bf16_engine):
+    """bench.py's headline configuration as a test (BASELINE.json configs[1]): batches of 8 x 16 s clips, 32 greedy tokens with EOS
+    suppressed, the decode scheduler at its DEFAULT shape (3 lanes x 32 rows, 192 slots), calls submitted back to back on three of the
+    engine's caller streams, four input sets rotating -- 28 calls, and every one of them must return exactly the ids of ONE isolated
+    oavsr_generate of its input set (what bench.py itself verifies after its timed region before it prints a line)."""
+    eng = bf16_engine
+    assert (eng.sched_lanes, eng.sched_rows, eng.sched_slots) == (3, 32, 192), "this case pins the engine's default scheduler shape"
+    B, Tv = 8, 400
+    sets = []
+    for s_ in range(4):
+        g = torch.Generator(device="cuda:0").manual_seed(100 + s_)
+        video = torch.randn(B * Tv, 88, 88, generator=g, device="cuda:0")
+        audio = torch.nn.functional.layer_norm(torch.randn(B, 640 * Tv, generator=g, device="cuda:0"), (640 * Tv,))
+        sets.append((video, audio))
+    Tvs, Ts = [Tv] * B, [640 * Tv] * B
+    iso = []
+    for video, audio in sets:
+        ids, lens = eng.generate("audiovisual", video, Tvs, audio, Ts, 4, 4, beams=1, max_new=32, force_len=True, video_is_flat=True)
+        torch.cuda.synchronize()
+        iso.append((ids.clone(), lens.clone()))
+    assert len({tuple(i[0].flatten().tolist()) for i in iso}) == 4, "the four input sets should decode to different ids (else the check below is vacuous)"
+    eng.reserve_scheduler("audiovisual", Tv, 640 * Tv, 4, 4, 32)
+    streams = [eng.caller_stream(i) for i in range(3)]
+    pend = []
+    for i in range(28):
+        video, audio = sets[i % 4]
+        with torch.cuda.stream(streams[i % 3]):
+            pend.append((i, eng.submit("audiovisual", video, Tvs, audio, Ts, 4, 4, max_new=32, force_len=True, video_is_flat=True, slot=i % 3)))
+    eng.flush()
+    torch.cuda.synchronize()
+    for i, (ids, lens, _) in pend:
+        assert torch.equal(lens, iso[i % 4][1]) and torch.equal(ids, iso[i % 4][0]), f"call {i} (input set {i % 4}) differs from the isolated call of that set"
+    st = eng.scheduler_stats()
+    assert st["rows_per_step"] > 20, st

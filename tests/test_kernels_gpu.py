@@ -839,30 +839,16 @@ def test_gemm_8p_identity_layout():
     close(out, wr.T, 1e-6, what="gemm 8p identity")
 
 
-def test_gemm_8p_bitwise_equals_16_wave_kernel(tmp_path):
-    """Same accumulation order per output element as the 16-wave 256 x 256 kernel (OAVSR_GEMM_8P=0 / 2, read once per process): the two
-    must agree bit for bit, so a tensor has the same bits whichever kernel the dispatcher picked."""
-    import subprocess
-    import sys
-    script = f"""
-import sys, math, torch
-sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r}); sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
-from gpu_util import gemm, DEV
-g = torch.Generator().manual_seed(11)
-a = torch.randn(6000, 1024, generator=g).to(DEV, torch.bfloat16)
-w = (torch.randn(4096, 1024, generator=g) / 32).to(DEV, torch.bfloat16)
-a2 = torch.randn(6000, 128, generator=g).to(DEV, torch.bfloat16)
-w2 = (torch.randn(4096, 128, generator=g) / 11).to(DEV, torch.bfloat16)
-b = torch.randn(4096, generator=g).to(DEV)
-out = gemm("bf16", a, w, A2=a2, W2=w2, bias=b, act=1)
-torch.save(out.cpu(), sys.argv[1])
-"""
-    outs = []
-    for flag in ("2", "0"):
-        f = str(tmp_path / f"o{flag}.pt")
-        r = subprocess.run([sys.executable, "-c", script, f], env=dict(os.environ, OAVSR_GEMM_8P=flag), capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(torch.load(f))
+def test_gemm_8p_bitwise_equals_16_wave_kernel():
+    """Same accumulation order per output element as the 16-wave 256 x 256 kernel (kernel selectors 2 / 5 of oavsr_op_gemm): the two must
+    agree bit for bit, so a tensor has the same bits whichever kernel the dispatcher picked."""
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn(6000, 1024, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(4096, 1024, generator=g) / 32).to(DEV, torch.bfloat16)
+    a2 = torch.randn(6000, 128, generator=g).to(DEV, torch.bfloat16)
+    w2 = (torch.randn(4096, 128, generator=g) / 11).to(DEV, torch.bfloat16)
+    b = torch.randn(4096, generator=g).to(DEV)
+    outs = [gemm("bf16", a, w, A2=a2, W2=w2, bias=b, act=1, skinny=sel) for sel in (2, 5)]
     assert torch.equal(outs[0], outs[1]), f"ping-pong vs 16-wave kernel: max diff {(outs[0].float() - outs[1].float()).abs().max().item():.3e}"
 
 
@@ -961,6 +947,92 @@ def test_gemm_8p_fused_swiglu_equals_gemm_plus_swiglu_kernel():
     two = torch.empty(M, I, dtype=tdt(dtype), device=DEV)
     L.check(L.load().oavsr_op_swiglu(dcode(dtype), P(gu), 2 * I, P(two), I, M, I, 1, stream()))
     assert torch.equal(fused, two), f"ping-pong fused SwiGLU differs from gemm + swiglu: {(fused.float() - two.float()).abs().max().item():.3e}"
+
+
+# ------------------------------------------------------------------------------------------------ persistent ping-pong GEMM (gemm4.hip)
+@pytest.mark.parametrize("M,N,K,grid,act", [
+    (2048, 1024, 192, 8, 1),          # 32 full tiles on 8 workgroups: 4 rounds, the shortest k loop (3 k-tiles: first, second-to-last, last)
+    (2048, 1024, 256, 8, 1),          # 4 k-tiles: one steady k-tile between them
+    (2048 + 77, 1280 + 40, 320, 16, 1),   # ragged M and N (edge tiles take the conservative waits), 5 k-tiles: the buffer parity flips per tile
+    (3000, 2048, 1024, 24, 0),        # 96 tiles on 24 workgroups; no activation
+    (4096, 2304, 512, 40, 4),         # 144 tiles / 40: a partial last round (24 tiles dealt over the 8 XCD groups)
+    (12000, 3072, 1024, 0, 0),        # Whisper QKV at the benchmark's size, the launcher's own grid (192 workgroups, 3 rounds)
+])
+def test_gemm_8pp_persistent(M, N, K, grid, act):
+    """Persistent ping-pong kernel: one workgroup walks several 256 x 256 tiles, the LDS-DMA stream continues across tiles and the C stores
+    are waited for by count only.  Against fp32 torch; bit-identical to the 16-wave kernel and to the non-persistent ping-pong kernel (same
+    accumulation order and epilogue expressions); repeated launches identical (a race in the cross-tile schedule would show as a diff)."""
+    dtype = "bf16"
+    a, ar = q(rnd(M, K, seed=1), dtype)
+    w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
+    bias = rnd(N, seed=7)
+    ref = ar @ wr.T + bias
+    ref = F.gelu(ref) if act == 1 else F.silu(ref) if act == 4 else ref
+    out = gemm(dtype, a, w, bias=bias.to(DEV), act=act, skinny=3, grid=grid)
+    close(out, ref, tol(dtype) * 2, what="gemm 8pp")
+    for sel in (5, 2):
+        other = gemm(dtype, a, w, bias=bias.to(DEV), act=act, skinny=sel)
+        assert torch.equal(out, other), f"persistent kernel vs kernel selector {sel}: max diff {(out.float() - other.float()).abs().max().item():.3e}"
+    for _ in range(3):
+        again = gemm(dtype, a, w, bias=bias.to(DEV), act=act, skinny=3, grid=grid)
+        assert torch.equal(out, again), "two launches of the persistent GEMM differ (race in the cross-tile schedule)"
+
+
+def test_gemm_8pp_identity_layout_and_tile_walk():
+    """A = I with an asymmetric W on 8 workgroups: every output element names its (row, column), so a tile written to the wrong place, a
+    skipped tile or a swapped quadrant of any round shows."""
+    n = 2048
+    a, _ = q(torch.eye(n), "bf16")
+    wv = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 253) / 64.0
+    w, wr = q(wv, "bf16")
+    for grid in (8, 16, 48, 64):
+        out = gemm("bf16", a, w, skinny=3, grid=grid)
+        close(out, wr.T, 1e-6, what=f"gemm 8pp identity grid {grid}")
+
+
+def test_gemm_8pp_under_load_is_deterministic():
+    """The counted waits only ever assume FEWER outstanding operations than there are; with a second stream hammering HBM (store
+    acknowledgements and DMA arrivals come late and out of step) the results must still be the bits of an undisturbed launch."""
+    dtype, M, N, K = "bf16", 6000, 2048, 1024
+    a, _ = q(rnd(M, K, seed=1), dtype)
+    w, _ = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
+    bias = rnd(N, seed=7).to(DEV)
+    ref = gemm(dtype, a, w, bias=bias, act=1, skinny=5)
+    side = torch.cuda.Stream()
+    junk = torch.empty(256 << 20, dtype=torch.uint8, device=DEV)
+    for grid in (64, 128, 0):
+        with torch.cuda.stream(side):
+            for _ in range(40):
+                junk.add_(1)
+        for _ in range(6):
+            out = gemm(dtype, a, w, bias=bias, act=1, skinny=3, grid=grid)
+            assert torch.equal(out, ref), f"persistent GEMM under load (grid {grid}) differs from the 16-wave kernel"
+        torch.cuda.synchronize()
+
+
+def test_gemm_8pp_fused_swiglu_equals_gemm_plus_swiglu_kernel():
+    dtype, M, I, K = "bf16", 2504, 4096, 256
+    x, xr = q(rnd(M, K, seed=1), dtype)
+    wg, _ = q(rnd(I, K, seed=2) / math.sqrt(K), dtype)
+    wu, _ = q(rnd(I, K, seed=3) / math.sqrt(K), dtype)
+    inter = torch.stack([wg.reshape(-1, 16, K), wu.reshape(-1, 16, K)], 1).reshape(2 * I, K).contiguous()
+    gu = gemm(dtype, x, inter, skinny=5)
+    two = torch.empty(M, I, dtype=tdt(dtype), device=DEV)
+    L.check(L.load().oavsr_op_swiglu(dcode(dtype), P(gu), 2 * I, P(two), I, M, I, 1, stream()))
+    for grid in (16, 0):
+        fused = gemm(dtype, x, inter, swiglu_pairs=1, skinny=3, grid=grid)
+        assert torch.equal(fused, two), f"persistent fused SwiGLU (grid {grid}) differs from gemm + swiglu: {(fused.float() - two.float()).abs().max().item():.3e}"
+
+
+def test_gemm_dispatch_takes_persistent_kernel_for_multi_round_launches():
+    """More 256 x 256 tiles than CUs, plain bf16 epilogue -> the dispatcher's choice is the persistent kernel; same bits as the 16-wave one."""
+    dtype, M, N, K = "bf16", 12000, 4096, 1024
+    a, _ = q(rnd(M, K, seed=1), dtype)
+    w, _ = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
+    bias = rnd(N, seed=7).to(DEV)
+    auto = gemm(dtype, a, w, bias=bias, act=1)
+    forced = gemm(dtype, a, w, bias=bias, act=1, skinny=5)
+    assert torch.equal(auto, forced)
 
 
 # ------------------------------------------------------------------------------------------------ 8-column decode tiles for 9..32 rows
