@@ -192,11 +192,15 @@ def parse_args():
     ap.add_argument("--no-scheduler", action="store_true",
                     help="round-2 mode: every call runs its own decode loop on its own stream (default: the engine's decode scheduler merges the "
                          "decode rows of the calls in flight; greedy only)")
-    ap.add_argument("--sched-rows", type=int, default=32, help="rows per decode step of the engine's scheduler (<= 32)")
+    ap.add_argument("--sched-rows", type=int, default=None, help="rows per decode step of the engine's scheduler (<= 64; default: the engine's)")
     ap.add_argument("--sched-slots", type=int, default=192, help="row slots of the scheduler's pool")
     ap.add_argument("--sched-stride", type=int, default=0, help="steps per admission (0 = automatic)")
     ap.add_argument("--sched-lanes", type=int, default=3, help="independent step loops of the scheduler")
     ap.add_argument("--no-stagger", action="store_true", help="let the encoder phases of in-flight batches share the chip (default: chained)")
+    ap.add_argument("--testset", type=int, default=0,
+                    help="N > 0: the test-set-shaped run instead of the step loop (BASELINE.json configs[4] / SURVEY.md 8d C5: N synthetic utterances, "
+                         "lengths U[1 s, 16 s], HOST inputs): duration-sorted sharding over the ranks -> batches -> harness.evaluate(in_flight=3) -> one "
+                         "all_gather of the hypotheses + all_reduce of the WER counters.  STRONG scaling: value = N / wall time of the whole set")
     ap.add_argument("--streams", type=int, default=None,
                     help="caller streams = batches whose encoder phases (and, without the scheduler, decode loops) may be in flight; default 3, "
                          "4 for beam search; 1 = strictly sequential calls")
@@ -279,6 +283,138 @@ def schedule_summary(recs, skip_calls):
                      "lanes), un-profiled run; fractions of the steady window; step_ms_beside_phases = burst time / steps of one lane")
 
 
+def testset_run(args, rank, world, local, use_dist):
+    """The reference's evaluation loop (eval_OmniAVSR.py:273-357: one Trainer.test pass over the test set) as this repo runs it: every rank
+    owns the utterances `dist.shard_utterances` deals it (duration-sorted round-robin), batches them longest first (`make_batches`), and
+    `harness.evaluate(in_flight=3)` keeps three batches in flight through the engine's decode scheduler with host inputs (collation and
+    host-to-device copies inside the timed region).  The only exchange: one all_gather of {utt_id, n, ids} records and one all_reduce of
+    the WER counters, inside the timed region before the closing barrier.  Strong scaling: the set is fixed, `value` = N / wall."""
+    import torch.distributed as dist
+    from omni_avsr_amd import harness as H
+    from omni_avsr_amd.dist import gather_hypotheses, pack_records, reduce_wer_counters, shard_utterances
+    from omni_avsr_amd.modeling import AVSR_LLMs
+    from omni_avsr_amd.synth import synth_state_dict
+    dev = torch.device(f"cuda:{local}")
+    pre = PRESETS[args.preset]
+    spec = build_spec(args, pre)
+    task = pre["task"]
+    B = args.batch or pre["batch"]
+    ra, rv = pre["rates"][0]
+    t0 = time.time()
+    model = AVSR_LLMs(task, None, True, args.llm or pre["llm"], spec.llm.hidden, 2048, None, None, None, None, None, pre["ra"], pre["rv"], None,
+                      "avg-pooling", None, args.max_new, 1, is_task_specific=True, is_matryoshka=True, spec=spec, dtype=args.dtype, device=str(dev))
+    model.load_state_dict(synth_state_dict(spec, seed=1234, device=dev))
+    eng = model.engine
+    if args.sched_rows is None:
+        args.sched_rows = eng.sched_rows
+    eng.sched_rows, eng.sched_slots, eng.sched_stride, eng.sched_lanes = args.sched_rows, args.sched_slots, args.sched_stride, args.sched_lanes
+    torch.cuda.empty_cache()
+    # the test set: N utterance descriptors (length, clip), identical on every rank (seeded); the media of utterance u is clip u % P of a
+    # pool of P distinct 16 s clips cut to the utterance's length (host memory: P x 50 MB instead of N x 27 MB)
+    N, P = args.testset, 24
+    g = torch.Generator().manual_seed(20260)
+    Tvs = [int(x) for x in torch.randint(25, args.frames + 1, (N,), generator=g)]           # U[1 s, 16 s] at 25 fps
+    owned = set(shard_utterances([float(t) for t in Tvs], world, rank))
+    pool = {}
+    samples = []
+    for u in range(N):
+        smp = {}
+        if u in owned:                         # only this rank's media are materialised
+            c = u % P
+            if c not in pool:
+                gc = torch.Generator().manual_seed(7000 + c)
+                v = torch.randn(args.frames, 1, 88, 88, generator=gc)
+                a = torch.randn(640 * args.frames, 1, generator=gc)
+                pool[c] = (v, a)
+            v, a = pool[c]
+            if task != "audio":
+                smp["video"] = v[: Tvs[u]]
+            if task != "video":
+                aw = a[: 640 * Tvs[u]]
+                smp["audio"] = torch.nn.functional.layer_norm(aw[:, 0], (aw.shape[0],)).unsqueeze(-1)      # transforms.py:123-125
+        else:                                  # a descriptor with the right duration is all evaluate() needs for the shards of other ranks
+            smp["video" if task != "audio" else "audio"] = torch.empty(Tvs[u] if task != "audio" else 640 * Tvs[u], 0)
+        samples.append((smp, " ".join(f"w{(u * 7 + k) % 23}" for k in range(5 + u % 9))))            # a synthetic transcript: the WER counters must flow
+    setup_s = time.time() - t0
+
+    def to_text(ids):                          # "tokenizer": one pseudo-word per token id; keeps the ids for the gather
+        out = []
+        for r in ids.tolist():
+            out.append(" ".join(f"w{t % 23}" for t in r))
+        to_text.rows.extend(ids.tolist())
+        return out
+    to_text.rows = []
+    kw = dict(batch_size=B, bos_id=spec.ids["bos"], rank=rank, world=world, in_flight=3, test_ratio_matry_audio=ra, test_ratio_matry_video=rv)
+    # warm-up: the first batches of this rank's own shard (workspaces, scheduler pool, step graphs, pinned staging)
+    H.evaluate(model, [samples[i] for i in sorted(owned, key=lambda i: -Tvs[i])[: 4 * B]], task, to_text, batch_size=B, bos_id=spec.ids["bos"], in_flight=3,
+               test_ratio_matry_audio=ra, test_ratio_matry_video=rv)
+    to_text.rows = []
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    meter = H.evaluate(model, samples, task, to_text, **kw)
+    torch.cuda.synchronize()
+    busy = time.perf_counter() - t0
+    W = args.max_new
+    ids_t = torch.full((len(to_text.rows), W), -1, dtype=torch.int32)
+    lens_t = torch.zeros(len(to_text.rows), dtype=torch.int32)
+    for k, r in enumerate(to_text.rows):
+        ids_t[k, : len(r)] = torch.tensor(r, dtype=torch.int32)
+        lens_t[k] = len(r)
+    rec = pack_records(meter.utt_ids, ids_t.to(dev), lens_t.to(dev), W)
+    hyp = gather_hypotheses(rec, N)
+    edits, words, failed = reduce_wer_counters(meter.total_edit_distance, meter.total_length, device=dev, failed=len(meter.failed))
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    busy_all = [busy]
+    if use_dist:
+        t = torch.tensor([elapsed, busy], device=dev, dtype=torch.float64)
+        tl = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(tl, t)
+        elapsed = max(float(x[0]) for x in tl)
+        busy_all = [float(x[1]) for x in tl]
+    assert len(hyp) == N and failed == 0, (len(hyp), failed)
+    # identity check on a sample of the set (outside the timed region): the first and the last batch this rank decoded, each again as ONE
+    # isolated call -- same ids as inside the pipelined evaluation
+    from omni_avsr_amd.dist import make_batches
+    mine = shard_utterances([float(t) for t in Tvs], world, rank)
+    bs = list(make_batches(mine, B))
+    for idxs in ([bs[0], bs[-1]] if len(bs) > 1 else bs):
+        m2 = H.evaluate(model, [samples[i] for i in idxs], task, lambda ids: [" ".join(str(int(t)) for t in r) for r in ids.tolist()], batch_size=B,
+                        bos_id=spec.ids["bos"], in_flight=1, test_ratio_matry_audio=ra, test_ratio_matry_video=rv)
+        got = {idxs[m2.utt_ids[k]]: [int(t) for t in m2.per_utt[k][1].split()] for k in range(len(idxs))}
+        for u_, ids_ in got.items():
+            if hyp[u_] != ids_:
+                print(f"bench.py --testset: rank {rank}: utterance {u_} decodes differently inside the evaluation than alone", file=sys.stderr, flush=True)
+                sys.exit(3)
+    if rank == 0:
+        secs = sum(Tvs) / 25.0
+        llm_name = (args.llm or pre["llm"]).split("/")[-1]
+        per_rank = [len(shard_utterances([float(t) for t in Tvs], world, r)) for r in range(world)]
+        line = {
+            "metric": "utterances/s + real-time-factor, LRS3 AVSR 16s clips, Llama-3.2-1B, 1/2/4/8 GPU",
+            "value": round(N / elapsed, 3), "unit": "utterances/s", "n_gpus": world, "steps": 1, "warmup": 1,
+            "ms_per_step": round(elapsed * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic", "rtf": round(elapsed / secs, 6),
+            "config": {"workload": f"test-set-shaped run (SURVEY.md 8d C5 / BASELINE.json configs[4] shape): {N} utterances, lengths U[1 s, {args.frames / 25:.0f} s], "
+                                   f"{task}, {llm_name} (Omni-LoRA ST r32/a4), batches of {B}, rates ({ra}, {rv}), greedy <= {args.max_new} tokens (natural EOS), "
+                                   f"HOST inputs (collation + host-to-device copies timed), preset {args.preset} (NOT the headline configuration)",
+                       "utterances": N, "audio_seconds": round(secs, 1), "batch_per_call": B, "in_flight": 3,
+                       "parallelism": f"utterance-sharded dp{world}, duration-sorted round-robin", "utterances_per_rank": per_rank,
+                       "rank_busy_s": [round(b, 3) for b in busy_all], "imbalance": round(max(busy_all) / max(1e-9, min(busy_all)), 4),
+                       "gathered_hypotheses": len(hyp), "wer_counters": {"edits": edits, "words": words, "failed": failed},
+                       "dist_backend": (dist.get_backend() if use_dist else None), "setup_s": round(setup_s, 1), "ids_verified": True,
+                       "decode_scheduler": eng.scheduler_stats(), "env": env_snapshot()},
+        }
+        print(json.dumps(line), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+
+
 def launch_ranks(args):
     """Parent of a multi-GPU run: never touches the GPU (device_count() does not initialise it), starts the ranks as a child
     process and hands their return code back."""
@@ -321,6 +457,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
 
+    if args.testset > 0:
+        return testset_run(args, rank, world, local, use_dist)
     from omni_avsr_amd.dist import gather_hypotheses, pack_records
     from omni_avsr_amd.modeling import OmniEngine
     from omni_avsr_amd.synth import synth_state_dict
@@ -360,6 +498,8 @@ def main():
     results = [None] * nstream
     # The decode scheduler (default): every call is still one batch of B utterances submitted on its own stream; the engine merges the
     # decode rows of the calls in flight into one step loop (oavsr_generate_submit).  Caller-side nothing is grouped (decode_group 1).
+    if args.sched_rows is None:
+        args.sched_rows = eng.sched_rows
     use_sched = not args.no_scheduler and args.beams == 1 and G == 1 and B <= args.sched_rows
     eng.sched_rows, eng.sched_slots, eng.sched_stride, eng.sched_lanes = args.sched_rows, args.sched_slots, args.sched_stride, args.sched_lanes
     if use_sched and nstream <= 8:

@@ -152,7 +152,7 @@ int oavsr_generate_chunked(const oavsr_model* m, oavsr_workspace* ws, int32_t ta
  * The reference evaluates one utterance per forward() (eval_OmniAVSR.py:18-24, datamodule/data_module.py:238-242): nothing to mirror,
  * this is the engine's own serving layer under the same per-utterance results.  Calls keep arriving one batch at a time on the caller's
  * streams (encoders + prefill of a call run there, as in oavsr_generate); the decode rows of every submitted call live in row slots of
- * ONE pool per model, and one step loop on the scheduler's own stream serves all admitted rows (up to max_rows <= 32 per step, each row
+ * ONE pool per model, and one step loop on the scheduler's own stream serves all admitted rows (up to max_rows <= 64 per step, each row
  * at its own step), so the LLM weights are streamed once per step for all of them.  Rows join after their call's prefill and leave after
  * their own max_new tokens.  The schedule is fixed by the host at submission time in units of steps -- no host thread, no host
  * synchronisation, no device-side queue -- and the ids of an utterance are bit-identical to oavsr_generate on that utterance alone.
@@ -168,8 +168,9 @@ uint64_t oavsr_scheduler_bytes(const oavsr_scheduler* s);
 /* Caller stream i (0 .. 7) of the scheduler: a HIP stream the ENGINE created, before its lanes' streams, for submitting calls on.  ROCm
  * binds a stream to one of its few hardware queues at creation, and which caller stream shares a queue with which lane decides how encoder
  * phases and decode bursts take turns: with streams of the caller's own making the same loop ran at 226-229 or at 255-260 utt/s depending
- * on when they were created (round 3).  Streams handed out here are in the fast order by construction; they belong to the MODEL
- * (created with its first scheduler, kept when a scheduler is destroyed and re-created, destroyed by oavsr_model_destroy).  Any other stream
+ * on when they were created (round 3).  Streams handed out here are in the fast order by construction; they belong to the PROCESS
+ * (one process per GPU: created with the first scheduler, shared by every scheduler created later, never destroyed -- a host framework
+ * that has recorded them, e.g. PyTorch's caching allocator, never holds a dangling stream).  Any other stream
  * still works (speed only, never results).  NULL: index out of range. */
 oavsr_stream oavsr_scheduler_caller_stream(oavsr_scheduler* s, int32_t i);
 /* oavsr_generate(beams = 1) split in two: submit queues encoders + prefill on `stream` (workspace ws, as oavsr_generate) and the

@@ -113,7 +113,8 @@ static const char* gemm_family(const GemmArgs& a, bool skinny) {
     const int mt = ceil_div(a.M, 16) <= 1 ? 1 : ceil_div(a.M, 16) <= 2 ? 2 : ceil_div(a.M, 16) <= 4 ? 4 : 8;
     const bool wide = a.N >= 8192;
     const int nt = a.swiglu_pairs ? (wide ? 4 : 2) : (mt <= 2 && wide ? 4 : 1);
-    const int r16_nt = wide ? 4 : (a.shared_chip && mt == 2 && a.N >= (a.norm_gain ? 2048 : 512)) ? ((a.norm_gain || a.N < 1024) ? 4 : 8) : 2;      // launch_sk_t's choice
+    const int r16_nt = wide ? 4 : mt == 4 ? ((!a.norm_gain && a.N >= 1024) ? 4 : 2)
+                       : (a.shared_chip && mt == 2 && a.N >= (a.norm_gain ? 2048 : 512)) ? ((a.norm_gain || a.N < 1024) ? 4 : 8) : 2;      // launch_sk_t's choice
     if (skinny_uses_r16(a)) snprintf(buf, sizeof(buf), "skinny_r16_mt%d_nt%d%s%s_%s", mt, r16_nt, a.norm_gain ? "_norm" : "", a.swiglu_pairs ? "_swiglu" : "", dt);
     else snprintf(buf, sizeof(buf), "skinny_mt%d_nt%d%s%s_%s", mt, nt, a.norm_gain ? "_norm" : "", a.swiglu_pairs ? "_swiglu" : "", dt);
     return buf;
@@ -175,6 +176,12 @@ struct Projector { const void *fc1w, *fc2w; const float *fc1b, *fc2b, *lnw, *lnb
 
 using namespace oavsr;
 
+// caller streams handed out by oavsr_scheduler_caller_stream: created with the process's FIRST scheduler, before that scheduler's lanes
+// (hardware-queue binding order); process lifetime
+static constexpr int kCallerStreams = 8;
+static std::vector<hipStream_t> g_caller_streams;
+static std::mutex g_caller_mu;
+
 struct oavsr_model {
   oavsr_config cfg;
   const char* blob = nullptr;
@@ -202,10 +209,6 @@ struct oavsr_model {
   mutable hipEvent_t enc_done = nullptr;       // recorded after the prefill of the most recent generate()
   mutable hipStream_t enc_last = nullptr;
   mutable bool enc_recorded = false;
-  // caller streams handed out by oavsr_scheduler_caller_stream: created with the model's FIRST scheduler, before that scheduler's lanes
-  // (hardware-queue binding order), kept across pool rebuilds, destroyed with the model
-  static constexpr int kCallerStreams = 8;
-  mutable std::vector<hipStream_t> caller_streams;
 
   const void* ptr(const std::string& n, bool required = true) const {
     auto it = t.find(n);
@@ -818,7 +821,10 @@ static int build_prompt_impl(const oavsr_model* m, oavsr_workspace* ws, int task
 // a row's fp32 summation order does not depend on how many other rows share the launch.
 // rows up to which decode GEMMs run on the weight-streaming kernels (mode 1); above: tiled split-K (mode 2).  (Round 3: the 16-column
 // weight-streaming kernels at 33..128 rows were measured on the beam-15 path -- 120 rows -- and lose: 59 vs 82 utt/s sequentially.)
-static constexpr int skinny_max_rows() { return 32; }
+// Greedy rows: up to 64 (round 4: the 64-row forms of the weight-streaming kernels give a row the bits of the <= 8-row kernel, so the
+// batch-independence of greedy decode now reaches 64 rows).  Beam search keeps its 32-row boundary: its > 32-row regime (tiled split-K)
+// is what the beam-search results of rounds 1-3 were produced with, and B x K rows grow in steps of K anyway.
+static constexpr int skinny_max_rows(int beams = 1) { return beams > 1 ? 32 : 64; }
 
 static int decode_split(int N, int Ktot, int esz) {
   const int ktiles = Ktot / (128 / esz);
@@ -859,7 +865,7 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
   const int dt = m->dtype, d = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, hd = c.llm_head_dim, I = c.llm_mlp;
   const int nq = H * hd, nqkv = (H + 2 * KV) * hd;
   const int tl = c.lora_task_specific ? task : 0;
-  const int mode = !decode ? 0 : (rows <= skinny_max_rows() ? 1 : 2);
+  const int mode = !decode ? 0 : (rows <= skinny_max_rows(beams) ? 1 : 2);
   const bool fused_norm = mode == 1;       // RMSNorm folded into the skinny GEMMs (gain on the A fragments, rstd in the epilogue)
   const bool can_prune = !decode && last_rows && cu_last;
   if (pruned) *pruned = false;
@@ -983,12 +989,13 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
 
 // chunk > 0 (prefill): the rows go through the fused weight-streaming kernel `chunk` at a time, whatever their number
 static int lm_head_rows(const oavsr_model* m, oavsr_workspace* ws, const void* x, int rows, float* logits, hipStream_t st, int chunk = 0,
-                        bool normed = false /* ws->lh already holds the final-norm rows (written by the last down_proj's reduce pass) */) {
+                        bool normed = false /* ws->lh already holds the final-norm rows (written by the last down_proj's reduce pass) */,
+                        int beams = 1) {
   const oavsr_config& c = m->cfg;
   const int d = c.llm_hidden;
   GemmArgs g; g.dtype = m->dtype; g.M = rows; g.N = c.llm_vocab; g.K = d; g.W = m->lm_head; g.ldw = d;
   g.C = logits; g.ldc = c.llm_vocab; g.out_f32 = 1;
-  if (rows <= skinny_max_rows() || chunk > 0) {          // final RMSNorm fused into the weight-streaming kernel
+  if (rows <= skinny_max_rows(beams) || chunk > 0) {     // final RMSNorm fused into the weight-streaming kernel
     const int step = chunk > 0 ? chunk : rows;
     for (int r0 = 0; r0 < rows; r0 += step) {
       g.M = std::min(step, rows - r0);
@@ -1149,8 +1156,8 @@ static int decode_beam(const oavsr_model* m, oavsr_workspace* ws, int task, int 
     OAVSR_TRY(launch_embed(m->dtype, m->embed, c.llm_hidden, ws->gs.tok, ws->lx, c.llm_hidden, R, c.llm_hidden, st));
     bool fnorm = false;
     OAVSR_TRY(llm_layers(m, ws, task, R, true, B, K, maxS + max_new, ws->gs.pos, ws->gs.cpos, anc[cur], ws->gs.step, st, nullptr, nullptr, nullptr, nullptr,
-                         R > skinny_max_rows() ? &fnorm : nullptr));
-    OAVSR_TRY(lm_head_rows(m, ws, ws->lx, R, ws->logits, st, 0, fnorm));
+                         R > skinny_max_rows(K) ? &fnorm : nullptr));
+    OAVSR_TRY(lm_head_rows(m, ws, ws->lx, R, ws->logits, st, 0, fnorm, K));
     ProfScope ps("beam_search", 0, (double)R * c.llm_vocab * 16, st);
     OAVSR_TRY(launch_beam_topk(ws->logits, c.llm_vocab, R, c.llm_vocab, K, ws->beam_scores, ws->cand_val, ws->cand_tok, ws->topk_flag, st));
     return launch_beam_step(a, 0, seq[cur], anc[cur], seq[cur ^ 1], anc[cur ^ 1], st);
@@ -1256,7 +1263,6 @@ void oavsr_model_destroy(oavsr_model* m) {
   if (m->melfb) hipFree(m->melfb);
   if (m->stem_wp) hipFree(m->stem_wp);
   if (m->enc_done) hipEventDestroy(m->enc_done);
-  for (auto cs : m->caller_streams) { hipStreamSynchronize(cs); hipStreamDestroy(cs); }
   delete m;
 }
 
@@ -1540,11 +1546,11 @@ static int sched_one_step(oavsr_scheduler* s, SchedLane& l, int R, int task, int
 static int sched_sync_membership(oavsr_scheduler* s, SchedLane& l) {
   if (!l.map_dirty) return 0;
   const oavsr_config& c = s->m->cfg;
-  IntPack32 map;
+  IntPack64 map;
   int r = 0;
   for (int i : l.active) { const SchedCall& k = s->ring[i]; for (int b = 0; b < k.B; ++b) map.v[r++] = k.slot0 + b; }
   const int R = std::max(8, (r + 7) / 8 * 8);
-  OAVSR_REQUIRE(R <= 32, "scheduler: %d rows in the step", r);
+  OAVSR_REQUIRE(R <= 64, "scheduler: %d rows in the step", r);
   for (; r < R; ++r) map.v[r] = s->n_slots;
   OAVSR_TRY(launch_set_ints(l.rowmap, map, R, l.st));
   OAVSR_TRY(launch_sched_embed(s->ss, l.rowmap, R, s->m->dtype, s->m->embed, c.llm_hidden, l.dws->lx, c.llm_hidden, c.llm_hidden, l.st));
@@ -1624,14 +1630,14 @@ static int sched_alloc(oavsr_scheduler* s, int B) {
 int oavsr_scheduler_create(const oavsr_model* m, int32_t n_slots, int32_t max_rows, int32_t lanes, int32_t max_prefix, int32_t max_new,
                            oavsr_scheduler** out) {
   OAVSR_REQUIRE(m && out, "scheduler_create: null argument");
-  OAVSR_REQUIRE(max_rows >= 1 && max_rows <= 32, "scheduler_create: max_rows=%d (the weight-streaming decode kernels serve up to 32 rows per step)", max_rows);
+  OAVSR_REQUIRE(max_rows >= 1 && max_rows <= 64, "scheduler_create: max_rows=%d (the weight-streaming decode kernels serve up to 64 rows per step)", max_rows);
   OAVSR_REQUIRE(lanes >= 1 && lanes <= 8, "scheduler_create: lanes=%d", lanes);
   OAVSR_REQUIRE(n_slots >= max_rows && n_slots <= 4096 && max_prefix >= 1 && max_new >= 1, "scheduler_create: bad sizes (n_slots >= max_rows)");
   const oavsr_config& c = m->cfg;
   oavsr_scheduler* s = new oavsr_scheduler();
   s->m = m; s->n_slots = n_slots; s->max_rows = max_rows; s->max_prefix = (max_prefix + 63) / 64 * 64; s->max_new = max_new;
   s->lanes.resize(lanes);
-  const size_t e = m->esz, NS = (size_t)n_slots + 1, R = 32;
+  const size_t e = m->esz, NS = (size_t)n_slots + 1, R = max_rows > 32 ? 64 : 32;
   const int d = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, hd = c.llm_head_dim, I = c.llm_mlp;
   const size_t nqkv = (size_t)(H + 2 * KV) * hd;
   oavsr_workspace* w = new oavsr_workspace();
@@ -1679,12 +1685,14 @@ int oavsr_scheduler_create(const oavsr_model* m, int32_t n_slots, int32_t max_ro
   // section 5).  The engine therefore creates the CALLER streams it hands out (oavsr_scheduler_caller_stream) first, then the lanes: the
   // order the round-3 scan found in the fast regime.  (Priority streams, CU-masked lanes, eagerly bound queues and placeholder streams
   // were measured in round 3 and removed in round 4: profiles/r03_sched_scan.txt.)
-  // (they belong to the MODEL, so that they survive a pool that has to be rebuilt: created once, with the model's first scheduler)
-  while ((int)m->caller_streams.size() < oavsr_model::kCallerStreams) {
-    hipStream_t cs = nullptr;
-    if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return fail("stream creation failed");
-    m->caller_streams.push_back(cs);
-  }
+  // (they belong to the PROCESS -- one process per GPU: created once, with the first scheduler, and never destroyed, so that a host
+  // framework that has seen them, e.g. PyTorch's caching allocator after record_stream, never holds a dangling stream)
+  { std::lock_guard<std::mutex> lk(g_caller_mu);
+    while ((int)g_caller_streams.size() < kCallerStreams) {
+      hipStream_t cs = nullptr;
+      if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return fail("stream creation failed");
+      g_caller_streams.push_back(cs);
+    } }
   for (auto& l : s->lanes) {
     oavsr_workspace* lw = l.dws;      // the lane's view: its own scratch, the shared pool
     lw->m = m; lw->max_B = n_slots; lw->max_beams = 1; lw->max_new = max_new; lw->max_prefix = s->max_prefix;
@@ -1717,8 +1725,9 @@ void oavsr_scheduler_destroy(oavsr_scheduler* s) {
 }
 uint64_t oavsr_scheduler_bytes(const oavsr_scheduler* s) { return s ? s->arena_bytes : 0; }
 oavsr_stream oavsr_scheduler_caller_stream(oavsr_scheduler* s, int32_t i) {
-  if (!s || i < 0 || i >= (int)s->m->caller_streams.size()) { set_last_error("scheduler_caller_stream: index %d out of range (0..%d)", (int)i, oavsr_model::kCallerStreams - 1); return nullptr; }
-  return (oavsr_stream)s->m->caller_streams[i];
+  std::lock_guard<std::mutex> lk(g_caller_mu);
+  if (!s || i < 0 || i >= (int)g_caller_streams.size()) { set_last_error("scheduler_caller_stream: index %d out of range (0..%d)", (int)i, kCallerStreams - 1); return nullptr; }
+  return (oavsr_stream)g_caller_streams[i];
 }
 
 int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_workspace* ws, int32_t task, const void* video_dev, const int32_t* Tv_host,
@@ -1809,7 +1818,7 @@ int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_worksp
     if (stride > issued) OAVSR_TRY(sched_run(s, l, stride - issued));
     // after the call's prefill; first token from the prefill's logits (step 0 of the row's own counter)
     OAVSR_CHECK_HIP(hipStreamWaitEvent(l.st, k.prefilled, 0));
-    IntPack32 Sp;
+    IntPack64 Sp;
     for (int b = 0; b < B; ++b) Sp.v[b] = S[b];
     OAVSR_TRY(launch_sched_init_slots(s->ss, slot0, B, Sp, max_new, c.id_pad, l.st));
     OAVSR_TRY(launch_argmax_partial(s->logits_pre + (size_t)slot0 * c.llm_vocab, c.llm_vocab, B, c.llm_vocab, banned, l.partials, l.st));

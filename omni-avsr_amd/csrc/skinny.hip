@@ -355,14 +355,17 @@ __device__ __forceinline__ void skinny_body(const GemmArgs& p, const int bid, ch
   }
 }
 
-// 8-column tiles for 9..32 rows (MT = 1: up to 16 rows, MT = 2: up to 32).  The weight fragment is HALF mode's -- MFMA rows 0-7 hold the
+// 8-column tiles for 9..64 rows (MT = 1: up to 16 rows, MT = 2: up to 32, MT = 4: up to 64 -- round 4, the decode scheduler's 64-row
+// steps: the weight stream of a step is what costs, twice the rows share it).  The weight fragment is HALF mode's -- MFMA rows 0-7 hold the
 // tile's 8 columns for the EVEN k block of a pair, rows 8-15 the same columns for the ODD block, so a wave load is 8 weight rows x one whole
 // 128-byte line and N / 8 workgroups fill the chip where 16-column tiles left half the CUs idle -- but the activation operand keeps all
 // 16 rows: two MFMAs per pair, one with the even-block activations (its result columns 0-7 are the even partial sums), one with the
 // odd-block activations (columns 8-15 = the odd partial sums); the other halves are discarded.  MFMA time is irrelevant here, the
 // weight stream is what costs.  The partial sums are combined exactly as HALF mode combines them (per wave: even, then odd), so a row
 // gets the same bits from this kernel as from the <= 8-row kernel: greedy decode does not depend on the batch up to 32 rows.
-template <typename T, int MT, int NT, bool NORM, int U, int W>
+// SEG2 = false: the launch has no second K segment (K2 == 0; launcher-checked): with the fused norm the LoRA segment's accumulators -- as many
+// registers again -- then do not exist (the 64-row x 32-column forms only fit the register file that way).
+template <typename T, int MT, int NT, bool NORM, int U, int W, bool SEG2 = true>
 __global__ __launch_bounds__(W * 64, (NT <= 2 && MT == 1) ? 4 : 2) void skinny_r16_kernel(const GemmArgs p) {
   constexpr int kWaves = W, kThreads = W * 64;
   constexpr int KBE = 64 / (int)sizeof(T);
@@ -370,10 +373,10 @@ __global__ __launch_bounds__(W * 64, (NT <= 2 && MT == 1) ? 4 : 2) void skinny_r
   constexpr int MR = MT * 16, NC = NT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sred = reinterpret_cast<float*>(smem);                   // [8][MR][NC]   columns 0-7 of a 16-block: even partials, 8-15: odd
-  float* sred2 = sred + kWaves * MR * NC;                         // [8][MR][NC]   (NORM && K2)
-  float* sssq = sred2 + (NORM ? kWaves * MR * NC : 0);            // [2][8][MR]    sum of squares per (parity, wave, row)
+  float* sred2 = sred + kWaves * MR * NC;                         // [8][MR][NC]   (NORM && K2: the LoRA segment's partial sums, kept apart from the normalised ones)
+  float* sssq = sred2 + ((NORM && p.K2) ? kWaves * MR * NC : 0);  // [2][8][MR]    sum of squares per (parity, wave, row)
   float* sgain = sssq + (NORM ? 2 * kWaves * MR : 0);             // [K]
-  constexpr bool GAIN_LDS = NORM && (kWaves * MR * NC * 8 + 2 * kWaves * MR * 4) <= 96 * 1024;
+  constexpr bool GAIN_LDS = NORM && (kWaves * MR * NC * 8 + 2 * kWaves * MR * 4) <= 96 * 1024;      // (sized for the two-image case: a compile-time property)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, g = lane >> 4;
   const int par = r16 >> 3, cw = r16 & 7;                         // weight operand: k-block parity, column within the tile
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(W * 64, (NT <= 2 && MT == 1) ? 4 : 2) void skinny_r
   const int nkb1 = p.K / KBE, nkb = nkb1 + p.K2 / KBE;
   const int nsteps = (nkb + 1) / 2;                               // pairs of k blocks (nkb1 even: a pair never straddles the segments)
 
-  f32x4 acc[MT][NT][2], acc2[NORM ? MT : 1][NORM ? NT : 1][2];
+  f32x4 acc[MT][NT][2], acc2[(NORM && SEG2) ? MT : 1][(NORM && SEG2) ? NT : 1][2];
   float ssq[MT][2];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(W * 64, (NT <= 2 && MT == 1) ? 4 : 2) void skinny_r
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         acc[i][j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (NORM) acc2[i][j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (NORM && SEG2) acc2[i][j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
   Chunk16 bf[U][NT], af[U][MT][2];
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(W * 64, (NT <= 2 && MT == 1) ? 4 : 2) void skinny_r
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
-            if (NORM && !s1) MmaS<T>::run(af[u][i][q], bf[u][j], acc2[i][j][q]);
+            if (NORM && SEG2 && !s1) MmaS<T>::run(af[u][i][q], bf[u][j], acc2[i][j][q]);
             else MmaS<T>::run(af[u][i][q], bf[u][j], acc[i][j][q]);
           }
       }
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(W * 64, (NT <= 2 && MT == 1) ? 4 : 2) void skinny_r
       for (int r = 0; r < 4; ++r) {
         const int o = (wave * MR + i * 16 + g * 4 + r) * NC + j * 16 + r16;
         sred[o] = par ? acc[i][j][1][r] : acc[i][j][0][r];
-        if (NORM && p.K2) sred2[o] = par ? acc2[i][j][1][r] : acc2[i][j][0][r];
+        if (NORM && SEG2 && p.K2) sred2[o] = par ? acc2[i][j][1][r] : acc2[i][j][0][r];
       }
   if (NORM) {
 #pragma unroll
@@ -558,14 +561,16 @@ __global__ __launch_bounds__(W * 64, (NT <= 2 && MT == 1) ? 4 : 2) void skinny_r
   }
 }
 
-template <typename T, int MT, int NT, bool NORM, int U, int W = kMaxWaves>
+template <typename T, int MT, int NT, bool NORM, int U, int W = kMaxWaves, bool SEG2 = true>
 int launch_r16(const GemmArgs& a, hipStream_t st) {
-  constexpr int smem0 = W * MT * 16 * NT * 16 * 4 * (NORM ? 2 : 1) + (NORM ? 2 * W * MT * 16 * 4 : 0);
-  static_assert(smem0 <= 160 * 1024, "LDS");
-  constexpr bool gain_lds = NORM && smem0 <= 96 * 1024;
+  OAVSR_REQUIRE(SEG2 || a.K2 == 0, "skinny gemm: this form has no second K segment");
+  constexpr int img = W * MT * 16 * NT * 16 * 4;
+  constexpr int smem_two = img * (NORM ? 2 : 1) + (NORM ? 2 * W * MT * 16 * 4 : 0);
+  constexpr bool gain_lds = NORM && smem_two <= 96 * 1024;                        // the kernel's GAIN_LDS
+  const int smem0 = img * ((NORM && a.K2) ? 2 : 1) + (NORM ? 2 * W * MT * 16 * 4 : 0);      // the second image only exists with a LoRA segment
   const int smem = smem0 + (gain_lds ? a.K * 4 : 0);
-  OAVSR_REQUIRE(smem <= 160 * 1024, "skinny gemm: K=%d too deep for the fused RMSNorm prologue", a.K);
-  auto kern = skinny_r16_kernel<T, MT, NT, NORM, U, W>;
+  OAVSR_REQUIRE(smem <= 160 * 1024, "skinny gemm: %d rows x %d columns x K=%d do not fit the LDS of a CU (%d bytes)", MT * 16, NT * 8, a.K, smem);
+  auto kern = skinny_r16_kernel<T, MT, NT, NORM, U, W, SEG2>;
   static bool attr_set = false;
   if (!attr_set) {
     OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1071,6 +1076,22 @@ int launch_sk_t(const GemmArgs& a, hipStream_t st) {
   // 9..32 rows: 8-column tiles with 16-row activation operands (skinny_r16_kernel) wherever the <= 8-row path would use its 8-column tiles
   constexpr int r16_on = 1;
   constexpr int kbe = 64 / (int)sizeof(T);
+  if (r16_on && half_enabled() && a.M > 32 && mt <= 4 && (a.K / kbe) % 2 == 0) {
+    // 33..64 rows (the decode scheduler's 64-row steps): the same 8-column-tile arithmetic with four 16-row activation operands per
+    // weight fragment -- a row's bits are those of the <= 8-row kernel (tested), only the weight stream is shared by twice the rows.
+    // Tile widths follow the LDS image (waves x 64 rows x columns x 4 B <= 128 KiB per image) and the accumulator registers.
+    if (wide && (!a.swiglu_pairs || a.N % 32 == 0)) {
+      if (a.K2 == 0) {
+        if (a.N >= 65536) return launch_r16<T, 4, 4, NORM, 1, 4, false>(a, st);          // lm_head class: 4 waves, like every other row count
+        return launch_r16<T, 4, 4, NORM, 1, kMaxWaves, false>(a, st);                    // gate / up (+ SwiGLU): 32 columns per workgroup
+      }
+      return a.N >= 65536 ? launch_r16<T, 4, 2, NORM, 1, 4>(a, st) : launch_r16<T, 4, 2, NORM, 1>(a, st);      // (a wide GEMV with a LoRA segment: no call site today)
+    }
+    if (!a.swiglu_pairs && a.N >= 64 && a.N / 16 < 384) {
+      if constexpr (!NORM) { if (a.N >= 1024) return launch_r16<T, 4, 4, NORM, 1>(a, st); }        // o_proj, down_proj (no norm: one accumulator set anyway)
+      return launch_r16<T, 4, 2, NORM, 1>(a, st);                                        // QKV (+ LoRA segment: two LDS images), LoRA down
+    }
+  }
   if (r16_on && half_enabled() && a.M > 8 && mt <= 2 && (a.K / kbe) % 2 == 0) {
     if (wide && (!a.swiglu_pairs || a.N % 32 == 0)) {
       // same wave count as the <= 8-row kernel picks for this N (4 waves for the many-round lm_head): the k blocks are dealt over
@@ -1136,7 +1157,7 @@ int launch_gemm_skinny_chain2(const GemmArgs& a0, const GemmArgs& a1, const Skin
 bool skinny_uses_r16(const GemmArgs& a) {
   constexpr int r16_on = 1;
   const int esz = a.dtype == DT_F32 ? 4 : 2, kbe = 64 / esz, mt = ceil_div(a.M, 16);
-  if (!(r16_on && half_enabled() && a.M > 8 && mt <= 2 && (a.K / kbe) % 2 == 0)) return false;
+  if (!(r16_on && half_enabled() && a.M > 8 && mt <= 4 && (a.K / kbe) % 2 == 0)) return false;
   if (a.N >= 8192 && (!a.swiglu_pairs || a.N % 32 == 0)) return true;
   return !a.swiglu_pairs && a.N >= 64 && a.N / 16 < 384;
 }

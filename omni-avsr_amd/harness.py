@@ -217,13 +217,15 @@ class WerMeter:
     total_length: int = 0
     per_utt: List[Tuple[str, str, int, int]] = field(default_factory=list)
     failed: List[int] = field(default_factory=list)      # utterance ids whose batch raised (reported; not in the counters)
+    utt_ids: List[Optional[int]] = field(default_factory=list)      # per_utt[k] belongs to utterance utt_ids[k] (evaluate() fills it; None otherwise)
 
-    def update(self, gold_text: str, generated_text: str):
+    def update(self, gold_text: str, generated_text: str, uid: Optional[int] = None):
         e = compute_word_level_distance(gold_text, generated_text)
         n = len(gold_text.split())
         self.total_edit_distance += e
         self.total_length += n
         self.per_utt.append((gold_text, generated_text, e, n))
+        self.utt_ids.append(uid)
 
     @property
     def wer(self) -> float:
@@ -262,10 +264,12 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
     kw_mod = modality if getattr(model, "is_task_specific", False) else None
     chunk_prev = getattr(model, "encoder_chunk", None)
     if decode_group > 1:
-        rows = batch_size * decode_group * int(getattr(model, "num_beams", 1) or 1)
-        if rows > 32 and not allow_regime_change:
-            raise ValueError(f"decode_group={decode_group} x batch_size={batch_size} x num_beams={getattr(model, 'num_beams', 1)} = {rows} decode rows: "
-                             "above 32 rows the decode GEMMs switch kernel family and bf16 ids may differ from the ungrouped evaluation "
+        beams_ = int(getattr(model, "num_beams", 1) or 1)
+        rows = batch_size * decode_group * beams_
+        lim = 64 if beams_ == 1 else 32          # rows up to which the weight-streaming decode kernels give a row the same bits whatever shares the step
+        if rows > lim and not allow_regime_change:
+            raise ValueError(f"decode_group={decode_group} x batch_size={batch_size} x num_beams={beams_} = {rows} decode rows: "
+                             f"above {lim} rows the decode GEMMs switch kernel family and bf16 ids may differ from the ungrouped evaluation "
                              "(pass allow_regime_change=True to accept that)")
         model.encoder_chunk = batch_size
         batch_size = batch_size * decode_group
@@ -279,7 +283,7 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
 
     def score(idxs, ids):
         for i, t in zip(idxs, to_text(ids)):
-            meter.update(samples[i][1], t)
+            meter.update(samples[i][1], t, uid=i)
 
     if in_flight <= 1 or not batches:
         raw = bool(batches) and "video_u8" in samples[batches[0][0]][0]

@@ -33,6 +33,9 @@ def whisper_keep_tokens(max_len: int) -> int:
     return min(max(int(max_len / 16000 * 50), 25), 1500)
 
 
+_CALLER_STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}      # (device, i) -> the engine's caller stream i (process lifetime, see OmniEngine.caller_stream)
+
+
 class OmniEngine:
     """Owns the device blob, the oavsr_model and one workspace; thin typed wrappers over the C ABI."""
 
@@ -47,7 +50,7 @@ class OmniEngine:
         self._sched = C.c_void_p(None)   # decode scheduler (continuous batching of the greedy decode across calls); created on first submit
         self._sched_key = None
         self._sched_gen = 0              # tickets carry the generation of the pool they belong to (a pool that had to grow is rebuilt)
-        self.sched_rows, self.sched_slots = 32, 192     # rows per decode step (<= 32) / row slots of the pool
+        self.sched_rows, self.sched_slots = 32, 192     # rows per decode step (<= 64) / row slots of the pool
         self.sched_lanes = 3                            # independent step loops sharing the pool (one loop serves ~380 utt/s)
         self.sched_stride = 0                           # steps per admission (0: automatic; oavsr_scheduler_set_stride)
         self._blob = None
@@ -343,14 +346,12 @@ class OmniEngine:
         """Caller stream i (0..7) of the decode scheduler, created by the ENGINE before its lanes' streams (oavsr_scheduler_caller_stream):
         submit calls on these and the loop's throughput no longer depends on when the caller happened to create its streams (ROCm binds a
         stream to a hardware queue at creation).  Needs the scheduler (reserve_scheduler / a first submit); the
-        streams belong to the model: they survive a pool that has to grow and die with `close()` / a new `load_state_dict`."""
+        streams belong to the process (one per GPU): they are never destroyed, every engine of the process hands out the same eight."""
         if not self._sched:
             raise RuntimeError("caller_stream: the decode scheduler does not exist yet (call reserve_scheduler first)")
-        cache = self.__dict__.setdefault("_caller_streams", {})
-        key = (self._model.value, int(i))
+        cache = _CALLER_STREAMS
+        key = (str(self.device), int(i))
         if key not in cache:
-            for k in [k for k in cache if k[0] != self._model.value]:
-                del cache[k]
             ptr = self.lib.oavsr_scheduler_caller_stream(self._sched, int(i))
             if not ptr:
                 raise IndexError(L.last_error())

@@ -70,7 +70,7 @@ def run_case(spec, sd, Tv, Ts, rate_a, rate_v, seed, max_new, task="audiovisual"
         logits = eng.prefill(task, emb, S)
         tokens = torch.full((1, 1), spec.ids["bos"]) if spec.llm.family == "llama" else torch.zeros(1, 0, dtype=torch.long)
         ref_emb = orc.prepare_inputs(dict(video=video, audio=audio, lengths=torch.tensor([Ts]), tokens=tokens), task, rate_a, rate_v, feats=(a_feat, v_feat))
-        _EMB_CACHE[(spec.llm.hidden, spec.llm.layers, Tv, Ts, rate_a, rate_v, seed, task)] = ref_emb
+        _EMB_CACHE[(repr(spec.llm), repr(spec.whisper), repr(spec.avhubert), spec.lora_rank, spec.is_task_specific, spec.shared_lora, Tv, Ts, rate_a, rate_v, seed, task)] = ref_emb
         check_enc("inputs_embeds", emb, ref_emb[0])
         mod = task if spec.is_task_specific else None
         path = orc.llm.score_path(ref_emb, got, mod)
@@ -120,7 +120,7 @@ def run_beam_case(spec, sd, Tv, Ts, rate_a, rate_v, seed, K=15):
     tokens = torch.full((1, 1), spec.ids["bos"]) if spec.llm.family == "llama" else torch.zeros(1, 0, dtype=torch.long)
     mod = "audiovisual" if spec.is_task_specific else None
     with torch.no_grad(), O.bf16_emulation():
-        emb = _EMB_CACHE.get((spec.llm.hidden, spec.llm.layers, Tv, Ts, rate_a, rate_v, seed, "audiovisual"))      # same weights (seed 1234), same clip
+        emb = _EMB_CACHE.get((repr(spec.llm), repr(spec.whisper), repr(spec.avhubert), spec.lora_rank, spec.is_task_specific, spec.shared_lora, Tv, Ts, rate_a, rate_v, seed, "audiovisual"))      # same architecture + weights (seed 1234) + clip
         if emb is None:
             emb = orc.prepare_inputs(dict(video=video, audio=audio, lengths=torch.tensor([Ts]), tokens=tokens), "audiovisual", rate_a, rate_v)
         want = orc.llm.generate_beam(emb, spec.max_dec_tokens, K, spec.ids["eos"], spec.ids["pad"], mod)

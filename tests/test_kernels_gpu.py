@@ -1038,10 +1038,14 @@ def test_gemm_dispatch_takes_persistent_kernel_for_multi_round_launches():
 # ------------------------------------------------------------------------------------------------ 8-column decode tiles for 9..32 rows
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K,K2,norm", [(9, 2048, 2048, 0, False), (16, 3072, 2048, 128, True), (24, 2048, 8192, 0, False), (32, 136, 256, 64, True),
-                                           (17, 128256 // 8, 512, 0, True), (12, 16384 + 40, 128, 0, False)])
+                                           (17, 128256 // 8, 512, 0, True), (12, 16384 + 40, 128, 0, False),
+                                           # 33..64 rows (round 4: the decode scheduler's 64-row steps): QKV + LoRA with the fused norm (two LDS images),
+                                           # o_proj / down_proj widths, a LoRA-down width, lm_head class (4 waves) and a wide gate-like N, ragged N
+                                           (64, 3072, 2048, 128, True), (48, 2048, 8192, 0, False), (33, 4096, 4096, 0, False), (64, 256, 2048, 0, True),
+                                           (40, 128256 // 8, 512, 0, True), (64, 65536 + 24, 256, 0, True), (56, 16384 + 40, 128, 0, False)])
 def test_gemm_skinny_r16_tiles(dtype, M, N, K, K2, norm):
-    """9..32 rows through 8-column tiles (skinny_r16_kernel): vs the fp32 reference, and the first 8 rows bit-identical to what the
-    <= 8-row kernel computes for them alone (same partial-sum order => greedy decode does not depend on the batch up to 32 rows)."""
+    """9..64 rows through 8-column tiles (skinny_r16_kernel): vs the fp32 reference, and the first 8 rows bit-identical to what the
+    <= 8-row kernel computes for them alone (same partial-sum order => greedy decode does not depend on the batch up to 64 rows)."""
     x, xr = q(rnd(M, K, seed=1) * 1.3, dtype)
     w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
     r, rr = q(rnd(M, N, seed=5), dtype)
@@ -1063,10 +1067,16 @@ def test_gemm_skinny_r16_tiles(dtype, M, N, K, K2, norm):
     close(out, ref, tol(dtype) * 2, what="skinny r16 gemm")
     out8 = gemm(dtype, x[:8].contiguous(), w, residual=r[:8].contiguous(), skinny=True, **kw8)
     assert torch.equal(out[:8], out8), f"rows 0-7 differ from the <= 8-row kernel: {(out[:8].float() - out8.float()).abs().max().item():.3e}"
+    if M > 40:      # ... and a block of rows from the upper half (the third / fourth 16-row operand)
+        kw8b = dict(kw8)
+        if K2:
+            kw8b["A2"] = a2[M - 8:].contiguous()
+        out8b = gemm(dtype, x[M - 8:].contiguous(), w, residual=r[M - 8:].contiguous(), skinny=True, **kw8b)
+        assert torch.equal(out[M - 8:], out8b), f"rows {M - 8}..{M - 1} differ from the <= 8-row kernel"
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,I,K", [(16, 8192, 2048), (24, 4096, 256), (32, 8192, 128)])
+@pytest.mark.parametrize("M,I,K", [(16, 8192, 2048), (24, 4096, 256), (32, 8192, 128), (64, 8192, 2048), (40, 14336, 4096)])
 def test_gemm_skinny_r16_swiglu(dtype, M, I, K):
     x, xr = q(rnd(M, K, seed=1), dtype)
     wg, wgr = q(rnd(I, K, seed=2) / math.sqrt(K), dtype)

@@ -85,6 +85,37 @@ def test_eos_lengths_and_different_max_new(dtype):
     assert got == ref
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("family,hd", [("llama", 64), ("qwen2", 128)])
+def test_64_row_steps_equal_isolated_calls(dtype, family, hd):
+    """max_rows = 64 (round 4): eleven calls of 3..12 rows through ONE lane whose steps carry up to 64 rows -- the 33..64-row forms of the
+    weight-streaming kernels (four 16-row activation operands per weight fragment) give a row the bits of the <= 8-row kernel, so every
+    call must decode exactly the ids of the same call run alone; also a call of 40 rows on its own (generate, no scheduler)."""
+    spec = tiny_spec(family=family, head_dim=hd, task_specific=True, shared=True)
+    eng = OmniEngine(spec, dtype=dtype).load_state_dict(synth_state_dict(spec, seed=1234))
+    eng.sched_lanes, eng.sched_rows, eng.sched_slots, eng.sched_stride = 1, 64, 128, 1
+    mn = spec.max_dec_tokens
+    sizes = [8, 12, 8, 3, 8, 8, 12, 5, 8, 8, 7]
+    calls = [clips(b, 300 + i) for i, b in enumerate(sizes)]
+    ref = [alone(eng, c, mn, True) for c in calls]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    pend = [submit(eng, c, mn, True, i % 3, streams[i % 3]) for i, c in enumerate(calls)]
+    eng.flush()
+    got = [collect(eng, pend[i], streams[i % 3]) for i in range(len(calls))]
+    for i in range(len(calls)):
+        assert got[i] == ref[i], f"{dtype}: call {i} ({sizes[i]} rows) decodes differently inside 64-row steps than alone"
+    st = eng.scheduler_stats()
+    assert st["rows_per_step"] > 36.0, f"the steps never reached the 33..64-row forms: {st}"
+    # 40 utterances in ONE plain call: rows 0..7 are the first call's utterances
+    video = torch.cat([c[0] for c in calls[:5]], 0)
+    audio = torch.cat([c[1] for c in calls[:5]], 0)
+    Tv = sum((c[2] for c in calls[:5]), [])
+    Ts = sum((c[3] for c in calls[:5]), [])
+    ids40, lens40 = eng.generate("audiovisual", video, Tv, audio, Ts, 4, 2, beams=1, max_new=mn, force_len=True)
+    torch.cuda.synchronize()
+    assert len(Tv) == 39 and ids40[:8].cpu().tolist() == ref[0][0], "39 rows in one decode loop: rows 0..7 differ from the 8-row call"
+
+
 def test_more_calls_than_rows_per_step_and_oracle_f32():
     """7 calls of 8 rows against a 32-row step: the host issues the steps that make room; ids equal the CPU oracle's (f32)"""
     spec = tiny_spec(family="llama", task_specific=True, shared=True)
