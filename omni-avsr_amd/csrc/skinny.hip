@@ -1083,7 +1083,7 @@ int launch_sk_t(const GemmArgs& a, hipStream_t st) {
     if (wide && (!a.swiglu_pairs || a.N % 32 == 0)) {
       if (a.K2 == 0) {
         if (a.N >= 65536) return launch_r16<T, 4, 4, NORM, 1, 4, false>(a, st);          // lm_head class: 4 waves, like every other row count
-        return launch_r16<T, 4, 4, NORM, 1, kMaxWaves, false>(a, st);                    // gate / up (+ SwiGLU): 32 columns per workgroup
+        return launch_r16<T, 4, 4, NORM, 1, kMaxWaves, false>(a, st);                    // gate / up (+ SwiGLU): 32 columns per workgroup (two k steps in flight per wave do not fit the register file with the fused norm)
       }
       return a.N >= 65536 ? launch_r16<T, 4, 2, NORM, 1, 4>(a, st) : launch_r16<T, 4, 2, NORM, 1>(a, st);      // (a wide GEMV with a LoRA segment: no call site today)
     }
@@ -1113,9 +1113,10 @@ int launch_sk_t(const GemmArgs& a, hipStream_t st) {
     }
   }
   if (a.swiglu_pairs) {
-    OAVSR_REQUIRE(mt <= 2 && a.N % 32 == 0, "skinny gemm: fused SwiGLU needs M <= 32 and N %% 32 == 0");
+    OAVSR_REQUIRE(mt <= 4 && a.N % 32 == 0, "skinny gemm: fused SwiGLU needs M <= 64 and N %% 32 == 0");
     if (mt <= 1) return wide ? launch_sk<T, 1, 4, NORM>(a, st) : launch_sk<T, 1, 2, NORM>(a, st);
-    return wide ? launch_sk<T, 2, 4, NORM>(a, st) : launch_sk<T, 2, 2, NORM>(a, st);
+    if (mt <= 2) return wide ? launch_sk<T, 2, 4, NORM>(a, st) : launch_sk<T, 2, 2, NORM>(a, st);
+    return launch_sk<T, 4, 2, NORM>(a, st);       // 33..64 rows below the wide class (small models): the 16-column kernel, as for <= 32 rows
   }
   if (mt <= 1) return wide ? launch_sk<T, 1, 4, NORM>(a, st) : launch_sk<T, 1, 1, NORM>(a, st);
   if (mt <= 2) return wide ? launch_sk<T, 2, 4, NORM>(a, st) : launch_sk<T, 2, 1, NORM>(a, st);

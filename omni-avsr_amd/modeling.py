@@ -50,7 +50,10 @@ class OmniEngine:
         self._sched = C.c_void_p(None)   # decode scheduler (continuous batching of the greedy decode across calls); created on first submit
         self._sched_key = None
         self._sched_gen = 0              # tickets carry the generation of the pool they belong to (a pool that had to grow is rebuilt)
-        self.sched_rows, self.sched_slots = 32, 192     # rows per decode step (<= 64) / row slots of the pool
+        # rows per decode step (<= 64) / row slots of the pool.  A decode step streams every LLM weight once whatever its row count, so the
+        # 7B / 8B models (14-15 GB per step) run 64-row steps: Llama-3.1-8B 102 -> 118, Qwen2.5-7B 85 -> 94 utt/s (round 4); with the 1B model
+        # the step is a chain of short launches whose 64-row forms cost more than the second step they save (headline 269 -> 264, VSR +3 %)
+        self.sched_rows, self.sched_slots = (64, 256) if spec.llm.hidden >= 3584 else (32, 192)
         self.sched_lanes = 3                            # independent step loops sharing the pool (one loop serves ~380 utt/s)
         self.sched_stride = 0                           # steps per admission (0: automatic; oavsr_scheduler_set_stride)
         self._blob = None

@@ -49,10 +49,12 @@ def test_greedy_alone_vs_batches_crossing_kernel_regimes(dtype):
     assert all(r == alone for r in same_regime), f"greedy ids depend on the batch inside the <= 8-row regime: {alone} vs {same_regime}"
     mid = [gen(eng, B, 1, spec.max_dec_tokens, base) for B in (9, 20, 32)]                  # 9..32 rows: 8-column tiles, 16-row operands
     assert all(r == alone for r in mid), f"greedy ids of an utterance change between 1 and 9..32 rows: {alone} vs {mid}"
-    big = [gen(eng, B, 1, spec.max_dec_tokens, base) for B in (33, 70, 130)]               # > 32 rows: split-K tiles, 1 and 2 M-tiles
-    assert all(r == big[0] for r in big), f"greedy ids depend on the batch inside the > 32-row regime: {big}"
+    mid2 = [gen(eng, B, 1, spec.max_dec_tokens, base) for B in (33, 48, 64)]               # 33..64 rows (round 4): the same tiles, four 16-row operands
+    assert all(r == alone for r in mid2), f"greedy ids of an utterance change between 1 and 33..64 rows: {alone} vs {mid2}"
+    big = [gen(eng, B, 1, spec.max_dec_tokens, base) for B in (65, 70, 130)]               # > 64 rows: split-K tiles, 1 and 2 M-tiles
+    assert all(r == big[0] for r in big), f"greedy ids depend on the batch inside the > 64-row regime: {big}"
     if dtype == "f32":
-        assert big[0] == alone, f"f32 ids differ across the 32-row boundary: {alone} / {big[0]}"
+        assert big[0] == alone, f"f32 ids differ across the 64-row boundary: {alone} / {big[0]}"
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
