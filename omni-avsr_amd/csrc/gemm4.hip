@@ -13,10 +13,10 @@
 //     tiles (2 x 16-byte stores per 16-row slab: 16 per wave; fused SwiGLU: 8) -- and the stores drain behind ~2 us of MFMA work.  Edge tiles
 //     (ragged M / N: row-guarded stores, unknown count) fall back to the plain counts, i.e. they wait for their stores: slower, never wrong
 //     (assuming FEWER outstanding operations than there are is the safe direction);
-//   * bias + activation (+ SwiGLU: gate and up columns of a pair sit in the same lane) are applied in the MFMA C layout; the transposition
-//     that turns the results into 16-byte row-segment stores goes through 32 KiB of LDS of its own (8 waves x 16 rows x 64 fp32,
-//     XOR-swizzled instead of padded), because the two k-tile buffers already hold the next tile; the bias is fetched once per tile
-//     BEFORE the first store (an ordinary load behind the stores would make the compiler wait for them);
+//   * bias + activation (+ SwiGLU: gate and up columns of a pair sit in the same lane) and the rounding to bf16 are applied in the MFMA C
+//     layout; the transposition that turns the results into 16-byte row-segment stores goes through LDS of its own (per wave 8 packed row
+//     pairs x 64 columns, XOR-swizzled instead of padded), because the two k-tile buffers already hold the next tile; the bias arrives by
+//     LDS-DMA during the tile's last k-tile (no ordinary global load anywhere in the loop: the compiler would drain vmcnt for it);
 //   * the two wave groups re-synchronise for the epilogue (waves 4-7 run one barrier behind in the k loop, see gemm3.hip) and re-stagger after.
 // Same accumulation order (k ascending, 32 per MFMA) and the same epilogue expressions as gemm2.hip / gemm3.hip: bit-identical to them
 // (tests/test_kernels_gpu.py).  No residual, no per-column scale / PReLU, bf16 output: what the multi-round launches of this model need
@@ -133,6 +133,21 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
     }
   };
 
+  // The tile's bias goes HBM -> LDS by DMA as well (an ordinary load in the epilogue would make the compiler drain vmcnt -- the next tile's
+  // half-tiles in flight -- at its first use): in the tile's LAST k-tile every wave fetches the 2 x 64 bias values of its own column halves
+  // into the spare half of its patch, two 4-byte-per-lane DMAs ahead of that phase's half-tile; they are older than everything the next
+  // three waits leave in flight, so they have landed when the epilogue starts (same wave: no barrier needed), and past N they read as
+  // zeros by the range check.
+  const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.col_bias), 0, p.col_bias ? p.N * 4 : 0, 0x00020000);
+  float* sbias = reinterpret_cast<float*>(smem + kPatch4 + wave * 4096 + 2048);      // [2][64]
+  auto issue_bias = [&]() __attribute__((always_inline)) {
+    if (!p.col_bias) return;
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (__attribute__((address_space(3))) void*)(sbias + nh * 64), 4, lane * 4,
+                                               (n0 + nh * 128 + Cw * 64) * 4, 0, 0);
+  };
+
   // fragment read addresses (gemm3.hip): row r of a half-tile lives at r*128 + ((chunk ^ (r & 7)) << 4)
   const int frow = lane & 15, fg = lane >> 4;
   const int sw0 = ((fg ^ (frow & 7)) << 4), sw1 = (((4 + fg) ^ (frow & 7)) << 4);
@@ -181,6 +196,7 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
     // p0
     load_a(buf, 0, af0);
     load_b(buf, 0);
+    if (KT == 4) issue_bias();
     if (KT == 4) issue_next(kA1, 0);
     else issue(kA1, t + 1);
     if (KT == 1) wait_se(c8, se); else wait_vm<8>();
@@ -222,14 +238,22 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
   PP_BARRIER();
   if (late) PP_BARRIER();
 
-  // epilogue geometry.  Bias and activation are applied in the MFMA C layout (a lane: rows fg*4 + r, column j*16 + frow); each 16 x 64
-  // (SwiGLU: 16 x 32) slab is then transposed through this wave's fp32 patch (XOR-swizzled, 16 x 64 floats) so that a lane owns 16 (8)
-  // consecutive columns of one row and every store is a 16-byte vector, four lanes per 128-byte (64-byte) row segment.
-  float* sw = reinterpret_cast<float*>(smem + kPatch4 + wave * 4096);
+  // epilogue geometry.  Bias and activation are applied in the MFMA C layout (a lane: rows fg*4 + r, column j*16 + frow) and the results are
+  // rounded to bf16 there; each 16 x 64 (SwiGLU: 16 x 32) slab is then transposed through this wave's LDS patch as PACKED ROW PAIRS -- one
+  // dword = (row 2q, row 2q+1) of one column, 8 row pairs x 64 columns, XOR-swizzled -- so that a lane ends up with 16 (8) consecutive
+  // columns of one row and every store is a 16-byte vector, four lanes per 128-byte (64-byte) row segment.  (Half the LDS write traffic of
+  // an fp32 patch: ds_write_b32 is the slowest LDS instruction, 64 B/clk per CU.)
+  unsigned* sw = reinterpret_cast<unsigned*>(smem + kPatch4 + wave * 4096);
   const bool c_vec = (p.ldc % VEC) == 0 && ((uintptr_t)p.C & 15) == 0;
-  // patch element (row, col) lives at float index row*64 + (col ^ ((row & 3) << 2)).  A lane writes (row fg*4 + r, column j*16 + frow):
-  // (wr_base ^ (r << 2)) + r*64 + j*16 -- the xor permutes frow's bits 2-3
-  const int wr_base = fg * 4 * 64 + frow;
+  // patch dword (row pair q, col) lives at index q*64 + (col ^ ((q & 3) << 2)).  A lane writes pairs q = fg*2 + h (its rows r = 2h, 2h+1), column
+  // j*16 + frow: wr_pair[h] + j*16; it reads row rr = lane >> 2 (pair rr >> 1, half rr & 1), columns c0 .. c0 + 15 (7)
+  int wr_pair[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) wr_pair[h] = (fg * 2 + h) * 64 + (frow ^ ((((fg & 1) << 1) + h) << 2));
+  const int rr = lane >> 2;
+  const int rd_pair = (rr >> 1) * 64, rd_x = ((rr >> 1) & 3) << 2;
+  const unsigned half_sel = (rr & 1) ? 0x07060302u : 0x05040100u;      // v_perm_b32: the high / low bf16 of two dwords
+  auto pack2 = [](float a, float b) -> unsigned { return __builtin_bit_cast(unsigned, bf16x2{(bf16_t)a, (bf16_t)b}); };
 
   int se = 0;                                   // S if the previous tile of this workgroup issued exactly S stores per wave, else 0
   for (;;) {
@@ -252,16 +276,12 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
     PP_FENCE();
 
     const bool full = m0 + 256 <= p.M && n0 + 256 <= p.N && c_vec;
-    // bias of the lane's 2 x 4 columns (C layout), requested before the first store: an ordinary load issued behind the stores would make
-    // the compiler wait for them
+    // bias of the lane's 2 x 4 columns (C layout), from the LDS copy the last k-tile's DMA made
     float cb[2][4];
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + nh * 128 + Cw * 64 + j * 16 + frow;
-        cb[nh][j] = (p.col_bias && n < p.N) ? p.col_bias[n] : 0.f;
-      }
+      for (int j = 0; j < 4; ++j) cb[nh][j] = p.col_bias ? sbias[nh * 64 + j * 16 + frow] : 0.f;
     auto epi = [&](f32x4 (&cq)[2][4], int mh, int nh) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -292,64 +312,71 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
 #pragma unroll
           for (int r = 0; r < 4; ++r) cq[i][j][r] = p.res_after_act ? v[r] + 0.f : v[r];
         }
-        const int rr = SWIGLU ? lane >> 2 : lane >> 2;
         const int m = m0 + mh * 128 + R * 32 + i * 16 + rr;
         if (SWIGLU) {
           // gate / up weight rows are interleaved in blocks of 16: n-tiles 0, 2 hold gate columns, 1, 3 the matching up columns -- in the C
           // layout both sit in the same lane.  Both are rounded to T first (what the unfused GEMM -> swiglu_kernel sequence reads back).
 #pragma unroll
-          for (int jj = 0; jj < 2; ++jj)
+          for (int jj = 0; jj < 2; ++jj) {
+            float o[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float o = silu(to_f32(from_f32<T>(cq[i][2 * jj][r]))) * to_f32(from_f32<T>(cq[i][2 * jj + 1][r]));
-              sw[(wr_base ^ (r << 2)) + r * 64 + jj * 16] = o;
-            }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          const int c0 = (lane & 3) * 8;          // 8 of the slab's 32 output columns
-          float y[8];
+            for (int r = 0; r < 4; ++r) o[r] = silu(to_f32(from_f32<T>(cq[i][2 * jj][r]))) * to_f32(from_f32<T>(cq[i][2 * jj + 1][r]));
 #pragma unroll
-          for (int e = 0; e < 8; e += 4) {
-            f32x4 t4 = *reinterpret_cast<const f32x4*>(sw + ((rr * 64 + c0 + e) ^ ((rr & 3) << 2)));
-            y[e] = t4[0]; y[e + 1] = t4[1]; y[e + 2] = t4[2]; y[e + 3] = t4[3];
+            for (int h = 0; h < 2; ++h) sw[wr_pair[h] + jj * 16] = pack2(o[2 * h], o[2 * h + 1]);
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const int c0 = (lane & 3) * 8;          // 8 of the slab's 32 output columns
+          u32x4 d[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) d[e] = *reinterpret_cast<const u32x4*>(sw + ((rd_pair + c0 + 4 * e) ^ rd_x));
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          Chunk16 out;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            out.v[2 * e] = __builtin_amdgcn_perm(d[e][1], d[e][0], half_sel);
+            out.v[2 * e + 1] = __builtin_amdgcn_perm(d[e][3], d[e][2], half_sel);
+          }
           const int nb = ((n0 + nh * 128 + Cw * 64) >> 1) + c0;     // output column (N / 2 columns in all)
           T* Ct = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + nb;
           if (full) {
-            *reinterpret_cast<Chunk16*>(Ct) = chunk_from_f32<T>(y);
+            *reinterpret_cast<Chunk16*>(Ct) = out;
           } else if (m < p.M && nb + 8 <= (p.N >> 1)) {
-            if (c_vec) *reinterpret_cast<Chunk16*>(Ct) = chunk_from_f32<T>(y);
+            if (c_vec) *reinterpret_cast<Chunk16*>(Ct) = out;
             else {
+              const bf16x8 ob = __builtin_bit_cast(bf16x8, out.v);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) Ct[e] = from_f32<T>(y[e]);
+              for (int e = 0; e < 8; ++e) Ct[e] = ob[e];
             }
           }
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sw[(wr_base ^ (r << 2)) + r * 64 + j * 16] = cq[i][j][r];
+            for (int h = 0; h < 2; ++h) sw[wr_pair[h] + j * 16] = pack2(cq[i][j][2 * h], cq[i][j][2 * h + 1]);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           const int c0 = (lane & 3) * 16;
-          float y[16];
+          u32x4 d[4];
 #pragma unroll
-          for (int e = 0; e < 16; e += 4) {
-            f32x4 t4 = *reinterpret_cast<const f32x4*>(sw + ((rr * 64 + c0 + e) ^ ((rr & 3) << 2)));
-            y[e] = t4[0]; y[e + 1] = t4[1]; y[e + 2] = t4[2]; y[e + 3] = t4[3];
-          }
+          for (int e = 0; e < 4; ++e) d[e] = *reinterpret_cast<const u32x4*>(sw + ((rd_pair + c0 + 4 * e) ^ rd_x));
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          Chunk16 out[2];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            out[e >> 1].v[2 * (e & 1)] = __builtin_amdgcn_perm(d[e][1], d[e][0], half_sel);
+            out[e >> 1].v[2 * (e & 1) + 1] = __builtin_amdgcn_perm(d[e][3], d[e][2], half_sel);
+          }
           const int nb = n0 + nh * 128 + Cw * 64 + c0;          // first of this lane's 16 columns
           T* Ct = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + nb;
           if (full) {
-            *reinterpret_cast<Chunk16*>(Ct) = chunk_from_f32<T>(y);
-            *reinterpret_cast<Chunk16*>(Ct + 8) = chunk_from_f32<T>(y + 8);
+            *reinterpret_cast<Chunk16*>(Ct) = out[0];
+            *reinterpret_cast<Chunk16*>(Ct + 8) = out[1];
           } else if (m < p.M && nb < p.N) {
             if (c_vec && nb + 16 <= p.N) {
-#pragma unroll
-              for (int e = 0; e < 16; e += VEC) *reinterpret_cast<Chunk16*>(Ct + e) = chunk_from_f32<T>(y + e);
+              *reinterpret_cast<Chunk16*>(Ct) = out[0];
+              *reinterpret_cast<Chunk16*>(Ct + 8) = out[1];
             } else {
 #pragma unroll
-              for (int e = 0; e < 16; ++e) if (nb + e < p.N) Ct[e] = from_f32<T>(y[e]);
+              for (int e = 0; e < 16; ++e) if (nb + e < p.N) Ct[e] = __builtin_bit_cast(bf16x8, out[e >> 3].v)[e & 7];
             }
           }
         }

@@ -105,7 +105,7 @@ def test_64_row_steps_equal_isolated_calls(dtype, family, hd):
     for i in range(len(calls)):
         assert got[i] == ref[i], f"{dtype}: call {i} ({sizes[i]} rows) decodes differently inside 64-row steps than alone"
     st = eng.scheduler_stats()
-    assert st["rows_per_step"] > 36.0, f"the steps never reached the 33..64-row forms: {st}"
+    assert st["rows_per_step"] > 32.0, f"the steps never reached the 33..64-row forms: {st}"
     # 40 utterances in ONE plain call: rows 0..7 are the first call's utterances
     video = torch.cat([c[0] for c in calls[:5]], 0)
     audio = torch.cat([c[1] for c in calls[:5]], 0)
