@@ -255,7 +255,8 @@ typedef struct oavsr_gemm_desc {
   int64_t rn_ld;
   const float* rn_gain;
   float rn_eps;
-  int32_t grid; /* persistent kernel only: workgroups (multiple of 8); 0 = the launcher's rule */
+  int32_t grid;        /* persistent kernel only: workgroups (multiple of 8); 0 = the launcher's rule */
+  int32_t shared_chip; /* decode kernel only: 1 = the forms the decode scheduler's steps run (fewer, wider workgroups); same bits */
 } oavsr_gemm_desc;
 int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream);
 

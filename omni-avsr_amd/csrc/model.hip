@@ -1958,6 +1958,7 @@ int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream) {
   g.ksplit = d->ksplit < 1 ? 1 : d->ksplit; g.partial = d->partial;
   g.rn_out = d->rn_out; g.rn_ld = d->rn_ld; g.rn_gain = d->rn_gain; g.rn_eps = d->rn_eps;
   OAVSR_REQUIRE(!g.rn_out || g.ksplit > 1, "gemm: rn_out needs split-K (ksplit > 1)");
+  g.shared_chip = d->skinny == 1 ? (d->shared_chip != 0) : 0;
   if (d->skinny == 2) {      // tests: the 8-wave ping-pong 256 x 256 kernel whatever the dispatcher's rule says
     OAVSR_REQUIRE(gemm_8p_supported(g), "op_gemm: shape / layout not supported by the ping-pong kernel");
     return launch_gemm_8p(g, (hipStream_t)stream);

@@ -63,7 +63,7 @@ class GemmDesc(C.Structure):
         ("skinny", C.c_int32), ("norm_gain", C.c_void_p), ("norm_eps", C.c_float), ("swiglu_pairs", C.c_int32),
         ("ksplit", C.c_int32), ("partial", C.c_void_p),
         ("rn_out", C.c_void_p), ("rn_ld", C.c_int64), ("rn_gain", C.c_void_p), ("rn_eps", C.c_float),
-        ("grid", C.c_int32),
+        ("grid", C.c_int32), ("shared_chip", C.c_int32),
     ]
 
 

@@ -25,5 +25,9 @@ for name, M, N, K in [("whisper qkv", 12000, 3072, 1024), ("whisper fc1", 12000,
         pp = timeit(lambda: gemm("bf16", a, w, C_out=out, skinny=2))      # the 8-wave ping-pong kernel whatever the dispatcher's rule says
     except Exception:
         pp = float("nan")
+    try:
+        ps = timeit(lambda: gemm("bf16", a, w, C_out=out, skinny=3))      # the persistent ping-pong kernel (round 4; the dispatcher takes it when tiles > CUs)
+    except Exception:
+        ps = float("nan")
     fl = 2.0 * M * N * K / 1e6
-    print(f"{name:12s} M={M:6d} N={N:6d} K={K:5d}: hipBLASLt {us:8.1f} us {fl / us:7.1f} TFLOP/s | this repo {ours:8.1f} us {fl / ours:7.1f} TFLOP/s | ping-pong {pp:8.1f} us {fl / pp:7.1f} TFLOP/s")
+    print(f"{name:12s} M={M:6d} N={N:6d} K={K:5d}: hipBLASLt {us:8.1f} us {fl / us:7.1f} TFLOP/s | this repo {ours:8.1f} us {fl / ours:7.1f} TFLOP/s | ping-pong {pp:8.1f} us {fl / pp:7.1f} TFLOP/s | persistent {ps:8.1f} us {fl / ps:7.1f} TFLOP/s")

@@ -9,7 +9,7 @@ import torch
 from gpu_util import gemm, DEV
 td = torch.bfloat16
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-# (M, N, K, K2, launches per step, gelu, residual)
+# (M, N, K, K2, launches per step, gelu, residual).  Round 4: the first three (more tiles than CUs) run on the persistent ping-pong kernel.
 MIX = [(12000, 4096, 1024, 0, 24, 1, 0), (2504, 16384, 2048, 0, 16, 0, 0), (12000, 3072, 1024, 0, 24, 0, 0), (12000, 1024, 4096, 0, 24, 0, 1),
        (3200, 4096, 1024, 0, 24, 1, 0), (12000, 1024, 1024, 0, 24, 0, 1), (3200, 3072, 1024, 128, 24, 0, 0)]
 for M, N, K, K2, n, gelu, res in MIX:

@@ -18,6 +18,7 @@ import sys
 from collections import defaultdict
 
 FAMILY = [  # rocprof kernel-name pattern -> bench.py family name
+    (r"gemm_8pp_kernel", "gemm_8pp_256x256_bf16"),
     (r"gemm_8p_kernel", "gemm_8p_256x256_bf16"),
     (r"gemm_dma_kernelIDF16bLi0ELi256ELi256E|gemm_dma_kernel<.*256, 256, 2", "gemm_dma_256x256_bf16"),
     (r"gemm_dma_kernelIDF16bLi0ELi256ELi128E|gemm_dma_kernel<[^>]*0, 256, 128", "gemm_dma_256x128_bf16"),
@@ -80,7 +81,8 @@ for f in sorted(set(fa) | set(sa)):
     write = wa[f].get("WRITE_SIZE", 0.0) / max(wc[f].get("WRITE_SIZE", 0), 1)
     ns = max(sc[f].get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0), 1)
     mops = sa[f].get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) / ns
-    what = "tools/skinny_mix.py 32" if "skinny32" in tag else "tools/skinny_mix.py 8" if "skinny" in tag else "tools/gemm_mix.py" if "gemm" in tag else \
+    what = "tools/skinny_mix.py 64 1 8b (64 rows, the scheduler's forms, Llama-3.1-8B widths)" if "skinny64s8b" in tag else \
+        "tools/skinny_mix.py 32 1 (32 rows, the scheduler's forms)" if "skinny32s" in tag else "tools/skinny_mix.py 32" if "skinny32" in tag else "tools/skinny_mix.py 8" if "skinny" in tag else "tools/gemm_mix.py" if "gemm" in tag else \
         "bench.py --streams 1 --steps 1 --warmup 1 --calls-per-step 2 --no-cpu-baseline --no-roofline"
     d = dict(note="rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*; separate runs, each with --kernel-trace) over `" + what + "`; traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B (gfx950 read-side "
                   "correction; the counters sit on the L2's memory side, Infinity-Cache hits included); mfma flops = SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512; "

@@ -3,7 +3,7 @@
 # inputs, rocprofv3 kernel stats (scheduler on / off) + the concurrency summary of the trace, the beam-search kernel stats.
 #   usage: round_profiles.sh <tag>      (e.g. r03) -> gpurun_out/profiles_<tag>/  (copy into profiles/)
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O="$R/gpurun_out/profiles_$TAG"
 mkdir -p "$O"
