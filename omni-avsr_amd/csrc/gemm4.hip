@@ -436,8 +436,7 @@ int launch_gemm_8pp(const GemmArgs& a, hipStream_t st, int grid) {
   const int64_t ntiles = (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 256);
   if (grid <= 0) grid = gemm_8pp_grid(ntiles);
   OAVSR_REQUIRE(grid % 8 == 0 && grid >= 8, "gemm_8pp: the grid must be a multiple of 8 (got %d)", grid);
-  if ((int64_t)grid > ntiles) grid = (int)(ntiles / 8 * 8);
-  OAVSR_REQUIRE(grid >= 8, "gemm_8pp: fewer than 8 tiles");
+  if ((int64_t)grid > (ntiles + 7) / 8 * 8) grid = (int)((ntiles + 7) / 8 * 8);     // (a ragged single round is dealt over the 8 XCD groups by tile_at)
   GemmArgs b = a;
   b.tile_order = 1;
   auto go = [&](auto kern) -> int {

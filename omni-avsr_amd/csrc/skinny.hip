@@ -1088,7 +1088,7 @@ int launch_sk_t(const GemmArgs& a, hipStream_t st) {
       return a.N >= 65536 ? launch_r16<T, 4, 2, NORM, 1, 4>(a, st) : launch_r16<T, 4, 2, NORM, 1>(a, st);      // (a wide GEMV with a LoRA segment: no call site today)
     }
     if (!a.swiglu_pairs && a.N >= 64 && a.N / 16 < 384) {
-      if constexpr (!NORM) { if (a.N >= 1024) return launch_r16<T, 4, 4, NORM, 1>(a, st); }        // o_proj, down_proj (no norm: one accumulator set anyway)
+      if constexpr (!NORM) { if (a.N >= 1024) return launch_r16<T, 4, 4, NORM, 2>(a, st); }        // o_proj, down_proj (no norm: one accumulator set, room for two k steps of weights in flight per wave)
       return launch_r16<T, 4, 2, NORM, 1>(a, st);                                        // QKV (+ LoRA segment: two LDS images), LoRA down
     }
   }

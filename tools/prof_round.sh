@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 for tag in main nosched; do
   mode=""; [ "$tag" = nosched ] && mode="--no-scheduler"
   rm -rf "$R/gpurun_out/prof_$tag"
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_$tag" -- python3 "$R/bench.py" --no-cpu-baseline --no-grouped --steps 4 --warmup 1 $mode > "$R/gpurun_out/prof_$tag.json" 2> "$R/gpurun_out/prof_$tag.err" || echo "rocprofv3 ($tag) failed"
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_$tag" -- python3 "$R/bench.py" --no-cpu-baseline --no-grouped --steps 8 --warmup 2 $mode > "$R/gpurun_out/prof_$tag.json" 2> "$R/gpurun_out/prof_$tag.err" || echo "rocprofv3 ($tag) failed"
   tr=$(find "$R/gpurun_out/prof_$tag" -name "*kernel_trace.csv" | head -1)
   if [ -n "$tr" ]; then
     python3 "$R/tools/trace_phases.py" "$tr" 0.4 > "$R/gpurun_out/prof_${tag}_overlap.txt" 2>&1 || true

@@ -13,6 +13,7 @@ python bench.py --preset c2 --steps 10 --warmup 2 --no-cpu-baseline > "$O/${TAG}
 python bench.py --preset c3 --steps 10 --warmup 2 --no-cpu-baseline > "$O/${TAG}_bench_configs3_qwen25_7b.json" 2>> "$O/bench.err"; echo "c3 rc=$?"
 python bench.py --preset c4 --steps 10 --warmup 2 --no-cpu-baseline > "$O/${TAG}_bench_configs4_llama31_8b.json" 2>> "$O/bench.err"; echo "c4 rc=$?"
 python bench.py --beams 15 --steps 8 --warmup 1 --no-cpu-baseline > "$O/${TAG}_bench_beam15.json" 2>> "$O/bench.err"; echo "beam rc=$?"
+python bench.py --testset 1321 > "$O/${TAG}_bench_testset1321.json" 2>> "$O/bench.err"; echo "testset rc=$?"
 timeout 1500 python tools/harness_throughput.py 960 > "$O/${TAG}_harness_throughput.txt" 2>&1; echo "harness rc=$?"
 bash tools/prof_round.sh > "$O/prof_round.log" 2>&1
 cp gpurun_out/prof_main_kernel_stats.csv "$O/${TAG}_kernel_stats.csv" 2>/dev/null
