@@ -19,8 +19,9 @@
 //     LDS-DMA during the tile's last k-tile (no ordinary global load anywhere in the loop: the compiler would drain vmcnt for it);
 //   * the two wave groups re-synchronise for the epilogue (waves 4-7 run one barrier behind in the k loop, see gemm3.hip) and re-stagger after.
 // Same accumulation order (k ascending, 32 per MFMA) and the same epilogue expressions as gemm2.hip / gemm3.hip: bit-identical to them
-// (tests/test_kernels_gpu.py).  No residual, no per-column scale / PReLU, bf16 output: what the multi-round launches of this model need
-// (Whisper QKV / fc1, LLM gate / up); everything else stays on gemm2.hip / gemm3.hip.
+// (tests/test_kernels_gpu.py).  No second K segment, no per-column scale / PReLU, bf16 output.  The dispatcher takes it for every dense
+// 256 x 256-tile launch it supports: with one tile per workgroup it still beats the 16-wave and the ping-pong kernel (leaner prologue and
+// epilogue; RES variant for o_proj / fc2 / down_proj); the LoRA-segment GEMMs stay on gemm2.hip / gemm3.hip.
 #include <stdlib.h>
 #include <type_traits>
 #include "kernels.h"
@@ -41,8 +42,11 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 #define PP_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PP_BARRIER() do { PP_FENCE(); __builtin_amdgcn_s_barrier(); PP_FENCE(); } while (0)
 
-// SWIGLU: fused SwiGLU epilogue (gate / up rows interleaved by 16).
-template <bool SWIGLU>
+// SWIGLU: fused SwiGLU epilogue (gate / up rows interleaved by 16).  RES: residual rows (o_proj, fc2, down_proj): the residual lives in the
+// row layout, so that variant transposes fp32 sums (bias already added in the C layout) and finishes -- residual, activation, rounding --
+// after the transposition, with the bias and ALL residual rows of the tile requested before the first store (ordinary loads: the
+// compiler waits for everything in flight at their first use, which costs nothing in the single-round launches this variant serves).
+template <bool SWIGLU, bool RES>
 __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, const int ntiles) {
   typedef bf16_t T;
   constexpr int BKE = 64, VEC = 8;
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
     // p0
     load_a(buf, 0, af0);
     load_b(buf, 0);
-    if (KT == 4) issue_bias();
+    if (KT == 4 && !RES) issue_bias();
     if (KT == 4) issue_next(kA1, 0);
     else issue(kA1, t + 1);
     if (KT == 1) wait_se(c8, se); else wait_vm<8>();
@@ -276,13 +280,108 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
     PP_FENCE();
 
     const bool full = m0 + 256 <= p.M && n0 + 256 <= p.N && c_vec;
-    // bias of the lane's 2 x 4 columns (C layout), from the LDS copy the last k-tile's DMA made
+    // bias of the lane's 2 x 4 columns (C layout), from the LDS copy the last k-tile's DMA made (RES: from global memory)
     float cb[2][4];
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) cb[nh][j] = p.col_bias ? sbias[nh * 64 + j * 16 + frow] : 0.f;
+      for (int j = 0; j < 4; ++j) {
+        if (RES) {
+          const int n = n0 + nh * 128 + Cw * 64 + j * 16 + frow;
+          cb[nh][j] = (p.col_bias && n < p.N) ? p.col_bias[n] : 0.f;
+        } else {
+          cb[nh][j] = p.col_bias ? sbias[nh * 64 + j * 16 + frow] : 0.f;
+        }
+      }
+    // RES: the residual row segments of the wave's eight slabs (row layout: a lane's 16 columns of row rr), raw bf16, requested up front
+    Chunk16 rsd[RES ? 2 : 1][RES ? 2 : 1][RES ? 2 : 1][2];
+    if constexpr (RES) {
+      const T* Rp = reinterpret_cast<const T*>(p.residual);
+      const bool r_vec = (p.ldr % VEC) == 0 && ((uintptr_t)Rp & 15) == 0;
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int m = m0 + mh * 128 + R * 32 + i * 16 + rr;
+            const int nb = n0 + nh * 128 + Cw * 64 + (lane & 3) * 16;
+            if (m < p.M && nb + 16 <= p.N && r_vec) {
+              rsd[mh][nh][i][0] = *reinterpret_cast<const Chunk16*>(Rp + (int64_t)m * p.ldr + nb);
+              rsd[mh][nh][i][1] = *reinterpret_cast<const Chunk16*>(Rp + (int64_t)m * p.ldr + nb + 8);
+            } else {
+              float t[16];
+#pragma unroll
+              for (int e = 0; e < 16; ++e) t[e] = (m < p.M && nb + e < p.N) ? to_f32(Rp[(int64_t)m * p.ldr + nb + e]) : 0.f;
+              rsd[mh][nh][i][0] = chunk_from_f32<T>(t);
+              rsd[mh][nh][i][1] = chunk_from_f32<T>(t + 8);
+            }
+          }
+    }
     auto epi = [&](f32x4 (&cq)[2][4], int mh, int nh) __attribute__((always_inline)) {
+      if constexpr (RES) {
+        float* swf = reinterpret_cast<float*>(sw);          // fp32 patch: element (row, col) at row*64 + (col ^ ((row & 3) << 2))
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) swf[((fg * 4 + r) * 64 + j * 16 + frow) ^ (r << 2)] = fmaf(cq[i][j][r], 1.f, cb[nh][j]);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const int c0 = (lane & 3) * 16;
+          float y[16], res[16];
+#pragma unroll
+          for (int e = 0; e < 16; e += 4) {
+            f32x4 t4 = *reinterpret_cast<const f32x4*>(swf + ((rr * 64 + c0 + e) ^ ((rr & 3) << 2)));
+            y[e] = t4[0]; y[e + 1] = t4[1]; y[e + 2] = t4[2]; y[e + 3] = t4[3];
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          chunk_to_f32<T>(rsd[mh][nh][i][0], res);
+          chunk_to_f32<T>(rsd[mh][nh][i][1], res + 8);
+          // gemm2.hip / gemm3.hip expression for expression (y already is fmaf(acc, 1, bias))
+#pragma unroll
+          for (int e4 = 0; e4 < 16; e4 += 4) {
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              v[q] = y[e4 + q];
+              if (!p.res_after_act) v[q] += res[e4 + q];
+            }
+            switch (p.act) {
+              case ACT_GELU:
+                gelu_act4<T>(v);
+                break;
+              case ACT_RELU:
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                break;
+              case ACT_SILU:
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
+                break;
+              default: break;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) y[e4 + q] = p.res_after_act ? v[q] + res[e4 + q] : v[q];
+          }
+          const int m = m0 + mh * 128 + R * 32 + i * 16 + rr;
+          const int nb = n0 + nh * 128 + Cw * 64 + c0;
+          T* Ct = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + nb;
+          if (full) {
+            *reinterpret_cast<Chunk16*>(Ct) = chunk_from_f32<T>(y);
+            *reinterpret_cast<Chunk16*>(Ct + 8) = chunk_from_f32<T>(y + 8);
+          } else if (m < p.M && nb < p.N) {
+            if (c_vec && nb + 16 <= p.N) {
+              *reinterpret_cast<Chunk16*>(Ct) = chunk_from_f32<T>(y);
+              *reinterpret_cast<Chunk16*>(Ct + 8) = chunk_from_f32<T>(y + 8);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 16; ++e) if (nb + e < p.N) Ct[e] = from_f32<T>(y[e]);
+            }
+          }
+        }
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         // per-element arithmetic: gemm2.hip / gemm3.hip expression for expression with col_scale = 1 and a zero residual (the `+ 0.f` is
@@ -412,7 +511,7 @@ int ncu8() {
 bool gemm_8pp_supported(const GemmArgs& a) {
   const int64_t abytes = ((int64_t)a.M - 1) * a.lda * 2 + (int64_t)a.K * 2, wbytes = ((int64_t)a.N - 1) * a.ldw * 2 + (int64_t)a.K * 2;
   if (abytes >= (1ll << 31) || wbytes >= (1ll << 31)) return false;      // 32-bit buffer offsets
-  return gemm_8p_supported(a) && a.K2 == 0 && a.K >= 192 && !a.residual && !a.col_scale && a.act != ACT_PRELU && !a.out_f32 && a.ldc % 8 == 0 &&
+  return gemm_8p_supported(a) && a.K2 == 0 && a.K >= 192 && !(a.residual && a.swiglu_pairs) && !a.col_scale && a.act != ACT_PRELU && !a.out_f32 && a.ldc % 8 == 0 &&
          ((uintptr_t)a.C & 15) == 0 && (!a.swiglu_pairs || a.N % 64 == 0);
 }
 // workgroups for `ntiles` tiles: as few rounds as the chip allows, then the smallest multiple of 8 that still needs that many rounds
@@ -424,12 +523,11 @@ int gemm_8pp_grid(int64_t ntiles) {
   g = (g + 7) / 8 * 8;
   return (int)(g > cap ? cap : g);
 }
-// the dispatcher's rule: more tiles than CUs (a single round gains nothing from persistence)
-bool gemm_8pp_eligible(const GemmArgs& a) {
-  if (!gemm_8pp_supported(a)) return false;
-  const int64_t ntiles = (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 256);
-  return ntiles > ncu8();
-}
+// the dispatcher's rule: every shape the 256 x 256 tiles serve (>= 144 tiles, launch_dma_mode) that the kernel supports.  With more tiles
+// than CUs persistence pays (Whisper QKV 104 -> 85 us); with one tile per workgroup this kernel still beats the 16-wave and the ping-pong
+// kernel through its leaner prologue and epilogue (scalar DMA addressing, C-layout bias / activation: Whisper fc2 108 -> 89 us, o_proj 34 ->
+// 30 us, 4096^3 1.13 -> 1.27 PFLOP/s; profiles/r04_vendor_yardstick.txt)
+bool gemm_8pp_eligible(const GemmArgs& a) { return gemm_8pp_supported(a); }
 
 int launch_gemm_8pp(const GemmArgs& a, hipStream_t st, int grid) {
   OAVSR_REQUIRE(gemm_8pp_supported(a), "gemm_8pp: shape / epilogue not supported by the persistent ping-pong kernel");
@@ -449,7 +547,8 @@ int launch_gemm_8pp(const GemmArgs& a, hipStream_t st, int grid) {
     OAVSR_CHECK_HIP(hipGetLastError());
     return 0;
   };
-  return a.swiglu_pairs ? go(gemm_8pp_kernel<true>) : go(gemm_8pp_kernel<false>);
+  if (a.residual) return go(gemm_8pp_kernel<false, true>);
+  return a.swiglu_pairs ? go(gemm_8pp_kernel<true, false>) : go(gemm_8pp_kernel<false, false>);
 }
 
 }  // namespace oavsr

@@ -1089,7 +1089,8 @@ int launch_sk_t(const GemmArgs& a, hipStream_t st) {
     }
     if (!a.swiglu_pairs && a.N >= 64 && a.N / 16 < 384) {
       if constexpr (!NORM) { if (a.N >= 1024) return launch_r16<T, 4, 4, NORM, 2>(a, st); }        // o_proj, down_proj (no norm: one accumulator set, room for two k steps of weights in flight per wave)
-      return launch_r16<T, 4, 2, NORM, 1>(a, st);                                        // QKV (+ LoRA segment: two LDS images), LoRA down
+      if (a.K2 == 0) return launch_r16<T, 4, 2, NORM, 2, kMaxWaves, false>(a, st);       // LoRA down (no second segment: one accumulator set, two k steps of weights in flight)
+      return launch_r16<T, 4, 2, NORM, 1>(a, st);                                        // QKV + LoRA segment: two LDS images, two accumulator sets
     }
   }
   if (r16_on && half_enabled() && a.M > 8 && mt <= 2 && (a.K / kbe) % 2 == 0) {

@@ -978,6 +978,35 @@ def test_gemm_8pp_persistent(M, N, K, grid, act):
         assert torch.equal(out, again), "two launches of the persistent GEMM differ (race in the cross-tile schedule)"
 
 
+@pytest.mark.parametrize("M,N,K,grid,act,raa", [
+    (12000, 1024, 4096, 0, 0, 0),       # Whisper fc2: 188 tiles, one per workgroup (ragged single round dealt over the XCD groups), residual
+    (2048 + 77, 1280 + 40, 320, 16, 1, 1),   # ragged edges, several rounds, GELU then residual
+    (3000, 1024, 1024, 8, 4, 0),        # 48 tiles on 8 workgroups: the residual variant across tile boundaries
+])
+def test_gemm_8pp_residual_variant(M, N, K, grid, act, raa):
+    """The residual form of the persistent kernel (o_proj / fc2 / down_proj: residual and activation after the transposition, bias before
+    it): vs fp32 torch, bit-identical to the 16-wave and the ping-pong kernel, in place (C aliases the residual, as the encoders call it)."""
+    dtype = "bf16"
+    a, ar = q(rnd(M, K, seed=1), dtype)
+    w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
+    r, rr = q(rnd(M, N, seed=5), dtype)
+    bias = rnd(N, seed=7)
+    ref = ar @ wr.T + bias
+    if raa:
+        ref = (F.gelu(ref) if act == 1 else F.silu(ref) if act == 4 else ref) + rr
+    else:
+        ref = ref + rr
+        ref = F.gelu(ref) if act == 1 else F.silu(ref) if act == 4 else ref
+    out = gemm(dtype, a, w, bias=bias.to(DEV), act=act, residual=r, res_after_act=raa, skinny=3, grid=grid)
+    close(out, ref, tol(dtype) * 2, what="gemm 8pp residual")
+    for sel in (5, 2):
+        other = gemm(dtype, a, w, bias=bias.to(DEV), act=act, residual=r, res_after_act=raa, skinny=sel)
+        assert torch.equal(out, other), f"persistent residual variant vs kernel selector {sel}: max diff {(out.float() - other.float()).abs().max().item():.3e}"
+    inplace = r.clone()
+    gemm(dtype, a, w, bias=bias.to(DEV), act=act, residual=inplace, res_after_act=raa, skinny=3, grid=grid, C_out=inplace)
+    assert torch.equal(inplace, out), "in-place (C == residual) differs"
+
+
 def test_gemm_8pp_identity_layout_and_tile_walk():
     """A = I with an asymmetric W on 8 workgroups: every output element names its (row, column), so a tile written to the wrong place, a
     skipped tile or a swapped quadrant of any round shows."""
