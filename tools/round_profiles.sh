@@ -19,6 +19,9 @@ bash tools/prof_round.sh > "$O/prof_round.log" 2>&1
 cp gpurun_out/prof_main_kernel_stats.csv "$O/${TAG}_kernel_stats.csv" 2>/dev/null
 cp gpurun_out/prof_nosched_kernel_stats.csv "$O/${TAG}_kernel_stats_nosched.csv" 2>/dev/null
 { echo "# rocprofv3 --kernel-trace of the headline run (decode scheduler on), tools/trace_phases.py over the last 60 % of the trace";
+  echo "# NOTE: under the profiler dispatches of different queues do not overlap (the profiled run takes ~1.6 x the un-profiled time per call,";
+  echo "# see ${TAG}_kernel_stats_bench.json vs ${TAG}_bench.json): the enc / dec split below is a sum of kernel durations, not the un-profiled concurrency";
+  echo "# (that is bench.py's schedule record: both_active_frac).";
   cat gpurun_out/prof_main_overlap.txt; echo; echo "# the same with --no-scheduler"; cat gpurun_out/prof_nosched_overlap.txt; } > "$O/${TAG}_trace_overlap.txt" 2>/dev/null
 cp gpurun_out/prof_main.json "$O/${TAG}_kernel_stats_bench.json" 2>/dev/null
 bash tools/beam_trace.sh > "$O/${TAG}_beam15_kernel_stats.txt" 2>&1
