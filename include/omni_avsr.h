@@ -241,7 +241,7 @@ typedef struct oavsr_gemm_desc {
   int32_t taps, Kvalid;
   const int32_t* frameinfo; /* int2 per frame */
   int32_t skinny;           /* kernel selector: 0 dispatcher's choice, 1 decode kernel (M <= 128); parity tests only: 2 ping-pong 256 x 256,
-                               3 persistent ping-pong, 5 16-wave 256 x 256 */
+                               3 persistent ping-pong, 5 16-wave 256 x 256, 6 160 x 128, 7 256 x 128 */
   /* skinny only: fused RMSNorm prologue (y = rstd * ((x*gain) W^T) + seg2) and SwiGLU epilogue (16-row interleaved gate/up) */
   const float* norm_gain;
   float norm_eps;

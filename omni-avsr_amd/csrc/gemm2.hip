@@ -4,7 +4,7 @@
 // but built around LDS-DMA (`global_load_lds_dwordx4`): tiles go HBM -> LDS without touching VGPRs, one raw `s_barrier` per
 // k-tile, counted `s_waitcnt vmcnt(N)` where more than one k-tile is in flight.  Wave tile 64 x 64 (4 x 4 MFMA 16x16) throughout;
 // tile shapes (launch_dma_mode): 256 x 256 / 16 waves / 2 stages (the workhorse), 256 x 128 / 8 waves / 3 stages (mid-size grids,
-// conv gathers, split-K), 128 x 64, 128 x 128 and 128 x 256 / 4-8 waves (<= 128 rows: beam-search decode; small GEMMs).
+// conv gathers, split-K), 160 x 128 / 4 waves of 80 x 64 / 4 stages (one ragged round), 128 x 64, 128 x 128 and 128 x 256 / 4-8 waves (<= 128 rows: beam-search decode; small GEMMs).
 //   * the DMA writes LDS linearly (wave-uniform base + lane*16), so the XOR swizzle that makes the ds_read_b128 fragment
 //     reads conflict-free is applied to the per-lane SOURCE address (chunk ^ (row & 7)) and again on the read
 //   * out-of-range rows / conv padding read a 16-byte zero page instead of branching
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
     const char* sB = sA + BM * kRowBytes;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      constexpr int TMH = TM > 4 ? 4 : TM;              // A fragments are consumed in groups of 4 row tiles (register budget)
+      constexpr int TMH = (TM > 4 && TM % 4 == 0) ? 4 : TM;      // A fragments are consumed in groups of 4 row tiles (register budget); 5 row tiles (the 160-row tiles) in one go
       Chunk16 bf[TN];
       const int chunk = kb * 4 + fg;
 #pragma unroll
@@ -445,10 +445,23 @@ static int dma_tile_choice(const GemmArgs& a) {
   return 0;
 }
 
+// One round of 256 x 128 tiles that leaves CUs idle (the LLM prefill's o_proj / down_proj, 2504 x 2048: 160 workgroups on 256 CUs): when
+// 160 x 128 tiles (4 waves of 80 x 64, 4 LDS stages = 144 KiB) still fit ONE round, the busiest CU owns 160 rows instead of 256 --
+// down_proj (K = 8192) 126 -> 110 us, o_proj 37.7 -> 35.4 us (tools/gemm_pp_bench.py; the 4-wave tile runs at 0.7 of the 8-wave tile's
+// per-CU rate, so it only pays where it adds CUs).  Same k order, same epilogue: same bits.
+static bool tile160_rule(const GemmArgs& a) {
+  if (a.amode != A_DENSE || a.groups != 1 || a.ksplit > 1 || a.swiglu_pairs || dma_tile_choice(a) != 1) return false;
+  static const int ncu = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
+  const int64_t w256 = (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 128), w160 = (int64_t)ceil_div(a.M, 160) * ceil_div(a.N, 128);
+  return w256 <= ncu && w160 <= ncu && w160 > w256;
+}
+
 template <typename T>
 int launch_dma_mode(const GemmArgs& a, hipStream_t st) {
   // 256x256: 16 waves (4 x 4) of 64 x 64, 2 stages; dense only.  256x128: 8 waves (4 x 2) of 64 x 64, 3 stages.
   if (a.force_tile == 2 && a.amode == A_DENSE && a.groups == 1 && a.ksplit <= 1 && a.N >= 256) return launch_dma<T, A_DENSE, 256, 256, 2, 4, 16>(a, st);
+  if (a.force_tile == 5 && a.amode == A_DENSE && a.groups == 1 && a.ksplit <= 1) return launch_dma<T, A_DENSE, 160, 128, 4, 2, 4>(a, st);
+  if (a.force_tile == 8 && a.amode == A_DENSE && a.groups == 1 && a.ksplit <= 1) return launch_dma<T, A_DENSE, 256, 128, 3, 4, 8>(a, st);
   if (dma_tile_choice(a) == 2) {
     if (gemm_8pp_eligible(a)) return launch_gemm_8pp(a, st);      // more tiles than CUs: persistent ping-pong kernel (gemm4.hip), bf16
     if (gemm_8p_eligible(a)) return launch_gemm_8p(a, st);        // 8-wave ping-pong schedule (gemm3.hip), bf16
@@ -464,6 +477,7 @@ int launch_dma_mode(const GemmArgs& a, hipStream_t st) {
     // and what counts there is how many of their workgroups fit beside each other (120.6 -> 125.1 utt/s, round 3).
     return launch_dma<T, A_DENSE, 128, 64, 3, 4, 4>(a, st);
   }
+  if (tile160_rule(a)) return launch_dma<T, A_DENSE, 160, 128, 4, 2, 4>(a, st);
   switch (a.amode) {
     case A_DENSE: return launch_dma<T, A_DENSE, 256, 128, 3, 4, 8>(a, st);
     case A_CONV2D: return launch_dma<T, A_CONV2D, 256, 128, 3, 4, 8>(a, st);
@@ -487,6 +501,7 @@ const char* gemm_dma_variant(const GemmArgs& a) {
   if (c == 4) return a.ksplit > 1 ? "dma_splitk_128x64" : "dma_128x64";
   if (c == 2 && gemm_8pp_eligible(a)) return "8pp_256x256";
   if (c == 2 && gemm_8p_eligible(a)) return "8p_256x256";
+  if (tile160_rule(a)) return "dma_160x128";
   return a.ksplit > 1 ? "dma_splitk_256x128" : c == 2 ? "dma_256x256" : "dma_256x128";
 }
 

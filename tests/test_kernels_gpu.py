@@ -1064,6 +1064,29 @@ def test_gemm_dispatch_takes_persistent_kernel_for_multi_round_launches():
     assert torch.equal(auto, forced)
 
 
+@pytest.mark.parametrize("M,N,K,K2", [(2504, 2048, 2048, 0), (2504, 2048, 8192, 0), (2397, 2048, 1024, 64), (1500, 3072, 512, 0)])
+def test_gemm_160_row_tile_for_one_ragged_round(M, N, K, K2):
+    """One round of 256 x 128 tiles that would leave CUs idle runs on 160 x 128 tiles (gemm2.hip: tile160_rule; the LLM prefill's o_proj /
+    down_proj): the dispatcher's choice, the forced 160 x 128 tile and the forced 256 x 128 tile give the same bits -- residual, bias,
+    a LoRA segment and a ragged last row tile included -- and match the fp32 reference."""
+    dtype = "bf16"
+    a, ar = q(rnd(M, K, seed=1), dtype)
+    w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
+    r, rr = q(rnd(M, N, seed=5), dtype)
+    bias = rnd(N, seed=7)
+    kw, ref = {}, ar @ wr.T + bias + rr
+    if K2:
+        a2, a2r = q(rnd(M, K2, seed=6), dtype)
+        w2, w2r = q(rnd(N, K2, seed=8) / math.sqrt(K2), dtype)
+        kw = dict(A2=a2, W2=w2)
+        ref = ref + a2r @ w2r.T
+    auto = gemm(dtype, a, w, bias=bias.to(DEV), residual=r, **kw)
+    t160 = gemm(dtype, a, w, bias=bias.to(DEV), residual=r, skinny=6, **kw)
+    t256 = gemm(dtype, a, w, bias=bias.to(DEV), residual=r, skinny=7, **kw)
+    close(auto, ref, tol(dtype) * 2, what="160-row tile gemm")
+    assert torch.equal(t160, t256) and torch.equal(auto, t160)
+
+
 # ------------------------------------------------------------------------------------------------ 8-column decode tiles for 9..32 rows
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K,K2,norm", [(9, 2048, 2048, 0, False), (16, 3072, 2048, 128, True), (24, 2048, 8192, 0, False), (32, 136, 256, 64, True),

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B timing of the 256 x 256 bf16 GEMM kernels on the benchmark's multi-round shapes, all variants interleaved in ONE process
 (guide rule 24): kernel selector 5 = 16-wave LDS-DMA, 2 = ping-pong, 3 = persistent ping-pong,
-0 = the dispatcher's choice.  Operand sets rotate so that no set survives in the 256 MiB Infinity Cache between its uses.
+6 = 160 x 128 tiles, 7 = 256 x 128, 0 = the dispatcher's choice.  Operand sets rotate so that no set survives in the 256 MiB Infinity Cache between its uses.
 
 usage: gemm_pp_bench.py [--rounds R] [--shapes qkv,fc1,gateup,fc2,sq4k,sq8k] [--grids 0,256]"""
 import argparse
@@ -25,6 +25,12 @@ SHAPES = {
     "sq4k": (4096, 4096, 4096, 0, 0, False),
     "sq8k": (8192, 8192, 8192, 0, 0, False),
     "qkv16": (24000, 3072, 1024, 0, 0, True),
+    # the LLM prefill's and AV-HuBERT's sub-round shapes (8 x 16 s clips: 2504 prompt rows, 3200 video frames)
+    "llm_qkv": (2504, 3072, 2048, 0, 0, False),
+    "llm_o": (2504, 2048, 2048, 0, 0, False),
+    "llm_down": (2504, 2048, 8192, 0, 0, False),
+    "avh_o": (3200, 1024, 1024, 0, 0, True),
+    "avh_fc2": (3200, 1024, 4096, 0, 0, True),
 }
 
 
