@@ -162,6 +162,7 @@ static int run_gemm_chain(const GemmArgs& a0, const GemmArgs& a1, int kind, cons
 struct EncLayer {
   const float *ln1w, *ln1b, *qkvb, *ob, *ln2w, *ln2b, *fc1b, *fc2b;
   const void *qkvw, *lora_dn, *lora_up, *ow, *fc1w, *fc2w;
+  const void* qkvw_cat = nullptr;      // [3D][D + k2] = [qkv.w | lora_up.w] (model_create: enc_cat), see run_encoder_layers
 };
 struct ConvBN { const void* w; const float *scale, *shift, *slope; };
 struct ResBlock { ConvBN c1, c2, down; bool has_down; int cin, cout, stride; };
@@ -193,6 +194,7 @@ struct oavsr_model {
   ConvBN stem; ResBlock blocks[8];
   const void *vproj_w, *vpost_w, *vpos_w; const float *vproj_b, *vln_w, *vln_b, *vpost_b, *vpos_b, *vlnf_w, *vlnf_b;
   std::vector<EncLayer> vlayers;
+  void* enc_cat = nullptr;               // the video layers' concatenated QKV + LoRA-up weights (one allocation)
   // audio
   const void *aconv1_w, *aconv2_w, *apos; const float *aconv1_b, *aconv2_b, *alnf_w, *alnf_b;
   std::vector<EncLayer> alayers;
@@ -231,6 +233,7 @@ struct oavsr_workspace {
   hipEvent_t host_ev[2] = {nullptr, nullptr}; unsigned call_idx = 0;
   // encoder scratch (shared by both encoders)
   void *enc_x, *enc_h, *enc_qkv, *enc_attn, *enc_ffn, *enc_lora, *enc_out_v, *enc_out_a;
+  void* enc_hcat = nullptr;      // [rows][D + k2]: LayerNorm output next to the LoRA-down output (run_encoder_layers; video encoder only)
   // video front
   void *pool_out, *trunk[2], *feat512, *featproj, *ln2d;
   int2* frameinfo; int4* rowinfo; int4* rowinfo2; int* cu_a; int* cu_b; int4* seg;
@@ -552,21 +555,34 @@ static int resolve_model(oavsr_model* m) {
 // must not depend on its batch) -- they run on the 128 x 64 small-GEMM tile (gemm2.hip: gemm_small_tile; the TILE may follow M, it never
 // changes a bit).
 
+// The LoRA term of the encoders' QKV projection, (h A^T)(s B)^T, as columns D .. D + k2 of ONE K range: LayerNorm writes h with a row
+// stride of D + k2, the LoRA-down GEMM writes t = h A^T next to it, and QKV = [h | t] . [W | s B]^T is a plain single-segment GEMM -- which
+// the persistent 256 x 256 kernel takes (it has no second K segment; AV-HuBERT's QKV ran on the 16-wave kernel: 40 -> 30 us).  Whole k-tiles
+// of 128 bytes on both sides, so the k-tile sequence -- hence every bit -- is that of the two-segment launch.
+static bool enc_cat_ok(int D, int k2, size_t esz) { return k2 > 0 && (D * esz) % 128 == 0 && (k2 * esz) % 128 == 0; }
+
 static int run_encoder_layers(const oavsr_model* m, oavsr_workspace* ws, const std::vector<EncLayer>& layers, int rows, int D,
                               int heads, int ffn, int lora_k2, const int* cu_dev, int n_seqs, int max_len, hipStream_t st) {
   const int dt = m->dtype;
   const int hd = D / heads;
   for (const EncLayer& L : layers) {
+    const bool cat = lora_k2 > 0 && L.qkvw_cat && ws->enc_hcat;
+    const int ldh = cat ? D + lora_k2 : D;
+    void* h = cat ? ws->enc_hcat : ws->enc_h;
     { ProfScope ps("layernorm", 0, 2.0 * rows * D * m->esz, st);
-      OAVSR_TRY(launch_layernorm(dt, ws->enc_x, D, ws->enc_h, D, L.ln1w, L.ln1b, rows, D, 1e-5f, st)); }
+      OAVSR_TRY(launch_layernorm(dt, ws->enc_x, D, h, ldh, L.ln1w, L.ln1b, rows, D, 1e-5f, st)); }
     GemmArgs g;
     if (lora_k2 > 0) {   // t = h . [A_q; A_v]^T
-      g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = lora_k2; g.K = D; g.A = ws->enc_h; g.lda = D; g.W = L.lora_dn; g.ldw = D;
-      g.C = ws->enc_lora; g.ldc = lora_k2;
+      g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = lora_k2; g.K = D; g.A = h; g.lda = ldh; g.W = L.lora_dn; g.ldw = D;
+      g.C = cat ? (void*)((char*)h + (size_t)D * m->esz) : ws->enc_lora; g.ldc = cat ? ldh : lora_k2;
       OAVSR_TRY(run_gemm(g, st));
     }
-    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 3 * D; g.K = D; g.A = ws->enc_h; g.lda = D; g.W = L.qkvw; g.ldw = D;
-    if (lora_k2 > 0) { g.A2 = ws->enc_lora; g.lda2 = lora_k2; g.W2 = L.lora_up; g.ldw2 = lora_k2; g.K2 = lora_k2; }
+    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 3 * D; g.A = h; g.lda = ldh;
+    if (cat) { g.K = D + lora_k2; g.W = L.qkvw_cat; g.ldw = D + lora_k2; }
+    else {
+      g.K = D; g.W = L.qkvw; g.ldw = D;
+      if (lora_k2 > 0) { g.A2 = ws->enc_lora; g.lda2 = lora_k2; g.W2 = L.lora_up; g.ldw2 = lora_k2; g.K2 = lora_k2; }
+    }
     g.col_bias = L.qkvb; g.C = ws->enc_qkv; g.ldc = 3 * D;
     OAVSR_TRY(run_gemm(g, st));
     AttnArgs a; a.dtype = dt; a.head_dim = hd; a.n_heads = heads; a.n_kv_heads = heads; a.n_seqs = n_seqs;
@@ -1251,6 +1267,19 @@ int oavsr_model_create(const oavsr_config* cfg, const void* blob_dev, uint64_t b
       set_last_error("model_create: stem repack failed"); oavsr_model_destroy(m); return -2;
     }
   }
+  if (m->has_video && enc_cat_ok(m->cfg.av_dim, m->cfg.av_lora_k2, m->esz)) {
+    // [qkv.w | lora_up.w] per video layer: the LoRA term rides in the QKV GEMM's ONE K range (run_encoder_layers)
+    const size_t D = m->cfg.av_dim, k2 = m->cfg.av_lora_k2, e = m->esz, per = 3 * D * (D + k2) * e;
+    if (hipMalloc(&m->enc_cat, per * m->vlayers.size()) != hipSuccess) { set_last_error("model_create: hipMalloc failed"); oavsr_model_destroy(m); return -2; }
+    for (size_t i = 0; i < m->vlayers.size(); ++i) {
+      char* dst = (char*)m->enc_cat + i * per;
+      if (hipMemcpy2D(dst, (D + k2) * e, m->vlayers[i].qkvw, D * e, D * e, 3 * D, hipMemcpyDeviceToDevice) != hipSuccess ||
+          hipMemcpy2D(dst + D * e, (D + k2) * e, m->vlayers[i].lora_up, k2 * e, k2 * e, 3 * D, hipMemcpyDeviceToDevice) != hipSuccess) {
+        set_last_error("model_create: QKV / LoRA concatenation failed"); oavsr_model_destroy(m); return -2;
+      }
+      m->vlayers[i].qkvw_cat = dst;
+    }
+  }
   // (as in workspace_create: what was put on the null stream above must be done before a caller's non-blocking stream reads it)
   if (hipDeviceSynchronize() != hipSuccess) { set_last_error("model_create: device synchronisation failed"); oavsr_model_destroy(m); return -2; }
   *out = m;
@@ -1262,6 +1291,7 @@ void oavsr_model_destroy(oavsr_model* m) {
   if (m->twiddle) hipFree(m->twiddle);
   if (m->melfb) hipFree(m->melfb);
   if (m->stem_wp) hipFree(m->stem_wp);
+  if (m->enc_cat) hipFree(m->enc_cat);
   if (m->enc_done) hipEventDestroy(m->enc_done);
   delete m;
 }
@@ -1313,6 +1343,7 @@ int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, 
   WANT(enc_x, NT * De * e); WANT(enc_h, NT * De * e); WANT(enc_qkv, NT * 3 * De * e); WANT(enc_attn, NT * De * e);
   WANT(enc_ffn, NT * Fe * e); WANT(enc_lora, NT * (size_t)std::max(64, c.av_lora_k2) * e);
   WANT(enc_out_v, F * Dv * e); WANT(enc_out_a, TA * Da * e);
+  if (m->has_video && m->enc_cat) WANT(enc_hcat, F * (size_t)(Dv + c.av_lora_k2) * e);
   if (m->has_video) {
     WANT(pool_out, F * 484 * 64 * e);
     for (int i = 0; i < 2; ++i) WANT(trunk[i], F * 484 * 64 * e);

@@ -1087,6 +1087,21 @@ def test_gemm_160_row_tile_for_one_ragged_round(M, N, K, K2):
     assert torch.equal(t160, t256) and torch.equal(auto, t160)
 
 
+@pytest.mark.parametrize("dtype,M,N,K,K2", [("bf16", 3200, 3072, 1024, 64), ("bf16", 1000, 3072, 1024, 64), ("f32", 700, 384, 128, 32)])
+def test_gemm_lora_segment_equals_one_concatenated_k_range(dtype, M, N, K, K2):
+    """model.hip: run_encoder_layers hands the video encoder's QKV + LoRA GEMM over as ONE K range -- A = [h | t] (row stride K + K2),
+    W = [W | s B] -- so that the persistent 256 x 256 kernel (no second K segment) can take it: whole 128-byte k-tiles on both sides, the same
+    k-tile sequence, hence the same bits as the two-segment launch."""
+    a, _ = q(rnd(M, K, seed=1), dtype)
+    w, _ = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
+    a2, _ = q(rnd(M, K2, seed=3), dtype)
+    w2, _ = q(rnd(N, K2, seed=4) / math.sqrt(K2), dtype)
+    bias = rnd(N, seed=7).to(DEV)
+    two = gemm(dtype, a, w, A2=a2, W2=w2, bias=bias)
+    one = gemm(dtype, torch.cat([a, a2], 1).contiguous(), torch.cat([w, w2], 1).contiguous(), bias=bias)
+    assert torch.equal(one, two)
+
+
 # ------------------------------------------------------------------------------------------------ 8-column decode tiles for 9..32 rows
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K,K2,norm", [(9, 2048, 2048, 0, False), (16, 3072, 2048, 128, True), (24, 2048, 8192, 0, False), (32, 136, 256, 64, True),
