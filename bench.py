@@ -355,9 +355,11 @@ def testset_run(args, rank, world, local, use_dist):
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    eng.__dict__["_eval_timing"] = {"wait_collate": 0.0, "submit": 0.0, "collect": 0.0, "batches": 0}      # harness.evaluate's host-side phase timers
     t0 = time.perf_counter()
     meter = H.evaluate(model, samples, task, to_text, **kw)
     torch.cuda.synchronize()
+    tm = dict(eng.__dict__["_eval_timing"])
     busy = time.perf_counter() - t0
     W = args.max_new
     ids_t = torch.full((len(to_text.rows), W), -1, dtype=torch.int32)
@@ -408,6 +410,7 @@ def testset_run(args, rank, world, local, use_dist):
                        "utterances": N, "audio_seconds": round(secs, 1), "batch_per_call": B, "in_flight": 3,
                        "parallelism": f"utterance-sharded dp{world}, duration-sorted round-robin", "utterances_per_rank": per_rank,
                        "rank_busy_s": [round(b, 3) for b in busy_all], "imbalance": round(max(busy_all) / max(1e-9, min(busy_all)), 4),
+                       "host_ms_per_batch": {k: round(tm[k] / max(1, tm["batches"]) * 1e3, 2) for k in ("wait_collate", "submit", "collect")},
                        "gathered_hypotheses": len(hyp), "wer_counters": {"edits": edits, "words": words, "failed": failed},
                        "dist_backend": (dist.get_backend() if use_dist else None), "setup_s": round(setup_s, 1), "ids_verified": True,
                        "decode_scheduler": eng.scheduler_stats(), "env": env_snapshot()},
