@@ -267,6 +267,8 @@ typedef struct oavsr_attn_desc {
   int64_t ldq, ldk, ldv, ldo;
   const int32_t *cu_q, *cu_k;
   float scale;
+  int32_t form;             /* bf16, head_dim 64: 0 = the dispatcher's kernels (16x16x32 MFMAs), 32 = the 32x32x16-MFMA kernel (another fp32
+                               summation order; the engine uses it for the Whisper encoder, whose sequences always have 1500 frames) */
 } oavsr_attn_desc;
 int oavsr_op_attention(const oavsr_attn_desc* d, oavsr_stream stream);
 

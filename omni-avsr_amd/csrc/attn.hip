@@ -482,6 +482,243 @@ __global__ __launch_bounds__(kThreads, 2) void attn_dma_kernel(const AttnArgs p)
 }
 
 // ------------------------------------------------------------------------------------------------
+// (1c) attn_dma32_kernel (round 4): (1b) on 32x32x16 MFMAs.  At head_dim 64 the kernel is bound by the vector ISSUE port, not by the matrix
+//      pipe (one exponential per 64 MFMA flop-lanes): per wave and 64-key tile (1b) issues 32 MFMAs (8 issue cycles
+//      each, as many as a 32x32x16 that does twice the work) and runs the soft-max bookkeeping of two query tiles.  Here a wave owns ONE
+//      tile of 32 queries (8 waves = 256 queries per workgroup): S^T = K.Q^T as 32 keys x 32 queries per MFMA chain (four 16-deep steps over d), half the MFMA instructions, one
+//      lane swap (xor 32) instead of two, one set of running statistics.  The C layout (lane = query l & 31, rows 8i + 4(l >> 5) + r) again IS
+//      the B operand of O^T = V^T.P^T: k step s of a 64-key tile takes the lane's accumulator groups i = 2s', 2s' + 1, i.e. keys
+//      16s + 4h + r and 16s + 8 + 4h + r, and the V^T fragment is read from LDS (two transposing 8-byte reads) for exactly those rows.
+//      Data movement (3-stage LDS-DMA ring, swizzled 128-byte rows) is (1b)'s.  A different summation order than (1b): used where every
+//      sequence of the launch takes it (AttnArgs::form, set by the Whisper encoder: always 1500 frames), never chosen by the batch.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float xor_max_32(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_max_f32 %0, %0, %1" : "+v"(a), "+v"(b));
+  return a;
+}
+
+template <int NW>
+__device__ __forceinline__ void attn_dma32_body(const AttnArgs& p) {
+  constexpr int HD = 64, RB = 128, NSTAGE = 3;
+  constexpr int QB = NW * 32;                          // queries per workgroup
+  constexpr int NSEG = 8 / NW;                         // 1-KiB segments of each image a wave fills per tile
+  constexpr int kStage = 2 * KT * RB;                  // K image then V image
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+  const int seq = blockIdx.z, head = blockIdx.y;
+  const int q0 = p.cu_q[seq], qlen = p.cu_q[seq + 1] - q0;
+  const int k0 = p.cu_k[seq], klen = p.cu_k[seq + 1] - k0;
+  const int qt0 = blockIdx.x * QB;
+  if (qt0 >= qlen) return;
+  const int kvh = head / (p.n_heads / p.n_kv_heads);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ql = lane & 31, h = lane >> 5;             // query column of the MFMA; k-group (A / B operands) = row-group half (C layout)
+  const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.Q);
+  const bf16_t* K = reinterpret_cast<const bf16_t*>(p.K) + (int64_t)kvh * HD;
+  const bf16_t* V = reinterpret_cast<const bf16_t*>(p.V) + (int64_t)kvh * HD;
+
+  const int shift = klen - qlen;                         // causal: key j visible iff j <= qrow + shift
+  int kend = klen;
+  if (p.causal) {
+    int last = qt0 + QB - 1 < qlen ? qt0 + QB - 1 : qlen - 1;
+    kend = last + shift + 1;
+    if (kend > klen) kend = klen;
+    if (kend < 0) kend = 0;
+  }
+  const int ntile = (kend + KT - 1) / KT;
+
+  // ---- K / V tiles by LDS-DMA: exactly attn_dma_kernel's ring (wave w fills segments w and w + 4 of both images)
+  const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
+  const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(K + (int64_t)k0 * p.ldk), 0,
+                                                                       klen > 0 ? (int)(((int64_t)klen - 1) * p.ldk * 2 + RB) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(V + (int64_t)k0 * p.ldv), 0,
+                                                                       klen > 0 ? (int)(((int64_t)klen - 1) * p.ldv * 2 + RB) : 0, 0x00020000);
+  int kvo[NSEG], vvo[NSEG];
+#pragma unroll
+  for (int hh = 0; hh < NSEG; ++hh) {
+    const int key = (wave + NW * hh) * 8 + lrow;
+    kvo[hh] = (key * (int)p.ldk + lchunk * 8) * 2;
+    vvo[hh] = (key * (int)p.ldv + lchunk * 8) * 2;
+  }
+  const int kstep = KT * (int)p.ldk * 2, vstep = KT * (int)p.ldv * 2;
+  int ksoff = 0, vsoff = 0;
+  unsigned dslot = 0;
+  auto issue = [&]() {
+#pragma unroll
+    for (int hh = 0; hh < NSEG; ++hh) {
+      char* dst = smem + (dslot + (wave + NW * hh) * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)dst, 16, kvo[hh], ksoff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (__attribute__((address_space(3))) void*)(dst + KT * RB), 16, vvo[hh], vsoff, 0, 0);
+    }
+    ksoff += kstep; vsoff += vstep;
+    dslot = dslot == (NSTAGE - 1) * kStage ? 0u : dslot + kStage;
+  };
+
+  if (ntile > 0) issue();
+  // Q^T fragments (B operand: lane = query ql, k-group h): d step ds covers d = 16 ds + 8 h .. + 7
+  Chunk16 qf[4];
+  const int qrow = qt0 + wave * 32 + ql;                 // query index inside the sequence (may be >= qlen)
+  {
+    const int qc = qrow < qlen ? qrow : qlen - 1;
+    const char* qp = reinterpret_cast<const char*>(Q + (int64_t)(q0 + qc) * p.ldq + (int64_t)head * HD);
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) qf[ds] = *reinterpret_cast<const Chunk16*>(qp + ds * 32 + h * 16);
+  }
+  if (ntile > 1) {
+    issue();
+    if constexpr (NSEG == 2) asm volatile("s_waitcnt vmcnt(4)" : "+v"(qf[0].v), "+v"(qf[1].v), "+v"(qf[2].v), "+v"(qf[3].v)::"memory");
+    else asm volatile("s_waitcnt vmcnt(2)" : "+v"(qf[0].v), "+v"(qf[1].v), "+v"(qf[2].v), "+v"(qf[3].v)::"memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0].v), "+v"(qf[1].v), "+v"(qf[2].v), "+v"(qf[3].v)::"memory");
+  }
+
+  // LDS byte offsets inside a stage.  K (A operand): row = key ql (+ 32 for the second key tile), 16-B chunk (2 ds + h) ^ (row & 7).
+  // V^T (transposing read: the 16 lanes of a group fetch a 4-row x 16-column block, lane 4 qq + pp gets rows 0..3 of ITS column):
+  // row 4 h + qq (+ 16 s, + 8), chunk (4 dtile + 2 d16 + (pp >> 1)) ^ (row & 7), + 8 bytes for odd pp; row offsets are multiples of 8.
+  unsigned kbase[4], vbase[2];
+  {
+    const int qi = lane & 15, d16 = (lane >> 4) & 1, qq = qi >> 2, pp = qi & 3, vrow = 4 * h + qq;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) kbase[ds] = ql * RB + (((ds * 2 + h) ^ (ql & 7)) << 4);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) vbase[dt] = vrow * RB + (((dt * 4 + d16 * 2 + (pp >> 1)) ^ (vrow & 7)) << 4) + (pp & 1) * 8;
+  }
+
+  const float sc = p.scale * 1.44269504088896340736f;    // softmax in base 2
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  unsigned cslot = 0;
+  auto tile = [&](const int t, auto masked_tag) __attribute__((always_inline)) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    if (t + 1 < ntile) { if constexpr (NSEG == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 2 < ntile) issue();
+    const unsigned so = cslot;
+    cslot = cslot == (NSTAGE - 1) * kStage ? 0u : cslot + kStage;
+    unsigned kaddr[4], vaddr[2];
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) kaddr[ds] = so + kbase[ds];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) vaddr[dt] = so + KT * RB + vbase[dt];
+    const int kt0 = t * KT;
+
+    // ---- S^T[key][q]: two tiles of 32 keys, four 16-deep steps over d each ----
+    f32x16 s[2];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[t2][e] = 0.f;
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) {
+        const Chunk16 kf = *reinterpret_cast<const Chunk16*>(smem + (kaddr[ds] + t2 * 32 * RB));
+        s[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf.v), __builtin_bit_cast(bf16x8, qf[ds].v), s[t2], 0, 0, 0);
+      }
+    }
+    // ---- online softmax (lane owns query ql; its keys: 32 t2 + 8 i + 4 h + r) ----
+    const bool need_mask = MASKED && (kt0 + KT > klen || (p.causal && kt0 + KT - 1 > qt0 + wave * 32 + shift));     // wave-uniform
+    if constexpr (MASKED) if (need_mask) {
+      int key0 = kt0 + 4 * h;
+      asm volatile("" : "+v"(key0));
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = key0 + t2 * 32 + (e >> 2) * 8 + (e & 3);
+          const bool vis = key < klen && (!p.causal || key <= qrow + shift);
+          if (!vis) s[t2][e] = -INFINITY;
+        }
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mt = fmaxf(mt, s[t2][e]);
+    mt = xor_max_32(mt);
+    mt *= sc;
+    const float m_new = fmaxf(m_run, mt);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+    float lsum2[2] = {0.f, 0.f};
+    const float nm = -m_use;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+    }
+    // Key tile t2 at a time: exponentials of its 16 values, then its two k steps of O^T += V^T P^T -- the second tile's exponentials issue
+    // in the shadow of the first tile's MFMAs (a 32x32x16 holds the vector issue port for 8 of its 32 cycles).
+    static_for<0, 2>([&](auto T2) {
+      constexpr int t2 = decltype(T2)::value;
+      u32x2 vt[4][2];
+      static_for<0, 4>([&](auto I) {
+        constexpr int dt = decltype(I)::value / 2, sl = decltype(I)::value % 2, sg = 2 * t2 + sl;
+        vt[dt * 2 + sl][0] = lds_tr16_b64<sg * 16 * RB>(vaddr[dt]);
+        vt[dt * 2 + sl][1] = lds_tr16_b64<sg * 16 * RB + 8 * RB>(vaddr[dt]);
+      });
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float ev = __builtin_amdgcn_exp2f(fmaf(s[t2][e], sc, nm));
+        s[t2][e] = ev;
+        lsum2[e & 1] += ev;
+      }
+      bf16x8 pf[2];
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pf[sl][r] = (bf16_t)s[t2][8 * sl + r]; pf[sl][4 + r] = (bf16_t)s[t2][8 * sl + 4 + r]; }
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(vt[0][0]), "+v"(vt[0][1]), "+v"(vt[1][0]), "+v"(vt[1][1]), "+v"(vt[2][0]), "+v"(vt[2][1]), "+v"(vt[3][0]), "+v"(vt[3][1]));
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const u32x4 vv = u32x4{vt[dt * 2 + sl][0][0], vt[dt * 2 + sl][0][1], vt[dt * 2 + sl][1][0], vt[dt * 2 + sl][1][1]};
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[sl], o[dt], 0, 0, 0);
+        }
+    });
+    l_run = l_run * alpha + (lsum2[0] + lsum2[1]);
+    m_run = m_new;
+    asm volatile("" ::: "memory");
+  };
+  int t_full = klen / KT;
+  if (p.causal) {
+    const int vis = qt0 + wave * 32 + shift + 1;         // keys visible to the wave's lowest query row
+    const int tc = vis > 0 ? vis / KT : 0;
+    t_full = tc < t_full ? tc : t_full;
+  }
+  t_full = __builtin_amdgcn_readfirstlane(t_full < ntile ? t_full : ntile);
+  int t = 0;
+  for (; t < t_full; ++t) tile(t, std::false_type{});
+  for (; t < ntile; ++t) tile(t, std::true_type{});
+  // ---- finalize: l over the two lane halves, write O[q][d = 32 dt + 8 i + 4 h + r] ----
+  float l = l_run;
+  l += __shfl_xor(l, 32, 64);
+  if (qrow < qlen) {
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    bf16_t* O = reinterpret_cast<bf16_t*>(p.O) + (int64_t)(q0 + qrow) * p.ldo + (int64_t)head * HD;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bf16x4 w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = (bf16_t)(o[dt][4 * i + r] * inv);
+        *reinterpret_cast<bf16x4*>(O + dt * 32 + 8 * i + 4 * h) = w;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Decode attention (q_len = 1 per row), flash-decoding inside one workgroup per (row, kv head):
 //   * the G query heads that share the kv head are the 16 "query columns" of the 16x16 MFMA (G <= 8 valid)
 //   * optional fused RoPE + KV-cache append (inv_freq != nullptr): q and the new k are rotated on load, the new k / v row
@@ -732,6 +969,25 @@ int launch_attn_dma(const AttnArgs& a, hipStream_t st) {
   return 0;
 }
 
+
+// 8 waves x 32 queries: 256-query workgroups halve how often a (sequence, head)'s K / V tiles are fetched (Whisper: 12 -> 6 workgroups per
+// head); two workgroups = 16 waves per CU at <= 128 VGPRs.  (Non-template entry point: hipcc emitted no host stub for a __global__ template
+// with this body.)
+__global__ __launch_bounds__(512, 2) void attn_dma32_kernel(const AttnArgs p) { attn_dma32_body<8>(p); }
+
+int launch_attn_dma32(const AttnArgs& a, hipStream_t st) {
+  constexpr int smem = 3 * 2 * KT * 128;
+  static bool attr = false;
+  if (!attr) {
+    OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dma32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr = true;
+  }
+  dim3 grid(ceil_div(a.max_q, 256), a.n_heads, a.n_seqs);
+  hipLaunchKernelGGL(attn_dma32_kernel, grid, dim3(512), smem, st, a);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 template <typename T, int HD, int NWF = 0>
 int launch_dec_t(const DecodeAttnArgs& a, hipStream_t st) {
   constexpr int RB = HD * (int)sizeof(T);
@@ -762,6 +1018,7 @@ int launch_attention(const AttnArgs& a, hipStream_t st) {
   OAVSR_REQUIRE((((uintptr_t)a.Q | (uintptr_t)a.K | (uintptr_t)a.V | (uintptr_t)a.O) & 15) == 0, "attention: pointers must be 16-byte aligned");
   if (a.dtype == DT_F32) return a.head_dim == 64 ? launch_attn_t<float, 64>(a, st) : launch_attn_t<float, 128>(a, st);
   if (a.head_dim == 64) {
+    if (a.form == 32) return launch_attn_dma32(a, st);      // the 32x32x16 form: a property of the CALL SITE (Whisper encoder), never of the batch
     // two query tiles per wave (128-row workgroups) once the sequences are long enough that the ragged last workgroup is cheap
     if (a.max_q >= 1024) return launch_attn_dma<2>(a, st);
     return launch_attn_dma<1>(a, st);

@@ -123,6 +123,7 @@ struct AttnArgs {
   int max_q = 0;                     // max query length (host) -> grid
   float scale = 1.f;
   int causal = 0;                    // key j visible to query i iff j <= i + (klen - qlen)
+  int form = 0;                      // bf16 / head_dim 64: 32 = the 32x32x16-MFMA kernel (another summation order: fixed per call site)
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);
 

@@ -562,7 +562,7 @@ static int resolve_model(oavsr_model* m) {
 static bool enc_cat_ok(int D, int k2, size_t esz) { return k2 > 0 && (D * esz) % 128 == 0 && (k2 * esz) % 128 == 0; }
 
 static int run_encoder_layers(const oavsr_model* m, oavsr_workspace* ws, const std::vector<EncLayer>& layers, int rows, int D,
-                              int heads, int ffn, int lora_k2, const int* cu_dev, int n_seqs, int max_len, hipStream_t st) {
+                              int heads, int ffn, int lora_k2, const int* cu_dev, int n_seqs, int max_len, hipStream_t st, int attn_form = 0) {
   const int dt = m->dtype;
   const int hd = D / heads;
   for (const EncLayer& L : layers) {
@@ -588,7 +588,7 @@ static int run_encoder_layers(const oavsr_model* m, oavsr_workspace* ws, const s
     AttnArgs a; a.dtype = dt; a.head_dim = hd; a.n_heads = heads; a.n_kv_heads = heads; a.n_seqs = n_seqs;
     a.Q = ws->enc_qkv; a.K = (const char*)ws->enc_qkv + (size_t)D * m->esz; a.V = (const char*)ws->enc_qkv + (size_t)2 * D * m->esz;
     a.ldq = a.ldk = a.ldv = 3 * D; a.O = ws->enc_attn; a.ldo = D; a.cu_q = cu_dev; a.cu_k = cu_dev; a.max_q = max_len;
-    a.scale = 1.0f / sqrtf((float)hd); a.causal = 0;
+    a.scale = 1.0f / sqrtf((float)hd); a.causal = 0; a.form = attn_form;
     { double fl = 0; /* 4*T*T*D per sequence, upper bound with max_len */ fl = 4.0 * (double)rows * max_len * D;
       ProfScope ps(dt == DT_F32 ? "attention_f32" : "attention_bf16", fl, 4.0 * rows * D * m->esz, st);
       OAVSR_TRY(launch_attention(a, st)); }
@@ -743,7 +743,8 @@ static int encode_audio_impl(const oavsr_model* m, oavsr_workspace* ws, const fl
   g.A = ws->conv1_out; g.lda = D; g.rowinfo = ws->rowinfo2; g.W = m->aconv2_w; g.ldw = 3 * D; g.col_bias = m->aconv2_b; g.act = ACT_GELU;
   g.residual = ws->pos_rep; g.ldr = D; g.res_after_act = 1; g.C = ws->enc_x; g.ldc = D;
   OAVSR_TRY(run_gemm(g, st));
-  OAVSR_TRY(run_encoder_layers(m, ws, m->alayers, B * 1500, D, c.wh_heads, c.wh_ffn, 0, ws->cu_b, B, 1500, st));
+  // attention on the 32x32x16-MFMA kernel: every Whisper sequence has 1500 frames whatever the clip, so the choice never depends on a batch
+  OAVSR_TRY(run_encoder_layers(m, ws, m->alayers, B * 1500, D, c.wh_heads, c.wh_ffn, 0, ws->cu_b, B, 1500, st, 32));
   void* enc = ws->enc_out_a;
   { ProfScope ps("layernorm", 0, 2.0 * B * 1500 * D * m->esz, st);
     OAVSR_TRY(launch_layernorm(dt, ws->enc_x, D, enc, D, m->alnf_w, m->alnf_b, B * 1500, D, 1e-5f, st)); }
@@ -2031,7 +2032,7 @@ int oavsr_op_attention(const oavsr_attn_desc* d, oavsr_stream stream) {
   OAVSR_REQUIRE(d, "op_attention: null desc");
   AttnArgs a; a.dtype = d->dtype; a.head_dim = d->head_dim; a.n_heads = d->n_heads; a.n_kv_heads = d->n_kv_heads; a.n_seqs = d->n_seqs;
   a.max_q = d->max_q; a.causal = d->causal; a.Q = d->Q; a.K = d->K; a.V = d->V; a.O = d->O; a.ldq = d->ldq; a.ldk = d->ldk; a.ldv = d->ldv;
-  a.ldo = d->ldo; a.cu_q = d->cu_q; a.cu_k = d->cu_k; a.scale = d->scale;
+  a.ldo = d->ldo; a.cu_q = d->cu_q; a.cu_k = d->cu_k; a.scale = d->scale; a.form = d->form;
   return launch_attention(a, (hipStream_t)stream);
 }
 

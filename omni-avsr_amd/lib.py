@@ -73,7 +73,7 @@ class AttnDesc(C.Structure):
         ("n_seqs", C.c_int32), ("max_q", C.c_int32), ("causal", C.c_int32),
         ("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("O", C.c_void_p),
         ("ldq", C.c_int64), ("ldk", C.c_int64), ("ldv", C.c_int64), ("ldo", C.c_int64),
-        ("cu_q", C.c_void_p), ("cu_k", C.c_void_p), ("scale", C.c_float),
+        ("cu_q", C.c_void_p), ("cu_k", C.c_void_p), ("scale", C.c_float), ("form", C.c_int32),
     ]
 
 

@@ -503,6 +503,36 @@ def test_attention_varlen(dtype, hd, H, KV, causal):
     close(out, ref, tol(dtype), what="attention")
 
 
+@pytest.mark.parametrize("H,KV,causal,lens", [(4, 4, 0, [1500, 1500]), (8, 2, 0, [70, 1, 130, 64, 333]), (4, 4, 1, [200, 129, 31]), (2, 1, 1, [1, 300])])
+def test_attention_32x32_form(H, KV, causal, lens):
+    """attn_dma32_kernel (form 32: 32x32x16 MFMAs, one tile of 32 queries per wave; what the Whisper encoder runs): against the fp32
+    reference like the 16x16 kernels -- ragged lengths, GQA, the causal edge tiles -- and within rounding of the default form."""
+    hd = 64
+    cu = [0]
+    for n in lens:
+        cu.append(cu[-1] + n)
+    rows, nq, nkv = cu[-1], H * hd, KV * hd
+    qkvd, qkvr = q(rnd(rows, nq + 2 * nkv, seed=21), "bf16")
+    cud = torch.tensor(cu, dtype=torch.int32, device=DEV)
+    outs = {}
+    for form in (0, 32):
+        out = torch.full((rows, nq), float("nan"), dtype=torch.bfloat16, device=DEV)
+        d = L.AttnDesc()
+        d.dtype, d.head_dim, d.n_heads, d.n_kv_heads, d.n_seqs, d.max_q, d.causal = dcode("bf16"), hd, H, KV, len(lens), max(lens), causal
+        d.Q, d.K, d.V, d.O = qkvd.data_ptr(), qkvd.data_ptr() + nq * 2, qkvd.data_ptr() + (nq + nkv) * 2, out.data_ptr()
+        d.ldq = d.ldk = d.ldv = nq + 2 * nkv
+        d.ldo = nq
+        d.cu_q, d.cu_k, d.scale, d.form = cud.data_ptr(), cud.data_ptr(), 1.0 / math.sqrt(hd), form
+        L.check(L.load().oavsr_op_attention(C.byref(d), stream()))
+        outs[form] = out
+    ref = _attn_ref(qkvr[:, :nq], qkvr[:, nq:nq + nkv], qkvr[:, nq + nkv:], cu, cu, H, KV, hd, 1.0 / math.sqrt(hd), causal)
+    close(outs[32], ref, tol("bf16"), what="attention, 32x32 form")
+    close(outs[32], outs[0].float().cpu(), tol("bf16"), what="attention, 32x32 form vs default form")
+    again = outs[32].clone()
+    L.check(L.load().oavsr_op_attention(C.byref(d), stream()))
+    assert torch.equal(outs[32], again)
+
+
 def test_attention_short_sequences_after_nan_poisoned_lds():
     """The bf16 / head_dim 64 kernel relies on the buffer range check for key rows past a sequence's end (they must land in LDS as
     zeros: a masked probability of 0 times a stale NaN would poison the output).  Poison the LDS of every CU with NaN patterns first

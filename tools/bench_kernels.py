@@ -80,7 +80,7 @@ def bench_gemm(dtype="bf16"):
 def bench_attn(dtype="bf16"):
     td = torch.bfloat16 if dtype == "bf16" else torch.float32
     print(f"--- attention, {dtype} ---")
-    for name, B, T, H, KV, hd, causal in [("whisper", 8, 1500, 16, 16, 64, 0), ("avhubert", 8, 400, 16, 16, 64, 0), ("llm prefill", 8, 313, 32, 8, 64, 1), ("long causal", 4, 4096, 32, 8, 64, 1)]:
+    for name, B, T, H, KV, hd, causal in [("whisper", 8, 1500, 16, 16, 64, 0), ("whisper b16", 16, 1500, 16, 16, 64, 0), ("whisper 1536", 8, 1536, 16, 16, 64, 0), ("avhubert", 8, 400, 16, 16, 64, 0), ("llm prefill", 8, 313, 32, 8, 64, 1), ("long causal", 4, 4096, 32, 8, 64, 1)]:
         nq, nkv = H * hd, KV * hd
         qkv = torch.randn(B * T, nq + 2 * nkv, device=DEV, dtype=td)
         out = torch.empty(B * T, nq, device=DEV, dtype=td)
@@ -93,9 +93,13 @@ def bench_attn(dtype="bf16"):
         d.ldo = nq
         d.cu_q, d.cu_k, d.scale = cu.data_ptr(), cu.data_ptr(), 1 / math.sqrt(hd)
         lib = L.load()
-        us = timeit(lambda i: L.check(lib.oavsr_op_attention(C.byref(d), stream())), iters=10)
         fl = 4.0 * B * T * T * nq / (2 if causal else 1)
-        print(f"{name:12s} B={B} T={T} H={H}/{KV} hd={hd}: {us:9.1f} us  {fl / us / 1e6:8.1f} TFLOP/s")
+        line = f"{name:12s} B={B} T={T} H={H}/{KV} hd={hd}:"
+        for form in ((0, 32) if (hd == 64 and dtype == "bf16") else (0,)):
+            d.form = form
+            us = timeit(lambda i: L.check(lib.oavsr_op_attention(C.byref(d), stream())), iters=10)
+            line += f"  form {form:2d}: {us:9.1f} us  {fl / us / 1e6:8.1f} TFLOP/s"
+        print(line)
 
 
 if __name__ == "__main__":
