@@ -694,7 +694,7 @@ static int encode_video_impl(const oavsr_model* m, oavsr_workspace* ws, const vo
   g.Cin = Cg; g.A = ws->enc_h; g.lda = D; g.groups = G; g.a_goff = Cg; g.rowinfo = ws->rowinfo; g.W = m->vpos_w; g.ldw = g.K;
   g.col_bias = m->vpos_b; g.act = ACT_GELU; g.residual = ws->enc_h; g.ldr = D; g.res_after_act = 1; g.C = ws->enc_x; g.ldc = D;
   OAVSR_TRY(run_gemm(g, st));
-  OAVSR_TRY(run_encoder_layers(m, ws, m->vlayers, F, D, c.av_heads, c.av_ffn, c.av_lora_k2, ws->cu_a, B, maxT, st));
+  OAVSR_TRY(run_encoder_layers(m, ws, m->vlayers, F, D, c.av_heads, c.av_ffn, c.av_lora_k2, ws->cu_a, B, maxT, st, 32));      // attention: the 32x32x16-MFMA kernel, like the Whisper encoder (VSR B = 16: 0.90 -> 0.72 ms per call)
   void* enc = ws->enc_out_v;
   { ProfScope ps("layernorm", 0, 2.0 * F * D * m->esz, st);
     OAVSR_TRY(launch_layernorm(dt, ws->enc_x, D, enc, D, m->vlnf_w, m->vlnf_b, F, D, 1e-5f, st)); }
@@ -743,7 +743,7 @@ static int encode_audio_impl(const oavsr_model* m, oavsr_workspace* ws, const fl
   g.A = ws->conv1_out; g.lda = D; g.rowinfo = ws->rowinfo2; g.W = m->aconv2_w; g.ldw = 3 * D; g.col_bias = m->aconv2_b; g.act = ACT_GELU;
   g.residual = ws->pos_rep; g.ldr = D; g.res_after_act = 1; g.C = ws->enc_x; g.ldc = D;
   OAVSR_TRY(run_gemm(g, st));
-  // attention on the 32x32x16-MFMA kernel: every Whisper sequence has 1500 frames whatever the clip, so the choice never depends on a batch
+  // attention on the 32x32x16-MFMA kernel: chosen by the call site (the encoders), so the choice never depends on a batch
   OAVSR_TRY(run_encoder_layers(m, ws, m->alayers, B * 1500, D, c.wh_heads, c.wh_ffn, 0, ws->cu_b, B, 1500, st, 32));
   void* enc = ws->enc_out_a;
   { ProfScope ps("layernorm", 0, 2.0 * B * 1500 * D * m->esz, st);
