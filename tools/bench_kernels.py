@@ -55,8 +55,6 @@ def bench_skinny(dtype="bf16"):
                     kw.update(norm_gain=gain, norm_eps=1e-5)
                 if swi:
                     kw.update(swiglu_pairs=1)
-                if os.environ.get("OAVSR_FAKE_TILED"):
-                    kw.update(taps=777)
                 gemm(dtype, x, Ws[i % ncopy], skinny=True, residual=res, C_out=out, out_f32=(name == "lm_head"), **kw)
             us = timeit(run, iters=max(20, ncopy * 2))
             gb = N * (K + K2) * esz / 1e9
