@@ -195,7 +195,7 @@ def parse_args():
     ap.add_argument("--sched-rows", type=int, default=None, help="rows per decode step of the engine's scheduler (<= 64; default: the engine's)")
     ap.add_argument("--sched-slots", type=int, default=None, help="row slots of the scheduler's pool (default: the engine's)")
     ap.add_argument("--sched-stride", type=int, default=0, help="steps per admission (0 = automatic)")
-    ap.add_argument("--sched-lanes", type=int, default=3, help="independent step loops of the scheduler")
+    ap.add_argument("--sched-lanes", type=int, default=None, help="independent step loops of the scheduler (default: the engine's: 4 for d < 3584, else 3)")
     ap.add_argument("--no-stagger", action="store_true", help="let the encoder phases of in-flight batches share the chip (default: chained)")
     ap.add_argument("--testset", type=int, default=0,
                     help="N > 0: the test-set-shaped run instead of the step loop (BASELINE.json configs[4] / SURVEY.md 8d C5: N synthetic utterances, "
@@ -307,6 +307,8 @@ def testset_run(args, rank, world, local, use_dist):
     eng = model.engine
     if args.sched_rows is None:
         args.sched_rows = eng.sched_rows
+    if args.sched_lanes is None:
+        args.sched_lanes = eng.sched_lanes
     if args.sched_slots is None:
         args.sched_slots = eng.sched_slots if args.sched_rows == eng.sched_rows else max(192, 4 * args.sched_rows)
     eng.sched_rows, eng.sched_slots, eng.sched_stride, eng.sched_lanes = args.sched_rows, args.sched_slots, args.sched_stride, args.sched_lanes
@@ -505,6 +507,8 @@ def main():
     # decode rows of the calls in flight into one step loop (oavsr_generate_submit).  Caller-side nothing is grouped (decode_group 1).
     if args.sched_rows is None:
         args.sched_rows = eng.sched_rows
+    if args.sched_lanes is None:
+        args.sched_lanes = eng.sched_lanes
     if args.sched_slots is None:
         args.sched_slots = eng.sched_slots if args.sched_rows == eng.sched_rows else max(192, 4 * args.sched_rows)
     use_sched = not args.no_scheduler and args.beams == 1 and G == 1 and B <= args.sched_rows

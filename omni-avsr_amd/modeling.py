@@ -54,7 +54,9 @@ class OmniEngine:
         # 7B / 8B models (14-15 GB per step) run 64-row steps: Llama-3.1-8B 102 -> 118, Qwen2.5-7B 85 -> 94 utt/s (round 4); with the 1B model
         # the step is a chain of short launches whose 64-row forms cost more than the second step they save (headline 269 -> 264, VSR +3 %)
         self.sched_rows, self.sched_slots = (64, 256) if spec.llm.hidden >= 3584 else (32, 192)
-        self.sched_lanes = 3                            # independent step loops sharing the pool (one loop serves ~380 utt/s)
+        # independent step loops sharing the pool (one loop serves ~380 utt/s).  Round 4, after the encoder side got 15 % faster:
+        # four lanes for the 1B model (headline 277 -> 286, VSR B = 16 527 -> 559 utt/s; five: 269), three for the 7B / 8B models (119 vs 117)
+        self.sched_lanes = 3 if spec.llm.hidden >= 3584 else 4
         self.sched_stride = 0                           # steps per admission (0: automatic; oavsr_scheduler_set_stride)
         self._blob = None
         self._names = None
