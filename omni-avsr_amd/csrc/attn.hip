@@ -946,6 +946,239 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnAr
   }
 }
 
+// Beam search (round 4): FOUR beams of one utterance per workgroup.  With a GQA group of 4 the per-row kernel above fills 4 of the MFMA's 16
+// query columns, and the 15 beams of an utterance each fetch the same prefix K / V (313 keys for a 16 s clip) -- 960 workgroups per layer
+// and step.  Here the 16 columns are (beam bi, head h) = 4 x 4: the prefix tiles are read once for four beams and every column is real
+// work; each beam's tail (its own ancestry-addressed rows, <= 64 positions) is one more key tile whose scores only count in that beam's four
+// columns (the others are masked to -inf).  Per column the arithmetic is the per-row kernel's (same tile softmax, same wave merge); what
+// changes is which keys share a tile, so the fp32 merge order differs from the per-row kernel's: the choice follows the decode MODE and the
+// model (beams > 1, bf16, head_dim 64, group 4), never a row count.  bf16 / head_dim 64 / 4 waves only.
+__global__ __launch_bounds__(256) void decode_attn_beam4_kernel(const DecodeAttnArgs p) {
+  typedef bf16_t T;
+  constexpr int HD = 64, NW = 4, G = 4, R = 4;
+  constexpr int kDecThreads = NW * 64;
+  constexpr int RB = HD * 2, NCH = RB / 16, SWZ = 7, NBLK = RB / 64, NDT = HD / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sq = smem;                                   // [16][RB]  rotated queries, row = bi * G + h (rows of missing beams are zero)
+  char* sknew = smem + 16 * RB;                      // [R][RB] rotated new keys, [R][RB] new values
+  char* svnew = sknew + R * RB;
+  char* sv = svnew + R * RB;                         // [NW waves][64][RB]  V tiles; reused for the merge
+  const int ngrp = (p.beams + R - 1) / R;
+  const int utt = blockIdx.x / ngrp, b0 = (blockIdx.x - utt * ngrp) * R, kvh = blockIdx.y;
+  const int nb = p.beams - b0 < R ? p.beams - b0 : R;          // beams of this workgroup
+  const int row0 = utt * p.beams + b0;
+  const int plen = p.prefix_len[utt];
+  const int ntail = *p.step;                                   // beam search: every row is at the same step
+  const int nP = (plen + 63) >> 6;                             // prefix key tiles; tile nP + bi = the tail of beam bi
+  const int ntiles = nP + nb;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qi = lane & 15, g = lane >> 4;
+  T* Kt = reinterpret_cast<T*>(const_cast<void*>(p.Kt));
+  T* Vt = reinterpret_cast<T*>(const_cast<void*>(p.Vt));
+
+  // K fragments straight from the caches (A operand row = key (lane & 15), 16-byte chunk blk * 4 + g); V row of key `lane`
+  auto key_row = [&](const void* pre, const void* tail, int tile, int kk, bool& ok) -> const char* {
+    if (tile < nP) {
+      const int j = tile * 64 + kk;
+      ok = j < plen;
+      return reinterpret_cast<const char*>(pre) + (((int64_t)utt * p.n_kv_heads + kvh) * p.max_prefix + j) * RB;
+    }
+    const int bi = tile - nP, row = row0 + bi;
+    const int newpos = p.inv_freq ? p.cpos[row] : -1;          // the token being appended comes from LDS, never from the just-written cache row
+    ok = kk < ntail && kk != newpos;
+    const int src = (ok && p.anc) ? p.anc[(int64_t)row * p.max_tail + kk] : row;
+    return reinterpret_cast<const char*>(tail) + (((int64_t)src * p.n_kv_heads + kvh) * p.max_tail + kk) * RB;
+  };
+  auto load_tile = [&](int tile, Chunk16 (&kf)[4][NBLK], Chunk16 (&vr)[NCH]) {
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      bool ok;
+      const char* kr = key_row(p.Kp, p.Kt, tile, kt * 16 + qi, ok);
+#pragma unroll
+      for (int b = 0; b < NBLK; ++b) {
+        if (ok) kf[kt][b] = *reinterpret_cast<const Chunk16*>(kr + (b * 4 + g) * 16);
+        else kf[kt][b].v = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+    bool okv;
+    const char* vp = key_row(p.Vp, p.Vt, tile, lane, okv);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if (okv) vr[c] = *reinterpret_cast<const Chunk16*>(vp + c * 16);
+      else vr[c].v = u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+
+  Chunk16 kf[4][NBLK], vr[NCH];
+  int tile = wave;
+  if (tile < ntiles) load_tile(tile, kf, vr);                  // the first tile's latency hides the RoPE phase
+
+  // ---- phase 0: queries (+ RoPE) into LDS; new k (+ RoPE) / v of every beam appended to its tail cache row and kept in LDS ----
+  for (int i = tid + nb * G * HD; i < 16 * HD; i += kDecThreads) reinterpret_cast<T*>(sq)[i] = from_f32<T>(0.f);
+  if (p.inv_freq) {
+    constexpr int half = HD / 2;
+    for (int i = tid; i < nb * (G + 1) * half; i += kDecThreads) {
+      const int bi = i / ((G + 1) * half), rem = i - bi * (G + 1) * half, h = rem / half, d = rem - h * half;
+      const int row = row0 + bi;
+      const T* qrow = reinterpret_cast<const T*>(p.Q) + (int64_t)row * p.ldq;
+      float sn, cs;
+      if (p.rope_cs) { const float2 t = p.rope_cs[(int64_t)row * half + d]; cs = t.x; sn = t.y; }
+      else sincosf((float)p.pos[row] * p.inv_freq[d], &sn, &cs);
+      const T* src = h < G ? qrow + (int64_t)(kvh * G + h) * HD : qrow + (int64_t)(p.n_heads + kvh) * HD;
+      const float x0 = to_f32(src[d]), x1 = to_f32(src[d + half]);
+      const T r0 = from_f32<T>(x0 * cs - x1 * sn), r1 = from_f32<T>(x1 * cs + x0 * sn);
+      if (h < G) {
+        T* dst = reinterpret_cast<T*>(sq + (bi * G + h) * RB);
+        dst[d] = r0; dst[d + half] = r1;
+      } else {
+        T* kd = Kt + (((int64_t)row * p.n_kv_heads + kvh) * p.max_tail + p.cpos[row]) * HD;
+        kd[d] = r0; kd[d + half] = r1;
+        reinterpret_cast<T*>(sknew + bi * RB)[d] = r0; reinterpret_cast<T*>(sknew + bi * RB)[d + half] = r1;
+      }
+    }
+    for (int i = tid; i < nb * HD; i += kDecThreads) {
+      const int bi = i / HD, d = i - bi * HD, row = row0 + bi;
+      const T v = (reinterpret_cast<const T*>(p.Q) + (int64_t)row * p.ldq + (int64_t)(p.n_heads + p.n_kv_heads + kvh) * HD)[d];
+      (Vt + (((int64_t)row * p.n_kv_heads + kvh) * p.max_tail + p.cpos[row]) * HD)[d] = v;
+      reinterpret_cast<T*>(svnew + bi * RB)[d] = v;
+    }
+  } else {
+    for (int i = tid; i < nb * G * HD; i += kDecThreads) {
+      const int bi = i / (G * HD), rem = i - bi * G * HD;
+      reinterpret_cast<T*>(sq)[i] = (reinterpret_cast<const T*>(p.Q) + (int64_t)(row0 + bi) * p.ldq)[(int64_t)kvh * G * HD + rem];
+    }
+  }
+  __syncthreads();
+
+  Chunk16 qf[NBLK];
+#pragma unroll
+  for (int b = 0; b < NBLK; ++b) qf[b] = *reinterpret_cast<const Chunk16*>(sq + qi * RB + (b * 4 + g) * 16);
+
+  const float sc = p.scale * 1.44269504088896340736f;
+  f32x4 o[NDT];
+#pragma unroll
+  for (int i = 0; i < NDT; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  char* svw = sv + wave * (64 * RB);
+  const int mybeam = qi >> 2;                                   // the beam this lane's query column belongs to (G = 4)
+
+  for (; tile < ntiles; tile += NW) {
+    if (tile != wave) load_tile(tile, kf, vr);
+    const bool is_tail = tile >= nP;
+    const int bi = tile - nP;                                   // (tail tiles)
+    const int nvalid = is_tail ? ntail : (plen - tile * 64 < 64 ? plen - tile * 64 : 64);
+    if (is_tail && p.inv_freq) {                                // this tile holds the token beam bi appends in this step
+      const int newpos = p.cpos[row0 + bi];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+        if (kt * 16 + qi == newpos) {
+#pragma unroll
+          for (int b = 0; b < NBLK; ++b) kf[kt][b] = *reinterpret_cast<const Chunk16*>(sknew + bi * RB + (b * 4 + g) * 16);
+        }
+      if (lane == newpos) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) vr[c] = *reinterpret_cast<const Chunk16*>(svnew + bi * RB + c * 16);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) *reinterpret_cast<Chunk16*>(svw + lane * RB + ((c ^ (lane & SWZ)) << 4)) = vr[c];
+    f32x4 s[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int b = 0; b < NBLK; ++b) MmaT<T>::run(kf[kt][b], qf[b], s[kt]);
+    }
+    const bool mine = !is_tail || mybeam == bi;                 // a tail tile only counts in its own beam's columns
+    float mt = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kk = kt * 16 + 4 * g + r;
+        float v = (mine && kk < nvalid) ? s[kt][r] * sc : -INFINITY;
+        s[kt][r] = v;
+        mt = fmaxf(mt, v);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = exp2f(m_run - m_use);
+    float lsum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { float e = exp2f(s[kt][r] - m_use); s[kt][r] = e; lsum += e; }
+    l_run = l_run * alpha + lsum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) o[i] *= alpha;
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's V tile writes have landed before its own reads
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      bf16x8 pf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pf[r] = (bf16_t)s[2 * u][r]; pf[4 + r] = (bf16_t)s[2 * u + 1][r]; }
+      const int qq = qi >> 2, pp = qi & 3;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const int c = dt * 2 + (pp >> 1);
+        const int rw0 = (2 * u) * 16 + 4 * g + qq, rw1 = rw0 + 16;
+        auto a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(svw + rw0 * RB + ((c ^ (rw0 & SWZ)) << 4) + (pp & 1) * 8));
+        auto a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(svw + rw1 * RB + ((c ^ (rw1 & SWZ)) << 4) + (pp & 1) * 8));
+        bf16x4 v0 = __builtin_bit_cast(bf16x4, a0), v1 = __builtin_bit_cast(bf16x4, a1);
+        bf16x8 vf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { vf[r] = v0[r]; vf[4 + r] = v1[r]; }
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // the tile's V reads are done before the next tile overwrites this wave's image
+  }
+  // ---- merge the NW waves: partials (m, l, O^T[d][column]) through LDS (reusing the V-tile region) ----
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  __syncthreads();
+  float* sm = reinterpret_cast<float*>(sv);            // [NW][16] m, [NW][16] l, [NW][HD][16] O^T
+  float* sl = sm + NW * 16;
+  float* so = sl + NW * 16;
+  if (g == 0) { sm[wave * 16 + qi] = m_run; sl[wave * 16 + qi] = l_run; }
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) so[(wave * HD + dt * 16 + 4 * g + r) * 16 + qi] = o[dt][r];
+  __syncthreads();
+  for (int i = tid; i < nb * G * HD; i += kDecThreads) {
+    const int col = i / HD, d = i - col * HD, bi = col / G, h = col - bi * G;
+    float mstar = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) mstar = fmaxf(mstar, sm[w * 16 + col]);
+    if (mstar == -INFINITY) mstar = 0.f;
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float f = exp2f(sm[w * 16 + col] - mstar);
+      num += f * so[(w * HD + d) * 16 + col];
+      den += f * sl[w * 16 + col];
+    }
+    T* O = reinterpret_cast<T*>(p.O) + (int64_t)(row0 + bi) * p.ldo + (int64_t)(kvh * G + h) * HD;
+    O[d] = from_f32<T>(den > 0.f ? num / den : 0.f);
+  }
+}
+
+int launch_dec_beam4(const DecodeAttnArgs& a, hipStream_t st) {
+  constexpr int RB = 128, NW = 4, R = 4;
+  constexpr size_t tiles = (size_t)NW * 64 * RB, merge = (size_t)(2 * NW * 16 + NW * 64 * 16) * 4;
+  constexpr size_t smem = 16 * RB + 2 * R * RB + (tiles > merge ? tiles : merge);
+  const int n_utts = a.rows / a.beams, ngrp = (a.beams + R - 1) / R;
+  hipLaunchKernelGGL(decode_attn_beam4_kernel, dim3(n_utts * ngrp, a.n_kv_heads), dim3(NW * 64), smem, st, a);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 template <typename T, int HD>
 int launch_attn_t(const AttnArgs& a, hipStream_t st) {
   dim3 grid(ceil_div(a.max_q, 64), a.n_heads, a.n_seqs);
@@ -1036,7 +1269,11 @@ int launch_decode_attention(const DecodeAttnArgs& a, hipStream_t st) {
   // beam search (B * K x kv heads workgroups, several per CU): 4-wave workgroups with half the LDS pack more of them onto a CU
   // than 8-wave ones.  The choice follows the decode MODE (beams > 1), never the row count: the key -> wave partition and with
   // it the fp32 merge order of a row is then the same whether its utterance is decoded alone or inside a batch.
-  if (a.head_dim == 64 && a.beams > 1) return launch_dec_t<bf16_t, 64, 4>(a, st);
+  if (a.head_dim == 64 && a.beams > 1) {
+    // GQA group of 4 (Llama-3.2-1B): four beams of an utterance per workgroup share the prefix K / V tiles (decode_attn_beam4_kernel)
+    if (a.n_heads == 4 * a.n_kv_heads && a.step && !a.rowmap && a.rows % a.beams == 0 && a.max_tail <= 64) return launch_dec_beam4(a, st);
+    return launch_dec_t<bf16_t, 64, 4>(a, st);
+  }
   return a.head_dim == 64 ? launch_dec_t<bf16_t, 64>(a, st) : launch_dec_t<bf16_t, 128>(a, st);
 }
 

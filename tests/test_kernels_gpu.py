@@ -663,6 +663,75 @@ def test_decode_attention_fused_rope_append(dtype, hd, H, KV):
     close(vt[:, :, step - 1], vn, 0.0, what="appended v")
 
 
+@pytest.mark.parametrize("beams,fused", [(15, True), (15, False), (6, True), (4, False)])
+def test_decode_attention_beam_groups_of_four(beams, fused):
+    """decode_attn_beam4_kernel (bf16, head_dim 64, GQA group 4, beams > 1): four beams of an utterance per workgroup share the prefix K / V
+    tiles; every beam's tail comes from ITS ancestry-addressed rows (another beam's tail must never leak into its columns), the last group
+    is ragged (15 = 4 + 4 + 4 + 3), the fused RoPE + append writes every beam's new k / v to its own tail row."""
+    from omni_avsr_amd.weights import rope_inv_freq
+    dtype, hd, H, KV = "bf16", 64, 8, 2
+    G = H // KV
+    utts, maxp, maxt = 3, 320, 32
+    rows = utts * beams
+    plen, step = [313, 64, 7], 6                  # tail: 5 old tokens (+ the appended 6th when fused)
+    ld = (H + 2 * KV) * hd
+    qkv, qkvr = q(rnd(rows, ld, seed=1), dtype)
+    kp, kpr = q(rnd(utts, KV, maxp, hd, seed=2), dtype)
+    vp, vpr = q(rnd(utts, KV, maxp, hd, seed=3), dtype)
+    kt, ktr = q(rnd(rows, KV, maxt, hd, seed=4), dtype)
+    vt, vtr = q(rnd(rows, KV, maxt, hd, seed=5), dtype)
+    g = torch.Generator().manual_seed(9)
+    anc = torch.empty(rows, maxt, dtype=torch.int32)
+    for u in range(utts):                          # position t of beam b lives in the tail row of a random beam of the same utterance
+        anc[u * beams:(u + 1) * beams] = u * beams + torch.randint(0, beams, (beams, maxt), generator=g, dtype=torch.int32)
+    nold = step - 1 if fused else step
+    if fused:
+        anc[:, step - 1] = torch.arange(rows, dtype=torch.int32)     # the appended token lands in the beam's own row
+    inv = rope_inv_freq(hd, 500000.0, None)
+    pos = torch.tensor([plen[r // beams] + step - 1 for r in range(rows)], dtype=torch.int32)
+    pl = torch.tensor(plen, dtype=torch.int32, device=DEV)
+    st = torch.tensor([step], dtype=torch.int32, device=DEV)
+    ancd, invd, posd = anc.to(DEV), inv.to(DEV), pos.to(DEV)
+    cposd = torch.full((rows,), step - 1, dtype=torch.int32, device=DEV)
+    out = torch.full((rows, H * hd), float("nan"), dtype=torch.bfloat16, device=DEV)
+    d = L.DecodeAttnDesc()
+    d.dtype, d.head_dim, d.n_heads, d.n_kv_heads, d.rows, d.beams, d.max_prefix, d.max_tail = dcode(dtype), hd, H, KV, rows, beams, maxp, maxt
+    d.Q, d.Kp, d.Vp, d.Kt, d.Vt, d.O = qkv.data_ptr(), kp.data_ptr(), vp.data_ptr(), kt.data_ptr(), vt.data_ptr(), out.data_ptr()
+    d.ldq, d.ldo = (ld if fused else H * hd), H * hd
+    if not fused:
+        qonly = qkv[:, :H * hd].contiguous()
+        d.Q = qonly.data_ptr()
+    d.prefix_len, d.step, d.anc, d.scale = pl.data_ptr(), st.data_ptr(), ancd.data_ptr(), 1.0 / math.sqrt(hd)
+    if fused:
+        d.inv_freq, d.pos, d.cpos = invd.data_ptr(), posd.data_ptr(), cposd.data_ptr()
+    L.check(L.load().oavsr_op_decode_attention(C.byref(d), stream()))
+    if fused:
+        ang = pos.float()[:, None] * inv[None]
+        cos, sin = torch.cat([ang, ang], -1).cos()[:, None], torch.cat([ang, ang], -1).sin()[:, None]
+        rot = lambda x: x * cos + torch.cat([-x[..., hd // 2:], x[..., :hd // 2]], -1) * sin
+        qh = rot(qkvr[:, :H * hd].reshape(rows, H, hd)).to(torch.bfloat16).float()
+        kn = rot(qkvr[:, H * hd:(H + KV) * hd].reshape(rows, KV, hd)).to(torch.bfloat16).float()
+        vn = qkvr[:, (H + KV) * hd:].reshape(rows, KV, hd)
+    else:
+        qh = qkvr[:, :H * hd].reshape(rows, H, hd)
+    refs = []
+    for r in range(rows):
+        u = r // beams
+        kts = torch.stack([ktr[int(anc[r, t]), :, t] for t in range(nold)], 1)      # [KV, nold, hd]
+        vts = torch.stack([vtr[int(anc[r, t]), :, t] for t in range(nold)], 1)
+        ks, vs = [kpr[u, :, :plen[u]], kts], [vpr[u, :, :plen[u]], vts]
+        if fused:
+            ks.append(kn[r][:, None]); vs.append(vn[r][:, None])
+        k = torch.cat(ks, 1).repeat_interleave(G, 0)
+        v = torch.cat(vs, 1).repeat_interleave(G, 0)
+        w = torch.softmax(qh[r][:, None] @ k.transpose(1, 2) / math.sqrt(hd), -1)
+        refs.append((w @ v).reshape(H * hd))
+    close(out, torch.stack(refs), tol(dtype), what="beam-grouped decode attention")
+    if fused:
+        close(kt[:, :, step - 1], kn, tol(dtype), what="appended k")
+        close(vt[:, :, step - 1], vn, 0.0, what="appended v")
+
+
 # ------------------------------------------------------------------------------------------------ norms & elementwise
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("mode", [0, 1, 2])
