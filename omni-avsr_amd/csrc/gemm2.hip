@@ -431,7 +431,7 @@ static bool small_tile_rule(const GemmArgs& a) {
 static int dma_tile_choice(const GemmArgs& a) {
   // 0: not eligible, 1: 256x128, 2: 256x256, 4: the <= 128-row / small-GEMM tiles
   // <= 128 rows (beam-search decode, tiny prefills): 128 x 64 tiles stream the weights with 4 x more workgroups per N
-  if (a.amode == A_DENSE && a.groups == 1 && a.M <= 128 && a.M > 32 && a.N >= 64) return 4;
+  if (a.amode == A_DENSE && a.groups == 1 && a.M <= 128 && (a.M > 32 || a.decode_tiled) && a.N >= 64) return 4;
   if (a.ksplit > 1) return (a.amode == A_DENSE && a.groups == 1 && a.N >= 64) ? 1 : 0;   // independent of M on purpose
   if (small_tile_rule(a)) return 4;
   if (a.amode == A_STEM || a.N < 128) return 0;

@@ -54,6 +54,7 @@ struct GemmArgs {
   int tile_order = 0;
   // parity tests / yardsticks (oavsr_op_gemm): 2 = the 16-wave 256 x 256 LDS-DMA kernel whatever the dispatcher would pick.  0 in the product.
   int force_tile = 0;
+  int decode_tiled = 0;      // <= 128-row decode GEMM of the tiled regime: the 128 x 64 LDS-DMA tile at ANY row count (speed only: the tile shape never changes a bit)
 };
 // (mt, nt) of linear tile index bid in the blocked order above; bijective for any ntm x ntn
 __host__ __device__ inline void blocked_tile(int bid, int ntm, int ntn, int& mt, int& nt) {

@@ -189,6 +189,7 @@ struct oavsr_model {
   uint64_t blob_bytes = 0;
   std::unordered_map<std::string, std::pair<uint64_t, uint64_t>> t;
   int dtype = DT_BF16; size_t esz = 2;
+  bool tiled_decode = false;             // greedy decode GEMMs on the tiled LDS-DMA kernels at every row count (d >= 3584: see llm_layers)
   // video
   bool has_video = false, has_audio = false;
   ConvBN stem; ResBlock blocks[8];
@@ -480,6 +481,7 @@ static int resolve_model(oavsr_model* m) {
   const oavsr_config& c = m->cfg;
   m->has_video = m->t.count("v.stem.w") > 0;
   m->has_audio = m->t.count("a.conv1.w") > 0;
+  m->tiled_decode = c.llm_hidden >= 3584;      // Qwen2.5-7B / Llama-3.1-8B widths (llm_layers: the greedy tiled regime)
   if (m->has_video) {
     OAVSR_TRY(resolve_convbn(m, "v.stem", true, m->stem));
     const int chans[5] = {64, 64, 128, 256, 512};
@@ -843,9 +845,11 @@ static int build_prompt_impl(const oavsr_model* m, oavsr_workspace* ws, int task
 // is what the beam-search results of rounds 1-3 were produced with, and B x K rows grow in steps of K anyway.
 static constexpr int skinny_max_rows(int beams = 1) { return beams > 1 ? 32 : 64; }
 
-static int decode_split(int N, int Ktot, int esz) {
+// target: workgroups per launch the split is sized for -- a constant of the regime (part of its summation order): 128 for beam search's
+// > 32-row decode (four decode chains in flight), 256 for the greedy tiled regime of the 7B / 8B models (kDecodeSplitTiled)
+constexpr int kDecodeSplitBeam = 128, kDecodeSplitTiled = 256;
+static int decode_split(int N, int Ktot, int esz, int target = kDecodeSplitBeam) {
   const int ktiles = Ktot / (128 / esz);
-  constexpr int target = 128;             // workgroups per launch the split is sized for (part of the > 32-row regime's summation order: a constant)
   int ks = target / std::max(1, ceil_div(N, 64));
   ks = std::min(ks, std::max(1, ktiles / 2));
   return std::max(1, std::min(ks, 16));
@@ -854,11 +858,12 @@ static int decode_split(int N, int Ktot, int esz) {
 // rn_gain (mode 2 only): ask the split-K reduce pass to also write RMSNorm(C) * rn_gain to ws->lh; *normed says whether it did (a GEMM
 // that needs no split has no reduce pass: the caller then runs the rmsnorm kernel as before).
 static int llm_gemm(const oavsr_model* m, oavsr_workspace* ws, GemmArgs& g, int mode /*0 prefill, 1 skinny, 2 split-K*/, hipStream_t st,
-                    const float* rn_gain = nullptr, bool* normed = nullptr) {
+                    const float* rn_gain = nullptr, bool* normed = nullptr, bool tiled = false /* the greedy tiled regime (mode 2 at any row count) */) {
   if (normed) *normed = false;
   if (mode == 0) return run_gemm(g, st, false);
   if (mode == 1) return run_gemm(g, st, true);
-  const int ks = decode_split(g.N, g.K + g.K2, (int)m->esz);
+  g.decode_tiled = tiled ? 1 : 0;
+  const int ks = decode_split(g.N, g.K + g.K2, (int)m->esz, tiled ? kDecodeSplitTiled : kDecodeSplitBeam);
   if (ks > 1) {
     OAVSR_REQUIRE((size_t)ks * g.M * g.N * 4 <= ws->partial_bytes, "decode GEMM: split-K slabs (%d x %d x %d) exceed the workspace", ks, g.M, g.N);
     g.ksplit = ks; g.partial = ws->partial;
@@ -882,7 +887,13 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
   const int dt = m->dtype, d = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, hd = c.llm_head_dim, I = c.llm_mlp;
   const int nq = H * hd, nqkv = (H + 2 * KV) * hd;
   const int tl = c.lora_task_specific ? task : 0;
-  const int mode = !decode ? 0 : (rows <= skinny_max_rows(beams) ? 1 : 2);
+  // Greedy decode of the 7B / 8B models (m->tiled_decode): the tiled LDS-DMA kernels at EVERY row count.  At 33..64 rows they stream the
+  // weights 2 x faster than the weight-streaming kernels, whose workgroups re-read all activation rows through a 36 GB/s register-load
+  // path (Llama-3.1-8B, 57 rows: gate / up 107 -> 53 us, down_proj 86 -> 37, lm_head 390 -> 190); their results do not depend on the row
+  // count either (rows are independent, split factors are functions of N and K), so greedy decode stays batch-independent -- in a
+  // different summation order than the weight-streaming regime, which is why the regime follows the MODEL, never a step's row count.
+  const bool tiled = decode && beams == 1 && m->tiled_decode;
+  const int mode = !decode ? 0 : (tiled ? 2 : (rows <= skinny_max_rows(beams) ? 1 : 2));
   const bool fused_norm = mode == 1;       // RMSNorm folded into the skinny GEMMs (gain on the A fragments, rstd in the epilogue)
   const bool can_prune = !decode && last_rows && cu_last;
   if (pruned) *pruned = false;
@@ -912,8 +923,8 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
       ch.counter = ws->sync + (size_t)(2 * li) * kChainCtrInts; ch.feeds_a2 = 1;
       OAVSR_TRY(run_gemm_chain(gl, g, 0, ch, st));
     } else {
-      if (c.lora_k2 > 0) OAVSR_TRY(llm_gemm(m, ws, gl, mode, st));
-      OAVSR_TRY(llm_gemm(m, ws, g, mode, st));
+      if (c.lora_k2 > 0) OAVSR_TRY(llm_gemm(m, ws, gl, mode, st, nullptr, nullptr, tiled));
+      OAVSR_TRY(llm_gemm(m, ws, g, mode, st, nullptr, nullptr, tiled));
     }
     if (!decode) {   // decode: RoPE + cache append are fused into the decode-attention kernel
       RopeArgs r; r.dtype = dt; r.rows = rows; r.n_heads = H; r.n_kv_heads = KV; r.head_dim = hd; r.qkv = ws->lqkv; r.ld = nqkv;
@@ -957,7 +968,7 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
       g = GemmArgs(); g.dtype = dt; g.M = trows; g.N = d; g.K = nq; g.A = attn_r; g.lda = nq; g.W = L.ow; g.ldw = nq;
       g.residual = xres; g.ldr = d; g.C = xres; g.ldc = d;
       bool h2 = false;                     // mode 2: ln2(x) written by o_proj's reduce pass
-      OAVSR_TRY(llm_gemm(m, ws, g, tmode, st, tmode == 2 ? L.ln2w : nullptr, &h2));
+      OAVSR_TRY(llm_gemm(m, ws, g, tmode, st, tmode == 2 ? L.ln2w : nullptr, &h2, tiled));
       bool mlp_chained = false;
       if (tfused) {   // RMSNorm + gate/up + SwiGLU in one launch
         g = GemmArgs(); g.dtype = dt; g.M = trows; g.N = 2 * I; g.K = d; g.A = xres; g.lda = d; g.W = L.guw; g.ldw = d;
@@ -979,10 +990,11 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
         // prefill, and beam-search decode (33..128 rows) when the 128 x 64 tiles already fill the chip without split-K:
         // SwiGLU in the GEMM epilogue, the [rows][2I] tensor never exists
         const bool dec_fill = mode == 2 && (int64_t)ceil_div(rows, 128) * ceil_div(2 * I, 64) >= 256;
+        gf.decode_tiled = tiled ? 1 : 0;
         if ((mode == 0 || dec_fill) && gemm_dma_swiglu_ok(gf)) {
           OAVSR_TRY(run_gemm(gf, st, false));
         } else {
-          OAVSR_TRY(llm_gemm(m, ws, g, mode, st));
+          OAVSR_TRY(llm_gemm(m, ws, g, mode, st, nullptr, nullptr, tiled));
           ProfScope ps("swiglu", 0, 3.0 * rows * I * m->esz, st);
           OAVSR_TRY(launch_swiglu(dt, ws->lgu, 2 * I, ws->lact, I, rows, I, 1, st));
         }
@@ -994,7 +1006,7 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
         const bool last = li == c.llm_layers - 1;
         const float* next_gain = tmode != 2 ? nullptr : (!last ? m->llayers[li + 1].ln1w : (final_normed ? m->norm_w : nullptr));
         bool hn = false;
-        OAVSR_TRY(llm_gemm(m, ws, g, tmode, st, next_gain, &hn));
+        OAVSR_TRY(llm_gemm(m, ws, g, tmode, st, next_gain, &hn, tiled));
         if (hn && !last) have_h = true;
         if (hn && last) *final_normed = true;
       }
@@ -1012,7 +1024,9 @@ static int lm_head_rows(const oavsr_model* m, oavsr_workspace* ws, const void* x
   const int d = c.llm_hidden;
   GemmArgs g; g.dtype = m->dtype; g.M = rows; g.N = c.llm_vocab; g.K = d; g.W = m->lm_head; g.ldw = d;
   g.C = logits; g.ldc = c.llm_vocab; g.out_f32 = 1;
-  if (rows <= skinny_max_rows(beams) || chunk > 0) {     // final RMSNorm fused into the weight-streaming kernel
+  const bool tiled = beams == 1 && chunk == 0 && m->tiled_decode;      // (the prefill's first lm_head keeps the chunked weight-streaming launches)
+  g.decode_tiled = tiled ? 1 : 0;
+  if (!tiled && (rows <= skinny_max_rows(beams) || chunk > 0)) {     // final RMSNorm fused into the weight-streaming kernel
     const int step = chunk > 0 ? chunk : rows;
     for (int r0 = 0; r0 < rows; r0 += step) {
       g.M = std::min(step, rows - r0);
@@ -1376,10 +1390,11 @@ int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, 
   WANT(gs.step, 256); WANT(gs.pos, rows_dec * 4); WANT(gs.cpos, rows_dec * 4); WANT(gs.rope_cs, rows_dec * (size_t)(hd / 2) * sizeof(float2));
   {   // split-K partial slabs: decode GEMMs with > 32 rows (beam search)
     size_t pb = 0;
-    if (rows_dec > 32) {   // every decode GEMM call site: ks(N, K) x rows x N fp32 (decode_split)
+    if (rows_dec > 32 || m->tiled_decode) {   // every decode GEMM call site: ks(N, K) x rows x N fp32 (decode_split)
       const int es = (int)e, qkv = (int)nqkv, nq_ = H * hd;
       const int sites[5][2] = {{c.lora_k2, d}, {qkv, d + c.lora_k2}, {d, nq_}, {2 * I, d}, {d, I}};
-      for (auto& s2 : sites) if (s2[0] > 0) pb = std::max(pb, (size_t)decode_split(s2[0], s2[1], es) * rows_dec * s2[0] * 4);
+      for (auto& s2 : sites) if (s2[0] > 0)
+        pb = std::max(pb, (size_t)std::max(decode_split(s2[0], s2[1], es, kDecodeSplitBeam), decode_split(s2[0], s2[1], es, kDecodeSplitTiled)) * rows_dec * s2[0] * 4);
     }
     ws->partial_bytes = pb;
     if (pb) WANT(partial, pb);
@@ -1693,6 +1708,13 @@ int oavsr_scheduler_create(const oavsr_model* m, int32_t n_slots, int32_t max_ro
     WANT(lw->lx, R * d * e); WANT(lw->lh, R * d * e); WANT(lw->lqkv, R * nqkv * e); WANT(lw->lattn, R * (size_t)H * hd * e);
     WANT(lw->lact, R * (size_t)I * e); WANT(lw->llora, R * (size_t)std::max(64, c.lora_k2) * e); WANT(lw->logits, R * (size_t)c.llm_vocab * 4);
     WANT(l.partials, R * 64 * 8); WANT(l.rowmap, 64 * 4);
+    if (m->tiled_decode) {   // the tiled regime's split-K slabs and (when SwiGLU is not fused) the [rows][2I] gate / up tensor
+      const int sites[5][2] = {{c.lora_k2, d}, {(int)nqkv, d + c.lora_k2}, {d, H * hd}, {2 * I, d}, {d, I}};
+      size_t pb = 0;
+      for (auto& s2 : sites) if (s2[0] > 0) pb = std::max(pb, (size_t)decode_split(s2[0], s2[1], (int)e, kDecodeSplitTiled) * R * s2[0] * 4);
+      lw->partial_bytes = pb;
+      WANT(lw->partial, pb); WANT(lw->lgu, R * 2 * (size_t)I * e);
+    }
   }
 #undef WANT
   size_t total = 0;
