@@ -195,15 +195,15 @@ def parse_args():
     ap.add_argument("--sched-rows", type=int, default=None, help="rows per decode step of the engine's scheduler (<= 64; default: the engine's)")
     ap.add_argument("--sched-slots", type=int, default=None, help="row slots of the scheduler's pool (default: the engine's)")
     ap.add_argument("--sched-stride", type=int, default=0, help="steps per admission (0 = automatic)")
-    ap.add_argument("--sched-lanes", type=int, default=None, help="independent step loops of the scheduler (default: the engine's: 4 for d < 3584, else 3)")
+    ap.add_argument("--sched-lanes", type=int, default=None, help="independent step loops of the scheduler (default: the engine's: 3)")
     ap.add_argument("--no-stagger", action="store_true", help="let the encoder phases of in-flight batches share the chip (default: chained)")
     ap.add_argument("--testset", type=int, default=0,
                     help="N > 0: the test-set-shaped run instead of the step loop (BASELINE.json configs[4] / SURVEY.md 8d C5: N synthetic utterances, "
                          "lengths U[1 s, 16 s], HOST inputs): duration-sorted sharding over the ranks -> batches -> harness.evaluate(in_flight=3) -> one "
                          "all_gather of the hypotheses + all_reduce of the WER counters.  STRONG scaling: value = N / wall time of the whole set")
     ap.add_argument("--streams", type=int, default=None,
-                    help="caller streams = batches whose encoder phases (and, without the scheduler, decode loops) may be in flight; default 3, "
-                         "4 for beam search; 1 = strictly sequential calls")
+                    help="caller streams = batches whose encoder phases (and, without the scheduler, decode loops) may be in flight; default 4; "
+                         "1 = strictly sequential calls")
     return ap.parse_args()
 
 
@@ -445,7 +445,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
     if args.streams is None:
-        args.streams = 4 if args.beams > 1 else 3
+        args.streams = 4
     if args.beams > 1:
         # beam search runs one decode chain per call on the call's own stream: four chains in flight need more than ROCm's default four
         # hardware queues to advance independently (120.6 -> 133.6 utt/s with 8; the greedy scheduler path is best at the default)

@@ -189,7 +189,7 @@ struct oavsr_model {
   uint64_t blob_bytes = 0;
   std::unordered_map<std::string, std::pair<uint64_t, uint64_t>> t;
   int dtype = DT_BF16; size_t esz = 2;
-  bool tiled_decode = false;             // greedy decode GEMMs on the tiled LDS-DMA kernels at every row count (d >= 3584: see llm_layers)
+  bool tiled_decode = false;             // greedy decode GEMMs on the tiled LDS-DMA kernels at every row count (see llm_layers)
   // video
   bool has_video = false, has_audio = false;
   ConvBN stem; ResBlock blocks[8];
@@ -481,7 +481,7 @@ static int resolve_model(oavsr_model* m) {
   const oavsr_config& c = m->cfg;
   m->has_video = m->t.count("v.stem.w") > 0;
   m->has_audio = m->t.count("a.conv1.w") > 0;
-  m->tiled_decode = c.llm_hidden >= 3584;      // Qwen2.5-7B / Llama-3.1-8B widths (llm_layers: the greedy tiled regime)
+  m->tiled_decode = true;      // greedy decode: the tiled regime for every model (llm_layers)      // Qwen2.5-7B / Llama-3.1-8B widths (llm_layers: the greedy tiled regime)
   if (m->has_video) {
     OAVSR_TRY(resolve_convbn(m, "v.stem", true, m->stem));
     const int chans[5] = {64, 64, 128, 256, 512};
@@ -846,7 +846,7 @@ static int build_prompt_impl(const oavsr_model* m, oavsr_workspace* ws, int task
 static constexpr int skinny_max_rows(int beams = 1) { return beams > 1 ? 32 : 64; }
 
 // target: workgroups per launch the split is sized for -- a constant of the regime (part of its summation order): 128 for beam search's
-// > 32-row decode (four decode chains in flight), 256 for the greedy tiled regime of the 7B / 8B models (kDecodeSplitTiled)
+// > 32-row decode (four decode chains in flight), 256 for the greedy tiled regime (kDecodeSplitTiled)
 constexpr int kDecodeSplitBeam = 128, kDecodeSplitTiled = 256;
 static int decode_split(int N, int Ktot, int esz, int target = kDecodeSplitBeam) {
   const int ktiles = Ktot / (128 / esz);
@@ -887,11 +887,13 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
   const int dt = m->dtype, d = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, hd = c.llm_head_dim, I = c.llm_mlp;
   const int nq = H * hd, nqkv = (H + 2 * KV) * hd;
   const int tl = c.lora_task_specific ? task : 0;
-  // Greedy decode of the 7B / 8B models (m->tiled_decode): the tiled LDS-DMA kernels at EVERY row count.  At 33..64 rows they stream the
-  // weights 2 x faster than the weight-streaming kernels, whose workgroups re-read all activation rows through a 36 GB/s register-load
-  // path (Llama-3.1-8B, 57 rows: gate / up 107 -> 53 us, down_proj 86 -> 37, lm_head 390 -> 190); their results do not depend on the row
-  // count either (rows are independent, split factors are functions of N and K), so greedy decode stays batch-independent -- in a
-  // different summation order than the weight-streaming regime, which is why the regime follows the MODEL, never a step's row count.
+  // Greedy decode (m->tiled_decode, every model since the end of round 4): the tiled LDS-DMA kernels at EVERY row count.  At 33..64 rows
+  // they stream the weights 2 x faster than the weight-streaming kernels, whose workgroups re-read all activation rows through a 36 GB/s
+  // register-load path (Llama-3.1-8B, 57 rows: gate / up 107 -> 53 us, down_proj 86 -> 37, lm_head 390 -> 190; Llama-3.2-1B: gate / up
+  // 33 -> 22, down_proj 49 -> 24), a 64-row step costs barely more than a 32-row one (1B: 1.80 vs 1.62 ms), and their results do not
+  // depend on the row count either (rows are independent, split factors are functions of N and K), so greedy decode stays
+  // batch-independent -- in a different summation order than the weight-streaming regime, which is why the regime is a property of the
+  // BUILD, never of a step's row count.  Beam search keeps its two regimes (<= 32 rows: weight-streaming, above: tiled with the beam split).
   const bool tiled = decode && beams == 1 && m->tiled_decode;
   const int mode = !decode ? 0 : (tiled ? 2 : (rows <= skinny_max_rows(beams) ? 1 : 2));
   const bool fused_norm = mode == 1;       // RMSNorm folded into the skinny GEMMs (gain on the A fragments, rstd in the epilogue)

@@ -50,13 +50,12 @@ class OmniEngine:
         self._sched = C.c_void_p(None)   # decode scheduler (continuous batching of the greedy decode across calls); created on first submit
         self._sched_key = None
         self._sched_gen = 0              # tickets carry the generation of the pool they belong to (a pool that had to grow is rebuilt)
-        # rows per decode step (<= 64) / row slots of the pool.  A decode step streams every LLM weight once whatever its row count, so the
-        # 7B / 8B models (14-15 GB per step) run 64-row steps: Llama-3.1-8B 102 -> 118, Qwen2.5-7B 85 -> 94 utt/s (round 4); with the 1B model
-        # the step is a chain of short launches whose 64-row forms cost more than the second step they save (headline 269 -> 264, VSR +3 %)
-        self.sched_rows, self.sched_slots = (64, 256) if spec.llm.hidden >= 3584 else (32, 192)
-        # independent step loops sharing the pool (one loop serves ~380 utt/s).  Round 4, after the encoder side got 15 % faster:
-        # four lanes for the 1B model (headline 277 -> 286, VSR B = 16 527 -> 559 utt/s; five: 269), three for the 7B / 8B models (119 vs 117)
-        self.sched_lanes = 3 if spec.llm.hidden >= 3584 else 4
+        # rows per decode step (<= 64) / row slots of the pool / independent step loops sharing the pool.  Greedy decode runs on the tiled
+        # LDS-DMA GEMMs at every row count (model.hip: llm_layers), where a step streams every LLM weight once and a 64-row step costs barely
+        # more than a 32-row one (Llama-3.2-1B: 1.80 vs 1.62 ms; Llama-3.1-8B: 6.2 ms): 64-row steps, three lanes for every model
+        # (round 4, same box: headline 284 -> 300-312, VSR B = 16 559 -> 653-666, Llama-3.1-8B 120 -> 155-158, Qwen2.5-7B 97 -> 113-115 utt/s)
+        self.sched_rows, self.sched_slots = 64, 256
+        self.sched_lanes = 3
         self.sched_stride = 0                           # steps per admission (0: automatic; oavsr_scheduler_set_stride)
         self._blob = None
         self._names = None

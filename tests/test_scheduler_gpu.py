@@ -121,7 +121,7 @@ def test_more_calls_than_rows_per_step_and_oracle_f32():
     spec = tiny_spec(family="llama", task_specific=True, shared=True)
     sd = synth_state_dict(spec, seed=1234)
     eng = OmniEngine(spec, dtype="f32").load_state_dict(sd)
-    eng.sched_lanes, eng.sched_slots = 1, 64
+    eng.sched_lanes, eng.sched_rows, eng.sched_slots = 1, 32, 64
     orc = O.OmniOracle(sd, spec.oracle_cfg())
     mn = spec.max_dec_tokens
     calls = [clips(8, 20 + i) for i in range(7)]
@@ -145,7 +145,7 @@ def test_two_lanes_share_the_pool(dtype):
     """two step loops (own streams) over one pool of row slots: calls alternate between them; same ids as isolated calls"""
     spec = tiny_spec(family="llama", task_specific=True, shared=True)
     eng = OmniEngine(spec, dtype=dtype).load_state_dict(synth_state_dict(spec, seed=1234))
-    eng.sched_lanes, eng.sched_slots = 2, 40             # a small pool: later calls wait for blocks of the earlier ones
+    eng.sched_lanes, eng.sched_rows, eng.sched_slots = 2, 32, 40             # a small pool: later calls wait for blocks of the earlier ones
     mn = spec.max_dec_tokens
     calls = [clips(8 if i % 3 else 6, 60 + i) for i in range(9)]
     ref = [alone(eng, c, mn, False) for c in calls]
