@@ -192,7 +192,7 @@ def parse_args():
     ap.add_argument("--no-scheduler", action="store_true",
                     help="round-2 mode: every call runs its own decode loop on its own stream (default: the engine's decode scheduler merges the "
                          "decode rows of the calls in flight; greedy only)")
-    ap.add_argument("--sched-rows", type=int, default=None, help="rows per decode step of the engine's scheduler (<= 64; default: the engine's)")
+    ap.add_argument("--sched-rows", type=int, default=None, help="rows per decode step of the engine's scheduler (<= 128; default: the engine's)")
     ap.add_argument("--sched-slots", type=int, default=None, help="row slots of the scheduler's pool (default: the engine's)")
     ap.add_argument("--sched-stride", type=int, default=0, help="steps per admission (0 = automatic)")
     ap.add_argument("--sched-lanes", type=int, default=None, help="independent step loops of the scheduler (default: the engine's: 3)")
@@ -654,7 +654,7 @@ def main():
                                      gbs=round(e["bytes"] / e["ms"] / 1e6, 1) if e["ms"] > 0 else None)
             if avg_us < 20.0:      # an event bracket resolves a launch to about +-2 us: rates of these families are indicative only
                 stages[e["name"]]["short"] = True
-        is_dec = lambda n: n.startswith(("skinny", "decode_attention", "argmax", "sched_", "beam_"))          # noqa: E731
+        is_dec = lambda n: n.startswith(("skinny", "decode_", "argmax", "sched_", "beam_"))          # noqa: E731
         # (the 128 x 64 split-K family is the 33..128-row decode GEMM of beam search: weights streamed once per step, HBM-bound like the skinny kernels)
         is_mfma = lambda e: e["flops"] > 0 and not is_dec(e["name"]) and "logmel" not in e["name"] and "splitk_128x64" not in e["name"]           # noqa: E731
         dom = max((e for e in ents if not is_dec(e["name"])), key=lambda e: e["ms"], default=None) or max(ents, key=lambda e: e["ms"])

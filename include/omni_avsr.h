@@ -152,7 +152,7 @@ int oavsr_generate_chunked(const oavsr_model* m, oavsr_workspace* ws, int32_t ta
  * The reference evaluates one utterance per forward() (eval_OmniAVSR.py:18-24, datamodule/data_module.py:238-242): nothing to mirror,
  * this is the engine's own serving layer under the same per-utterance results.  Calls keep arriving one batch at a time on the caller's
  * streams (encoders + prefill of a call run there, as in oavsr_generate); the decode rows of every submitted call live in row slots of
- * ONE pool per model, and one step loop on the scheduler's own stream serves all admitted rows (up to max_rows <= 64 per step, each row
+ * ONE pool per model, and one step loop on the scheduler's own stream serves all admitted rows (up to max_rows <= 128 per step, each row
  * at its own step), so the LLM weights are streamed once per step for all of them.  Rows join after their call's prefill and leave after
  * their own max_new tokens.  The schedule is fixed by the host at submission time in units of steps -- no host thread, no host
  * synchronisation, no device-side queue -- and the ids of an utterance are bit-identical to oavsr_generate on that utterance alone.

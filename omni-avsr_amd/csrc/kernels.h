@@ -257,11 +257,11 @@ struct SchedState {
   const float* inv_freq = nullptr; int rope_half = 0;
   int out_ld = 0, scratch_slot = 0;
 };
-struct IntPack64 { int v[64]; };
-// dst[i] = v[i], i < n <= 64 (kernel arguments by value: no pinned staging, replay-safe ordering on the stream)
-int launch_set_ints(int* dst, const IntPack64& v, int n, hipStream_t st);
+struct IntPack128 { int v[128]; };
+// dst[i] = v[i], i < n <= 128 (kernel arguments by value: no pinned staging, replay-safe ordering on the stream)
+int launch_set_ints(int* dst, const IntPack128& v, int n, hipStream_t st);
 // a call's rows enter the pool: slot0 + b gets pos = S[b] - 1, cpos = -1, nstep = 0, finished = 0, out_len = 0, out_ids row = pad
-int launch_sched_init_slots(const SchedState& s, int slot0, int B, const IntPack64& S, int limit, int pad, hipStream_t st);
+int launch_sched_init_slots(const SchedState& s, int slot0, int B, const IntPack128& S, int limit, int pad, hipStream_t st);
 // first stage of the two-stage arg-max only (partials [rows][64] {value, index}); any V
 int launch_argmax_partial(const float* logits, int64_t ld, int rows, int V, int banned, void* partials, hipStream_t st);
 // One launch for the tail of a decode step, one workgroup per row: final arg-max over the row's partials -> HF greedy bookkeeping of

@@ -123,7 +123,9 @@ static const char* gemm_family(const GemmArgs& a, bool skinny) {
   const char* tile = (a.ksplit > 1 && !gemm_dma_eligible(a)) ? "splitk_128x128" : gemm_dma_eligible(a) ? gemm_dma_variant(a) : (a.N <= 64 ? "128x64" : "128x128");
   static const bool shapes = knob("OAVSR_PROF_SHAPES") != 0;      // developer aid: one family per GEMM shape
   if (shapes) { snprintf(buf, sizeof(buf), "%c%s %dx%dx%d", mode[0], tile, a.M, a.N, a.K + a.K2); buf[31] = 0; return buf; }
-  snprintf(buf, sizeof(buf), "%s_%s_%s", mode, tile, dt);
+  // greedy decode GEMMs of the tiled regime: a family of their own ("decode_..."), so that bench.py keeps the decode side apart from the
+  // encoder / prefill GEMMs that run on the same kernels
+  snprintf(buf, sizeof(buf), "%s%s_%s_%s", a.decode_tiled ? "decode_" : "", mode, tile, dt);
   return buf;
 }
 
@@ -904,7 +906,7 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
   for (int li = 0; li < c.llm_layers; ++li) {
     const LlmLayer& L = m->llayers[li];
     const bool prune = can_prune && li == c.llm_layers - 1;
-    if (!fused_norm && !have_h) { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
+    if (!fused_norm && !have_h) { ProfScope ps(decode ? "decode_rmsnorm" : "rmsnorm", 0, 2.0 * rows * d * m->esz, st);
       OAVSR_TRY(launch_rmsnorm(dt, ws->lx, d, ws->lh, d, L.ln1w, rows, d, c.llm_rms_eps, st)); }
     have_h = false;
     const void* hin = fused_norm ? ws->lx : ws->lh;
@@ -985,7 +987,7 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
           OAVSR_TRY(run_gemm(g, st, true));
         }
       } else {
-        if (!h2) { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
+        if (!h2) { ProfScope ps(decode ? "decode_rmsnorm" : "rmsnorm", 0, 2.0 * rows * d * m->esz, st);
           OAVSR_TRY(launch_rmsnorm(dt, ws->lx, d, ws->lh, d, L.ln2w, rows, d, c.llm_rms_eps, st)); }
         g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 2 * I; g.K = d; g.A = ws->lh; g.lda = d; g.W = L.guw; g.ldw = d; g.C = ws->lgu; g.ldc = 2 * I;
         GemmArgs gf = g; gf.swiglu_pairs = 1; gf.C = ws->lact; gf.ldc = I;
@@ -997,7 +999,7 @@ static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int r
           OAVSR_TRY(run_gemm(gf, st, false));
         } else {
           OAVSR_TRY(llm_gemm(m, ws, g, mode, st, nullptr, nullptr, tiled));
-          ProfScope ps("swiglu", 0, 3.0 * rows * I * m->esz, st);
+          ProfScope ps(decode ? "decode_swiglu" : "swiglu", 0, 3.0 * rows * I * m->esz, st);
           OAVSR_TRY(launch_swiglu(dt, ws->lgu, 2 * I, ws->lact, I, rows, I, 1, st));
         }
       }
@@ -1038,7 +1040,7 @@ static int lm_head_rows(const oavsr_model* m, oavsr_workspace* ws, const void* x
     }
     return 0;
   }
-  if (!normed) { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
+  if (!normed) { ProfScope ps("decode_rmsnorm", 0, 2.0 * rows * d * m->esz, st);
     OAVSR_TRY(launch_rmsnorm(m->dtype, x, d, ws->lh, d, m->norm_w, rows, d, c.llm_rms_eps, st)); }
   g.A = ws->lh; g.lda = d;
   return run_gemm(g, st, false);
@@ -1595,11 +1597,11 @@ static int sched_one_step(oavsr_scheduler* s, SchedLane& l, int R, int task, int
 static int sched_sync_membership(oavsr_scheduler* s, SchedLane& l) {
   if (!l.map_dirty) return 0;
   const oavsr_config& c = s->m->cfg;
-  IntPack64 map;
+  IntPack128 map;
   int r = 0;
   for (int i : l.active) { const SchedCall& k = s->ring[i]; for (int b = 0; b < k.B; ++b) map.v[r++] = k.slot0 + b; }
   const int R = std::max(8, (r + 7) / 8 * 8);
-  OAVSR_REQUIRE(R <= 64, "scheduler: %d rows in the step", r);
+  OAVSR_REQUIRE(R <= 128, "scheduler: %d rows in the step", r);
   for (; r < R; ++r) map.v[r] = s->n_slots;
   OAVSR_TRY(launch_set_ints(l.rowmap, map, R, l.st));
   OAVSR_TRY(launch_sched_embed(s->ss, l.rowmap, R, s->m->dtype, s->m->embed, c.llm_hidden, l.dws->lx, c.llm_hidden, c.llm_hidden, l.st));
@@ -1679,14 +1681,14 @@ static int sched_alloc(oavsr_scheduler* s, int B) {
 int oavsr_scheduler_create(const oavsr_model* m, int32_t n_slots, int32_t max_rows, int32_t lanes, int32_t max_prefix, int32_t max_new,
                            oavsr_scheduler** out) {
   OAVSR_REQUIRE(m && out, "scheduler_create: null argument");
-  OAVSR_REQUIRE(max_rows >= 1 && max_rows <= 64, "scheduler_create: max_rows=%d (the weight-streaming decode kernels serve up to 64 rows per step)", max_rows);
+  OAVSR_REQUIRE(max_rows >= 1 && max_rows <= 128, "scheduler_create: max_rows=%d (a decode step is one 128-row tile of the tiled GEMMs at most)", max_rows);
   OAVSR_REQUIRE(lanes >= 1 && lanes <= 8, "scheduler_create: lanes=%d", lanes);
   OAVSR_REQUIRE(n_slots >= max_rows && n_slots <= 4096 && max_prefix >= 1 && max_new >= 1, "scheduler_create: bad sizes (n_slots >= max_rows)");
   const oavsr_config& c = m->cfg;
   oavsr_scheduler* s = new oavsr_scheduler();
   s->m = m; s->n_slots = n_slots; s->max_rows = max_rows; s->max_prefix = (max_prefix + 63) / 64 * 64; s->max_new = max_new;
   s->lanes.resize(lanes);
-  const size_t e = m->esz, NS = (size_t)n_slots + 1, R = max_rows > 32 ? 64 : 32;
+  const size_t e = m->esz, NS = (size_t)n_slots + 1, R = max_rows > 64 ? 128 : (max_rows > 32 ? 64 : 32);
   const int d = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, hd = c.llm_head_dim, I = c.llm_mlp;
   const size_t nqkv = (size_t)(H + 2 * KV) * hd;
   oavsr_workspace* w = new oavsr_workspace();
@@ -1709,7 +1711,7 @@ int oavsr_scheduler_create(const oavsr_model* m, int32_t n_slots, int32_t max_ro
     oavsr_workspace* lw = l.dws;
     WANT(lw->lx, R * d * e); WANT(lw->lh, R * d * e); WANT(lw->lqkv, R * nqkv * e); WANT(lw->lattn, R * (size_t)H * hd * e);
     WANT(lw->lact, R * (size_t)I * e); WANT(lw->llora, R * (size_t)std::max(64, c.lora_k2) * e); WANT(lw->logits, R * (size_t)c.llm_vocab * 4);
-    WANT(l.partials, R * 64 * 8); WANT(l.rowmap, 64 * 4);
+    WANT(l.partials, R * 64 * 8); WANT(l.rowmap, 128 * 4);
     if (m->tiled_decode) {   // the tiled regime's split-K slabs and (when SwiGLU is not fused) the [rows][2I] gate / up tensor
       const int sites[5][2] = {{c.lora_k2, d}, {(int)nqkv, d + c.lora_k2}, {d, H * hd}, {2 * I, d}, {d, I}};
       size_t pb = 0;
@@ -1874,7 +1876,7 @@ int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_worksp
     if (stride > issued) OAVSR_TRY(sched_run(s, l, stride - issued));
     // after the call's prefill; first token from the prefill's logits (step 0 of the row's own counter)
     OAVSR_CHECK_HIP(hipStreamWaitEvent(l.st, k.prefilled, 0));
-    IntPack64 Sp;
+    IntPack128 Sp;
     for (int b = 0; b < B; ++b) Sp.v[b] = S[b];
     OAVSR_TRY(launch_sched_init_slots(s->ss, slot0, B, Sp, max_new, c.id_pad, l.st));
     OAVSR_TRY(launch_argmax_partial(s->logits_pre + (size_t)slot0 * c.llm_vocab, c.llm_vocab, B, c.llm_vocab, banned, l.partials, l.st));

@@ -422,11 +422,11 @@ __global__ void greedy_update_kernel(const int* __restrict__ amax, GreedyState s
 }
 
 // ---- decode scheduler (kernels.h: SchedState) ------------------------------------------------------------------------------
-__global__ void set_ints_kernel(int* __restrict__ dst, IntPack64 v, int n) {
+__global__ void set_ints_kernel(int* __restrict__ dst, IntPack128 v, int n) {
   if ((int)threadIdx.x < n) dst[threadIdx.x] = v.v[threadIdx.x];
 }
 
-__global__ void sched_init_slots_kernel(SchedState s, int slot0, int B, IntPack64 S, int limit, int pad) {
+__global__ void sched_init_slots_kernel(SchedState s, int slot0, int B, IntPack128 S, int limit, int pad) {
   const int b = blockIdx.x;
   if (b >= B) return;
   const int slot = slot0 + b;
@@ -626,15 +626,15 @@ int launch_argmax_partial(const float* logits, int64_t ld, int rows, int V, int 
   return 0;
 }
 
-int launch_set_ints(int* dst, const IntPack64& v, int n, hipStream_t st) {
-  OAVSR_REQUIRE(n >= 0 && n <= 64, "set_ints: n=%d", n);
+int launch_set_ints(int* dst, const IntPack128& v, int n, hipStream_t st) {
+  OAVSR_REQUIRE(n >= 0 && n <= 128, "set_ints: n=%d", n);
   if (n == 0) return 0;
-  hipLaunchKernelGGL(set_ints_kernel, dim3(1), dim3(64), 0, st, dst, v, n);
+  hipLaunchKernelGGL(set_ints_kernel, dim3(1), dim3(128), 0, st, dst, v, n);
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
-int launch_sched_init_slots(const SchedState& s, int slot0, int B, const IntPack64& S, int limit, int pad, hipStream_t st) {
+int launch_sched_init_slots(const SchedState& s, int slot0, int B, const IntPack128& S, int limit, int pad, hipStream_t st) {
   OAVSR_REQUIRE(B >= 1 && B <= 64, "sched_init_slots: B=%d", B);
   hipLaunchKernelGGL(sched_init_slots_kernel, dim3(B), dim3(64), 0, st, s, slot0, B, S, limit, pad);
   OAVSR_CHECK_HIP(hipGetLastError());

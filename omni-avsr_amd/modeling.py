@@ -50,11 +50,12 @@ class OmniEngine:
         self._sched = C.c_void_p(None)   # decode scheduler (continuous batching of the greedy decode across calls); created on first submit
         self._sched_key = None
         self._sched_gen = 0              # tickets carry the generation of the pool they belong to (a pool that had to grow is rebuilt)
-        # rows per decode step (<= 64) / row slots of the pool / independent step loops sharing the pool.  Greedy decode runs on the tiled
-        # LDS-DMA GEMMs at every row count (model.hip: llm_layers), where a step streams every LLM weight once and a 64-row step costs barely
-        # more than a 32-row one (Llama-3.2-1B: 1.80 vs 1.62 ms; Llama-3.1-8B: 6.2 ms): 64-row steps, three lanes for every model
-        # (round 4, same box: headline 284 -> 300-312, VSR B = 16 559 -> 653-666, Llama-3.1-8B 120 -> 155-158, Qwen2.5-7B 97 -> 113-115 utt/s)
-        self.sched_rows, self.sched_slots = 64, 256
+        # rows per decode step (<= 128) / row slots of the pool / independent step loops sharing the pool.  Greedy decode runs on the tiled
+        # LDS-DMA GEMMs at every row count (model.hip: llm_layers): a step is ONE 128-row tile whatever its row count and streams every LLM
+        # weight once, so the more rows share it the better -- 128-row steps, three lanes, for every model (round 4, same boxes, against the
+        # weight-streaming kernels' best shapes: headline 284 -> 300-312, VSR B = 16 559 -> 713-733, Llama-3.1-8B 120 -> 156-161,
+        # Qwen2.5-7B 97 -> 113-118 utt/s; 64-row steps: VSR 653-666, Llama-3.1-8B 155-158)
+        self.sched_rows, self.sched_slots = 128, 512
         self.sched_lanes = 3
         self.sched_stride = 0                           # steps per admission (0: automatic; oavsr_scheduler_set_stride)
         self._blob = None

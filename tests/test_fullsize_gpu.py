@@ -186,11 +186,11 @@ def test_fullsize_scheduler_equals_separate_calls(bf16_engine):
 
 def test_headline_configuration_returns_the_ids_of_isolated_calls(bf16_engine):
     """bench.py's headline configuration as a test (BASELINE.json configs[1]): batches of 8 x 16 s clips, 32 greedy tokens with EOS
-    suppressed, the decode scheduler at its DEFAULT shape (3 lanes x 64 rows, 256 slots), calls submitted back to back on three of the
+    suppressed, the decode scheduler at its DEFAULT shape (3 lanes x 128 rows, 512 slots), calls submitted back to back on three of the
     engine's caller streams, four input sets rotating -- 28 calls, and every one of them must return exactly the ids of ONE isolated
     oavsr_generate of its input set (what bench.py itself verifies after its timed region before it prints a line)."""
     eng = bf16_engine
-    assert (eng.sched_lanes, eng.sched_rows, eng.sched_slots) == (3, 64, 256), "this case pins the engine's default scheduler shape"
+    assert (eng.sched_lanes, eng.sched_rows, eng.sched_slots) == (3, 128, 512), "this case pins the engine's default scheduler shape"
     B, Tv = 8, 400
     sets = []
     for s_ in range(4):
