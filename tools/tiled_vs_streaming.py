@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""scratch: 33..64-row decode GEMMs of the 7B/8B widths: weight-streaming kernels (shared-chip forms) vs the tiled LDS-DMA GEMM."""
+"""Decode GEMMs at the scheduler's row counts, 1B and 7B / 8B widths: the weight-streaming kernels (shared-chip forms) against the tiled
+LDS-DMA GEMM (un-split and split 2 / 4), weight copies rotating beyond the Infinity Cache.  What made greedy decode move to the tiled regime
+(DESIGN.md section 5)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
