@@ -19,7 +19,7 @@ headline).  Weights are seeded random tensors of the real architecture (no check
 fp32 accumulate (the reference evaluates in bf16-true, eval_OmniAVSR.py:19).
 
 Every call is one batch of B utterances, submitted on one of `--streams` caller streams (`oavsr_generate_submit`: encoders +
-prefill there); the ENGINE's decode scheduler serves the decode rows of the calls in flight from its own step loops (up to 32 rows
+prefill there); the ENGINE's decode scheduler serves the decode rows of the calls in flight from its own step loops (up to 128 rows
 per weight pass, `--sched-*`), nothing is grouped on the caller's side.  The timed region ends with the scheduler's flush and a device
 synchronisation: every hypothesis of every timed call is complete inside it.  `--no-scheduler`: one decode loop per call (round 2).
 
@@ -195,7 +195,7 @@ def parse_args():
     ap.add_argument("--sched-rows", type=int, default=None, help="rows per decode step of the engine's scheduler (<= 128; default: the engine's)")
     ap.add_argument("--sched-slots", type=int, default=None, help="row slots of the scheduler's pool (default: the engine's)")
     ap.add_argument("--sched-stride", type=int, default=0, help="steps per admission (0 = automatic)")
-    ap.add_argument("--sched-lanes", type=int, default=None, help="independent step loops of the scheduler (default: the engine's: 3)")
+    ap.add_argument("--sched-lanes", type=int, default=None, help="independent step loops of the scheduler (default: the engine's)")
     ap.add_argument("--no-stagger", action="store_true", help="let the encoder phases of in-flight batches share the chip (default: chained)")
     ap.add_argument("--testset", type=int, default=0,
                     help="N > 0: the test-set-shaped run instead of the step loop (BASELINE.json configs[4] / SURVEY.md 8d C5: N synthetic utterances, "
@@ -654,9 +654,8 @@ def main():
                                      gbs=round(e["bytes"] / e["ms"] / 1e6, 1) if e["ms"] > 0 else None)
             if avg_us < 20.0:      # an event bracket resolves a launch to about +-2 us: rates of these families are indicative only
                 stages[e["name"]]["short"] = True
-        is_dec = lambda n: n.startswith(("skinny", "decode_", "argmax", "sched_", "beam_"))          # noqa: E731
-        # (the 128 x 64 split-K family is the 33..128-row decode GEMM of beam search: weights streamed once per step, HBM-bound like the skinny kernels)
-        is_mfma = lambda e: e["flops"] > 0 and not is_dec(e["name"]) and "logmel" not in e["name"] and "splitk_128x64" not in e["name"]           # noqa: E731
+        is_dec = lambda n: n.startswith(("decode_", "argmax", "sched_", "beam_"))          # noqa: E731   (decode-shaped launches: HBM-bound, weights streamed once per step)
+        is_mfma = lambda e: e["flops"] > 0 and not is_dec(e["name"]) and "logmel" not in e["name"]           # noqa: E731
         dom = max((e for e in ents if not is_dec(e["name"])), key=lambda e: e["ms"], default=None) or max(ents, key=lambda e: e["ms"])
         traffic = pmc_traffic(dom["name"])
         if is_mfma(dom):

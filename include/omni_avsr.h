@@ -21,8 +21,11 @@ extern "C" {
 #endif
 
 /* 2 (round 4): oavsr_op_stem_pool takes the pixel format (three ints after `video`), oavsr_gemm_desc gained `grid`, the decode scheduler entry
- * points (oavsr_scheduler_*, oavsr_generate_submit / _wait / _poll) and oavsr_trace_rec were added.  A binding built against version 1 must not load. */
-#define OAVSR_ABI_VERSION 2
+ * points (oavsr_scheduler_*, oavsr_generate_submit / _wait / _poll) and oavsr_trace_rec were added.
+ * 3 (round 5): oavsr_gemm_desc follows the single decode regime (weight-streaming decode kernels removed: no `skinny` / norm_gain / rn_* /
+ * shared_chip; `kernel`, decode_tiled, sync, row_scale, ng_* added); oavsr_generate / _submit take optional per-utterance digest buffers.
+ * A binding built against an older version must not load. */
+#define OAVSR_ABI_VERSION 3
 #define OAVSR_DT_F32 0  /* parity mode: exact-f32 MFMA */
 #define OAVSR_DT_BF16 1 /* throughput mode: bf16 storage, f32 accumulate (reference: bf16-true, eval_OmniAVSR.py:19) */
 #define OAVSR_MAX_RATES 8
@@ -97,6 +100,12 @@ uint64_t oavsr_workspace_bytes(const oavsr_workspace* ws);
  * the host code's order (same bits), so a 16 s clip is uploaded as 3.7 MB (gray) / 11 MB (RGB 96 x 96) instead of 12.4 MB of floats and
  * the host does no per-pixel work. */
 int oavsr_workspace_set_video_format(oavsr_workspace* ws, int32_t channels, int32_t height, int32_t width);
+/* Input-sensitivity digests (tests / benchmarks: does a call under a pipelined schedule see ITS inputs and ITS cache rows?).  digests_dev:
+ * device array of max_B x 2 uint64, or NULL (default: off).  Every later oavsr_prefill / oavsr_generate / oavsr_generate_chunked /
+ * oavsr_generate_submit on this workspace writes, on the call's stream, for utterance b of the call: [2b] = digest of its inputs_embeds
+ * rows (the spliced prompt, modeling_OmniAVSR.py:397-458, as stored in the compute dtype), [2b + 1] = digest of its first-step logits row
+ * (fp32, the prefill's last position).  Digest of 32-bit words w_0..w_{n-1}: sum_i splitmix64_finalizer(w_i | (i + 1) << 32) mod 2^64. */
+int oavsr_workspace_set_digests(oavsr_workspace* ws, uint64_t* digests_dev);
 
 /* ---- stage entry points (each replaces the reference function cited) ------------------------------------ */
 
@@ -240,24 +249,30 @@ typedef struct oavsr_gemm_desc {
   const int32_t* rowinfo; /* int4 per output row */
   int32_t taps, Kvalid;
   const int32_t* frameinfo; /* int2 per frame */
-  int32_t skinny;           /* kernel selector: 0 dispatcher's choice, 1 decode kernel (M <= 128); parity tests only: 2 ping-pong 256 x 256,
-                               3 persistent ping-pong, 5 16-wave 256 x 256, 6 160 x 128, 7 256 x 128 */
-  /* skinny only: fused RMSNorm prologue (y = rstd * ((x*gain) W^T) + seg2) and SwiGLU epilogue (16-row interleaved gate/up) */
-  const float* norm_gain;
-  float norm_eps;
-  int32_t swiglu_pairs;
-  /* classic kernel only: split-K with fp32 partial slabs [ksplit][M][N] and a deterministic reduce + epilogue pass */
+  int32_t kernel;           /* kernel selector: 0 dispatcher's choice; parity tests only: 2 ping-pong 256 x 256, 3 persistent ping-pong,
+                               5 16-wave 256 x 256, 6 160 x 128, 7 256 x 128 */
+  int32_t swiglu_pairs;     /* fused SwiGLU epilogue (gate / up weight rows interleaved by 16) */
+  int32_t decode_tiled;     /* 1: decode-shaped launch (M <= 128): the 128-row LDS-DMA tiles at any row count */
+  /* decode-shaped launches (M <= 128): split-K with fp32 partial slabs [ksplit][M][N], summed in slab order by the tile's last-arriving
+     workgroup INSIDE the launch; `sync`: OAVSR_GEMM_SYNC_INTS zeroed ints (arrival counters; they are zero again when the launch ends) */
   int32_t ksplit;
   float* partial;
-  /* split-K only (optional): the reduce pass also writes RMSNorm(C row) * rn_gain to rn_out (row stride rn_ld) -- the consumer's
-     normalised input, Llama_LoRA.py:618-640 (residual add, then the next RMSNorm).  Plain epilogue (no activation, C in `dtype`). */
-  void* rn_out;
-  int64_t rn_ld;
-  const float* rn_gain;
-  float rn_eps;
+  int32_t* sync;
+  /* per-row multiplier of the accumulator, before col_scale / col_bias: the decode path's deferred RMSNorm (Llama_LoRA.py:587-655 computes
+     norm(x) W^T = row_scale[m] * ((x * gain) W^T) with row_scale = 1 / rms(x)) */
+  const float* row_scale;
+  /* split-K only (optional): "next norm" outputs for the consumer of the residual stream C = x (plain epilogue, C in `dtype`, N a multiple
+     of 64): ng_out[m][n] = T(x[m][n] * ng_gain[n]) (row stride ng_ld), ng_rstd[m] = rsqrt(mean_n x[m][n]^2 + ng_eps); ng_rowsq: scratch
+     of ceil(N / 64) * M floats */
+  void* ng_out;
+  int64_t ng_ld;
+  const float* ng_gain;
+  float* ng_rowsq;
+  float* ng_rstd;
+  float ng_eps;
   int32_t grid;        /* persistent kernel only: workgroups (multiple of 8); 0 = the launcher's rule */
-  int32_t shared_chip; /* decode kernel only: 1 = the forms the decode scheduler's steps run (fewer, wider workgroups); same bits */
 } oavsr_gemm_desc;
+#define OAVSR_GEMM_SYNC_INTS (4096 + 64)
 int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream);
 
 typedef struct oavsr_attn_desc {
@@ -288,6 +303,10 @@ int oavsr_op_decode_attention(const oavsr_decode_attn_desc* d, oavsr_stream stre
 /* mode: 0 LayerNorm, 1 RMSNorm, 2 LayerNorm over [zeros(D), x] */
 int oavsr_op_norm(int32_t mode, int32_t dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, const float* b,
                   int32_t rows, int32_t D, float eps, oavsr_stream stream);
+/* Deferred RMSNorm of the decode path (Llama_LoRA.py:587-655 input_layernorm / post_attention_layernorm / model.norm): y = T(x * w),
+ * rstd[row] = rsqrt(mean(x[row]^2) + eps); the consumer GEMM takes y as A and rstd as oavsr_gemm_desc.row_scale. */
+int oavsr_op_rms_prep(int32_t dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, float* rstd, int32_t rows, int32_t D,
+                      float eps, oavsr_stream stream);
 /* Fused visual stem: Conv3d(1->64, k (5,7,7), s (1,2,2), p (2,3,3)) + folded BN + PReLU + MaxPool3d((1,3,3), s (1,2,2), p (0,1,1))
  * (reference resnet.py:137-141).  video: f32 [F][88][88] (channels = 0) or uint8 [F][channels][height][width] with the test-time
  * transform fused (oavsr_workspace_set_video_format); frameinfo int32 pairs {t, len} per frame; w [64][256] in the model

@@ -190,18 +190,11 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(const GemmArgs p) {
     for (int j = 0; j < NB; ++j) *reinterpret_cast<Chunk16*>(s + b_lds[j]) = rb[j];
   };
 
-  // split-K (ksplit > 1): blockIdx.y owns k-tiles [t0, t1) and writes raw fp32 partial sums; splitk_reduce_kernel finishes
-  int t0 = 0, t1 = ntot;
-  if (p.ksplit > 1) {
-    const int per = (ntot + p.ksplit - 1) / p.ksplit;
-    t0 = blockIdx.y * per; t1 = t0 + per < ntot ? t0 + per : ntot;
-  }
+  const int t0 = 0, t1 = ntot;      // (split-K lives in the LDS-DMA kernels only, gemm2.hip)
   const int frow = lane & 15, fg = lane >> 4;
-  if (t0 < t1) {
   gload(t0);
   swrite(0);
   __syncthreads();
-  }
   for (int t = t0; t < t1; ++t) {
     const int cur = (t - t0) & 1;
     if (t + 1 < t1) gload(t + 1);
@@ -231,22 +224,6 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(const GemmArgs p) {
   }
 
   // ---- epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = 4*(lane>>4) + reg -------------
-  if (p.ksplit > 1) {
-    float* P = p.partial + (int64_t)blockIdx.y * p.M * p.N;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * (TN * 16) + j * 16 + frow;
-      if (n >= p.N) continue;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = m0 + wm * (TM * 16) + i * 16 + fg * 4 + r;
-          if (m < p.M) P[(int64_t)m * p.N + n] = acc[i][j][r];
-        }
-    }
-    return;
-  }
   const T* R = reinterpret_cast<const T*>(p.residual);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -262,7 +239,7 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(const GemmArgs p) {
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm * (TM * 16) + i * 16 + fg * 4 + r;
         if (m >= p.M) continue;
-        float y = fmaf(acc[i][j][r], sc, bi);
+        float y = fmaf(p.row_scale ? acc[i][j][r] * p.row_scale[m] : acc[i][j][r], sc, bi);
         float res = R ? to_f32(R[(int64_t)m * p.ldr + ng]) : 0.f;
         if (!p.res_after_act) y += res;
         switch (p.act) {
@@ -291,92 +268,11 @@ int launch_one(const GemmArgs& a, hipStream_t st) {
   }
   int64_t nblk = (int64_t)ceil_div(a.M, BM) * ceil_div(a.N, BN);
   OAVSR_REQUIRE(nblk < (1ll << 31), "gemm: grid too large");
-  dim3 grid((unsigned)nblk, a.ksplit > 1 ? a.ksplit : 1, a.groups);
+  dim3 grid((unsigned)nblk, 1, a.groups);
   hipLaunchKernelGGL(kern, grid, dim3(kThreads), smem, st, a);
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;
 }
-
-template <typename T>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
-  const int64_t total = (int64_t)p.M * p.N;
-  const T* R = reinterpret_cast<const T*>(p.residual);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int m = (int)(i / p.N), n = (int)(i - (int64_t)m * p.N);
-    float y = 0.f;
-    for (int s = 0; s < p.ksplit; ++s) y += p.partial[(int64_t)s * total + i];     // fixed order: deterministic
-    y = fmaf(y, p.col_scale ? p.col_scale[n] : 1.f, p.col_bias ? p.col_bias[n] : 0.f);
-    float res = R ? to_f32(R[(int64_t)m * p.ldr + n]) : 0.f;
-    if (!p.res_after_act) y += res;
-    switch (p.act) {
-      case ACT_GELU: y = gelu_act<T>(y); break;
-      case ACT_RELU: y = fmaxf(y, 0.f); break;
-      case ACT_PRELU: y = y >= 0.f ? y : p.prelu[n] * y; break;
-      case ACT_SILU: y = silu(y); break;
-      default: break;
-    }
-    if (p.res_after_act) y += res;
-    if (p.out_f32) reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n] = y;
-    else reinterpret_cast<T*>(p.C)[(int64_t)m * p.ldc + n] = from_f32<T>(y);
-  }
-}
-
-// Split-K reduce + epilogue + RMSNorm of the finished row, one workgroup per row (beam-search decode: o_proj -> ln2, down_proj -> the next
-// layer's ln1 / the final norm).  The slab sum and the epilogue are splitk_reduce_kernel's expressions in the same order (same C bits);
-// the norm reads the values as rounded to T, like the separate rmsnorm kernel that this replaces would have read them from memory
-// (Llama_LoRA.py:618-640: residual add, then the next RMSNorm).  Sum of squares: per thread in column order, wave_sum, the 4 wave
-// partials in wave order -- fixed, so deterministic and independent of the row count.
-template <typename T>
-__global__ __launch_bounds__(256) void splitk_reduce_rmsnorm_kernel(const GemmArgs p) {
-  constexpr int VEC = TypeInfo<T>::kVec;
-  __shared__ float wsum[4];
-  const int m = blockIdx.x, tid = threadIdx.x;
-  const int64_t total = (int64_t)p.M * p.N;
-  const T* R = reinterpret_cast<const T*>(p.residual);
-  T* Cr = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc;
-  float ss = 0.f;
-  for (int c = tid * VEC; c < p.N; c += 256 * VEC) {
-    float y[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) y[e] = 0.f;
-    const float* ps = p.partial + (int64_t)m * p.N + c;
-    for (int s = 0; s < p.ksplit; ++s) {
-#pragma unroll
-      for (int e = 0; e < VEC; e += 4) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(ps + (int64_t)s * total + e);
-        y[e] += v[0]; y[e + 1] += v[1]; y[e + 2] += v[2]; y[e + 3] += v[3];
-      }
-    }
-    float res[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) res[e] = 0.f;
-    if (R) chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(R + (int64_t)m * p.ldr + c), res);
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      y[e] = fmaf(y[e], p.col_scale ? p.col_scale[c + e] : 1.f, p.col_bias ? p.col_bias[c + e] : 0.f);
-      y[e] += res[e];
-    }
-    const Chunk16 out = chunk_from_f32<T>(y);
-    *reinterpret_cast<Chunk16*>(Cr + c) = out;
-    chunk_to_f32<T>(out, y);
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) ss += y[e] * y[e];
-  }
-  ss = wave_sum(ss);
-  if ((tid & 63) == 0) wsum[tid >> 6] = ss;
-  __syncthreads();
-  const float tot = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
-  const float rstd = rsqrtf(tot / (float)p.N + p.rn_eps);
-  T* Yr = reinterpret_cast<T*>(p.rn_out) + (int64_t)m * p.rn_ld;
-  for (int c = tid * VEC; c < p.N; c += 256 * VEC) {
-    float x[VEC], o[VEC];
-    chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(Cr + c), x);     // this thread's own stores
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) o[e] = p.rn_gain[c + e] * (x[e] * rstd);
-    *reinterpret_cast<Chunk16*>(Yr + c) = chunk_from_f32<T>(o);
-  }
-}
-
 
 template <typename T, int AMODE>
 int launch_tile(const GemmArgs& a, hipStream_t st) {
@@ -398,13 +294,6 @@ int launch_mode(const GemmArgs& a, hipStream_t st) {
 
 }  // namespace
 
-bool splitk_rmsnorm_ok(const GemmArgs& a) {
-  const int vec = a.dtype == DT_F32 ? 4 : 8;
-  return a.ksplit > 1 && a.rn_out && a.rn_gain && !a.out_f32 && a.act == ACT_NONE && a.N % vec == 0 && a.ldc % vec == 0 && a.rn_ld % vec == 0 &&
-         (!a.residual || a.ldr % vec == 0) && ((uintptr_t)a.C & 15) == 0 && ((uintptr_t)a.rn_out & 15) == 0 && ((uintptr_t)a.partial & 15) == 0 &&
-         (!a.residual || ((uintptr_t)a.residual & 15) == 0);
-}
-
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0) return 0;
   const int esz = a.dtype == DT_F32 ? 4 : 2;
@@ -425,22 +314,21 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   if (a.amode == A_STEM) OAVSR_REQUIRE(a.frameinfo && a.K == 256 && a.M % 1936 == 0, "gemm/stem: bad geometry");
   OAVSR_REQUIRE(a.act != ACT_PRELU || a.prelu, "gemm: PReLU needs slopes");
   if (a.ksplit > 1) {
-    OAVSR_REQUIRE(a.partial && a.groups == 1 && a.amode == A_DENSE, "gemm: split-K needs a partial buffer, dense A, no groups");
-    if (gemm_dma_eligible(a)) OAVSR_TRY(launch_gemm_dma(a, st));   // same k order as the classic kernel
-    else OAVSR_TRY(a.dtype == DT_F32 ? launch_mode<float>(a, st) : launch_mode<bf16_t>(a, st));
-    if (a.rn_out) {
-      OAVSR_REQUIRE(splitk_rmsnorm_ok(a), "gemm: split-K reduce + RMSNorm needs a plain bf16 / f32 epilogue on 16-byte rows");
-      if (a.dtype == DT_F32) hipLaunchKernelGGL(splitk_reduce_rmsnorm_kernel<float>, dim3(a.M), dim3(256), 0, st, a);
-      else hipLaunchKernelGGL(splitk_reduce_rmsnorm_kernel<bf16_t>, dim3(a.M), dim3(256), 0, st, a);
-      OAVSR_CHECK_HIP(hipGetLastError());
-      return 0;
+    // split-K: the 128 x 64 LDS-DMA tile only, with the reduce inside the launch (gemm2.hip) -- the decode-shaped GEMMs, <= 128 rows per launch
+    const int vec_t = a.dtype == DT_F32 ? 4 : 8;
+    OAVSR_REQUIRE(a.partial && a.sync && a.groups == 1 && a.amode == A_DENSE && !a.swiglu_pairs, "gemm: split-K needs slabs, arrival counters, dense A, no groups");
+    OAVSR_REQUIRE(a.M <= 128 && a.N >= 64, "gemm: split-K serves decode-shaped launches (M <= 128, N >= 64), got %d x %d", a.M, a.N);
+    OAVSR_REQUIRE(a.N % 16 == 0 && ((uintptr_t)a.partial & 15) == 0 && ((uintptr_t)a.C & 15) == 0 && a.ldc % (a.out_f32 ? 4 : vec_t) == 0 &&
+                  (!a.residual || (a.ldr % vec_t == 0 && ((uintptr_t)a.residual & 15) == 0)), "gemm: split-K reduce needs N %% 16 == 0 and 16-byte rows");
+    const int bn = 64;
+    const int64_t ntm = 1, ntn = ceil_div(a.N, bn);
+    OAVSR_REQUIRE(ntm * ntn <= kSyncTiles && ntm <= kSyncMTiles, "gemm: split-K launch of %lld x %lld tiles exceeds the arrival counters", (long long)ntm, (long long)ntn);
+    OAVSR_REQUIRE((int64_t)a.ksplit * a.M * a.N * 4 < (1ll << 31), "gemm: split-K slabs exceed 2 GiB");
+    if (a.ng_out) {
+      OAVSR_REQUIRE(a.ng_gain && a.ng_rowsq && a.ng_rstd && !a.out_f32 && a.act == ACT_NONE && a.N % bn == 0 && a.ng_ld % vec_t == 0 && ((uintptr_t)a.ng_out & 15) == 0,
+                    "gemm: next-norm outputs need a plain epilogue, whole column tiles and 16-byte rows");
     }
-    int64_t total = (int64_t)a.M * a.N;
-    int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    if (a.dtype == DT_F32) hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, a);
-    OAVSR_CHECK_HIP(hipGetLastError());
-    return 0;
+    return launch_gemm_dma(a, st);
   }
   if (a.swiglu_pairs) OAVSR_REQUIRE(gemm_dma_swiglu_ok(a), "gemm: fused SwiGLU epilogue unavailable for this shape (check gemm_dma_swiglu_ok)");
   if (gemm_dma_eligible(a)) return launch_gemm_dma(a, st);

@@ -93,6 +93,20 @@ __device__ __forceinline__ const void* a_src_tap(const GemmArgs& p, const ARow2&
   return A + (r.base + d) * p.lda + (int64_t)g * p.a_goff + c;
 }
 
+// ---- hand-off between workgroups of ONE launch (the split-K reduce below).  MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement &
+// inter-workgroup visibility", first row of the table of measured forms: every byte stored write-through (sc1), every storing wave drains
+// its stores, one lane per workgroup adds to the tile's agent-scope counter behind a workgroup barrier, the workgroup whose add came
+// last -- told by the value the add returned -- reads the bytes with sc1 loads (L1 bypassed) after a barrier that lane has joined.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t raw_rsrc2(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, byte_off, 0, 16);      // aux bit 4 = sc1 on gfx950
+}
+__device__ __forceinline__ f32x4 ld16_sc1f(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 16));
+}
+
 __device__ __forceinline__ void dma16(const void* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -277,6 +291,12 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
   const bool e_f32 = split || p.out_f32;
   void* e_C = split ? (void*)(p.partial + (int64_t)blockIdx.y * p.M * p.N) : p.C;
   const int64_t e_ldc = split ? (int64_t)p.N : p.ldc;
+  // the tiles the decode-shaped GEMMs run on (<= 128 rows per launch: 128 x 64 / 128 x 128 / 128 x 256): row_scale, and -- on the one that
+  // serves split-K launches -- the reduce inside the launch.  Compiled out of every other instantiation (registers: the 16-wave tile has none to spare).
+  constexpr bool kRowScale = AMODE == A_DENSE && BM == 128;
+  constexpr bool kFusedReduce = AMODE == A_DENSE && BM == 128 && BN == 64;
+  const bool fused = kFusedReduce && split && p.sync != nullptr;      // the reduce happens below, in this launch: slabs go out write-through
+  const __amdgpu_buffer_rsrc_t prs = raw_rsrc2(p.partial);
   const int rr = lane >> 2, c0 = (lane & 3) * 16;
   const int nb = n0 + wn * 64 + c0;                  // first of this lane's 16 columns
   const int ngb = g * p.N + nb;
@@ -298,6 +318,19 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int m = m0 + wm * (TM * 16) + i * 16 + rr;
     if (m >= p.M) continue;
+    if constexpr (kFusedReduce) if (fused) {      // raw fp32 partial sums, 16-byte write-through stores (N % 16 == 0, checked by the launcher)
+      if (nb < p.N) {
+        const unsigned off = (unsigned)((((int64_t)blockIdx.y * p.M + m) * p.N + nb) * 4);
+#pragma unroll
+        for (int e = 0; e < 16; e += 4) st16_sc1(prs, off + e * 4, f32x4{y[e], y[e + 1], y[e + 2], y[e + 3]});
+      }
+      continue;
+    }
+    if constexpr (kRowScale) if (!split && p.row_scale) {
+      const float rs = p.row_scale[m];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) y[e] *= rs;
+    }
     float res[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) res[e] = 0.f;
@@ -398,6 +431,133 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
       }
     }
   }
+
+  // ---- split-K reduce inside the launch: the LAST workgroup to arrive at this output tile sums the slabs in slab order (fixed: the
+  //      result does not depend on which workgroup came last, nor on the row count) and applies the epilogue; optionally it also prepares
+  //      the consumer's RMSNorm (GemmArgs::ng_*).  Nobody ever waits: no assumption about co-residency or dispatch order.
+  if constexpr (kFusedReduce) {
+    if (fused) {
+      int* sflag = reinterpret_cast<int*>(smem + NWAVES * (16 * PW) * 4);      // behind the waves' patches
+      const int tile_id = mt * ntn + nt_;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's slab stores have left the chip's caches
+      __syncthreads();
+      if (tid == 0) {
+        const int old = __hip_atomic_fetch_add(p.sync + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *sflag = old == (int)gridDim.y - 1;
+      }
+      __syncthreads();
+      if (!*sflag) return;
+      constexpr int SEG = BN / 16;                           // 16-column segments of a tile row: adjacent lanes
+      const unsigned KS = gridDim.y, sstride = (unsigned)((int64_t)p.M * p.N * 4);
+      const T* Rr = reinterpret_cast<const T*>(p.residual);
+      const bool want_ng = p.ng_out != nullptr;
+      for (int w = tid; w < BM * SEG; w += kThreads) {
+        const int r = w / SEG, sg = w % SEG;
+        const int m = m0 + r, nc = n0 + sg * 16;
+        const bool live = m < p.M && nc < p.N;
+        float ss = 0.f;
+        if (live) {
+          float y[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) y[e] = 0.f;
+          const unsigned base = (unsigned)(((int64_t)m * p.N + nc) * 4);
+          unsigned s = 0;
+          for (; s + 4 <= KS; s += 4) {                      // four slabs' loads in flight, added in slab order
+            f32x4 v[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[j][q] = ld16_sc1f(prs, base + (s + j) * sstride + q * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { y[4 * q] += v[j][q][0]; y[4 * q + 1] += v[j][q][1]; y[4 * q + 2] += v[j][q][2]; y[4 * q + 3] += v[j][q][3]; }
+          }
+          for (; s < KS; ++s) {
+            f32x4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = ld16_sc1f(prs, base + s * sstride + q * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { y[4 * q] += v[q][0]; y[4 * q + 1] += v[q][1]; y[4 * q + 2] += v[q][2]; y[4 * q + 3] += v[q][3]; }
+          }
+          if (p.row_scale) {
+            const float rs = p.row_scale[m];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) y[e] *= rs;
+          }
+          float res[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) res[e] = 0.f;
+          if (Rr) {
+#pragma unroll
+            for (int e = 0; e < 16; e += VEC) chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(Rr + (int64_t)m * p.ldr + nc + e), res + e);
+          }
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            float v = fmaf(y[e], p.col_scale ? p.col_scale[nc + e] : 1.f, p.col_bias ? p.col_bias[nc + e] : 0.f);
+            if (!p.res_after_act) v += res[e];
+            switch (p.act) {
+              case ACT_GELU: v = gelu_act<T>(v); break;
+              case ACT_RELU: v = fmaxf(v, 0.f); break;
+              case ACT_PRELU: v = v >= 0.f ? v : p.prelu[nc + e] * v; break;
+              case ACT_SILU: v = silu(v); break;
+              default: break;
+            }
+            y[e] = p.res_after_act ? v + res[e] : v;
+          }
+          if (p.out_f32) {
+            float* Cf = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + nc;
+#pragma unroll
+            for (int e = 0; e < 16; e += 4) *reinterpret_cast<f32x4*>(Cf + e) = f32x4{y[e], y[e + 1], y[e + 2], y[e + 3]};
+          } else {
+            T* Ct = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + nc;
+            Chunk16 oc[16 / VEC];
+#pragma unroll
+            for (int e = 0; e < 16; e += VEC) { oc[e / VEC] = chunk_from_f32<T>(y + e); *reinterpret_cast<Chunk16*>(Ct + e) = oc[e / VEC]; }
+            if (want_ng) {      // the consumer's RMSNorm: x * gain now (x as stored), 1 / rms(x) once the whole row is known
+              float xr[16], xg[16];
+#pragma unroll
+              for (int e = 0; e < 16; e += VEC) chunk_to_f32<T>(oc[e / VEC], xr + e);
+#pragma unroll
+              for (int e = 0; e < 16; ++e) { xg[e] = xr[e] * p.ng_gain[nc + e]; ss = fmaf(xr[e], xr[e], ss); }
+              T* Gt = reinterpret_cast<T*>(p.ng_out) + (int64_t)m * p.ng_ld + nc;
+#pragma unroll
+              for (int e = 0; e < 16; e += VEC) *reinterpret_cast<Chunk16*>(Gt + e) = chunk_from_f32<T>(xg + e);
+            }
+          }
+        }
+        if (want_ng) {      // the row's sum of squares over this tile's columns: the SEG adjacent lanes, fixed butterfly
+#pragma unroll
+          for (int o = 1; o < SEG; o <<= 1) ss += __shfl_xor(ss, o, 64);
+          if (live && sg == 0)
+            __hip_atomic_store(p.ng_rowsq + (int64_t)nt_ * p.M + m, ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (!want_ng) {
+        if (tid == 0) __hip_atomic_store(p.sync + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+        return;
+      }
+      // second level: the workgroup that completes the M-tile's LAST column tile turns the per-tile sums into 1 / rms per row
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __hip_atomic_store(p.sync + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int old = __hip_atomic_fetch_add(p.sync + kSyncTiles + mt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *sflag = old == ntn - 1;
+      }
+      __syncthreads();
+      if (!*sflag) return;
+      for (int r = tid; r < BM; r += kThreads) {
+        const int m = m0 + r;
+        if (m >= p.M) continue;
+        float tot = 0.f;
+#pragma unroll 8
+        for (int t = 0; t < ntn; ++t) tot += __hip_atomic_load(p.ng_rowsq + (int64_t)t * p.M + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        p.ng_rstd[m] = rsqrtf(tot / (float)p.N + p.ng_eps);
+      }
+      if (tid == 0) __hip_atomic_store(p.sync + kSyncTiles + mt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 template <typename T, int AMODE, int BM, int BN, int kStages, int WAVES_M, int NWAVES, int DW = NWAVES>
@@ -430,9 +590,9 @@ static bool small_tile_rule(const GemmArgs& a) {
 
 static int dma_tile_choice(const GemmArgs& a) {
   // 0: not eligible, 1: 256x128, 2: 256x256, 4: the <= 128-row / small-GEMM tiles
-  // <= 128 rows (beam-search decode, tiny prefills): 128 x 64 tiles stream the weights with 4 x more workgroups per N
-  if (a.amode == A_DENSE && a.groups == 1 && a.M <= 128 && (a.M > 32 || a.decode_tiled) && a.N >= 64) return 4;
-  if (a.ksplit > 1) return (a.amode == A_DENSE && a.groups == 1 && a.N >= 64) ? 1 : 0;   // independent of M on purpose
+  // <= 128 rows (the decode-shaped GEMMs, tiny prefills): 128 x 64 tiles stream the weights with 4 x more workgroups per N
+  if (a.amode == A_DENSE && a.groups == 1 && a.M <= 128 && (a.M > 32 || a.decode_tiled || a.ksplit > 1) && a.N >= 64) return 4;
+  if (a.ksplit > 1) return 0;      // split-K: decode-shaped launches only (launch_gemm checks)
   if (small_tile_rule(a)) return 4;
   if (a.amode == A_STEM || a.N < 128) return 0;
   const int64_t n128 = (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 128) * a.groups;

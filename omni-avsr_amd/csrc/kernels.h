@@ -35,27 +35,27 @@ struct GemmArgs {
   const int4* rowinfo = nullptr; int taps = 0; int Kvalid = 0;   // Kvalid = taps*Cin (<= K, rest zero)
   // A_STEM: input f32 video [frame][88][88]; frameinfo[frame] = {t, len}; M = frames*44*44, K = 256 (245 valid)
   const int2* frameinfo = nullptr;
-  // skinny kernel only: fused RMSNorm prologue (gain[K], eps) and SwiGLU epilogue on 16-row interleaved gate/up weights
-  const float* norm_gain = nullptr; float norm_eps = 0.f;
-  // split-K only: the reduce pass also writes RMSNorm(C row) * rn_gain to rn_out (the consumer's normalised input): one launch instead of
-  // reduce + rmsnorm.  Needs !out_f32, no activation, N % (16 bytes of T) == 0.
-  void* rn_out = nullptr; int64_t rn_ld = 0; const float* rn_gain = nullptr; float rn_eps = 0.f;
-  int swiglu_pairs = 0;
-  // classic kernel only: split-K over blockIdx.y with fp32 partial slabs [ksplit][M][N] + deterministic reduce/epilogue kernel
+  int swiglu_pairs = 0;          // fused SwiGLU epilogue: gate / up weight rows interleaved in blocks of 16 (LDS-DMA kernels)
+  // split-K over blockIdx.y: fp32 partial slabs [ksplit][M][N], summed in slab order (deterministic) by the LAST workgroup to arrive at the
+  // output tile, inside the GEMM launch (gemm2.hip: sync = the workspace's arrival counters, self-resetting); the decode GEMMs only
   int ksplit = 1; float* partial = nullptr;
-  // Weight-streaming decode kernels at 17..32 rows: 1 = the launch shares the chip with other streams' MFMA-bound kernels (the decode
-  // scheduler's steps): fewer, wider workgroups -- 64-column tiles for the narrow projections, half as many persistent workgroups -- which
-  // fetch the activation rows less often and block fewer CUs.  Slower alone (step 1.55 -> 2.1 ms), faster beside the encoders (+3..4 % on the
-  // headline); never changes a bit (a column's k order and cross-wave sums do not depend on how many columns its workgroup owns).
-  int shared_chip = 0;
+  // per-row multiplier of the accumulator, applied before col_scale / col_bias: the decode path's deferred RMSNorm -- the producer of A
+  // stored bf16(x * gain) and 1 / rms(x) per row (ng_* below), so  norm(x) W^T = row_scale[m] * (A W^T)
+  const float* row_scale = nullptr;
+  // "next norm" outputs of the split-K reduce (C = the residual stream x; !out_f32, no activation): ng_out[m][n] = T(x[m][n] * ng_gain[n]),
+  // ng_rowsq[nt][m] = sum over column tile nt of x[m][n]^2 (x as rounded to T); the workgroup that finishes an M-tile's last column tile
+  // writes ng_rstd[m] = rsqrt(sum_nt ng_rowsq[nt][m] / N + ng_eps).  Every sum in a fixed order: a row's bits never depend on the row count.
+  void* ng_out = nullptr; int64_t ng_ld = 0; const float* ng_gain = nullptr; float* ng_rowsq = nullptr; float* ng_rstd = nullptr; float ng_eps = 0.f;
+  int* sync = nullptr;       // [kSyncInts] arrival counters: one per output tile, then one per M-tile (zero between launches)
   // LDS-DMA kernels: order in which an XCD's contiguous range of workgroups walks the output tiles.  0: row-major (or column-major when
   // M < N); 1: blocks of 8 M-tiles x 4 N-tiles, so the 32 tiles an XCD's CUs work on at one time share 8 A panels and 4 W panels in
   // its L2 (12 panel fetches per k-step for 64 panel reads).  Speed only, never results.  Set by the launcher.
   int tile_order = 0;
   // parity tests / yardsticks (oavsr_op_gemm): 2 = the 16-wave 256 x 256 LDS-DMA kernel whatever the dispatcher would pick.  0 in the product.
   int force_tile = 0;
-  int decode_tiled = 0;      // <= 128-row decode GEMM of the tiled regime: the 128 x 64 LDS-DMA tile at ANY row count (speed only: the tile shape never changes a bit)
+  int decode_tiled = 0;      // decode-shaped launch (M <= 128): the 128-row LDS-DMA tiles at ANY row count (speed only: the tile shape never changes a bit)
 };
+constexpr int kSyncTiles = 4096, kSyncMTiles = 64, kSyncInts = kSyncTiles + kSyncMTiles;      // GemmArgs::sync
 // (mt, nt) of linear tile index bid in the blocked order above; bijective for any ntm x ntn
 __host__ __device__ inline void blocked_tile(int bid, int ntm, int ntn, int& mt, int& nt) {
   constexpr int GM = 8, GN = 4;
@@ -90,24 +90,6 @@ bool gemm_8pp_supported(const GemmArgs& a);
 int gemm_8pp_grid(int64_t ntiles);             // workgroups the launcher uses for `ntiles` tiles
 // grid: workgroups (multiple of 8; 0 = gemm_8pp_grid)
 int launch_gemm_8pp(const GemmArgs& a, hipStream_t st, int grid = 0);
-
-// Skinny (decode) GEMM: M <= 128 rows, weights streamed once.  Same math/epilogue subset.
-int launch_gemm_skinny(const GemmArgs& a, hipStream_t st);
-bool splitk_rmsnorm_ok(const GemmArgs& a);      // gemm.hip: can the split-K reduce pass also write RMSNorm(C) (rn_* fields)?
-bool skinny_uses_r16(const GemmArgs& a);     // 9..32 rows on 8-column tiles (skinny_r16_kernel)
-// Two dependent skinny GEMMs (M <= 8) fused into one launch (skinny.hip): kind 0 = LoRA down -> QKV (stage 0's output is stage 1's A2),
-// kind 1 = gate/up + SwiGLU -> down_proj (stage 0's output is stage 1's A).  Same bits as the two separate launches.
-struct SkinnySync {            // device-side view of one stage's hand-off
-  const int* wait_ctr = nullptr; int wait_n = 0;   // consumer: wait until *wait_ctr >= *step * wait_n
-  int* signal_ctr = nullptr; int signal_n = 0;      // producer: signal_ctr[32 * (1 + bid % 8)] += 1; the shard's last arriver bumps signal_ctr[0]
-  const int* step = nullptr;                        // device scalar: decode step (1-based), the counters are zeroed once per decode call
-  int a1_sc1 = 0, a2_sc1 = 0;                       // which A segment was produced inside this launch (read through L2)
-  int* err = nullptr;                               // set if the bounded spin gives up
-};
-constexpr int kChainCtrInts = 9 * 32;               // one fused launch: top counter + 8 shard counters, 128-byte lines
-struct SkinnyChain { int* counter = nullptr; const int* step = nullptr; int* err = nullptr; int feeds_a2 = 0; };
-bool skinny_chain_supported(const GemmArgs& a0, const GemmArgs& a1, int kind);
-int launch_gemm_skinny_chain2(const GemmArgs& a0, const GemmArgs& a1, const SkinnyChain& c, int kind, hipStream_t st);
 
 // ---- attention ---------------------------------------------------------------------------------
 struct AttnArgs {
@@ -161,6 +143,8 @@ int launch_layernorm_zero_prefix(int dtype, const void* x, int64_t ldx, void* y,
                                  const float* b, int rows, int D, float eps, hipStream_t st);
 int launch_rmsnorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, int rows, int D,
                    float eps, hipStream_t st);
+// decode path's deferred RMSNorm for rows no GEMM produced: y = T(x * w), rstd[row] = 1 / rms(x[row])  (ops.hip: rms_prep_kernel)
+int launch_rms_prep(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, float* rstd, int rows, int D, float eps, hipStream_t st);
 // Fused visual stem (stem.hip): Conv3d(1->64, 5x7x7, s (1,2,2)) + BN + PReLU + MaxPool(3x3, s2) on f32 video [F][88][88];
 // frameinfo[f] = {t, len}; wp = weights repacked by launch_stem_repack ([64][256] -> [64][288]); out [F][22][22][64].
 int launch_stem_repack(int dtype, const void* w, void* wp, hipStream_t st);
@@ -214,6 +198,8 @@ int launch_swiglu(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, i
 // argmax over fp32 logits rows (ties -> lowest index, as torch.argmax); optional banned token
 // scratch: optional [rows][64] float2 for the two-stage variant
 int launch_argmax(const float* logits, int64_t ld, int rows, int V, int banned, int* out, void* scratch, hipStream_t st);
+// per-utterance 64-bit digest of rows [cu[b], cu[b + 1]) (cu == nullptr: row b) of `words_per_row` 32-bit words each -> out[b * out_stride + out_col]
+int launch_digest(const void* base, const int* cu, int64_t words_per_row, int n_utts, uint64_t* out, int out_stride, int out_col, hipStream_t st);
 // segment metadata
 int launch_build_rowinfo(const int* cu_out, const int* cu_in, int n_seqs, int stride, int4* rowinfo, int rows,
                          hipStream_t st);

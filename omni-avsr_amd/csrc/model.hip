@@ -9,7 +9,8 @@
 //   build_prompt  : row gathers into inputs_embeds
 //   prefill       : Llama/Qwen2 layers on all prompt rows of all utterances (var-len causal attention), KV prefix cache,
 //                   last-position logits only
-//   decode        : greedy loop, one skinny-GEMM step per token, no host sync inside the loop
+//   decode        : greedy / beam loop, one step of decode-shaped GEMMs (tiled LDS-DMA kernels, split-K reduced inside the launch) per token,
+//                   no host sync inside the loop
 #include <stdarg.h>
 #include <stdlib.h>
 #include <math.h>
@@ -39,9 +40,6 @@ struct KnobDef { const char* name; int dflt; const char* what; };
 static const KnobDef kKnobs[] = {
     {"OAVSR_PROF_SHAPES", 0, "profiling hook: one family per GEMM shape instead of per kernel"},
     {"OAVSR_DECODE_GRAPH", 1, "0: decode steps are launched eagerly instead of replayed from hipGraphs (same kernels, same bits)"},
-    {"OAVSR_SKINNY_PERSIST", 1, "0: per-tile decode GEMVs instead of the persistent forms (bit-identical, tests compare them)"},
-    {"OAVSR_SKINNY_PERSIST_GU", 1, "0: per-tile gate / up GEMV at <= 8 rows (bit-identical)"},
-    {"OAVSR_SKINNY_CHAIN", 0, "1 / 2 / 3: two dependent decode GEMVs in one launch (bit-identical, measured slower; tests)"},
 };
 int knob(const char* name) {
   for (const KnobDef& k : kKnobs)
@@ -106,56 +104,29 @@ struct ProfScope {
 
 // Profiling families are named after the kernel instantiation that will actually run, so that the HIP-event averages
 // bench.py reports line up 1:1 with the rows of a `rocprofv3 --kernel-trace --stats` summary.
-static const char* gemm_family(const GemmArgs& a, bool skinny) {
+static const char* gemm_family(const GemmArgs& a) {
   static thread_local char buf[64];
   const char* dt = a.dtype == DT_F32 ? "f32" : "bf16";
-  if (skinny) {
-    const int mt = ceil_div(a.M, 16) <= 1 ? 1 : ceil_div(a.M, 16) <= 2 ? 2 : ceil_div(a.M, 16) <= 4 ? 4 : 8;
-    const bool wide = a.N >= 8192;
-    const int nt = a.swiglu_pairs ? (wide ? 4 : 2) : (mt <= 2 && wide ? 4 : 1);
-    const int r16_nt = wide ? 4 : mt == 4 ? ((!a.norm_gain && a.N >= 1024) ? 4 : 2)
-                       : (a.shared_chip && mt == 2 && a.N >= (a.norm_gain ? 2048 : 512)) ? ((a.norm_gain || a.N < 1024) ? 4 : 8) : 2;      // launch_sk_t's choice
-    if (skinny_uses_r16(a)) snprintf(buf, sizeof(buf), "skinny_r16_mt%d_nt%d%s%s_%s", mt, r16_nt, a.norm_gain ? "_norm" : "", a.swiglu_pairs ? "_swiglu" : "", dt);
-    else snprintf(buf, sizeof(buf), "skinny_mt%d_nt%d%s%s_%s", mt, nt, a.norm_gain ? "_norm" : "", a.swiglu_pairs ? "_swiglu" : "", dt);
-    return buf;
-  }
   const char* mode = a.amode == A_DENSE ? "gemm" : a.amode == A_CONV2D ? "conv2d_gemm" : a.amode == A_CONV1D ? "conv1d_gemm" : "stem_gemm";
-  const char* tile = (a.ksplit > 1 && !gemm_dma_eligible(a)) ? "splitk_128x128" : gemm_dma_eligible(a) ? gemm_dma_variant(a) : (a.N <= 64 ? "128x64" : "128x128");
+  const char* tile = gemm_dma_eligible(a) ? gemm_dma_variant(a) : (a.N <= 64 ? "128x64" : "128x128");
   static const bool shapes = knob("OAVSR_PROF_SHAPES") != 0;      // developer aid: one family per GEMM shape
-  if (shapes) { snprintf(buf, sizeof(buf), "%c%s %dx%dx%d", mode[0], tile, a.M, a.N, a.K + a.K2); buf[31] = 0; return buf; }
-  // greedy decode GEMMs of the tiled regime: a family of their own ("decode_..."), so that bench.py keeps the decode side apart from the
-  // encoder / prefill GEMMs that run on the same kernels
+  if (shapes) { snprintf(buf, sizeof(buf), "%s%c%s %dx%dx%d", a.decode_tiled ? "decode_" : "", mode[0], tile, a.M, a.N, a.K + a.K2); buf[31] = 0; return buf; }
+  // decode-shaped GEMMs: a family of their own ("decode_..."), so that bench.py keeps the decode side apart from the encoder / prefill
+  // GEMMs that run on the same kernels
   snprintf(buf, sizeof(buf), "%s%s_%s_%s", a.decode_tiled ? "decode_" : "", mode, tile, dt);
   return buf;
 }
 
-// Split-K factors are STATIC per call site (functions of the layer's N and K, never of the row count), so that an utterance
-// gets the same bits whether it runs alone or inside a batch: the k-slices are summed in a fixed order by the reduce kernel.
-constexpr int kPrefillTailChunk = 8;    // rows per launch of the pruned last prefill layer / first lm_head (batch-independent kernels)
-// (Round 3: the narrow encoder projections and the LoRA down projections are never split any more -- they run un-split on the small-GEMM
-// tile, gemm2.hip -- so the only split-K call sites left are the > 32-row decode GEMMs of beam search, decode_split below.)
-
-static thread_local int g_shared_chip = 0;      // set by the decode scheduler around its steps: GemmArgs::shared_chip of the launches below
-
-static int run_gemm(const GemmArgs& a_, hipStream_t st, bool skinny = false) {
-  GemmArgs a = a_;
-  a.shared_chip = skinny ? g_shared_chip : 0;
+// Split-K factors are STATIC per call site (functions of the layer's N and K, never of the row count), so that an utterance gets the same
+// bits whether it runs alone or inside a batch.  The only split-K call sites are the decode-shaped GEMMs (decode_gemm below); the narrow
+// encoder projections and the prefill's LoRA down projections run un-split on the small-GEMM tile (gemm2.hip).
+static int run_gemm(const GemmArgs& a, hipStream_t st) {
   const double esz = a.dtype == DT_F32 ? 4 : 2;
   const double kk = (double)a.K + a.K2;
   const double flops = 2.0 * a.M * a.N * kk * a.groups;
   const double bytes = esz * ((double)a.M * kk + (double)a.N * kk * a.groups) + (a.out_f32 ? 4 : esz) * (double)a.M * a.N * a.groups;
-  ProfScope ps(gemm_family(a, skinny), flops, bytes, st);
-  return skinny ? launch_gemm_skinny(a, st) : launch_gemm(a, st);
-}
-
-// two dependent decode GEMMs in one launch (skinny.hip: skinny_chain2_kernel)
-static int run_gemm_chain(const GemmArgs& a0, const GemmArgs& a1, int kind, const SkinnyChain& c, hipStream_t st) {
-  const double esz = a0.dtype == DT_F32 ? 4 : 2;
-  const double w0 = (double)a0.N * (a0.K + a0.K2), w1 = (double)a1.N * (a1.K + a1.K2);
-  char name[48];
-  snprintf(name, sizeof(name), "skinny_chain_%s_%s", kind == 0 ? "lora_qkv" : "mlp", a0.dtype == DT_F32 ? "f32" : "bf16");
-  ProfScope ps(name, 2.0 * a0.M * (w0 + w1), esz * (w0 + w1), st);
-  return launch_gemm_skinny_chain2(a0, a1, c, kind, st);
+  ProfScope ps(gemm_family(a), flops, bytes, st);
+  return launch_gemm(a, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -191,7 +162,6 @@ struct oavsr_model {
   uint64_t blob_bytes = 0;
   std::unordered_map<std::string, std::pair<uint64_t, uint64_t>> t;
   int dtype = DT_BF16; size_t esz = 2;
-  bool tiled_decode = false;             // greedy decode GEMMs on the tiled LDS-DMA kernels at every row count (see llm_layers)
   // video
   bool has_video = false, has_audio = false;
   ConvBN stem; ResBlock blocks[8];
@@ -250,7 +220,8 @@ struct oavsr_workspace {
   void *kpre, *vpre, *ktail, *vtail; int max_prefix = 0; size_t kpre_layer = 0, ktail_layer = 0;
   int *pos, *slot, *cpos, *cu_s, *prefix_len, *last_rows;
   int *amax; void* amax_scratch; GreedyState gs;
-  int* sync = nullptr; size_t sync_bytes = 0;   // (2 * layers) x kChainCtrInts stage counters of the fused decode launches + an error line; zeroed per decode call
+  // decode-shaped GEMMs: arrival counters of the split-K reduce (GemmArgs::sync), the deferred RMSNorm's 1 / rms per row and its per-tile sums
+  int* gsync = nullptr; float *rstd = nullptr, *rowsq = nullptr;
   // beam search state
   float *beam_scores, *cand_val, *partial; int *cand_tok, *topk_flag, *hyp_n, *hyp_len, *hyp_tok, *seq[2], *anc[2]; double* hyp_score; size_t partial_bytes = 0;
   int max_tok_enc = 0, max_S_total = 0;
@@ -260,6 +231,7 @@ struct oavsr_workspace {
   void *pf_k = nullptr, *pf_v = nullptr; size_t pf_layer = 0; int pf_max_prefix = 0;
   const int* rowmap = nullptr;                 // decode scheduler only: activation row -> row slot (DecodeAttnArgs::rowmap)
   StemSrc vsrc;                                // what `video_dev` of the calls on this workspace holds (oavsr_workspace_set_video_format)
+  uint64_t* digests = nullptr;                 // optional [utterance][2]: {inputs_embeds, first-step logits} digests of the calls on this workspace (oavsr_workspace_set_digests)
 
   void* take(size_t bytes) {
     size_t off = align_up(used, 256);
@@ -483,7 +455,6 @@ static int resolve_model(oavsr_model* m) {
   const oavsr_config& c = m->cfg;
   m->has_video = m->t.count("v.stem.w") > 0;
   m->has_audio = m->t.count("a.conv1.w") > 0;
-  m->tiled_decode = true;      // greedy decode: the tiled regime for every model (llm_layers)      // Qwen2.5-7B / Llama-3.1-8B widths (llm_layers: the greedy tiled regime)
   if (m->has_video) {
     OAVSR_TRY(resolve_convbn(m, "v.stem", true, m->stem));
     const int chans[5] = {64, 64, 128, 256, 512};
@@ -831,219 +802,195 @@ static int build_prompt_impl(const oavsr_model* m, oavsr_workspace* ws, int task
 }
 
 // ------------------------------------------------------------------------------------------------
-// LLM layer stack; rows = prompt rows (prefill, big GEMM) or decode rows (skinny GEMM)
+// LLM layer stack; rows = prompt rows (prefill: the MFMA-bound GEMM families) or decode-shaped rows
 // ------------------------------------------------------------------------------------------------
-// GEMM dispatch of the LLM stack: prefill rows -> tiled MFMA GEMM; decode with <= 32 rows -> weight-streaming skinny kernel
-// (RMSNorm / SwiGLU fused); decode with more rows (beam search: B*K) -> 128-row tiles with split-K so every CU streams weights.
-// Split-K factor of the 33+-row decode GEMMs (128 x 64 weight-streaming tiles, gemm2.hip): k-slices so that N / 64 column tiles x slices
-// give ~128 workgroups (rounds 1-2: 256, one per CU; beam search keeps four decode chains in flight beside the encoder phases, and there
-// half as many workgroups of twice the k range -- half the fp32 slabs for the reduce pass -- are worth 134 -> 138 utt/s; 64: 137, 512:
-// 125).  A function of N and K ONLY (one M-tile's worth of column tiles), never of the row count, so
-// a row's fp32 summation order does not depend on how many other rows share the launch.
-// rows up to which decode GEMMs run on the weight-streaming kernels (mode 1); above: tiled split-K (mode 2).  (Round 3: the 16-column
-// weight-streaming kernels at 33..128 rows were measured on the beam-15 path -- 120 rows -- and lose: 59 vs 82 utt/s sequentially.)
-// Greedy rows: up to 64 (round 4: the 64-row forms of the weight-streaming kernels give a row the bits of the <= 8-row kernel, so the
-// batch-independence of greedy decode now reaches 64 rows).  Beam search keeps its 32-row boundary: its > 32-row regime (tiled split-K)
-// is what the beam-search results of rounds 1-3 were produced with, and B x K rows grow in steps of K anyway.
-static constexpr int skinny_max_rows(int beams = 1) { return beams > 1 ? 32 : 64; }
-
-// target: workgroups per launch the split is sized for -- a constant of the regime (part of its summation order): 128 for beam search's
-// > 32-row decode (four decode chains in flight), 256 for the greedy tiled regime (kDecodeSplitTiled)
-constexpr int kDecodeSplitBeam = 128, kDecodeSplitTiled = 256;
-static int decode_split(int N, int Ktot, int esz, int target = kDecodeSplitBeam) {
+// DECODE-SHAPED GEMMs (one new token per row: greedy and beam-search steps, the decode scheduler's steps, and the pruned tail of the
+// prefill's last layer + the first lm_head) all run ONE regime, whatever the row count: the tiled LDS-DMA kernels (128 x 64 tiles up to
+// 128 rows, 256 x 128 above), K split over workgroups with fp32 slabs, the slabs summed in slab order by the tile's last-arriving
+// workgroup inside the launch (gemm2.hip).  Rows are independent and the split factor is a function of N and K ONLY, so a row's bits do
+// not depend on how many rows share the launch: an utterance decodes to the same ids alone, in a batch, as one of K beams x B
+// utterances or inside a 128-row scheduler step, in f32 and in bf16.
+// RMSNorm is DEFERRED (Llama_LoRA.py:587-655 computes norm(x) W^T): the GEMM that produces the residual stream x (o_proj, down_proj) also
+// stores bf16(x * gain_next) and 1 / rms(x) per row (GemmArgs::ng_*); the consumer takes the former as its A operand and multiplies its
+// fp32 accumulator by the latter (row_scale) -- six launches per layer (LoRA-down, QKV, attention, o_proj, gate/up + SwiGLU, down_proj).
+constexpr int kDecodeSplitTarget = 256;      // workgroups per launch the split is sized for: part of the regime's summation order
+static int decode_split(int N, int Ktot, int esz, int min_ks = 1) {
   const int ktiles = Ktot / (128 / esz);
-  int ks = target / std::max(1, ceil_div(N, 64));
+  int ks = kDecodeSplitTarget / std::max(1, ceil_div(N, 64));
   ks = std::min(ks, std::max(1, ktiles / 2));
-  return std::max(1, std::min(ks, 16));
+  ks = std::max(1, std::min(ks, 16));
+  return std::max(ks, std::min(min_ks, std::max(1, ktiles)));
 }
 
-// rn_gain (mode 2 only): ask the split-K reduce pass to also write RMSNorm(C) * rn_gain to ws->lh; *normed says whether it did (a GEMM
-// that needs no split has no reduce pass: the caller then runs the rmsnorm kernel as before).
-static int llm_gemm(const oavsr_model* m, oavsr_workspace* ws, GemmArgs& g, int mode /*0 prefill, 1 skinny, 2 split-K*/, hipStream_t st,
-                    const float* rn_gain = nullptr, bool* normed = nullptr, bool tiled = false /* the greedy tiled regime (mode 2 at any row count) */) {
-  if (normed) *normed = false;
-  if (mode == 0) return run_gemm(g, st, false);
-  if (mode == 1) return run_gemm(g, st, true);
-  g.decode_tiled = tiled ? 1 : 0;
-  const int ks = decode_split(g.N, g.K + g.K2, (int)m->esz, tiled ? kDecodeSplitTiled : kDecodeSplitBeam);
-  if (ks > 1) {
-    OAVSR_REQUIRE((size_t)ks * g.M * g.N * 4 <= ws->partial_bytes, "decode GEMM: split-K slabs (%d x %d x %d) exceed the workspace", ks, g.M, g.N);
-    g.ksplit = ks; g.partial = ws->partial;
-    if (rn_gain && normed) {
-      g.rn_out = ws->lh; g.rn_ld = g.N; g.rn_gain = rn_gain; g.rn_eps = m->cfg.llm_rms_eps;
-      if (splitk_rmsnorm_ok(g)) *normed = true;
-      else { g.rn_out = nullptr; g.rn_gain = nullptr; }
-    }
-  }
-  return run_gemm(g, st, false);
-}
-
-// last_rows / cu_last (prefill only): row index of every utterance's final prompt token and the device array 0..B.  Only those rows
-// feed lm_head (the reference materialises all positions, Llama_LoRA.py:372-373), so in the LAST layer everything after the KV
-// append -- attention queries, o_proj, the MLP -- runs on the B gathered rows (compact residual stream ws->lastx) through the
-// decode-shaped kernels; *pruned tells the caller that ws->lastx already holds the final hidden rows.
-static int llm_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int rows, bool decode, int B, int beams, int max_S,
-                      const int* pos, const int* cpos, const int* anc, const int* step, hipStream_t st, const float2* rope_cs = nullptr,
-                      const int* last_rows = nullptr, const int* cu_last = nullptr, bool* pruned = nullptr, bool* final_normed = nullptr) {
-  const oavsr_config& c = m->cfg;
-  const int dt = m->dtype, d = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, hd = c.llm_head_dim, I = c.llm_mlp;
-  const int nq = H * hd, nqkv = (H + 2 * KV) * hd;
-  const int tl = c.lora_task_specific ? task : 0;
-  // Greedy decode (m->tiled_decode, every model since the end of round 4): the tiled LDS-DMA kernels at EVERY row count.  At 33..64 rows
-  // they stream the weights 2 x faster than the weight-streaming kernels, whose workgroups re-read all activation rows through a 36 GB/s
-  // register-load path (Llama-3.1-8B, 57 rows: gate / up 107 -> 53 us, down_proj 86 -> 37, lm_head 390 -> 190; Llama-3.2-1B: gate / up
-  // 33 -> 22, down_proj 49 -> 24), a 64-row step costs barely more than a 32-row one (1B: 1.80 vs 1.62 ms), and their results do not
-  // depend on the row count either (rows are independent, split factors are functions of N and K), so greedy decode stays
-  // batch-independent -- in a different summation order than the weight-streaming regime, which is why the regime is a property of the
-  // BUILD, never of a step's row count.  Beam search keeps its two regimes (<= 32 rows: weight-streaming, above: tiled with the beam split).
-  const bool tiled = decode && beams == 1 && m->tiled_decode;
-  const int mode = !decode ? 0 : (tiled ? 2 : (rows <= skinny_max_rows(beams) ? 1 : 2));
-  const bool fused_norm = mode == 1;       // RMSNorm folded into the skinny GEMMs (gain on the A fragments, rstd in the epilogue)
-  const bool can_prune = !decode && last_rows && cu_last;
-  if (pruned) *pruned = false;
-  if (final_normed) *final_normed = false;
-  bool have_h = false;                     // mode 2: ws->lh already holds ln1(x) of this layer, written by the previous down_proj's reduce pass
-  for (int li = 0; li < c.llm_layers; ++li) {
-    const LlmLayer& L = m->llayers[li];
-    const bool prune = can_prune && li == c.llm_layers - 1;
-    if (!fused_norm && !have_h) { ProfScope ps(decode ? "decode_rmsnorm" : "rmsnorm", 0, 2.0 * rows * d * m->esz, st);
-      OAVSR_TRY(launch_rmsnorm(dt, ws->lx, d, ws->lh, d, L.ln1w, rows, d, c.llm_rms_eps, st)); }
-    have_h = false;
-    const void* hin = fused_norm ? ws->lx : ws->lh;
-    GemmArgs g, gl;
-    // greedy decode with <= 8 rows: dependent weight-streaming GEMMs share a launch (LoRA down -> QKV, gate/up -> down_proj)
-    const bool chain_ok = decode && mode == 1 && beams == 1 && rows <= 8 && step && ws->sync;
-    SkinnyChain ch; ch.step = step; ch.err = ws->sync ? ws->sync + (size_t)2 * c.llm_layers * kChainCtrInts : nullptr;
-    if (c.lora_k2 > 0) {
-      gl = GemmArgs(); gl.dtype = dt; gl.M = rows; gl.N = c.lora_k2; gl.K = d; gl.A = hin; gl.lda = d; gl.W = L.lora_dn[tl]; gl.ldw = d;
-      gl.C = ws->llora; gl.ldc = c.lora_k2;
-      if (fused_norm) { gl.norm_gain = L.ln1w; gl.norm_eps = c.llm_rms_eps; }
-    }
-    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = nqkv; g.K = d; g.A = hin; g.lda = d; g.W = L.qkvw; g.ldw = d; g.col_bias = L.qkvb;
-    if (c.lora_k2 > 0) { g.A2 = ws->llora; g.lda2 = c.lora_k2; g.W2 = L.lora_up[tl]; g.ldw2 = c.lora_k2; g.K2 = c.lora_k2; }
-    if (fused_norm) { g.norm_gain = L.ln1w; g.norm_eps = c.llm_rms_eps; }
-    g.C = ws->lqkv; g.ldc = nqkv;
-    if (c.lora_k2 > 0 && chain_ok && skinny_chain_supported(gl, g, 0)) {
-      ch.counter = ws->sync + (size_t)(2 * li) * kChainCtrInts; ch.feeds_a2 = 1;
-      OAVSR_TRY(run_gemm_chain(gl, g, 0, ch, st));
-    } else {
-      if (c.lora_k2 > 0) OAVSR_TRY(llm_gemm(m, ws, gl, mode, st, nullptr, nullptr, tiled));
-      OAVSR_TRY(llm_gemm(m, ws, g, mode, st, nullptr, nullptr, tiled));
-    }
-    if (!decode) {   // decode: RoPE + cache append are fused into the decode-attention kernel
-      RopeArgs r; r.dtype = dt; r.rows = rows; r.n_heads = H; r.n_kv_heads = KV; r.head_dim = hd; r.qkv = ws->lqkv; r.ld = nqkv;
-      r.inv_freq = m->inv_freq; r.pos = pos; r.slot = ws->slot; r.cpos = cpos;
-      r.kcache = (char*)ws->pf_k + li * ws->pf_layer; r.vcache = (char*)ws->pf_v + li * ws->pf_layer; r.max_ctx = ws->pf_max_prefix;
-      { ProfScope ps("rope_kv", 0, 2.0 * rows * nqkv * m->esz, st);
-        OAVSR_TRY(launch_rope_kv(r, st)); }
-      AttnArgs a; a.dtype = dt; a.head_dim = hd; a.n_heads = H; a.n_kv_heads = KV; a.n_seqs = B;
-      a.Q = ws->lqkv; a.K = (const char*)ws->lqkv + (size_t)nq * m->esz; a.V = (const char*)ws->lqkv + (size_t)(nq + KV * hd) * m->esz;
-      a.ldq = a.ldk = a.ldv = nqkv; a.O = ws->lattn; a.ldo = nq; a.cu_q = ws->cu_s; a.cu_k = ws->cu_s; a.max_q = max_S;
-      a.scale = 1.0f / sqrtf((float)hd); a.causal = 1;
-      if (prune) {   // one query row per utterance: gathered q rows (ws->lh is free after the QKV GEMM) against the full K / V
-        OAVSR_TRY(launch_copy_rows(dt, ws->lqkv, nqkv, last_rows, ws->lh, nqkv, B, nqkv, st));
-        OAVSR_TRY(launch_copy_rows(dt, ws->lx, d, last_rows, ws->lastx, d, B, d, st));
-        a.Q = ws->lh; a.cu_q = cu_last; a.max_q = 1;
-      }
-      ProfScope ps(dt == DT_F32 ? "attention_f32" : "attention_bf16", 2.0 * (prune ? B : rows) * max_S * nq, 4.0 * (prune ? B : rows) * nq * m->esz, st);
-      OAVSR_TRY(launch_attention(a, st));
-    } else {
-      DecodeAttnArgs a; a.dtype = dt; a.head_dim = hd; a.n_heads = H; a.n_kv_heads = KV; a.rows = rows; a.beams = beams;
-      a.Q = ws->lqkv; a.ldq = nqkv; a.O = ws->lattn; a.ldo = nq;
-      a.Kp = (char*)ws->kpre + li * ws->kpre_layer; a.Vp = (char*)ws->vpre + li * ws->kpre_layer; a.max_prefix = ws->max_prefix;
-      a.Kt = (char*)ws->ktail + li * ws->ktail_layer; a.Vt = (char*)ws->vtail + li * ws->ktail_layer; a.max_tail = ws->max_new;
-      a.prefix_len = ws->prefix_len; a.step = step; a.anc = anc; a.scale = 1.0f / sqrtf((float)hd);
-      a.inv_freq = m->inv_freq; a.pos = pos; a.cpos = cpos; a.rope_cs = rope_cs; a.rowmap = ws->rowmap;
-      ProfScope ps("decode_attention", 0, 2.0 * rows * max_S * KV * hd * m->esz, st);
-      OAVSR_TRY(launch_decode_attention(a, st));
-    }
-    // tail of the layer: on all rows, or (pruned last prefill layer) on the B gathered rows with the decode-shaped kernels, in
-    // chunks of 8 rows: every chunk then runs the same 8-column weight-streaming kernels whatever B is, so an utterance's first-token
-    // logits do not depend on its batch (a batch of 8 -- the benchmark configuration -- is one chunk)
-    const int tmode = prune ? 1 : mode;
-    const bool tfused = tmode == 1;
-    const int tstep = prune ? kPrefillTailChunk : rows;
-    for (int r0 = 0; r0 < (prune ? B : rows); r0 += tstep) {
-      const int trows = std::min(tstep, (prune ? B : rows) - r0);
-      const size_t e = m->esz;
-      char* xres = (char*)(prune ? ws->lastx : ws->lx) + (size_t)r0 * d * e;
-      const char* attn_r = (const char*)ws->lattn + (size_t)r0 * nq * e;
-      char* act_r = (char*)ws->lact + (size_t)r0 * I * e;
-      g = GemmArgs(); g.dtype = dt; g.M = trows; g.N = d; g.K = nq; g.A = attn_r; g.lda = nq; g.W = L.ow; g.ldw = nq;
-      g.residual = xres; g.ldr = d; g.C = xres; g.ldc = d;
-      bool h2 = false;                     // mode 2: ln2(x) written by o_proj's reduce pass
-      OAVSR_TRY(llm_gemm(m, ws, g, tmode, st, tmode == 2 ? L.ln2w : nullptr, &h2, tiled));
-      bool mlp_chained = false;
-      if (tfused) {   // RMSNorm + gate/up + SwiGLU in one launch
-        g = GemmArgs(); g.dtype = dt; g.M = trows; g.N = 2 * I; g.K = d; g.A = xres; g.lda = d; g.W = L.guw; g.ldw = d;
-        g.norm_gain = L.ln2w; g.norm_eps = c.llm_rms_eps; g.swiglu_pairs = 1; g.C = act_r; g.ldc = I;
-        GemmArgs gd; gd.dtype = dt; gd.M = trows; gd.N = d; gd.K = I; gd.A = act_r; gd.lda = I; gd.W = L.downw; gd.ldw = I;
-        gd.residual = xres; gd.ldr = d; gd.C = xres; gd.ldc = d;
-        if (chain_ok && !prune && skinny_chain_supported(g, gd, 1)) {      // ... and down_proj behind it in the same launch
-          ch.counter = ws->sync + (size_t)(2 * li + 1) * kChainCtrInts; ch.feeds_a2 = 0;
-          OAVSR_TRY(run_gemm_chain(g, gd, 1, ch, st));
-          mlp_chained = true;
-        } else {
-          OAVSR_TRY(run_gemm(g, st, true));
-        }
-      } else {
-        if (!h2) { ProfScope ps(decode ? "decode_rmsnorm" : "rmsnorm", 0, 2.0 * rows * d * m->esz, st);
-          OAVSR_TRY(launch_rmsnorm(dt, ws->lx, d, ws->lh, d, L.ln2w, rows, d, c.llm_rms_eps, st)); }
-        g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 2 * I; g.K = d; g.A = ws->lh; g.lda = d; g.W = L.guw; g.ldw = d; g.C = ws->lgu; g.ldc = 2 * I;
-        GemmArgs gf = g; gf.swiglu_pairs = 1; gf.C = ws->lact; gf.ldc = I;
-        // prefill, and beam-search decode (33..128 rows) when the 128 x 64 tiles already fill the chip without split-K:
-        // SwiGLU in the GEMM epilogue, the [rows][2I] tensor never exists
-        const bool dec_fill = mode == 2 && (int64_t)ceil_div(rows, 128) * ceil_div(2 * I, 64) >= 256;
-        gf.decode_tiled = tiled ? 1 : 0;
-        if ((mode == 0 || dec_fill) && gemm_dma_swiglu_ok(gf)) {
-          OAVSR_TRY(run_gemm(gf, st, false));
-        } else {
-          OAVSR_TRY(llm_gemm(m, ws, g, mode, st, nullptr, nullptr, tiled));
-          ProfScope ps(decode ? "decode_swiglu" : "swiglu", 0, 3.0 * rows * I * m->esz, st);
-          OAVSR_TRY(launch_swiglu(dt, ws->lgu, 2 * I, ws->lact, I, rows, I, 1, st));
-        }
-      }
-      if (!mlp_chained) {
-        g = GemmArgs(); g.dtype = dt; g.M = trows; g.N = d; g.K = I; g.A = act_r; g.lda = I; g.W = L.downw; g.ldw = I;
-        g.residual = xres; g.ldr = d; g.C = xres; g.ldc = d;
-        // mode 2: the reduce pass also writes the next consumer's normalised rows (next layer's ln1, or the final norm before lm_head)
-        const bool last = li == c.llm_layers - 1;
-        const float* next_gain = tmode != 2 ? nullptr : (!last ? m->llayers[li + 1].ln1w : (final_normed ? m->norm_w : nullptr));
-        bool hn = false;
-        OAVSR_TRY(llm_gemm(m, ws, g, tmode, st, next_gain, &hn, tiled));
-        if (hn && !last) have_h = true;
-        if (hn && last) *final_normed = true;
+// One decode-shaped GEMM over g.M rows, 128 rows (one M-tile of the 128-row tiles) per launch -- every kernel on this path then has the
+// row_scale epilogue and the in-launch reduce, whatever the row count (beam search with B x K > 128 rows: two launches).
+// next_gain: the GEMM's output is the residual stream; also write T(x * next_gain) to `ng_out` and 1 / rms(x) to `ng_rstd`.
+static int decode_gemm(const oavsr_model* m, oavsr_workspace* ws, const GemmArgs& g0, hipStream_t st, const float* next_gain = nullptr, void* ng_out = nullptr,
+                       float* ng_rstd = nullptr) {
+  const size_t e = m->esz;
+  const int ks = g0.swiglu_pairs ? 1 : decode_split(g0.N, g0.K + g0.K2, (int)e, next_gain ? 2 : 1);
+  OAVSR_REQUIRE(!next_gain || ks > 1, "decode GEMM %d x %d x %d: the next-norm outputs need a split-K launch", g0.M, g0.N, g0.K + g0.K2);
+  for (int r0 = 0; r0 < g0.M; r0 += 128) {
+    GemmArgs g = g0;
+    g.M = std::min(128, g0.M - r0);
+    g.decode_tiled = 1;
+    auto adv = [&](const void* p, int64_t ld, size_t es) -> const void* { return p ? (const char*)p + (size_t)r0 * ld * es : nullptr; };
+    g.A = adv(g0.A, g0.lda, e); g.A2 = adv(g0.A2, g0.lda2, e); g.residual = adv(g0.residual, g0.ldr, e);
+    g.C = (void*)adv(g0.C, g0.ldc, g0.out_f32 ? 4 : e);
+    if (g0.row_scale) g.row_scale = g0.row_scale + r0;
+    OAVSR_REQUIRE(gemm_dma_eligible(g), "decode GEMM %d x %d x %d: no LDS-DMA tile (N >= 64 needed)", g.M, g.N, g.K + g.K2);
+    if (ks > 1) {
+      OAVSR_REQUIRE((size_t)ks * g.M * g.N * 4 <= ws->partial_bytes, "decode GEMM: split-K slabs (%d x %d x %d) exceed the workspace", ks, g.M, g.N);
+      g.ksplit = ks; g.partial = ws->partial; g.sync = ws->gsync;
+      if (next_gain) {
+        g.ng_out = (char*)ng_out + (size_t)r0 * g.N * e; g.ng_ld = g.N; g.ng_gain = next_gain; g.ng_rowsq = ws->rowsq; g.ng_rstd = ng_rstd + r0;
+        g.ng_eps = m->cfg.llm_rms_eps;
       }
     }
-    if (prune && pruned) *pruned = true;
+    OAVSR_TRY(run_gemm(g, st));
   }
   return 0;
 }
 
-// chunk > 0 (prefill): the rows go through the fused weight-streaming kernel `chunk` at a time, whatever their number
-static int lm_head_rows(const oavsr_model* m, oavsr_workspace* ws, const void* x, int rows, float* logits, hipStream_t st, int chunk = 0,
-                        bool normed = false /* ws->lh already holds the final-norm rows (written by the last down_proj's reduce pass) */,
-                        int beams = 1) {
+// Everything of a decoder layer behind the attention, on decode-shaped rows: o_proj (+ residual; prepares ln2), gate / up + SwiGLU,
+// down_proj (+ residual; prepares `next_gain`: the next layer's ln1 or the final norm).  xres: residual stream rows (in place); xg / rstd:
+// where the two norms' operands go (and come from).
+static int decode_layer_tail(const oavsr_model* m, oavsr_workspace* ws, const LlmLayer& L, int rows, void* xres, const void* attn_r, void* act_r,
+                             void* xg, float* rstd, const float* next_gain, hipStream_t st) {
+  const oavsr_config& c = m->cfg;
+  const int dt = m->dtype, d = c.llm_hidden, nq = c.llm_heads * c.llm_head_dim, I = c.llm_mlp;
+  GemmArgs g; g.dtype = dt; g.M = rows; g.N = d; g.K = nq; g.A = attn_r; g.lda = nq; g.W = L.ow; g.ldw = nq;
+  g.residual = xres; g.ldr = d; g.C = xres; g.ldc = d;
+  OAVSR_TRY(decode_gemm(m, ws, g, st, L.ln2w, xg, rstd));
+  g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 2 * I; g.K = d; g.A = xg; g.lda = d; g.W = L.guw; g.ldw = d; g.row_scale = rstd;
+  GemmArgs gf = g; gf.swiglu_pairs = 1; gf.C = act_r; gf.ldc = I; gf.decode_tiled = 1;
+  // SwiGLU in the GEMM epilogue when the 128 x 64 tiles fill the chip without a split (every real model: 2 I / 64 >= 256 column tiles)
+  GemmArgs gp = gf; gp.M = std::min(rows, 128);
+  if (decode_split(g.N, g.K, (int)m->esz) == 1 && gemm_dma_swiglu_ok(gp)) {
+    OAVSR_TRY(decode_gemm(m, ws, gf, st));
+  } else {
+    g.C = ws->lgu; g.ldc = 2 * I;
+    OAVSR_TRY(decode_gemm(m, ws, g, st));
+    ProfScope ps("decode_swiglu", 0, 3.0 * rows * I * m->esz, st);
+    OAVSR_TRY(launch_swiglu(dt, ws->lgu, 2 * I, act_r, I, rows, I, 1, st));
+  }
+  g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = d; g.K = I; g.A = act_r; g.lda = I; g.W = L.downw; g.ldw = I;
+  g.residual = xres; g.ldr = d; g.C = xres; g.ldc = d;
+  return decode_gemm(m, ws, g, st, next_gain, xg, rstd);
+}
+
+// One decode step through every layer.  In: ws->lx = the rows' input embeddings.  Out: ws->lx = final hidden rows, ws->lh = T(x * norm.w),
+// ws->rstd = 1 / rms(x): lm_head's operands (lm_head_rows with normed = true).
+static int llm_decode_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int rows, int beams, int max_S, const int* pos, const int* cpos,
+                             const int* anc, const int* step, hipStream_t st, const float2* rope_cs = nullptr) {
+  const oavsr_config& c = m->cfg;
+  const int dt = m->dtype, d = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, hd = c.llm_head_dim;
+  const int nq = H * hd, nqkv = (H + 2 * KV) * hd;
+  const int tl = c.lora_task_specific ? task : 0;
+  { ProfScope ps("decode_rms_prep", 0, 2.0 * rows * d * m->esz, st);
+    OAVSR_TRY(launch_rms_prep(dt, ws->lx, d, ws->lh, d, m->llayers[0].ln1w, ws->rstd, rows, d, c.llm_rms_eps, st)); }
+  for (int li = 0; li < c.llm_layers; ++li) {
+    const LlmLayer& L = m->llayers[li];
+    GemmArgs g;
+    if (c.lora_k2 > 0) {      // t = (x * g) A^T, rounded to T WITHOUT 1 / rms: the QKV launch scales both of its K segments by it
+      g.dtype = dt; g.M = rows; g.N = c.lora_k2; g.K = d; g.A = ws->lh; g.lda = d; g.W = L.lora_dn[tl]; g.ldw = d; g.C = ws->llora; g.ldc = c.lora_k2;
+      OAVSR_TRY(decode_gemm(m, ws, g, st));
+    }
+    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = nqkv; g.K = d; g.A = ws->lh; g.lda = d; g.W = L.qkvw; g.ldw = d; g.col_bias = L.qkvb;
+    if (c.lora_k2 > 0) { g.A2 = ws->llora; g.lda2 = c.lora_k2; g.W2 = L.lora_up[tl]; g.ldw2 = c.lora_k2; g.K2 = c.lora_k2; }
+    g.row_scale = ws->rstd; g.C = ws->lqkv; g.ldc = nqkv;
+    OAVSR_TRY(decode_gemm(m, ws, g, st));
+    // RoPE + cache append are fused into the decode-attention kernel
+    DecodeAttnArgs a; a.dtype = dt; a.head_dim = hd; a.n_heads = H; a.n_kv_heads = KV; a.rows = rows; a.beams = beams;
+    a.Q = ws->lqkv; a.ldq = nqkv; a.O = ws->lattn; a.ldo = nq;
+    a.Kp = (char*)ws->kpre + li * ws->kpre_layer; a.Vp = (char*)ws->vpre + li * ws->kpre_layer; a.max_prefix = ws->max_prefix;
+    a.Kt = (char*)ws->ktail + li * ws->ktail_layer; a.Vt = (char*)ws->vtail + li * ws->ktail_layer; a.max_tail = ws->max_new;
+    a.prefix_len = ws->prefix_len; a.step = step; a.anc = anc; a.scale = 1.0f / sqrtf((float)hd);
+    a.inv_freq = m->inv_freq; a.pos = pos; a.cpos = cpos; a.rope_cs = rope_cs; a.rowmap = ws->rowmap;
+    { ProfScope ps("decode_attention", 0, 2.0 * rows * max_S * KV * hd * m->esz, st);
+      OAVSR_TRY(launch_decode_attention(a, st)); }
+    const float* next_gain = li + 1 < c.llm_layers ? m->llayers[li + 1].ln1w : m->norm_w;
+    OAVSR_TRY(decode_layer_tail(m, ws, L, rows, ws->lx, ws->lattn, ws->lact, ws->lh, ws->rstd, next_gain, st));
+  }
+  return 0;
+}
+
+// Prefill: all prompt rows of all utterances through the MFMA-bound GEMM families (var-len causal attention, prefix KV written by the RoPE
+// kernel).  last_rows / cu_last: row index of every utterance's final prompt token and the device array 0..B.  Only those rows feed lm_head
+// (the reference materialises all positions, Llama_LoRA.py:372-373), so in the LAST layer everything after the KV append -- attention
+// queries, o_proj, the MLP -- runs on the B gathered rows (compact residual stream ws->lastx) through the decode-shaped path above, 128
+// rows at a time: an utterance's first-token logits do not depend on its batch.  On return ws->lastx holds the final hidden rows, ws->lh /
+// ws->rstd the final norm's operands for lm_head_rows(normed = true).
+static int llm_prefill_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int rows, int B, int max_S, const int* pos, const int* cpos,
+                              const int* last_rows, const int* cu_last, hipStream_t st) {
+  const oavsr_config& c = m->cfg;
+  const int dt = m->dtype, d = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, hd = c.llm_head_dim, I = c.llm_mlp;
+  const int nq = H * hd, nqkv = (H + 2 * KV) * hd;
+  const int tl = c.lora_task_specific ? task : 0;
+  for (int li = 0; li < c.llm_layers; ++li) {
+    const LlmLayer& L = m->llayers[li];
+    const bool prune = li == c.llm_layers - 1;
+    { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
+      OAVSR_TRY(launch_rmsnorm(dt, ws->lx, d, ws->lh, d, L.ln1w, rows, d, c.llm_rms_eps, st)); }
+    GemmArgs g;
+    if (c.lora_k2 > 0) {
+      g.dtype = dt; g.M = rows; g.N = c.lora_k2; g.K = d; g.A = ws->lh; g.lda = d; g.W = L.lora_dn[tl]; g.ldw = d; g.C = ws->llora; g.ldc = c.lora_k2;
+      OAVSR_TRY(run_gemm(g, st));
+    }
+    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = nqkv; g.K = d; g.A = ws->lh; g.lda = d; g.W = L.qkvw; g.ldw = d; g.col_bias = L.qkvb;
+    if (c.lora_k2 > 0) { g.A2 = ws->llora; g.lda2 = c.lora_k2; g.W2 = L.lora_up[tl]; g.ldw2 = c.lora_k2; g.K2 = c.lora_k2; }
+    g.C = ws->lqkv; g.ldc = nqkv;
+    OAVSR_TRY(run_gemm(g, st));
+    RopeArgs r; r.dtype = dt; r.rows = rows; r.n_heads = H; r.n_kv_heads = KV; r.head_dim = hd; r.qkv = ws->lqkv; r.ld = nqkv;
+    r.inv_freq = m->inv_freq; r.pos = pos; r.slot = ws->slot; r.cpos = cpos;
+    r.kcache = (char*)ws->pf_k + li * ws->pf_layer; r.vcache = (char*)ws->pf_v + li * ws->pf_layer; r.max_ctx = ws->pf_max_prefix;
+    { ProfScope ps("rope_kv", 0, 2.0 * rows * nqkv * m->esz, st);
+      OAVSR_TRY(launch_rope_kv(r, st)); }
+    AttnArgs a; a.dtype = dt; a.head_dim = hd; a.n_heads = H; a.n_kv_heads = KV; a.n_seqs = B;
+    a.Q = ws->lqkv; a.K = (const char*)ws->lqkv + (size_t)nq * m->esz; a.V = (const char*)ws->lqkv + (size_t)(nq + KV * hd) * m->esz;
+    a.ldq = a.ldk = a.ldv = nqkv; a.O = ws->lattn; a.ldo = nq; a.cu_q = ws->cu_s; a.cu_k = ws->cu_s; a.max_q = max_S;
+    a.scale = 1.0f / sqrtf((float)hd); a.causal = 1;
+    if (prune) {   // one query row per utterance: gathered q rows (ws->lh is free after the QKV GEMM) against the full K / V
+      OAVSR_TRY(launch_copy_rows(dt, ws->lqkv, nqkv, last_rows, ws->lh, nqkv, B, nqkv, st));
+      OAVSR_TRY(launch_copy_rows(dt, ws->lx, d, last_rows, ws->lastx, d, B, d, st));
+      a.Q = ws->lh; a.cu_q = cu_last; a.max_q = 1;
+    }
+    { ProfScope ps(dt == DT_F32 ? "attention_f32" : "attention_bf16", 2.0 * (prune ? B : rows) * max_S * nq, 4.0 * (prune ? B : rows) * nq * m->esz, st);
+      OAVSR_TRY(launch_attention(a, st)); }
+    if (prune) {      // (ws->lh held the gathered queries: free again)
+      OAVSR_TRY(decode_layer_tail(m, ws, L, B, ws->lastx, ws->lattn, ws->lact, ws->lh, ws->rstd, m->norm_w, st));
+      break;
+    }
+    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = d; g.K = nq; g.A = ws->lattn; g.lda = nq; g.W = L.ow; g.ldw = nq;
+    g.residual = ws->lx; g.ldr = d; g.C = ws->lx; g.ldc = d;
+    OAVSR_TRY(run_gemm(g, st));
+    { ProfScope ps("rmsnorm", 0, 2.0 * rows * d * m->esz, st);
+      OAVSR_TRY(launch_rmsnorm(dt, ws->lx, d, ws->lh, d, L.ln2w, rows, d, c.llm_rms_eps, st)); }
+    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 2 * I; g.K = d; g.A = ws->lh; g.lda = d; g.W = L.guw; g.ldw = d; g.C = ws->lgu; g.ldc = 2 * I;
+    GemmArgs gf = g; gf.swiglu_pairs = 1; gf.C = ws->lact; gf.ldc = I;
+    if (gemm_dma_swiglu_ok(gf)) {      // SwiGLU in the GEMM epilogue: the [rows][2I] tensor never exists
+      OAVSR_TRY(run_gemm(gf, st));
+    } else {
+      OAVSR_TRY(run_gemm(g, st));
+      ProfScope ps("swiglu", 0, 3.0 * rows * I * m->esz, st);
+      OAVSR_TRY(launch_swiglu(dt, ws->lgu, 2 * I, ws->lact, I, rows, I, 1, st));
+    }
+    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = d; g.K = I; g.A = ws->lact; g.lda = I; g.W = L.downw; g.ldw = I;
+    g.residual = ws->lx; g.ldr = d; g.C = ws->lx; g.ldc = d;
+    OAVSR_TRY(run_gemm(g, st));
+  }
+  return 0;
+}
+
+// logits[rows][vocab] (fp32, Llama_LoRA.py:372-373) of decode-shaped rows: A = ws->lh rows (T(x * norm.w), written by the last
+// down_proj's reduce), accumulator x ws->rstd
+static int lm_head_rows(const oavsr_model* m, oavsr_workspace* ws, int rows, float* logits, hipStream_t st) {
   const oavsr_config& c = m->cfg;
   const int d = c.llm_hidden;
   GemmArgs g; g.dtype = m->dtype; g.M = rows; g.N = c.llm_vocab; g.K = d; g.W = m->lm_head; g.ldw = d;
-  g.C = logits; g.ldc = c.llm_vocab; g.out_f32 = 1;
-  const bool tiled = beams == 1 && chunk == 0 && m->tiled_decode;      // (the prefill's first lm_head keeps the chunked weight-streaming launches)
-  g.decode_tiled = tiled ? 1 : 0;
-  if (!tiled && (rows <= skinny_max_rows(beams) || chunk > 0)) {     // final RMSNorm fused into the weight-streaming kernel
-    const int step = chunk > 0 ? chunk : rows;
-    for (int r0 = 0; r0 < rows; r0 += step) {
-      g.M = std::min(step, rows - r0);
-      g.A = (const char*)x + (size_t)r0 * d * m->esz; g.lda = d; g.norm_gain = m->norm_w; g.norm_eps = c.llm_rms_eps;
-      g.C = logits + (size_t)r0 * c.llm_vocab;
-      OAVSR_TRY(run_gemm(g, st, true));
-    }
-    return 0;
-  }
-  if (!normed) { ProfScope ps("decode_rmsnorm", 0, 2.0 * rows * d * m->esz, st);
-    OAVSR_TRY(launch_rmsnorm(m->dtype, x, d, ws->lh, d, m->norm_w, rows, d, c.llm_rms_eps, st)); }
-  g.A = ws->lh; g.lda = d;
-  return run_gemm(g, st, false);
+  g.A = ws->lh; g.lda = d; g.row_scale = ws->rstd; g.C = logits; g.ldc = c.llm_vocab; g.out_f32 = 1; g.swiglu_pairs = 0;
+  // (N = the vocabulary: the column tiles alone fill the chip; decode_split gives 1)
+  return decode_gemm(m, ws, g, st);
 }
 
 // Where a prefill puts what the decode loop needs: the row slots slot0.. of a decode scheduler's pool instead of the workspace's own caches.
@@ -1074,16 +1021,17 @@ static int prefill_impl(const oavsr_model* m, oavsr_workspace* ws, int task, int
   OAVSR_TRY(h2d(ws->last_rows, last, sizeof(int) * B, st));
   OAVSR_TRY(h2d(dest ? dest->prefix_len + dest->slot0 : ws->prefix_len + utt0, plen, sizeof(int) * B, st));
   if (embeds != ws->lx) OAVSR_CHECK_HIP(hipMemcpyAsync(ws->lx, embeds, (size_t)total * c.llm_hidden * m->esz, hipMemcpyDeviceToDevice, st));
+  // what this call's prompt rows hold (the spliced inputs_embeds, modeling_OmniAVSR.py:397-458), per utterance, before the layers overwrite them
+  if (ws->digests) OAVSR_TRY(launch_digest(ws->lx, ws->cu_s, (int64_t)c.llm_hidden * m->esz / 4, B, ws->digests + (size_t)utt0 * 2, 2, 0, st));
   int* cul = ws->stage<int>(B + 1);
   OAVSR_REQUIRE(cul, "host staging exhausted");
   for (int b = 0; b <= B; ++b) cul[b] = b;
   OAVSR_TRY(h2d(ws->cu_b, cul, sizeof(int) * (B + 1), st));   // cu_b: encoder scratch, idle during prefill
-  bool pruned = false;
-  OAVSR_TRY(llm_layers(m, ws, task, total, false, B, 1, maxS, ws->pos, ws->cpos, nullptr, nullptr, st, nullptr, ws->last_rows, ws->cu_b, &pruned));
-  // last position of every utterance only (the reference materialises all positions, Llama_LoRA.py:372-373)
-  if (!pruned) OAVSR_TRY(launch_copy_rows(m->dtype, ws->lx, c.llm_hidden, ws->last_rows, ws->lastx, c.llm_hidden, B, c.llm_hidden, st));
+  // logits of every utterance's last position only (the reference materialises all positions, Llama_LoRA.py:372-373)
+  OAVSR_TRY(llm_prefill_layers(m, ws, task, total, B, maxS, ws->pos, ws->cpos, ws->last_rows, ws->cu_b, st));
   float* lg = dest ? dest->logits + (size_t)dest->slot0 * c.llm_vocab : ws->logits + (size_t)utt0 * c.llm_vocab;
-  OAVSR_TRY(lm_head_rows(m, ws, ws->lastx, B, lg, st, kPrefillTailChunk));
+  OAVSR_TRY(lm_head_rows(m, ws, B, lg, st));
+  if (ws->digests) OAVSR_TRY(launch_digest(lg, nullptr, c.llm_vocab, B, ws->digests + (size_t)utt0 * 2, 2, 1, st));      // the first step's logits row
   if (logits_out) OAVSR_CHECK_HIP(hipMemcpyAsync(logits_out, lg, (size_t)B * c.llm_vocab * 4, hipMemcpyDeviceToDevice, st));
   return 0;
 }
@@ -1120,13 +1068,12 @@ static int decode_greedy(const oavsr_model* m, oavsr_workspace* ws, int task, in
   for (int b = 0; b < B; ++b) slot[b] = b;
   OAVSR_TRY(h2d(ws->slot, slot, sizeof(int) * B, st));
   const int banned = force_len ? c.id_eos : -1;
-  OAVSR_CHECK_HIP(hipMemsetAsync(ws->sync, 0, ws->sync_bytes, st));   // stage counters of the fused launches: step s expects s x n arrivals
   OAVSR_TRY(launch_argmax(ws->logits, c.llm_vocab, B, c.llm_vocab, banned, ws->amax, ws->amax_scratch, st));
   OAVSR_TRY(launch_greedy_update(ws->amax, gs, B, max_new, c.id_eos, c.id_pad, st));
   auto one_step = [&]() -> int {
     OAVSR_TRY(launch_embed(m->dtype, m->embed, c.llm_hidden, gs.tok, ws->lx, c.llm_hidden, B, c.llm_hidden, st));
-    OAVSR_TRY(llm_layers(m, ws, task, B, true, B, 1, maxS + max_new, gs.pos, gs.cpos, nullptr, gs.step, st, gs.rope_cs));
-    OAVSR_TRY(lm_head_rows(m, ws, ws->lx, B, ws->logits, st));
+    OAVSR_TRY(llm_decode_layers(m, ws, task, B, 1, maxS + max_new, gs.pos, gs.cpos, nullptr, gs.step, st, gs.rope_cs));
+    OAVSR_TRY(lm_head_rows(m, ws, B, ws->logits, st));
     OAVSR_TRY(launch_argmax(ws->logits, c.llm_vocab, B, c.llm_vocab, banned, ws->amax, ws->amax_scratch, st));
     return launch_greedy_update(ws->amax, gs, B, max_new, c.id_eos, c.id_pad, st);
   };
@@ -1189,10 +1136,8 @@ static int decode_beam(const oavsr_model* m, oavsr_workspace* ws, int task, int 
   // one step reads ping-pong side `cur` of the sequence / ancestry tables and writes the other one
   auto one_step = [&](int cur) -> int {
     OAVSR_TRY(launch_embed(m->dtype, m->embed, c.llm_hidden, ws->gs.tok, ws->lx, c.llm_hidden, R, c.llm_hidden, st));
-    bool fnorm = false;
-    OAVSR_TRY(llm_layers(m, ws, task, R, true, B, K, maxS + max_new, ws->gs.pos, ws->gs.cpos, anc[cur], ws->gs.step, st, nullptr, nullptr, nullptr, nullptr,
-                         R > skinny_max_rows(K) ? &fnorm : nullptr));
-    OAVSR_TRY(lm_head_rows(m, ws, ws->lx, R, ws->logits, st, 0, fnorm, K));
+    OAVSR_TRY(llm_decode_layers(m, ws, task, R, K, maxS + max_new, ws->gs.pos, ws->gs.cpos, anc[cur], ws->gs.step, st));
+    OAVSR_TRY(lm_head_rows(m, ws, R, ws->logits, st));
     ProfScope ps("beam_search", 0, (double)R * c.llm_vocab * 16, st);
     OAVSR_TRY(launch_beam_topk(ws->logits, c.llm_vocab, R, c.llm_vocab, K, ws->beam_scores, ws->cand_val, ws->cand_tok, ws->topk_flag, st));
     return launch_beam_step(a, 0, seq[cur], anc[cur], seq[cur ^ 1], anc[cur ^ 1], st);
@@ -1275,13 +1220,12 @@ int oavsr_model_create(const oavsr_config* cfg, const void* blob_dev, uint64_t b
   std::vector<double> tw(800);
   for (int k = 0; k < 400; ++k) { tw[2 * k] = cos(2.0 * M_PI * k / 400.0); tw[2 * k + 1] = sin(2.0 * M_PI * k / 400.0); }
   std::vector<float> fb; build_melfb(fb);
-  if (hipMalloc(&m->twiddle, 800 * sizeof(double)) != hipSuccess || hipMalloc(&m->melfb, fb.size() * sizeof(float)) != hipSuccess) {
-    set_last_error("model_create: hipMalloc failed"); delete m; return -2;
-  }
+  { hipError_t e1 = hipMalloc(&m->twiddle, 800 * sizeof(double)), e2 = e1 == hipSuccess ? hipMalloc(&m->melfb, fb.size() * sizeof(float)) : e1;
+    if (e2 != hipSuccess) { set_last_error("model_create: hipMalloc of the log-mel constants failed: %s", hipGetErrorString(e2)); delete m; return -2; } }
   hipMemcpy(m->twiddle, tw.data(), 800 * sizeof(double), hipMemcpyHostToDevice);
   hipMemcpy(m->melfb, fb.data(), fb.size() * sizeof(float), hipMemcpyHostToDevice);
   if (m->has_video) {
-    if (hipMalloc(&m->stem_wp, 64 * 288 * m->esz) != hipSuccess) { set_last_error("model_create: hipMalloc failed"); oavsr_model_destroy(m); return -2; }
+    if (hipError_t e1 = hipMalloc(&m->stem_wp, 64 * 288 * m->esz); e1 != hipSuccess) { set_last_error("model_create: hipMalloc of the stem weights failed: %s", hipGetErrorString(e1)); oavsr_model_destroy(m); return -2; }
     if (launch_stem_repack(m->dtype, m->stem.w, m->stem_wp, nullptr) != 0 || hipDeviceSynchronize() != hipSuccess) {
       set_last_error("model_create: stem repack failed"); oavsr_model_destroy(m); return -2;
     }
@@ -1289,7 +1233,7 @@ int oavsr_model_create(const oavsr_config* cfg, const void* blob_dev, uint64_t b
   if (m->has_video && enc_cat_ok(m->cfg.av_dim, m->cfg.av_lora_k2, m->esz)) {
     // [qkv.w | lora_up.w] per video layer: the LoRA term rides in the QKV GEMM's ONE K range (run_encoder_layers)
     const size_t D = m->cfg.av_dim, k2 = m->cfg.av_lora_k2, e = m->esz, per = 3 * D * (D + k2) * e;
-    if (hipMalloc(&m->enc_cat, per * m->vlayers.size()) != hipSuccess) { set_last_error("model_create: hipMalloc failed"); oavsr_model_destroy(m); return -2; }
+    if (hipError_t e1 = hipMalloc(&m->enc_cat, per * m->vlayers.size()); e1 != hipSuccess) { set_last_error("model_create: hipMalloc of the concatenated QKV + LoRA weights (%zu bytes) failed: %s", per * m->vlayers.size(), hipGetErrorString(e1)); oavsr_model_destroy(m); return -2; }
     for (size_t i = 0; i < m->vlayers.size(); ++i) {
       char* dst = (char*)m->enc_cat + i * per;
       if (hipMemcpy2D(dst, (D + k2) * e, m->vlayers[i].qkvw, D * e, D * e, 3 * D, hipMemcpyDeviceToDevice) != hipSuccess ||
@@ -1388,20 +1332,17 @@ int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, 
   WANT(ktail, ws->ktail_layer * c.llm_layers); WANT(vtail, ws->ktail_layer * c.llm_layers);
   WANT(pos, Rl * 4); WANT(slot, Rl * 4); WANT(cpos, Rl * 4); WANT(cu_s, (max_B + 1) * 4); WANT(prefix_len, max_B * 4); WANT(last_rows, max_B * 4);
   WANT(amax, rows_dec * 4); WANT(amax_scratch, rows_dec * 64 * 8);
-  ws->sync_bytes = ((size_t)2 * c.llm_layers * kChainCtrInts + 32) * 4;
-  WANT(sync, ws->sync_bytes);
+  WANT(gsync, kSyncInts * 4); WANT(rstd, Rl * 4); WANT(rowsq, ((size_t)ceil_div(d, 64) + 2) * Rl * 4);
   WANT(gs.tok, rows_dec * 4); WANT(gs.finished, rows_dec * 4); WANT(gs.out_ids, rows_dec * (size_t)max_new * 4); WANT(gs.out_len, rows_dec * 4);
   WANT(gs.step, 256); WANT(gs.pos, rows_dec * 4); WANT(gs.cpos, rows_dec * 4); WANT(gs.rope_cs, rows_dec * (size_t)(hd / 2) * sizeof(float2));
-  {   // split-K partial slabs: decode GEMMs with > 32 rows (beam search)
+  {   // split-K partial slabs of the decode-shaped GEMMs: ks(N, K) x rows x N fp32 per call site (decode_split; o_proj / down_proj split >= 2)
+    const size_t rows_sl = 128;      // every decode-shaped GEMM launch covers <= 128 rows (decode_gemm)
+    const int es = (int)e, qkv = (int)nqkv, nq_ = H * hd;
+    const int sites[5][3] = {{c.lora_k2, d, 1}, {qkv, d + c.lora_k2, 1}, {d, nq_, 2}, {2 * I, d, 1}, {d, I, 2}};
     size_t pb = 0;
-    if (rows_dec > 32 || m->tiled_decode) {   // every decode GEMM call site: ks(N, K) x rows x N fp32 (decode_split)
-      const int es = (int)e, qkv = (int)nqkv, nq_ = H * hd;
-      const int sites[5][2] = {{c.lora_k2, d}, {qkv, d + c.lora_k2}, {d, nq_}, {2 * I, d}, {d, I}};
-      for (auto& s2 : sites) if (s2[0] > 0)
-        pb = std::max(pb, (size_t)std::max(decode_split(s2[0], s2[1], es, kDecodeSplitBeam), decode_split(s2[0], s2[1], es, kDecodeSplitTiled)) * rows_dec * s2[0] * 4);
-    }
+    for (auto& s2 : sites) if (s2[0] > 0) pb = std::max(pb, (size_t)decode_split(s2[0], s2[1], es, s2[2]) * rows_sl * s2[0] * 4);
     ws->partial_bytes = pb;
-    if (pb) WANT(partial, pb);
+    WANT(partial, std::max<size_t>(pb, 256));
   }
   if (max_beams > 1) {
     WANT(beam_scores, rows_dec * 4); WANT(cand_val, rows_dec * 2 * max_beams * 4); WANT(cand_tok, rows_dec * 2 * max_beams * 4); WANT(topk_flag, rows_dec * 4);
@@ -1452,6 +1393,12 @@ int oavsr_workspace_set_video_format(oavsr_workspace* ws, int32_t channels, int3
   OAVSR_REQUIRE((channels == 1 || channels == 3) && height >= 88 && width >= 88 && height <= 4096 && width <= 4096,
                 "workspace_set_video_format: uint8 frames must be [1 or 3][H >= 88][W >= 88], got [%d][%d][%d]", channels, height, width);
   ws->vsrc = StemSrc::u8(channels, height, width);
+  return 0;
+}
+
+int oavsr_workspace_set_digests(oavsr_workspace* ws, uint64_t* digests_dev) {
+  OAVSR_REQUIRE(ws, "workspace_set_digests: null workspace");
+  ws->digests = digests_dev;
   return 0;
 }
 
@@ -1584,9 +1531,8 @@ static int lane_max_remaining(const oavsr_scheduler* s, const SchedLane& l) { in
 // one decode step over the R compact rows of the lane's current membership (every launch on the lane's stream; hipGraph-capturable)
 static int sched_one_step(oavsr_scheduler* s, SchedLane& l, int R, int task, int banned) {
   const oavsr_model* m = s->m; const oavsr_config& c = m->cfg; oavsr_workspace* w = l.dws;
-  struct Shared { Shared() { g_shared_chip = 1; } ~Shared() { g_shared_chip = 0; } } shared_chip_scope;      // the step runs beside other calls' encoder phases
-  OAVSR_TRY(llm_layers(m, w, task, R, true, R, 1, s->max_prefix + s->max_new, s->ss.pos, s->ss.cpos, nullptr, nullptr, l.st, s->ss.rope_cs));
-  OAVSR_TRY(lm_head_rows(m, w, w->lx, R, w->logits, l.st));
+  OAVSR_TRY(llm_decode_layers(m, w, task, R, 1, s->max_prefix + s->max_new, s->ss.pos, s->ss.cpos, nullptr, nullptr, l.st, s->ss.rope_cs));
+  OAVSR_TRY(lm_head_rows(m, w, R, w->logits, l.st));
   { ProfScope ps("argmax_partial", 0, (double)R * c.llm_vocab * 4, l.st);
     OAVSR_TRY(launch_argmax_partial(w->logits, c.llm_vocab, R, c.llm_vocab, banned, l.partials, l.st)); }
   ProfScope ps("sched_tail", 0, 2.0 * R * c.llm_hidden * m->esz, l.st);
@@ -1712,12 +1658,13 @@ int oavsr_scheduler_create(const oavsr_model* m, int32_t n_slots, int32_t max_ro
     WANT(lw->lx, R * d * e); WANT(lw->lh, R * d * e); WANT(lw->lqkv, R * nqkv * e); WANT(lw->lattn, R * (size_t)H * hd * e);
     WANT(lw->lact, R * (size_t)I * e); WANT(lw->llora, R * (size_t)std::max(64, c.lora_k2) * e); WANT(lw->logits, R * (size_t)c.llm_vocab * 4);
     WANT(l.partials, R * 64 * 8); WANT(l.rowmap, 128 * 4);
-    if (m->tiled_decode) {   // the tiled regime's split-K slabs and (when SwiGLU is not fused) the [rows][2I] gate / up tensor
-      const int sites[5][2] = {{c.lora_k2, d}, {(int)nqkv, d + c.lora_k2}, {d, H * hd}, {2 * I, d}, {d, I}};
+    {   // the decode-shaped GEMMs' split-K slabs, arrival counters, deferred-norm scratch and (when SwiGLU is not fused) the [rows][2I] gate / up tensor
+      const int sites[5][3] = {{c.lora_k2, d, 1}, {(int)nqkv, d + c.lora_k2, 1}, {d, H * hd, 2}, {2 * I, d, 1}, {d, I, 2}};
       size_t pb = 0;
-      for (auto& s2 : sites) if (s2[0] > 0) pb = std::max(pb, (size_t)decode_split(s2[0], s2[1], (int)e, kDecodeSplitTiled) * R * s2[0] * 4);
+      for (auto& s2 : sites) if (s2[0] > 0) pb = std::max(pb, (size_t)decode_split(s2[0], s2[1], (int)e, s2[2]) * 128 * s2[0] * 4);
       lw->partial_bytes = pb;
-      WANT(lw->partial, pb); WANT(lw->lgu, R * 2 * (size_t)I * e);
+      WANT(lw->partial, std::max<size_t>(pb, 256)); WANT(lw->lgu, R * 2 * (size_t)I * e);
+      WANT(lw->gsync, kSyncInts * 4); WANT(lw->rstd, R * 4); WANT(lw->rowsq, ((size_t)ceil_div(d, 64) + 2) * R * 4);
     }
   }
 #undef WANT
@@ -2012,25 +1959,27 @@ int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream) {
   g.res_after_act = d->res_after_act; g.groups = d->groups < 1 ? 1 : d->groups; g.a_goff = d->a_goff; g.amode = d->amode;
   g.H = d->H; g.Wd = d->W_; g.Cin = d->Cin; g.OH = d->OH; g.OW = d->OW; g.stride = d->stride; g.pad = d->pad; g.ksize = d->ksize;
   g.rowinfo = (const int4*)d->rowinfo; g.taps = d->taps; g.Kvalid = d->Kvalid; g.frameinfo = (const int2*)d->frameinfo;
-  g.norm_gain = d->norm_gain; g.norm_eps = d->norm_eps; g.swiglu_pairs = d->swiglu_pairs;
-  g.ksplit = d->ksplit < 1 ? 1 : d->ksplit; g.partial = d->partial;
-  g.rn_out = d->rn_out; g.rn_ld = d->rn_ld; g.rn_gain = d->rn_gain; g.rn_eps = d->rn_eps;
-  OAVSR_REQUIRE(!g.rn_out || g.ksplit > 1, "gemm: rn_out needs split-K (ksplit > 1)");
-  g.shared_chip = d->skinny == 1 ? (d->shared_chip != 0) : 0;
-  if (d->skinny == 2) {      // tests: the 8-wave ping-pong 256 x 256 kernel whatever the dispatcher's rule says
+  g.swiglu_pairs = d->swiglu_pairs; g.decode_tiled = d->decode_tiled != 0;
+  g.ksplit = d->ksplit < 1 ? 1 : d->ksplit; g.partial = d->partial; g.sync = d->sync; g.row_scale = d->row_scale;
+  g.ng_out = d->ng_out; g.ng_ld = d->ng_ld; g.ng_gain = d->ng_gain; g.ng_rowsq = d->ng_rowsq; g.ng_rstd = d->ng_rstd; g.ng_eps = d->ng_eps;
+  OAVSR_REQUIRE(!g.ng_out || g.ksplit > 1, "op_gemm: the next-norm outputs need split-K (ksplit > 1)");
+  OAVSR_REQUIRE(!g.row_scale || (g.M <= 128 && g.amode == A_DENSE && g.groups == 1 && g.N >= 64 && d->kernel == 0), "op_gemm: row_scale is an epilogue of the decode-shaped launches (dense, M <= 128, N >= 64)");
+  if (g.row_scale) g.decode_tiled = 1;
+  if (d->kernel == 2) {      // tests: the 8-wave ping-pong 256 x 256 kernel whatever the dispatcher's rule says
     OAVSR_REQUIRE(gemm_8p_supported(g), "op_gemm: shape / layout not supported by the ping-pong kernel");
     return launch_gemm_8p(g, (hipStream_t)stream);
   }
-  if (d->skinny == 3) return launch_gemm_8pp(g, (hipStream_t)stream, d->grid);      // tests: the persistent ping-pong kernel on d->grid workgroups
-  if (d->skinny == 5) {      // tests / yardsticks: the 16-wave 256 x 256 LDS-DMA kernel whatever the dispatcher's rule says
+  if (d->kernel == 3) return launch_gemm_8pp(g, (hipStream_t)stream, d->grid);      // tests: the persistent ping-pong kernel on d->grid workgroups
+  if (d->kernel == 5) {      // tests / yardsticks: the 16-wave 256 x 256 LDS-DMA kernel whatever the dispatcher's rule says
     g.force_tile = 2;
     return launch_gemm(g, (hipStream_t)stream);
   }
-  if (d->skinny == 6 || d->skinny == 7) {      // tests / yardsticks: the 160 x 128 (6) / 256 x 128 (7) LDS-DMA tiles whatever the dispatcher's rule says
-    g.force_tile = d->skinny == 6 ? 5 : 8;
+  if (d->kernel == 6 || d->kernel == 7) {      // tests / yardsticks: the 160 x 128 (6) / 256 x 128 (7) LDS-DMA tiles whatever the dispatcher's rule says
+    g.force_tile = d->kernel == 6 ? 5 : 8;
     return launch_gemm_dma(g, (hipStream_t)stream);
   }
-  return d->skinny ? launch_gemm_skinny(g, (hipStream_t)stream) : launch_gemm(g, (hipStream_t)stream);
+  OAVSR_REQUIRE(d->kernel == 0, "op_gemm: unknown kernel selector %d", d->kernel);
+  return launch_gemm(g, (hipStream_t)stream);
 }
 
 int oavsr_op_stem_pool(int32_t dtype, const void* video, int32_t channels, int32_t height, int32_t width, const int32_t* frameinfo_dev, int32_t F,
@@ -2079,6 +2028,11 @@ int oavsr_op_norm(int32_t mode, int32_t dtype, const void* x, int64_t ldx, void*
   if (mode == 2) return launch_layernorm_zero_prefix(dtype, x, ldx, y, ldy, w, b, rows, D, eps, st);
   set_last_error("op_norm: bad mode %d", mode);
   return -1;
+}
+int oavsr_op_rms_prep(int32_t dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, float* rstd, int32_t rows, int32_t D, float eps,
+                      oavsr_stream stream) {
+  OAVSR_REQUIRE(x && y && w && rstd, "op_rms_prep: null argument");
+  return launch_rms_prep(dtype, x, ldx, y, ldy, w, rstd, rows, D, eps, (hipStream_t)stream);
 }
 int oavsr_op_maxpool3x3s2(int32_t dtype, const void* x, void* y, int32_t imgs, int32_t H, int32_t W, int32_t C, oavsr_stream stream) {
   return launch_maxpool3x3s2(dtype, x, y, imgs, H, W, C, (hipStream_t)stream);

@@ -168,6 +168,31 @@ int launch_norm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, con
   return 0;
 }
 
+// Deferred RMSNorm of the decode path (Llama_LoRA.py:587-655: input_layernorm / post_attention_layernorm / model.norm): the consumer GEMM
+// takes y = T(x * gain) as its A operand and multiplies its accumulator by rstd[row] = 1 / rms(x) (GemmArgs::row_scale).  This kernel
+// prepares the pair for rows that no GEMM produced (the embedding rows at the start of a decode step); inside a step the split-K reduce
+// of o_proj / down_proj writes it (gemm2.hip).  One wave per row; sum of squares per lane in column order, then wave_sum.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void rms_prep_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy,
+                                                             const float* __restrict__ w, float* __restrict__ rstd, int rows, int D, float eps) {
+  constexpr int VEC = TypeInfo<T>::kVec;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * kWavesPerBlock + wave;
+  if (row >= rows) return;
+  const T* xr = x + (int64_t)row * ldx;
+  T* yr = y + (int64_t)row * ldy;
+  float s2 = 0.f;
+  for (int c = lane * VEC; c < D; c += 64 * VEC) {
+    float f[VEC], o[VEC];
+    chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(xr + c), f);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { s2 = fmaf(f[e], f[e], s2); o[e] = f[e] * w[c + e]; }
+    *reinterpret_cast<Chunk16*>(yr + c) = chunk_from_f32<T>(o);
+  }
+  s2 = wave_sum(s2);
+  if (lane == 0) rstd[row] = rsqrtf(s2 / (float)D + eps);
+}
+
 // ---------------------------------------------------------------------------------------------
 // NHWC pools
 // ---------------------------------------------------------------------------------------------
@@ -506,6 +531,36 @@ __global__ void sched_retire_kernel(SchedState s, int slot0, int max_new, int* _
   if (threadIdx.x == 0) out_len[b] = s.out_len[slot];
 }
 
+// Per-utterance 64-bit digest of a device region (tests / bench.py: does every call see ITS inputs?): sum over the region's 32-bit words w_i of
+// splitmix64(w_i | (i + 1) << 32) mod 2^64 -- position-sensitive, order of summation irrelevant (integer adds), so any reduction tree gives
+// the same value.  Utterance b owns rows [cu[b], cu[b + 1]) of `words_per_row` words (cu == nullptr: row b alone).
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+  z ^= z >> 30; z *= 0xbf58476d1ce4e5b9ull; z ^= z >> 27; z *= 0x94d049bb133111ebull; z ^= z >> 31;
+  return z;
+}
+__global__ __launch_bounds__(kThreads) void digest_kernel(const unsigned* __restrict__ base, const int* __restrict__ cu, long long words_per_row,
+                                                           unsigned long long* __restrict__ out, int out_stride, int out_col) {
+  __shared__ unsigned long long part[kWavesPerBlock];
+  const int b = blockIdx.x;
+  const long long r0 = cu ? cu[b] : b, r1 = cu ? cu[b + 1] : b + 1;
+  const unsigned* p = base + r0 * words_per_row;
+  const long long n = (r1 - r0) * words_per_row;
+  unsigned long long acc = 0;
+  for (long long i = threadIdx.x; i < n; i += kThreads) acc += mix64((unsigned long long)p[i] | ((unsigned long long)(i + 1) << 32));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)acc, o, 64), hi = __shfl_xor((unsigned)(acc >> 32), o, 64);
+    acc += ((unsigned long long)hi << 32) | lo;
+  }
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < kWavesPerBlock; ++w) t += part[w];
+    out[(long long)b * out_stride + out_col] = t;
+  }
+}
+
 __global__ void rowinfo_kernel(const int* __restrict__ cu_out, const int* __restrict__ cu_in, int n_seqs, int stride, int4* __restrict__ ri, int rows) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= rows) return;
@@ -529,6 +584,17 @@ int launch_layernorm_zero_prefix(int dtype, const void* x, int64_t ldx, void* y,
 int launch_rmsnorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, int rows, int D, float eps,
                    hipStream_t st) {
   return launch_norm<1>(dtype, x, ldx, y, ldy, w, nullptr, rows, D, eps, st);
+}
+
+int launch_rms_prep(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, float* rstd, int rows, int D, float eps, hipStream_t st) {
+  if (rows <= 0) return 0;
+  const int vec = dtype == DT_F32 ? 4 : 8;
+  OAVSR_REQUIRE(D % vec == 0 && ldx % vec == 0 && ldy % vec == 0, "rms_prep: D=%d must be a multiple of %d", D, vec);
+  dim3 grid(ceil_div(rows, kWavesPerBlock));
+  if (dtype == DT_F32) hipLaunchKernelGGL(rms_prep_kernel<float>, grid, dim3(kThreads), 0, st, (const float*)x, ldx, (float*)y, ldy, w, rstd, rows, D, eps);
+  else hipLaunchKernelGGL(rms_prep_kernel<bf16_t>, grid, dim3(kThreads), 0, st, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, w, rstd, rows, D, eps);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
 }
 
 static int grid_for(int64_t total) {
@@ -635,7 +701,7 @@ int launch_set_ints(int* dst, const IntPack128& v, int n, hipStream_t st) {
 }
 
 int launch_sched_init_slots(const SchedState& s, int slot0, int B, const IntPack128& S, int limit, int pad, hipStream_t st) {
-  OAVSR_REQUIRE(B >= 1 && B <= 64, "sched_init_slots: B=%d", B);
+  OAVSR_REQUIRE(B >= 1 && B <= 128, "sched_init_slots: B=%d", B);      // one call's rows: up to a whole 128-row step (IntPack128)
   hipLaunchKernelGGL(sched_init_slots_kernel, dim3(B), dim3(64), 0, st, s, slot0, B, S, limit, pad);
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;
@@ -676,6 +742,13 @@ int launch_greedy_update(const int* amax, GreedyState s, int B, int max_new, int
   int threads = ((B + 63) / 64) * 64;
   if (s.rope_cs && threads < 256) threads = 256;
   hipLaunchKernelGGL(greedy_update_kernel, dim3(1), dim3(threads), 0, st, amax, s, B, max_new, eos, pad);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_digest(const void* base, const int* cu, int64_t words_per_row, int n_utts, uint64_t* out, int out_stride, int out_col, hipStream_t st) {
+  if (n_utts <= 0) return 0;
+  hipLaunchKernelGGL(digest_kernel, dim3(n_utts), dim3(kThreads), 0, st, (const unsigned*)base, cu, (long long)words_per_row, (unsigned long long*)out, out_stride, out_col);
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -253,15 +253,14 @@ class WerMeter:
 
 def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], modality: str, to_text: Callable[[torch.Tensor], List[str]],
              batch_size: int = 8, bos_id: Optional[int] = None, rank: int = 0, world: int = 1, in_flight: int = 1, decode_group: int = 1,
-             allow_failures: bool = False, allow_regime_change: bool = False, **forward_kw) -> WerMeter:
+             allow_failures: bool = False, **forward_kw) -> WerMeter:
     """Evaluation loop of eval_OmniAVSR.py:273-357 for one (task, rates) cell, utterance-sharded over `world` ranks
      and batched (the reference runs batch 1).  `samples`: [(transformed sample dict, gold text)].
     `in_flight` > 1 keeps that many batches in flight on their own HIP streams / workspaces (the encoders of one overlap the decode loop
     of the others; same ids, same counters, ~1.4x the throughput on MI355X) -- needs the HIP-backed model (`model.engine`).
     `decode_group` = G > 1 (HIP-backed model): a call takes G x batch_size utterances, runs encoders / prefill in chunks of batch_size and
-    ONE decode loop over all rows (`model.encoder_chunk`): the LLM weights are streamed once per step for G batches; keep G x batch_size x
-    num_beams <= 32 rows for ids that are bit-identical to the ungrouped loop (invariance contract) -- a larger group is
-    refused unless `allow_regime_change` (the > 32-row decode kernels sum in another order: bf16 ids may differ from the ungrouped run).
+    ONE decode loop over all rows (`model.encoder_chunk`): the LLM weights are streamed once per step for G batches (up to 128 rows per
+    launch); the ids are bit-identical to the ungrouped loop at any group size (one decode regime at every row count).
     With the HIP-backed model and greedy decode, `in_flight` > 1 alone already shares the decode steps between the batches in flight
     (the engine's decode scheduler); `decode_group` remains for beam search.
     Failures: like the reference (whose loop simply crashes), the first batch that raises ends the evaluation -- unless
@@ -279,13 +278,6 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
     kw_mod = modality if getattr(model, "is_task_specific", False) else None
     chunk_prev = getattr(model, "encoder_chunk", None)
     if decode_group > 1:
-        beams_ = int(getattr(model, "num_beams", 1) or 1)
-        rows = batch_size * decode_group * beams_
-        lim = 64 if beams_ == 1 else 32          # rows up to which the weight-streaming decode kernels give a row the same bits whatever shares the step
-        if rows > lim and not allow_regime_change:
-            raise ValueError(f"decode_group={decode_group} x batch_size={batch_size} x num_beams={beams_} = {rows} decode rows: "
-                             f"above {lim} rows the decode GEMMs switch kernel family and bf16 ids may differ from the ungrouped evaluation "
-                             "(pass allow_regime_change=True to accept that)")
         model.encoder_chunk = batch_size
         batch_size = batch_size * decode_group
     batches = list(make_batches(owned, batch_size))

@@ -10,8 +10,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # OAVSR_LIB points the binding at another build of the same library (A/B timing of kernel variants on one box)
 LIB_PATH = os.environ.get("OAVSR_LIB") or os.path.join(_HERE, "libomniavsr_hip.so")
 
-ABI_VERSION = 2      # OAVSR_ABI_VERSION of include/omni_avsr.h this binding's structures and argument lists follow
+ABI_VERSION = 3      # OAVSR_ABI_VERSION of include/omni_avsr.h this binding's structures and argument lists follow
 MAX_RATES = 8
+GEMM_SYNC_INTS = 4096 + 64      # OAVSR_GEMM_SYNC_INTS: zeroed ints a split-K oavsr_op_gemm launch needs (GemmDesc.sync)
 DT_F32, DT_BF16 = 0, 1
 TASK_ID = {"audio": 0, "video": 1, "audiovisual": 2}
 
@@ -60,10 +61,10 @@ class GemmDesc(C.Structure):
         ("H", C.c_int32), ("W_", C.c_int32), ("Cin", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32),
         ("stride", C.c_int32), ("pad", C.c_int32), ("ksize", C.c_int32),
         ("rowinfo", C.c_void_p), ("taps", C.c_int32), ("Kvalid", C.c_int32), ("frameinfo", C.c_void_p),
-        ("skinny", C.c_int32), ("norm_gain", C.c_void_p), ("norm_eps", C.c_float), ("swiglu_pairs", C.c_int32),
-        ("ksplit", C.c_int32), ("partial", C.c_void_p),
-        ("rn_out", C.c_void_p), ("rn_ld", C.c_int64), ("rn_gain", C.c_void_p), ("rn_eps", C.c_float),
-        ("grid", C.c_int32), ("shared_chip", C.c_int32),
+        ("kernel", C.c_int32), ("swiglu_pairs", C.c_int32), ("decode_tiled", C.c_int32),
+        ("ksplit", C.c_int32), ("partial", C.c_void_p), ("sync", C.c_void_p), ("row_scale", C.c_void_p),
+        ("ng_out", C.c_void_p), ("ng_ld", C.c_int64), ("ng_gain", C.c_void_p), ("ng_rowsq", C.c_void_p), ("ng_rstd", C.c_void_p), ("ng_eps", C.c_float),
+        ("grid", C.c_int32),
     ]
 
 
@@ -101,6 +102,7 @@ SYMBOLS = {
     "oavsr_workspace_destroy": (None, [_P]),
     "oavsr_workspace_bytes": (C.c_uint64, [_P]),
     "oavsr_workspace_set_video_format": (C.c_int, [_P, _I, _I, _I]),
+    "oavsr_workspace_set_digests": (C.c_int, [_P, _P]),
     "oavsr_encode_video": (C.c_int, [_P, _P, _P, C.POINTER(_I), _I, _I, _P, _P, _P]),
     "oavsr_encode_audio": (C.c_int, [_P, _P, _P, _L, C.POINTER(_I), C.POINTER(_I), _I, _I, _P, _P, _P, _P]),
     "oavsr_project": (C.c_int, [_P, _P, _I, _I, _P, _I, _P, _P]),
@@ -128,6 +130,7 @@ SYMBOLS = {
     "oavsr_op_attention": (C.c_int, [C.POINTER(AttnDesc), _P]),
     "oavsr_op_decode_attention": (C.c_int, [C.POINTER(DecodeAttnDesc), _P]),
     "oavsr_op_norm": (C.c_int, [_I, _I, _P, _L, _P, _L, _P, _P, _I, _I, _F, _P]),
+    "oavsr_op_rms_prep": (C.c_int, [_I, _P, _L, _P, _L, _P, _P, _I, _I, _F, _P]),
     "oavsr_op_stem_pool": (C.c_int, [_I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "oavsr_op_conv3x3_c64": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "oavsr_op_beam_topk": (C.c_int, [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P]),
@@ -153,6 +156,9 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP extension has not been built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C omni-avsr_amd/csrc`). omni_avsr_amd has no CPU / PyTorch fallback.")
+    # torch first: its wheel bundles a HIP runtime, and the process must end up with ONE -- loaded the other way round (this library pulling in
+    # /opt/rocm's libamdhip64 before torch brings its own) the second runtime finds "no ROCm-capable device"
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
@@ -185,9 +191,12 @@ class DeviceError(RuntimeError):
     the same way -- unlike an argument the library refused, which only concerns the call that carried it."""
 
 
-def check(rc: int):
+def check(rc: int, after=None):
+    """Raise for a non-zero return code of the library; `after` (optional) runs first either way (e.g. detach a per-call buffer)."""
+    msg = last_error() if rc != 0 else ""
+    if after is not None:
+        after()
     if rc != 0:
-        msg = last_error()
         if msg.startswith("KeyError"):
             raise KeyError(msg[len("KeyError: "):])
         if " HIP error " in msg or rc == -2:

@@ -50,11 +50,9 @@ class OmniEngine:
         self._sched = C.c_void_p(None)   # decode scheduler (continuous batching of the greedy decode across calls); created on first submit
         self._sched_key = None
         self._sched_gen = 0              # tickets carry the generation of the pool they belong to (a pool that had to grow is rebuilt)
-        # rows per decode step (<= 128) / row slots of the pool / independent step loops sharing the pool.  Greedy decode runs on the tiled
-        # LDS-DMA GEMMs at every row count (model.hip: llm_layers): a step is ONE 128-row tile whatever its row count and streams every LLM
-        # weight once, so the more rows share it the better -- 128-row steps, three lanes, for every model (round 4, same boxes, against the
-        # weight-streaming kernels' best shapes: headline 284 -> 300-312, VSR B = 16 559 -> 713-733, Llama-3.1-8B 120 -> 156-161,
-        # Qwen2.5-7B 97 -> 113-118 utt/s; 64-row steps: VSR 653-666, Llama-3.1-8B 155-158)
+        # rows per decode step (<= 128) / row slots of the pool / independent step loops sharing the pool.  Every decode-shaped GEMM runs on the
+        # tiled LDS-DMA kernels (model.hip: llm_decode_layers): a step is ONE 128-row tile whatever its row count and streams every LLM weight
+        # once, so the more rows share it the better -- 128-row steps, three lanes, for every model
         self.sched_rows, self.sched_slots = 128, 512
         self.sched_lanes = 3
         self.sched_stride = 0                           # steps per admission (0: automatic; oavsr_scheduler_set_stride)
@@ -282,10 +280,13 @@ class OmniEngine:
 
     def generate(self, task: str, video: Optional[torch.Tensor], Tv: Optional[Sequence[int]], audio: Optional[torch.Tensor],
                  lengths: Optional[Sequence[int]], rate_a: int, rate_v: int, beams: int = 1, max_new: Optional[int] = None,
-                 force_len: bool = False, video_is_flat: bool = False, slot: int = 0, chunk: Optional[int] = None):
+                 force_len: bool = False, video_is_flat: bool = False, slot: int = 0, chunk: Optional[int] = None,
+                 digests: Optional[torch.Tensor] = None):
         """End-to-end `forward(is_trainval=False)`: returns (ids int32 [B,max_new] pad-filled, lens int32 [B]) on device.
         No host synchronisation happens inside.  `chunk`: run encoders / prefill in chunks of that many utterances and decode all B
-        rows together (oavsr_generate_chunked: same results, the LLM weights are streamed once per step for the whole group)."""
+        rows together (oavsr_generate_chunked: same results, the LLM weights are streamed once per step for the whole group).
+        `digests`: optional int64 [B, 2] device tensor the call fills with {inputs_embeds, first-step logits} digests per utterance
+        (oavsr_workspace_set_digests: input-sensitivity checks of bench.py / tests)."""
         max_new = max_new or self.spec.max_dec_tokens
         use_a, use_v = task in ("audio", "audiovisual"), task in ("video", "audiovisual")
         B = len(Tv) if use_v else len(lengths)
@@ -301,16 +302,25 @@ class OmniEngine:
             keep = [whisper_keep_tokens(int(n)) for n in lengths]
         ids = torch.empty(B, max_new, dtype=torch.int32, device=self.device)
         lens = torch.empty(B, dtype=torch.int32, device=self.device)
+        self._set_digests(ws, digests, B)
         L.check(self.lib.oavsr_generate_chunked(
             self._model, ws, L.TASK_ID[task],
             C.c_void_p(flat.data_ptr()) if use_v else None, _i32arr(Tv) if use_v else None,
             C.c_void_p(a.data_ptr()) if use_a else None, a.stride(0) if use_a else 0,
             _i32arr(lengths) if use_a else None, _i32arr(keep) if use_a else None,
             B, int(chunk or B), int(rate_a or 1), int(rate_v or 1), beams, max_new, int(force_len),
-            C.c_void_p(ids.data_ptr()), C.c_void_p(lens.data_ptr()), self._stream()))
+            C.c_void_p(ids.data_ptr()), C.c_void_p(lens.data_ptr()), self._stream()), after=lambda: self._set_digests(ws, None, B))
         self._keepalive = getattr(self, "_keepalive", {})
         self._keepalive[slot] = (flat, a)
         return ids, lens
+
+    def _set_digests(self, ws, digests: Optional[torch.Tensor], B: int):
+        if digests is None:
+            L.check(self.lib.oavsr_workspace_set_digests(ws, None))
+            return
+        if digests.dtype != torch.int64 or tuple(digests.shape) != (B, 2) or digests.device != self.device or not digests.is_contiguous():
+            raise ValueError("digests must be a contiguous int64 [B, 2] tensor on the engine's device")
+        L.check(self.lib.oavsr_workspace_set_digests(ws, C.c_void_p(digests.data_ptr())))
 
     # ---- decode scheduler: calls of any size keep arriving one at a time, their decode rows share the weight passes ----------
     def prompt_rows(self, task: str, Tv, lengths, rate_a: int, rate_v: int) -> int:
@@ -364,7 +374,7 @@ class OmniEngine:
         return cache[key]
 
     def submit(self, task: str, video, Tv, audio, lengths, rate_a: int, rate_v: int, max_new: Optional[int] = None, force_len: bool = False,
-               video_is_flat: bool = False, slot: int = 0):
+               video_is_flat: bool = False, slot: int = 0, digests: Optional[torch.Tensor] = None):
         """`generate(beams=1)` through the decode scheduler: encoders + prefill are queued on the current stream (workspace `slot`), the
         rows then join the engine's shared decode loop.  Returns (ids, lens, ticket); ids / lens are valid after `wait(ticket)`."""
         max_new = max_new or self.spec.max_dec_tokens
@@ -387,6 +397,7 @@ class OmniEngine:
         lens = torch.empty(B, dtype=torch.int32, device=self.device)
         host = torch.empty(B * (max_new + 1), dtype=torch.int32, pin_memory=True)      # [ids | lens], filled by the scheduler's stream when the call leaves
         ticket = C.c_int64(-1)
+        self._set_digests(ws, digests, B)
         L.check(self.lib.oavsr_generate_submit(
             self._model, self._sched, ws, L.TASK_ID[task],
             C.c_void_p(flat.data_ptr()) if use_v else None, _i32arr(Tv) if use_v else None,
@@ -394,9 +405,9 @@ class OmniEngine:
             _i32arr(lengths) if use_a else None, _i32arr(keep) if use_a else None,
             B, int(rate_a or 1), int(rate_v or 1), max_new, int(force_len),
             C.c_void_p(ids.data_ptr()), C.c_void_p(lens.data_ptr()), C.c_void_p(host.data_ptr()), C.c_void_p(host.data_ptr() + 4 * B * max_new),
-            self._stream(), C.byref(ticket)))
+            self._stream(), C.byref(ticket)), after=lambda: self._set_digests(ws, None, B))
         self._keepalive = getattr(self, "_keepalive", {})
-        self._keepalive[("s", slot)] = (flat, a)
+        self._keepalive[("s", slot)] = (flat, a, digests)
         self._inflight = getattr(self, "_inflight", {})
         tk = (self._sched_gen, ticket.value)
         self._reap()

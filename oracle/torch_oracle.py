@@ -421,10 +421,6 @@ class LLMOracle:
         self.sd, self.cfg, self.p = sd, cfg, prefix
         self.inv_freq = rope_inv_freq(cfg["head_dim"], cfg["rope_theta"], cfg.get("rope_scaling"))
         self.scaling = cfg["lora_alpha"] / cfg["lora_rank"] if cfg.get("lora_rank") else 0.0   # Llama_LoRA.py:120
-        # bf16 emulation only: how many utterances share the engine call being emulated (the engine picks its decode kernels by
-        # the total row count B * K: weight-streaming kernels up to 32 rows, tiled split-K GEMMs beyond)
-        self.emu_batch = 1
-
     def _lora(self, lp: str, which: str, x: Tensor, modality: Optional[str], rstd: Optional[Tensor] = None) -> Tensor:
         sd, cfg = self.sd, self.cfg
         if cfg.get("task_specific"):                           # Llama_LoRA.py:250-251
@@ -439,35 +435,30 @@ class LLMOracle:
             for d_, u_ in pairs[1:]:
                 out = out + F.linear(F.linear(x, sd[d_].float()), sd[u_].float())
             return out * self.scaling
-        # engine: t = x A^T stored in bf16 (rstd of the fused RMSNorm applied before the store), alpha / rank folded into the
-        # stored up-projection, all adapters summed in the QKV GEMM's fp32 accumulator
+        # engine: t = x A^T stored in bf16, alpha / rank folded into the stored up-projection, all adapters summed in the QKV GEMM's fp32
+        # accumulator.  Decode-shaped rows (rstd given): x is T(x * gain), t is rounded WITHOUT 1 / rms, and the accumulator -- this term
+        # and the base projection alike -- is multiplied by 1 / rms afterwards (model.hip: llm_decode_layers)
         out = 0
         for d_, u_ in pairs:
-            t = F.linear(x, _qw(sd[d_]))
-            if rstd is not None:
-                t = t * rstd
-            out = out + F.linear(_q(t), _q(sd[u_].float() * self.scaling))
-        return out
+            out = out + F.linear(_q(F.linear(x, _qw(sd[d_]))), _q(sd[u_].float() * self.scaling))
+        return out * rstd if rstd is not None else out
 
     def embed(self, ids: Tensor) -> Tensor:
         return _q(self.sd[self.p + "model.embed_tokens.weight"].float()[ids])
 
     def forward(self, x: Tensor, pos0: int, cache: Optional[list], modality: Optional[str],
-                last_only: bool = False, return_hidden: bool = False, skinny: Optional[bool] = None):
+                last_only: bool = False, return_hidden: bool = False):
         """x: [B,S,d] embeddings, positions pos0..pos0+S-1, cache: list of (k,v) per layer
         ([B,kvh,ctx,hd]) appended in place.  Returns fp32 logits [B,S,V] (Llama_LoRA.py:372-373).
-        `skinny` (bf16 emulation only): the rows run through the engine's weight-streaming decode kernels (RMSNorm fused into
-        the GEMM: the gain multiplies the bf16 activations, 1/rms scales the fp32 accumulator; SwiGLU on unrounded gate / up) --
-        decode steps with <= 32 rows; default: S == 1."""
+        bf16 emulation only: decode-shaped rows -- every decode step (S == 1, any number of rows) and, in a prefill with `last_only`, the
+        last layer's MLP and lm_head on each utterance's final row -- follow the engine's deferred RMSNorm: the producer of the residual
+        stream stores T(x * gain) and 1 / rms(x), the consumer GEMM multiplies its fp32 accumulator by the latter."""
         sd, cfg, p = self.sd, self.cfg, self.p
         B, S, d = x.shape
         H, KV, hd = cfg["heads"], cfg["kv_heads"], cfg["head_dim"]
         emu = _P.emu
-        if skinny is None:
-            skinny = S == 1 and B * self.emu_batch <= 32
-        # prefill: the engine prunes the last layer to each utterance's final row and sends it (and lm_head) through the fused
-        # weight-streaming kernels 8 rows at a time, whatever the batch; decode: those kernels serve up to 32 rows
-        few_rows = (last_only and S > 1) or B * S * self.emu_batch <= 32
+        dec = S == 1                                         # a decode step: decode-shaped GEMMs throughout, whatever B is
+        tail = last_only and S > 1                           # prefill: the engine prunes the LAST layer to each utterance's final row
         pos = torch.arange(pos0, pos0 + S, dtype=torch.float32)
         freqs = pos[:, None] * self.inv_freq[None, :]
         emb = torch.cat((freqs, freqs), dim=-1)
@@ -475,14 +466,14 @@ class LLMOracle:
         x = _q(x.float())
         hiddens = []
 
-        def fused_norm(xx, gain):        # skinny.hip NORM prologue: (bf16(x * g), 1 / rms(x))
+        def fused_norm(xx, gain):        # deferred RMSNorm (gemm2.hip ng_* outputs / ops.hip rms_prep_kernel): (T(x * g), 1 / rms(x))
             return _q(xx * gain.float()), torch.rsqrt(xx.pow(2).mean(-1, keepdim=True) + cfg["rms_eps"])
 
         for i in range(cfg["layers"]):
             lp = f"{p}model.layers.{i}."
             ap = lp + "self_attn."
             last = i == cfg["layers"] - 1
-            if emu and skinny:
+            if emu and dec:
                 h, rstd = fused_norm(x, sd[lp + "input_layernorm.weight"])
                 bias = lambda n: (sd[ap + n + ".bias"].float() if ap + n + ".bias" in sd else 0.0)    # noqa: E731
                 q = F.linear(h, _qw(sd[ap + "q_proj.weight"])) * rstd + bias("q_proj")
@@ -521,9 +512,9 @@ class LLMOracle:
             a = a.transpose(1, 2).reshape(B, S, H * hd)
             x = _q(x + _linear(a, sd, ap + "o_proj"))
             # the engine prunes the LAST prefill layer to each utterance's final row and runs its MLP through the decode kernels
-            if emu and (skinny or (last and last_only and S > 1 and few_rows)):
+            if emu and (dec or (last and tail)):
                 h, rstd = fused_norm(x, sd[lp + "post_attention_layernorm.weight"])
-                g = F.silu(F.linear(h, _qw(sd[lp + "mlp.gate_proj.weight"])) * rstd) * (F.linear(h, _qw(sd[lp + "mlp.up_proj.weight"])) * rstd)
+                g = F.silu(_q(F.linear(h, _qw(sd[lp + "mlp.gate_proj.weight"])) * rstd)) * _q(F.linear(h, _qw(sd[lp + "mlp.up_proj.weight"])) * rstd)
             else:
                 h = _q(_rms(x, sd[lp + "post_attention_layernorm.weight"], cfg["rms_eps"]))
                 g = F.silu(_q(_linear(h, sd, lp + "mlp.gate_proj"))) * _q(_linear(h, sd, lp + "mlp.up_proj"))
@@ -533,7 +524,7 @@ class LLMOracle:
         if last_only:
             x = x[:, -1:]
         W = _qw(sd[p + "lm_head.weight"])
-        if emu and few_rows:                                   # lm_head with the final RMSNorm fused (<= 32 rows)
+        if emu and (dec or tail):                              # lm_head on decode-shaped rows: the final RMSNorm deferred the same way
             h, rstd = fused_norm(x, sd[p + "model.norm.weight"])
             logits = (F.linear(h, W) * rstd).float()
         else:

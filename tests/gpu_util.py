@@ -30,7 +30,7 @@ def tol(dtype, k=1):
 
 
 def gemm(dtype, A, W, *, A2=None, W2=None, scale=None, bias=None, prelu=None, act=0, residual=None, res_after_act=0,
-         out_f32=False, skinny=False, M=None, N=None, K=None, C_out=None, **geom):
+         out_f32=False, kernel=0, M=None, N=None, K=None, C_out=None, **geom):
     lib = L.load()
     d = L.GemmDesc()
     d.dtype = dcode(dtype)
@@ -51,11 +51,27 @@ def gemm(dtype, A, W, *, A2=None, W2=None, scale=None, bias=None, prelu=None, ac
     if residual is not None:
         d.residual, d.ldr = P(residual), residual.stride(0)
     d.groups = groups
-    d.skinny = int(skinny)
+    d.kernel = int(kernel)
     for k, v in geom.items():
-        if k in ("rowinfo", "frameinfo", "norm_gain", "partial", "rn_out", "rn_gain"):
+        if k in ("rowinfo", "frameinfo", "partial", "sync", "row_scale", "ng_out", "ng_gain", "ng_rowsq", "ng_rstd"):
             setattr(d, k, P(v))
         elif k != "groups":
             setattr(d, k, v)
     L.check(lib.oavsr_op_gemm(C.byref(d), stream()))
     return out
+
+
+def digest_words(t):
+    """The library's region digest (include/omni_avsr.h: oavsr_workspace_set_digests) of a tensor's bytes, computed on the host:
+    sum_i splitmix64_finalizer(w_i | (i + 1) << 32) mod 2^64 over its 32-bit words; returned as a signed int64 like the device tensor holds it."""
+    import numpy as np
+    w = t.detach().contiguous().cpu().reshape(-1).view(torch.uint8).numpy().view(np.uint32).astype(np.uint64)
+    z = w | ((np.arange(1, w.size + 1, dtype=np.uint64)) << np.uint64(32))
+    with np.errstate(over="ignore"):
+        z ^= z >> np.uint64(30)
+        z *= np.uint64(0xbf58476d1ce4e5b9)
+        z ^= z >> np.uint64(27)
+        z *= np.uint64(0x94d049bb133111eb)
+        z ^= z >> np.uint64(31)
+        tot = np.uint64(z.sum(dtype=np.uint64))
+    return int(tot.astype(np.int64))

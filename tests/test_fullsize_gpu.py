@@ -87,7 +87,7 @@ def test_fullsize_batch_invariance_and_determinism(bf16_engine):
         _, venc1, _ = eng.encode_video(v1, [t], 4, return_enc=True)
         assert torch.equal(venc1, venc_b[off:off + t]), f"utterance {b}: video encoder output depends on its batch mates"
         off += t
-    # ... and inside a batch of 12 (9..32 decode rows: the 16-row-operand kernels; lm_head with 4 waves as for <= 8 rows)
+    # ... and inside a batch of 12 (the decode-shaped GEMMs give a row the same bits whatever shares the launch)
     Tv12 = Tv + [61, 40, 33, 61, 50, 61, 27, 61]
     video12, audio12, Ts12 = clips(Tv12, seed=9)
     video12[:4, : video.shape[1]], audio12[:4, : audio.shape[1]] = video, audio
@@ -97,8 +97,8 @@ def test_fullsize_batch_invariance_and_determinism(bf16_engine):
 
 
 def test_fullsize_grouped_decode_equals_separate_calls(bf16_engine):
-    """harness decode_group / bench --decode-group: 24 utterances in one call (encoders / prefill in chunks of 8, ONE decode loop over 24 rows:
-    the 32-row forms of the decode kernels, persistent lm_head and gate / up included) decode the ids of three separate calls of 8."""
+    """harness decode_group / bench --decode-group: 24 utterances in one call (encoders / prefill in chunks of 8, ONE decode loop over 24 rows)
+    decode the ids of three separate calls of 8."""
     eng = bf16_engine
     g = torch.Generator().manual_seed(21)
     Tv = [int(x) for x in torch.randint(30, 101, (24,), generator=g)]
@@ -112,50 +112,9 @@ def test_fullsize_grouped_decode_equals_separate_calls(bf16_engine):
         assert torch.equal(ids_c.cpu(), ids_g[sl]), f"utterances {8 * c}..{8 * c + 7}: grouped decode differs from the separate call"
 
 
-def test_fused_decode_launches_equal_separate_launches(tmp_path):
-    """Opt-in (OAVSR_SKINNY_CHAIN=1, read once per process; off by default because it does not pay, see skinny.hip): greedy decode with
-    <= 8 rows fuses LoRA-down -> QKV and gate/up -> down_proj into single launches with in-kernel hand-offs.  Same arithmetic => identical ids, at the full model size, with three
-    batches in flight on three streams (hand-offs under uneven load) and run twice."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = f"""
-import sys, torch
-sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
-from test_fullsize_gpu import full_spec, clips
-from omni_avsr_amd.modeling import OmniEngine
-from omni_avsr_amd.synth import synth_state_dict
-spec = full_spec()
-eng = OmniEngine(spec, dtype="bf16").load_state_dict(synth_state_dict(spec, seed=1234, device="cuda:0", dtype=torch.bfloat16))
-outs = []
-streams = [torch.cuda.Stream() for _ in range(3)]
-sets = [clips([100, 61, 80, 100, 33, 100, 75, 90][: 8 - s], seed=20 + s) for s in range(3)]
-for rep in range(2):
-    res = []
-    for s in range(3):
-        video, audio, Ts = sets[s]
-        Tv = [100, 61, 80, 100, 33, 100, 75, 90][: 8 - s]
-        with torch.cuda.stream(streams[s]):
-            res.append(eng.generate("audiovisual", video, Tv, audio, Ts, 4, 4, beams=1, max_new=32, force_len=True, slot=s))
-    torch.cuda.synchronize()
-    outs.append([r[0].cpu() for r in res])
-assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])), "two rounds differ"
-torch.save(outs[0], sys.argv[1])
-"""
-    got = []
-    for flag in ("1", "0"):
-        f = str(tmp_path / f"ids{flag}.pt")
-        r = subprocess.run([sys.executable, "-c", script, f], env=dict(os.environ, OAVSR_SKINNY_CHAIN=flag), capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stderr[-3000:]
-        got.append(torch.load(f))
-    for a, b in zip(got[0], got[1]):
-        assert torch.equal(a, b), "fused launches decode different ids than separate launches"
-
-
 def test_fullsize_scheduler_equals_separate_calls(bf16_engine):
     """The headline configuration's own mechanism at the full model size: three calls of 8 utterances (ragged lengths) submitted one after another
-    through the decode scheduler -- encoders / prefill per call on three streams, decode rows sharing the 32-row steps of one lane -- decode the
+    through the decode scheduler -- encoders / prefill per call on three streams, decode rows sharing the steps of one lane -- decode the
     ids of the same calls run on their own (bf16, EOS suppressed and free-running)."""
     eng = bf16_engine
     lanes0 = eng.sched_lanes
@@ -201,22 +160,72 @@ def test_headline_configuration_returns_the_ids_of_isolated_calls(bf16_engine):
     Tvs, Ts = [Tv] * B, [640 * Tv] * B
     iso = []
     for video, audio in sets:
-        ids, lens = eng.generate("audiovisual", video, Tvs, audio, Ts, 4, 4, beams=1, max_new=32, force_len=True, video_is_flat=True)
+        dg = torch.zeros(B, 2, dtype=torch.int64, device="cuda:0")
+        ids, lens = eng.generate("audiovisual", video, Tvs, audio, Ts, 4, 4, beams=1, max_new=32, force_len=True, video_is_flat=True, digests=dg)
         torch.cuda.synchronize()
-        iso.append((ids.clone(), lens.clone()))
-    # (With seeded random weights the 32 forced tokens hardly depend on the clip -- the residual stream at the last prompt position is dominated
-    # by the prompt's own embedding -- so this is a check on state handling under the full-size pipelined schedule: slots, KV rows, row maps,
-    # cross-tile GEMM state; input sensitivity is what the oracle comparisons of the other files pin.)
+        iso.append((ids.clone(), lens.clone(), dg.clone()))
+    # With seeded random weights the 32 forced tokens hardly depend on the clip (the residual stream at the last prompt position is dominated
+    # by the prompt's own embedding), so the ids alone guard state handling only.  The DIGESTS are input-sensitive: every utterance of every
+    # input set has its own {inputs_embeds, first-step logits} pair, and a call that received another call's encoder output, prompt rows,
+    # KV slots or logits row reports a different pair (test_input_sensitive_weights_under_the_scheduler adds weights whose ids depend on the clip).
+    alld = torch.cat([d for _, _, d in iso])
+    assert len({int(x) for x in alld[:, 0]}) == 4 * B and len({int(x) for x in alld[:, 1]}) == 4 * B, "digests of different clips collide"
     eng.reserve_scheduler("audiovisual", Tv, 640 * Tv, 4, 4, 32)
     streams = [eng.caller_stream(i) for i in range(3)]
     pend = []
     for i in range(28):
         video, audio = sets[i % 4]
+        dg = torch.zeros(B, 2, dtype=torch.int64, device="cuda:0")
         with torch.cuda.stream(streams[i % 3]):
-            pend.append((i, eng.submit("audiovisual", video, Tvs, audio, Ts, 4, 4, max_new=32, force_len=True, video_is_flat=True, slot=i % 3)))
+            pend.append((i, eng.submit("audiovisual", video, Tvs, audio, Ts, 4, 4, max_new=32, force_len=True, video_is_flat=True, slot=i % 3, digests=dg), dg))
     eng.flush()
     torch.cuda.synchronize()
-    for i, (ids, lens, _) in pend:
+    for i, (ids, lens, _), dg in pend:
         assert torch.equal(lens, iso[i % 4][1]) and torch.equal(ids, iso[i % 4][0]), f"call {i} (input set {i % 4}) differs from the isolated call of that set"
+        assert torch.equal(dg, iso[i % 4][2]), f"call {i} (input set {i % 4}): digests differ from the isolated call's -- the call did not see its own inputs"
     st = eng.scheduler_stats()
     assert st["rows_per_step"] > 20, st
+
+
+def test_input_sensitive_weights_under_the_scheduler():
+    """The same pipelined schedule with weights that make the IDS depend on the clip: the LLM's attention output projections scaled up (x 8), so
+    the residual stream at the last prompt position is dominated by what attention mixes in from the ~300 audio / video tokens instead of by
+    the prompt's own embedding.  Asserted first: the four input sets (and the utterances inside a set) decode to different ids.  Then 16
+    calls through the decode scheduler must return exactly the ids -- and digests -- of the isolated call of their input set: a call that got
+    another call's encoder output, KV rows or slots fails on ids here."""
+    spec = full_spec()
+    sd = synth_state_dict(spec, seed=4321, device="cuda:0", dtype=torch.bfloat16)
+    for k in sd:
+        if k.startswith("llm.") and k.endswith("self_attn.o_proj.weight"):
+            sd[k] = sd[k] * 8
+    eng = OmniEngine(spec, dtype="bf16").load_state_dict(sd)
+    del sd
+    torch.cuda.empty_cache()
+    B, Tv = 8, 400
+    Tvs, Ts = [Tv] * B, [640 * Tv] * B
+    sets, iso = [], []
+    for s_ in range(4):
+        g = torch.Generator(device="cuda:0").manual_seed(300 + s_)
+        video = torch.randn(B * Tv, 88, 88, generator=g, device="cuda:0")
+        audio = torch.nn.functional.layer_norm(torch.randn(B, 640 * Tv, generator=g, device="cuda:0"), (640 * Tv,))
+        sets.append((video, audio))
+        dg = torch.zeros(B, 2, dtype=torch.int64, device="cuda:0")
+        ids, lens = eng.generate("audiovisual", video, Tvs, audio, Ts, 4, 4, beams=1, max_new=32, force_len=True, video_is_flat=True, digests=dg)
+        torch.cuda.synchronize()
+        iso.append((ids.clone(), lens.clone(), dg.clone()))
+    rows = {tuple(r) for ids, _, _ in iso for r in ids.cpu().tolist()}
+    assert len(rows) >= 4 * B - 2, f"the ids of these weights do not depend on the clip: only {len(rows)} distinct hypotheses among {4 * B} utterances"
+    assert len({tuple(ids.flatten().tolist()) for ids, _, _ in iso}) == 4
+    eng.reserve_scheduler("audiovisual", Tv, 640 * Tv, 4, 4, 32)
+    streams = [eng.caller_stream(i) for i in range(3)]
+    pend = []
+    for i in range(16):
+        video, audio = sets[(3 * i) % 4]
+        dg = torch.zeros(B, 2, dtype=torch.int64, device="cuda:0")
+        with torch.cuda.stream(streams[i % 3]):
+            pend.append(((3 * i) % 4, eng.submit("audiovisual", video, Tvs, audio, Ts, 4, 4, max_new=32, force_len=True, video_is_flat=True, slot=i % 3, digests=dg), dg))
+    eng.flush()
+    torch.cuda.synchronize()
+    for k, (ids, lens, _), dg in pend:
+        assert torch.equal(ids, iso[k][0]) and torch.equal(lens, iso[k][1]) and torch.equal(dg, iso[k][2]), f"a scheduled call of input set {k} differs from the isolated call"
+    eng.close()

@@ -95,7 +95,7 @@ def test_bf16_within_the_emulation_bound_and_scheduler_invariance(name):
     gaps = [float(path[t].max() - path[t][got[t]]) for t in range(len(got))]
     print(f"{name} bf16 vs emulation: prefill logits max err {el:.3e}, worst decoded-token gap {max(gaps):.3e}")
     assert el <= LOGIT_TOL and max(gaps) <= LOGIT_TOL
-    # (b) three calls of 8 share the scheduler's steps (24 rows: the 17..32-row forms of every decode kernel at this width)
+    # (b) three calls of 8 share the scheduler's steps (24 rows per step at this width)
     calls = [clips(8, 40 + i) for i in range(3)]
     ref = []
     for v, a, tv, ts in calls:

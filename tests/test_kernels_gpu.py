@@ -47,14 +47,17 @@ def test_gemm_dense(dtype, M, N, K):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K,K2,S", [(120, 2048, 8192, 0, 16), (120, 3072, 2048, 256, 4), (45, 200, 384, 0, 5), (120, 256, 2048, 0, 8),
-                                        (3200, 1024, 4096, 0, 2), (700, 96, 2048, 0, 8), (1000, 1024 + 24, 1024, 128, 3), (300, 128, 512, 0, 5)])
-def test_gemm_splitk(dtype, M, N, K, K2, S):
-    """Split-K: fp32 partial slabs + deterministic reduce with the fused epilogue.  M <= 128 (beam-search decode rows) runs the
-    classic kernel, larger M (narrow encoder projections, LoRA down projections) the LDS-DMA kernel with the same k order."""
+@pytest.mark.parametrize("M,N,K,K2,S", [(120, 2048, 8192, 0, 16), (120, 3072, 2048, 256, 4), (45, 192, 384, 0, 5), (120, 256, 2048, 0, 8),
+                                        (8, 1024, 4096, 0, 2), (1, 64, 2048, 0, 8), (128, 1024 + 16, 1024, 128, 3), (97, 128, 512, 0, 5), (33, 2048, 2048, 0, 13)])
+def test_gemm_splitk_reduced_inside_the_launch(dtype, M, N, K, K2, S):
+    """Split-K of the decode-shaped GEMMs (M <= 128): fp32 partial slabs, summed in slab order by the tile's last-arriving workgroup inside
+    the GEMM launch (gemm2.hip), with the fused epilogue (row_scale, bias, residual).  Against fp32 torch; repeated launches on the same
+    counters and slabs give the same bits (the counters are zero again when a launch ends; the sum never depends on who came last)."""
     a, ar = q(rnd(M, K, seed=1), dtype)
     w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
     r, rr = q(rnd(M, N, seed=5), dtype)
+    rs = (rnd(M, seed=8).abs() + 0.5)
+    bias = rnd(N, seed=9)
     kw, ref = {}, ar @ wr.T
     if K2:
         a2, a2r = q(rnd(M, K2, seed=3), dtype)
@@ -62,33 +65,94 @@ def test_gemm_splitk(dtype, M, N, K, K2, S):
         kw = dict(A2=a2, W2=w2)
         ref = ref + a2r @ w2r.T
     part = torch.empty(S * M * N, dtype=torch.float32, device=DEV)
-    out = gemm(dtype, a, w, residual=r, ksplit=S, partial=part, **kw)
-    close(out, ref + rr, tol(dtype) * 2, what="gemm split-K")
+    sync = torch.zeros(L.GEMM_SYNC_INTS, dtype=torch.int32, device=DEV)
+    out = gemm(dtype, a, w, residual=r, bias=bias.to(DEV), row_scale=rs.to(DEV), ksplit=S, partial=part, sync=sync, **kw).clone()
+    close(out, ref * rs[:, None] + bias + rr, tol(dtype) * 2, rtol=(8e-3 if dtype == "bf16" else 1e-5), what="gemm split-K")
+    for _ in range(3):
+        again = gemm(dtype, a, w, residual=r, bias=bias.to(DEV), row_scale=rs.to(DEV), ksplit=S, partial=part, sync=sync, **kw)
+        assert torch.equal(again, out), "repeated split-K launches differ"
+    torch.cuda.synchronize()
+    assert int(sync.abs().sum()) == 0, "the arrival counters are not zero after the launch"
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K,S", [(120, 2048, 8192, 16), (120, 2048, 2048, 8), (45, 4096, 1024, 4), (33, 3584, 512, 2), (300, 2048, 512, 3)])
-def test_gemm_splitk_reduce_with_rmsnorm(dtype, M, N, K, S):
-    """Split-K whose reduce pass also writes RMSNorm(C) * gain (beam-search decode: o_proj -> ln2, down_proj -> the next ln1).  C must be
-    bit-identical to the plain reduce pass; the normalised rows are checked against fp32 torch on the rounded C."""
+@pytest.mark.parametrize("M,N,K,S", [(120, 2048, 8192, 16), (120, 2048, 2048, 8), (45, 4096, 1024, 4), (33, 3584, 512, 2), (8, 256, 256, 2), (128, 512, 384, 3)])
+def test_gemm_splitk_next_norm_outputs(dtype, M, N, K, S):
+    """The decode path's deferred RMSNorm (Llama_LoRA.py:587-655: residual add, then the next RMSNorm): the split-K reduce of o_proj /
+    down_proj also writes T(x * gain) and 1 / rms(x) per row for the consumer.  C is bit-identical to the launch without those outputs;
+    they are checked against fp32 torch on the rounded C; in place on the residual rows, as the decoder uses it."""
     a, _ = q(rnd(M, K, seed=1), dtype)
     w, _ = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
     r, _ = q(rnd(M, N, seed=5), dtype)
     gain = (rnd(N, seed=6) * 0.1 + 1).to(DEV)
     part = torch.empty(S * M * N, dtype=torch.float32, device=DEV)
-    ref_c = gemm(dtype, a, w, residual=r, ksplit=S, partial=part)
-    h = torch.full((M, N), float("nan"), dtype=tdt(dtype), device=DEV)
+    sync = torch.zeros(L.GEMM_SYNC_INTS, dtype=torch.int32, device=DEV)
+    ref_c = gemm(dtype, a, w, residual=r, ksplit=S, partial=part, sync=sync).clone()
+    rowsq = torch.empty((N + 63) // 64 * M, dtype=torch.float32, device=DEV)
     for _ in range(2):
-        out = gemm(dtype, a, w, residual=r, ksplit=S, partial=part, rn_out=h, rn_ld=N, rn_gain=gain, rn_eps=1e-5)
-        assert torch.equal(out, ref_c), "C differs from the plain reduce pass"
+        xg = torch.full((M, N), float("nan"), dtype=tdt(dtype), device=DEV)
+        rstd = torch.full((M,), float("nan"), dtype=torch.float32, device=DEV)
+        out = gemm(dtype, a, w, residual=r, ksplit=S, partial=part, sync=sync, ng_out=xg, ng_ld=N, ng_gain=gain, ng_rowsq=rowsq, ng_rstd=rstd, ng_eps=1e-5)
+        assert torch.equal(out, ref_c), "C differs from the launch without the next-norm outputs"
         x = out.float()
-        ref_h = x * torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-5) * gain
-        close(h, ref_h.cpu(), tol(dtype) if dtype == "bf16" else 1e-5, rtol=0.0, what="reduce + rmsnorm")
-    # in-place residual (C aliases the residual rows), as the decoder uses it
+        close(xg, (x * gain).cpu(), tol(dtype) if dtype == "bf16" else 1e-6, what="x * gain")
+        close(rstd, torch.rsqrt((x * x).mean(-1) + 1e-5).cpu(), 1e-5, rtol=1e-5, what="1 / rms")
     r2 = r.clone()
-    h2 = torch.empty_like(h)
-    gemm(dtype, a, w, residual=r2, ksplit=S, partial=part, C_out=r2, rn_out=h2, rn_ld=N, rn_gain=gain, rn_eps=1e-5)
-    assert torch.equal(r2, ref_c) and torch.equal(h2, h)
+    xg2, rstd2 = torch.empty_like(xg), torch.empty_like(rstd)
+    gemm(dtype, a, w, residual=r2, ksplit=S, partial=part, sync=sync, C_out=r2, ng_out=xg2, ng_ld=N, ng_gain=gain, ng_rowsq=rowsq, ng_rstd=rstd2, ng_eps=1e-5)
+    assert torch.equal(r2, ref_c) and torch.equal(xg2, xg) and torch.equal(rstd2, rstd)
+    torch.cuda.synchronize()
+    assert int(sync.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_decode_shaped_gemm_rows_do_not_depend_on_the_row_count(dtype):
+    """The invariance the decode regime rests on: row r of a decode-shaped GEMM has the same bits whether the launch carries 1, 8, 33 or 128
+    rows -- split (reduce inside the launch, next-norm outputs) and un-split (row_scale epilogue, fused SwiGLU, fp32 logits)."""
+    N, K, S = 2048, 2048, 8
+    a, _ = q(rnd(128, K, seed=1), dtype)
+    w, _ = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
+    r, _ = q(rnd(128, N, seed=5), dtype)
+    rs = (rnd(128, seed=8).abs() + 0.5).to(DEV)
+    gain = (rnd(N, seed=6) * 0.1 + 1).to(DEV)
+    part = torch.empty(S * 128 * N, dtype=torch.float32, device=DEV)
+    sync = torch.zeros(L.GEMM_SYNC_INTS, dtype=torch.int32, device=DEV)
+    rowsq = torch.empty(N // 64 * 128, dtype=torch.float32, device=DEV)
+    wl, _ = q(rnd(4096 + 64, K, seed=3) / math.sqrt(K), dtype)          # "lm_head" / gate-up shaped: no split
+    full = {}
+    for M in (128, 33, 8, 1):
+        xg = torch.empty(M, N, dtype=tdt(dtype), device=DEV)
+        rstd = torch.empty(M, dtype=torch.float32, device=DEV)
+        c = gemm(dtype, a[:M], w, residual=r[:M].clone(), row_scale=rs[:M], ksplit=S, partial=part, sync=sync, ng_out=xg, ng_ld=N, ng_gain=gain,
+                 ng_rowsq=rowsq, ng_rstd=rstd, ng_eps=1e-5)
+        lg = gemm(dtype, a[:M], wl, row_scale=rs[:M], out_f32=True, decode_tiled=1)
+        sg = gemm(dtype, a[:M], wl, row_scale=rs[:M], swiglu_pairs=1, decode_tiled=1)
+        got = [t.clone() for t in (c, xg, rstd, lg, sg)]
+        if M == 128:
+            full = got
+        else:
+            for t, f, what in zip(got, full, ("C", "x * gain", "1 / rms", "fp32 logits", "SwiGLU")):
+                assert torch.equal(t, f[:M]), f"{dtype}: {what} of rows 0..{M - 1} depends on the row count ({M} vs 128)"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_rms_prep_and_row_scale_equal_rmsnorm_then_gemm(dtype):
+    """oavsr_op_norm mode 3 (the rows of a decode step's first layer: y = T(x * gain), rstd = 1 / rms(x)) followed by a row_scale GEMM computes
+    RMSNorm(x) W^T (Llama_LoRA.py:587-655) -- against fp32 torch."""
+    M, N, K = 24, 256, 512
+    x, xr = q(rnd(M, K, seed=1) * 1.7, dtype)
+    w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
+    gain = rnd(K, seed=3) * 0.1 + 1
+    lib = L.load()
+    y = torch.empty(M, K, dtype=tdt(dtype), device=DEV)
+    rstd = torch.empty(M, dtype=torch.float32, device=DEV)
+    gd = gain.to(DEV)
+    L.check(lib.oavsr_op_rms_prep(dcode(dtype), P(x), K, P(y), K, P(gd), P(rstd), M, K, 1e-5, stream()))
+    close(rstd, torch.rsqrt(xr.pow(2).mean(-1) + 1e-5), 1e-5, rtol=1e-5, what="rstd")
+    close(y, xr * gain, tol(dtype) if dtype == "bf16" else 1e-6, what="x * gain")
+    out = gemm(dtype, y, w, row_scale=rstd, decode_tiled=1)
+    ref = (gain * xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5)) @ wr.T
+    close(out, ref, tol(dtype) * 2, what="deferred rmsnorm gemm")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -185,84 +249,17 @@ def test_gemm_epilogue(dtype, act, res_after):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("skinny", [False, True])
-def test_gemm_lora_segment(dtype, skinny):
+@pytest.mark.parametrize("decode", [False, True])
+def test_gemm_lora_segment(dtype, decode):
     """C = A1 W1^T + A2 W2^T (fused W + BA), fp32 logits output."""
-    M, N, K, K2 = (8 if skinny else 100), 320, 256, 64
+    M, N, K, K2 = (8 if decode else 100), 320, 256, 64
     a, ar = q(rnd(M, K, seed=1), dtype)
     w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
     a2, a2r = q(rnd(M, K2, seed=3), dtype)
     w2, w2r = q(rnd(N, K2, seed=4) / math.sqrt(K2), dtype)
     bias = rnd(N, seed=9).to(DEV)
-    out = gemm(dtype, a, w, A2=a2, W2=w2, bias=bias, out_f32=True, skinny=skinny)
+    out = gemm(dtype, a, w, A2=a2, W2=w2, bias=bias, out_f32=True, decode_tiled=int(decode))
     close(out, ar @ wr.T + a2r @ w2r.T + bias.cpu(), tol(dtype), what="gemm 2-segment")
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(1, 64, 64), (8, 1000, 256), (16, 16384 + 48, 128), (8, 16384 + 64, 256), (6, 8192 + 24, 128), (17, 200, 512), (40, 96, 256), (120, 333, 192)])
-def test_gemm_skinny(dtype, M, N, K):
-    a, ar = q(rnd(M, K, seed=1), dtype)
-    w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
-    r, rr = q(rnd(M, N, seed=5), dtype)
-    out = gemm(dtype, a, w, residual=r, skinny=True)
-    close(out, ar @ wr.T + rr, tol(dtype), what="skinny gemm")
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K,K2", [(8, 2048, 8192, 96), (8, 2048, 2048, 96), (7, 136, 8192 + 64, 32), (3, 64, 128, 0), (8, 16384 + 37, 256, 0), (5, 203, 512, 64)])
-def test_gemm_skinny_half_tiles(dtype, M, N, K, K2):
-    """M <= 8 rows: 8-column workgroups (even / odd k blocks in the two diagonal 8x8 blocks of the MFMA tile), incl. an odd
-    number of LoRA k blocks and the deep-K (down_proj) unroll; residual epilogue."""
-    a, ar = q(rnd(M, K, seed=1), dtype)
-    w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
-    r, rr = q(rnd(M, N, seed=5), dtype)
-    kw, ref = {}, ar @ wr.T + rr
-    if K2:
-        a2, a2r = q(rnd(M, K2, seed=3), dtype)
-        w2, w2r = q(rnd(N, K2, seed=4) / math.sqrt(K2), dtype)
-        kw = dict(A2=a2, W2=w2)
-        ref = ref + a2r @ w2r.T
-    out = gemm(dtype, a, w, residual=r, skinny=True, **kw)
-    close(out, ref, tol(dtype) * 2, what="skinny half-tile gemm")
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K,K2", [(8, 320, 256, 64), (20, 96, 512, 0), (8, 16384, 128, 0), (100, 64, 256, 64),
-                                      (8, 3072, 2048, 96), (5, 72, 192, 32), (1, 96, 2048, 0)])
-def test_gemm_skinny_fused_rmsnorm(dtype, M, N, K, K2):
-    """y = rstd * ((x*g) W^T) + t B^T  ==  rmsnorm(x) W^T + t B^T   (decode-step fusion)."""
-    x, xr = q(rnd(M, K, seed=1) * 1.7, dtype)
-    w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
-    gain = (rnd(K, seed=3) * 0.1 + 1)
-    bias = rnd(N, seed=4)
-    eps = 1e-5
-    kw = {}
-    ref = (gain * xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + eps)) @ wr.T
-    if K2:
-        a2, a2r = q(rnd(M, K2, seed=5), dtype)
-        w2, w2r = q(rnd(N, K2, seed=6) / math.sqrt(K2), dtype)
-        kw = dict(A2=a2, W2=w2)
-        ref = ref + a2r @ w2r.T
-    gd = gain.to(DEV)
-    out = gemm(dtype, x, w, bias=bias.to(DEV), skinny=True, norm_gain=gd, norm_eps=eps, **kw)
-    close(out, ref + bias, tol(dtype) * 2, what="skinny fused rmsnorm")
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,I,K", [(8, 8192, 128), (3, 256, 256), (24, 512, 128), (32, 4096 + 16, 64), (8, 8192, 2048), (5, 4096 + 16, 192)])
-def test_gemm_skinny_fused_rmsnorm_swiglu(dtype, M, I, K):
-    x, xr = q(rnd(M, K, seed=1), dtype)
-    wg, wgr = q(rnd(I, K, seed=2) / math.sqrt(K), dtype)
-    wu, wur = q(rnd(I, K, seed=3) / math.sqrt(K), dtype)
-    inter = torch.stack([wg.reshape(-1, 16, K), wu.reshape(-1, 16, K)], 1).reshape(2 * I, K).contiguous()
-    gain = (rnd(K, seed=4) * 0.1 + 1)
-    eps = 1e-6
-    h = gain * xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + eps)
-    ref = F.silu(h @ wgr.T) * (h @ wur.T)
-    gd = gain.to(DEV)
-    out = gemm(dtype, x, inter, skinny=True, norm_gain=gd, norm_eps=eps, swiglu_pairs=1)
-    assert out.shape == (M, I)
-    close(out, ref, tol(dtype) * 2, rtol=(8e-3 if dtype == "bf16" else 0.0), what="skinny fused rmsnorm+swiglu")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -922,9 +919,9 @@ def test_gemm_8p_pipeline(M, N, K, K2):
         w2, w2r = q(rnd(N, K2, seed=4) / math.sqrt(K2), dtype)
         kw = dict(A2=a2, W2=w2)
         ref = ref + a2r @ w2r.T
-    out = gemm(dtype, a, w, bias=bias.to(DEV), act=1, residual=r, res_after_act=1, skinny=2, **kw)
+    out = gemm(dtype, a, w, bias=bias.to(DEV), act=1, residual=r, res_after_act=1, kernel=2, **kw)
     close(out, F.gelu(ref + bias) + rr, tol(dtype) * 2, what="gemm 8p")
-    out2 = gemm(dtype, a, w, bias=bias.to(DEV), act=1, residual=r, res_after_act=1, skinny=2, **kw)
+    out2 = gemm(dtype, a, w, bias=bias.to(DEV), act=1, residual=r, res_after_act=1, kernel=2, **kw)
     assert torch.equal(out, out2), "two launches of the ping-pong GEMM differ (race in the k-loop schedule)"
 
 
@@ -934,7 +931,7 @@ def test_gemm_8p_identity_layout():
     a, _ = q(torch.eye(n), "bf16")
     wv = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 253) / 64.0
     w, wr = q(wv, "bf16")
-    out = gemm("bf16", a, w, skinny=2)
+    out = gemm("bf16", a, w, kernel=2)
     close(out, wr.T, 1e-6, what="gemm 8p identity")
 
 
@@ -947,92 +944,8 @@ def test_gemm_8p_bitwise_equals_16_wave_kernel():
     a2 = torch.randn(6000, 128, generator=g).to(DEV, torch.bfloat16)
     w2 = (torch.randn(4096, 128, generator=g) / 11).to(DEV, torch.bfloat16)
     b = torch.randn(4096, generator=g).to(DEV)
-    outs = [gemm("bf16", a, w, A2=a2, W2=w2, bias=b, act=1, skinny=sel) for sel in (2, 5)]
+    outs = [gemm("bf16", a, w, A2=a2, W2=w2, bias=b, act=1, kernel=sel) for sel in (2, 5)]
     assert torch.equal(outs[0], outs[1]), f"ping-pong vs 16-wave kernel: max diff {(outs[0].float() - outs[1].float()).abs().max().item():.3e}"
-
-
-def test_skinny_persistent_lm_head_bitwise_equals_tile_kernel(tmp_path):
-    """lm_head-shaped GEMVs (<= 8 rows, N >= 65536) run on persistent workgroups (skinny_persist_kernel) that keep the tile arithmetic of
-    the per-tile kernel: identical bits (OAVSR_SKINNY_PERSIST=1 / 0, read once per process) for both dtypes, both depths (K = 2048: 8
-    k steps per wave; K = 3584 / 4096: the 16-step variant incl. its ragged last trips), ragged N, 1..8 rows, with and without the
-    fused RMSNorm, f32 and bf16 outputs -- and the value agrees with fp32 torch."""
-    import subprocess
-    import sys
-    script = f"""
-import sys, math, torch
-sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r}); sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
-from gpu_util import gemm, DEV
-g = torch.Generator().manual_seed(5)
-outs = []
-for dtype, td in (("bf16", torch.bfloat16), ("f32", torch.float32)):
-    for M, N, K, norm, of32 in ((8, 128256, 2048, True, True), (5, 65536 + 24, 2048, False, False), (1, 70000, 4096, True, True),
-                                (8, 152064 // 2, 3584, True, False), (3, 65536, 1024, True, True),
-                                # 9..32 rows: the persistent form of the 16-row-operand kernel (MT = 1 / 2; 16 rows also with 16 k steps per wave)
-                                (16, 128256, 2048, True, True), (24, 128256, 2048, True, True), (9, 65536 + 40, 2048, False, False),
-                                (32, 70000, 1024, True, False), (16, 66000, 4096, True, True), (12, 152064 // 2, 3584, False, True)):
-        if dtype == "f32" and K > 2048: continue                      # f32: 16 elements per 64-byte k block, the 16-step variant covers K <= 2048
-        x = torch.randn(M, K, generator=g).to(DEV, td)
-        w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV, td)
-        kw = dict(norm_gain=(torch.randn(K, generator=g) * 0.1 + 1).to(DEV), norm_eps=1e-5) if norm else {{}}
-        bias = torch.randn(N, generator=g).to(DEV) if not norm else None
-        out = gemm(dtype, x, w, skinny=True, out_f32=of32, bias=bias, **kw)
-        xf = x.float()
-        if norm: xf = (xf * kw["norm_gain"]).to(td).float() * torch.rsqrt((x.float() ** 2).mean(-1, keepdim=True) + 1e-5)
-        ref = xf @ w.float().T + (bias if bias is not None else 0)
-        err = (out.float() - ref).abs().max().item()
-        assert err < (3e-2 if dtype == "bf16" else 2e-4), (dtype, M, N, K, err)
-        outs.append(out.cpu())
-torch.save(outs, sys.argv[1])
-"""
-    got = []
-    for flag in ("1", "0"):
-        f = str(tmp_path / f"o{flag}.pt")
-        r = subprocess.run([sys.executable, "-c", script, f], env=dict(os.environ, OAVSR_SKINNY_PERSIST=flag), capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stderr[-2000:]
-        got.append(torch.load(f))
-    assert len(got[0]) == len(got[1]) >= 14
-    for i, (a_, b_) in enumerate(zip(got[0], got[1])):
-        assert torch.equal(a_, b_), f"case {i}: persistent vs per-tile kernel differ by {(a_.float() - b_.float()).abs().max().item():.3e}"
-
-
-def test_skinny_persistent_gate_up_bitwise_equals_tile_kernel(tmp_path):
-    """gate / up with the fused RMSNorm + SwiGLU at 9..32 rows: persistent 8-wave workgroups (skinny_persist_r16_kernel<.., 8, true>) against
-    the per-tile kernel, bit for bit (OAVSR_SKINNY_PERSIST=1 / 0), and against fp32 torch."""
-    import subprocess
-    import sys
-    script = f"""
-import sys, math, torch
-sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r}); sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
-from gpu_util import gemm, DEV
-g = torch.Generator().manual_seed(7)
-outs = []
-for dtype, td in (("bf16", torch.bfloat16), ("f32", torch.float32)):
-    for M, I, K in ((16, 8192, 2048), (24, 8192, 2048), (9, 8192 + 512, 1024), (32, 8192, 2048), (12, 18944, 3584),
-                    (8, 8192, 2048), (3, 8192 + 512, 1024), (8, 18944, 3584)):          # <= 8 rows: the 8-wave form of skinny_persist_kernel
-        if dtype == "f32" and K > 2048: continue
-        x = torch.randn(M, K, generator=g).to(DEV, td)
-        wg_ = (torch.randn(I, K, generator=g) / math.sqrt(K)).to(td)
-        wu_ = (torch.randn(I, K, generator=g) / math.sqrt(K)).to(td)
-        w = torch.stack([wg_.view(I // 16, 16, K), wu_.view(I // 16, 16, K)], 1).reshape(2 * I, K).to(DEV)     # [gate block | up block] by 16 rows
-        gain = (torch.randn(K, generator=g) * 0.1 + 1).to(DEV)
-        out = gemm(dtype, x, w, skinny=True, norm_gain=gain, norm_eps=1e-5, swiglu_pairs=1)
-        xn = (x.float() * gain).to(td).float() * torch.rsqrt((x.float() ** 2).mean(-1, keepdim=True) + 1e-5)
-        ref = torch.nn.functional.silu(xn @ wg_.float().T.to(DEV)) * (xn @ wu_.float().T.to(DEV))
-        err = (out.float() - ref).abs().max().item()
-        assert err < (4e-2 if dtype == "bf16" else 2e-4), (dtype, M, I, K, err)
-        outs.append(out.cpu())
-torch.save(outs, sys.argv[1])
-"""
-    got = []
-    for flag in ("1", "0"):
-        f = str(tmp_path / f"o{flag}.pt")
-        r = subprocess.run([sys.executable, "-c", script, f], env=dict(os.environ, OAVSR_SKINNY_PERSIST=flag),
-                           capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stderr[-2000:]
-        got.append(torch.load(f))
-    assert len(got[0]) == len(got[1]) >= 14
-    for i, (a_, b_) in enumerate(zip(got[0], got[1])):
-        assert torch.equal(a_, b_), f"case {i}: persistent vs per-tile kernel differ by {(a_.float() - b_.float()).abs().max().item():.3e}"
 
 
 def test_gemm_8p_fused_swiglu_equals_gemm_plus_swiglu_kernel():
@@ -1041,7 +954,7 @@ def test_gemm_8p_fused_swiglu_equals_gemm_plus_swiglu_kernel():
     wg, _ = q(rnd(I, K, seed=2) / math.sqrt(K), dtype)
     wu, _ = q(rnd(I, K, seed=3) / math.sqrt(K), dtype)
     inter = torch.stack([wg.reshape(-1, 16, K), wu.reshape(-1, 16, K)], 1).reshape(2 * I, K).contiguous()
-    fused = gemm(dtype, x, inter, swiglu_pairs=1, skinny=2)
+    fused = gemm(dtype, x, inter, swiglu_pairs=1, kernel=2)
     gu = gemm(dtype, x, inter)
     two = torch.empty(M, I, dtype=tdt(dtype), device=DEV)
     L.check(L.load().oavsr_op_swiglu(dcode(dtype), P(gu), 2 * I, P(two), I, M, I, 1, stream()))
@@ -1067,13 +980,13 @@ def test_gemm_8pp_persistent(M, N, K, grid, act):
     bias = rnd(N, seed=7)
     ref = ar @ wr.T + bias
     ref = F.gelu(ref) if act == 1 else F.silu(ref) if act == 4 else ref
-    out = gemm(dtype, a, w, bias=bias.to(DEV), act=act, skinny=3, grid=grid)
+    out = gemm(dtype, a, w, bias=bias.to(DEV), act=act, kernel=3, grid=grid)
     close(out, ref, tol(dtype) * 2, what="gemm 8pp")
     for sel in (5, 2):
-        other = gemm(dtype, a, w, bias=bias.to(DEV), act=act, skinny=sel)
+        other = gemm(dtype, a, w, bias=bias.to(DEV), act=act, kernel=sel)
         assert torch.equal(out, other), f"persistent kernel vs kernel selector {sel}: max diff {(out.float() - other.float()).abs().max().item():.3e}"
     for _ in range(3):
-        again = gemm(dtype, a, w, bias=bias.to(DEV), act=act, skinny=3, grid=grid)
+        again = gemm(dtype, a, w, bias=bias.to(DEV), act=act, kernel=3, grid=grid)
         assert torch.equal(out, again), "two launches of the persistent GEMM differ (race in the cross-tile schedule)"
 
 
@@ -1096,13 +1009,13 @@ def test_gemm_8pp_residual_variant(M, N, K, grid, act, raa):
     else:
         ref = ref + rr
         ref = F.gelu(ref) if act == 1 else F.silu(ref) if act == 4 else ref
-    out = gemm(dtype, a, w, bias=bias.to(DEV), act=act, residual=r, res_after_act=raa, skinny=3, grid=grid)
+    out = gemm(dtype, a, w, bias=bias.to(DEV), act=act, residual=r, res_after_act=raa, kernel=3, grid=grid)
     close(out, ref, tol(dtype) * 2, what="gemm 8pp residual")
     for sel in (5, 2):
-        other = gemm(dtype, a, w, bias=bias.to(DEV), act=act, residual=r, res_after_act=raa, skinny=sel)
+        other = gemm(dtype, a, w, bias=bias.to(DEV), act=act, residual=r, res_after_act=raa, kernel=sel)
         assert torch.equal(out, other), f"persistent residual variant vs kernel selector {sel}: max diff {(out.float() - other.float()).abs().max().item():.3e}"
     inplace = r.clone()
-    gemm(dtype, a, w, bias=bias.to(DEV), act=act, residual=inplace, res_after_act=raa, skinny=3, grid=grid, C_out=inplace)
+    gemm(dtype, a, w, bias=bias.to(DEV), act=act, residual=inplace, res_after_act=raa, kernel=3, grid=grid, C_out=inplace)
     assert torch.equal(inplace, out), "in-place (C == residual) differs"
 
 
@@ -1114,7 +1027,7 @@ def test_gemm_8pp_identity_layout_and_tile_walk():
     wv = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 253) / 64.0
     w, wr = q(wv, "bf16")
     for grid in (8, 16, 48, 64):
-        out = gemm("bf16", a, w, skinny=3, grid=grid)
+        out = gemm("bf16", a, w, kernel=3, grid=grid)
         close(out, wr.T, 1e-6, what=f"gemm 8pp identity grid {grid}")
 
 
@@ -1125,7 +1038,7 @@ def test_gemm_8pp_under_load_is_deterministic():
     a, _ = q(rnd(M, K, seed=1), dtype)
     w, _ = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
     bias = rnd(N, seed=7).to(DEV)
-    ref = gemm(dtype, a, w, bias=bias, act=1, skinny=5)
+    ref = gemm(dtype, a, w, bias=bias, act=1, kernel=5)
     side = torch.cuda.Stream()
     junk = torch.empty(256 << 20, dtype=torch.uint8, device=DEV)
     for grid in (64, 128, 0):
@@ -1133,7 +1046,7 @@ def test_gemm_8pp_under_load_is_deterministic():
             for _ in range(40):
                 junk.add_(1)
         for _ in range(6):
-            out = gemm(dtype, a, w, bias=bias, act=1, skinny=3, grid=grid)
+            out = gemm(dtype, a, w, bias=bias, act=1, kernel=3, grid=grid)
             assert torch.equal(out, ref), f"persistent GEMM under load (grid {grid}) differs from the 16-wave kernel"
         torch.cuda.synchronize()
 
@@ -1144,11 +1057,11 @@ def test_gemm_8pp_fused_swiglu_equals_gemm_plus_swiglu_kernel():
     wg, _ = q(rnd(I, K, seed=2) / math.sqrt(K), dtype)
     wu, _ = q(rnd(I, K, seed=3) / math.sqrt(K), dtype)
     inter = torch.stack([wg.reshape(-1, 16, K), wu.reshape(-1, 16, K)], 1).reshape(2 * I, K).contiguous()
-    gu = gemm(dtype, x, inter, skinny=5)
+    gu = gemm(dtype, x, inter, kernel=5)
     two = torch.empty(M, I, dtype=tdt(dtype), device=DEV)
     L.check(L.load().oavsr_op_swiglu(dcode(dtype), P(gu), 2 * I, P(two), I, M, I, 1, stream()))
     for grid in (16, 0):
-        fused = gemm(dtype, x, inter, swiglu_pairs=1, skinny=3, grid=grid)
+        fused = gemm(dtype, x, inter, swiglu_pairs=1, kernel=3, grid=grid)
         assert torch.equal(fused, two), f"persistent fused SwiGLU (grid {grid}) differs from gemm + swiglu: {(fused.float() - two.float()).abs().max().item():.3e}"
 
 
@@ -1159,7 +1072,7 @@ def test_gemm_dispatch_takes_persistent_kernel_for_multi_round_launches():
     w, _ = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
     bias = rnd(N, seed=7).to(DEV)
     auto = gemm(dtype, a, w, bias=bias, act=1)
-    forced = gemm(dtype, a, w, bias=bias, act=1, skinny=5)
+    forced = gemm(dtype, a, w, bias=bias, act=1, kernel=5)
     assert torch.equal(auto, forced)
 
 
@@ -1180,8 +1093,8 @@ def test_gemm_160_row_tile_for_one_ragged_round(M, N, K, K2):
         kw = dict(A2=a2, W2=w2)
         ref = ref + a2r @ w2r.T
     auto = gemm(dtype, a, w, bias=bias.to(DEV), residual=r, **kw)
-    t160 = gemm(dtype, a, w, bias=bias.to(DEV), residual=r, skinny=6, **kw)
-    t256 = gemm(dtype, a, w, bias=bias.to(DEV), residual=r, skinny=7, **kw)
+    t160 = gemm(dtype, a, w, bias=bias.to(DEV), residual=r, kernel=6, **kw)
+    t256 = gemm(dtype, a, w, bias=bias.to(DEV), residual=r, kernel=7, **kw)
     close(auto, ref, tol(dtype) * 2, what="160-row tile gemm")
     assert torch.equal(t160, t256) and torch.equal(auto, t160)
 
@@ -1201,58 +1114,3 @@ def test_gemm_lora_segment_equals_one_concatenated_k_range(dtype, M, N, K, K2):
     assert torch.equal(one, two)
 
 
-# ------------------------------------------------------------------------------------------------ 8-column decode tiles for 9..32 rows
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K,K2,norm", [(9, 2048, 2048, 0, False), (16, 3072, 2048, 128, True), (24, 2048, 8192, 0, False), (32, 136, 256, 64, True),
-                                           (17, 128256 // 8, 512, 0, True), (12, 16384 + 40, 128, 0, False),
-                                           # 33..64 rows (round 4: the decode scheduler's 64-row steps): QKV + LoRA with the fused norm (two LDS images),
-                                           # o_proj / down_proj widths, a LoRA-down width, lm_head class (4 waves) and a wide gate-like N, ragged N
-                                           (64, 3072, 2048, 128, True), (48, 2048, 8192, 0, False), (33, 4096, 4096, 0, False), (64, 256, 2048, 0, True),
-                                           (40, 128256 // 8, 512, 0, True), (64, 65536 + 24, 256, 0, True), (56, 16384 + 40, 128, 0, False)])
-def test_gemm_skinny_r16_tiles(dtype, M, N, K, K2, norm):
-    """9..64 rows through 8-column tiles (skinny_r16_kernel): vs the fp32 reference, and the first 8 rows bit-identical to what the
-    <= 8-row kernel computes for them alone (same partial-sum order => greedy decode does not depend on the batch up to 64 rows)."""
-    x, xr = q(rnd(M, K, seed=1) * 1.3, dtype)
-    w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
-    r, rr = q(rnd(M, N, seed=5), dtype)
-    gain = (rnd(K, seed=3) * 0.1 + 1)
-    eps = 1e-5
-    kw, kw8 = {}, {}
-    h = gain * xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + eps) if norm else xr
-    ref = h @ wr.T + rr
-    if K2:
-        a2, a2r = q(rnd(M, K2, seed=6), dtype)
-        w2, w2r = q(rnd(N, K2, seed=7) / math.sqrt(K2), dtype)
-        kw, kw8 = dict(A2=a2, W2=w2), dict(A2=a2[:8].contiguous(), W2=w2)
-        ref = ref + a2r @ w2r.T
-    if norm:
-        gd = gain.to(DEV)
-        kw.update(norm_gain=gd, norm_eps=eps)
-        kw8.update(norm_gain=gd, norm_eps=eps)
-    out = gemm(dtype, x, w, residual=r, skinny=True, **kw)
-    close(out, ref, tol(dtype) * 2, what="skinny r16 gemm")
-    out8 = gemm(dtype, x[:8].contiguous(), w, residual=r[:8].contiguous(), skinny=True, **kw8)
-    assert torch.equal(out[:8], out8), f"rows 0-7 differ from the <= 8-row kernel: {(out[:8].float() - out8.float()).abs().max().item():.3e}"
-    if M > 40:      # ... and a block of rows from the upper half (the third / fourth 16-row operand)
-        kw8b = dict(kw8)
-        if K2:
-            kw8b["A2"] = a2[M - 8:].contiguous()
-        out8b = gemm(dtype, x[M - 8:].contiguous(), w, residual=r[M - 8:].contiguous(), skinny=True, **kw8b)
-        assert torch.equal(out[M - 8:], out8b), f"rows {M - 8}..{M - 1} differ from the <= 8-row kernel"
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,I,K", [(16, 8192, 2048), (24, 4096, 256), (32, 8192, 128), (64, 8192, 2048), (40, 14336, 4096)])
-def test_gemm_skinny_r16_swiglu(dtype, M, I, K):
-    x, xr = q(rnd(M, K, seed=1), dtype)
-    wg, wgr = q(rnd(I, K, seed=2) / math.sqrt(K), dtype)
-    wu, wur = q(rnd(I, K, seed=3) / math.sqrt(K), dtype)
-    inter = torch.stack([wg.reshape(-1, 16, K), wu.reshape(-1, 16, K)], 1).reshape(2 * I, K).contiguous()
-    gain = (rnd(K, seed=4) * 0.1 + 1)
-    eps = 1e-6
-    h = gain * xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + eps)
-    gd = gain.to(DEV)
-    out = gemm(dtype, x, inter, skinny=True, norm_gain=gd, norm_eps=eps, swiglu_pairs=1)
-    close(out, F.silu(h @ wgr.T) * (h @ wur.T), tol(dtype) * 2, rtol=(8e-3 if dtype == "bf16" else 0.0), what="skinny r16 rmsnorm+swiglu")
-    out8 = gemm(dtype, x[:8].contiguous(), inter, skinny=True, norm_gain=gd, norm_eps=eps, swiglu_pairs=1)
-    assert torch.equal(out[:8], out8), "rows 0-7 differ from the <= 8-row kernel"

@@ -88,9 +88,9 @@ def test_eos_lengths_and_different_max_new(dtype):
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("family,hd", [("llama", 64), ("qwen2", 128)])
 def test_64_row_steps_equal_isolated_calls(dtype, family, hd):
-    """max_rows = 64 (round 4): eleven calls of 3..12 rows through ONE lane whose steps carry up to 64 rows -- the 33..64-row forms of the
-    weight-streaming kernels (four 16-row activation operands per weight fragment) give a row the bits of the <= 8-row kernel, so every
-    call must decode exactly the ids of the same call run alone; also a call of 40 rows on its own (generate, no scheduler)."""
+    """max_rows = 64: eleven calls of 3..12 rows through ONE lane whose steps carry up to 64 rows -- the decode-shaped GEMMs give a row the
+    same bits at every row count, so every call must decode exactly the ids of the same call run alone; also a call of 39 rows on its own
+    (generate, no scheduler)."""
     spec = tiny_spec(family=family, head_dim=hd, task_specific=True, shared=True)
     eng = OmniEngine(spec, dtype=dtype).load_state_dict(synth_state_dict(spec, seed=1234))
     eng.sched_lanes, eng.sched_rows, eng.sched_slots, eng.sched_stride = 1, 64, 128, 1
@@ -105,7 +105,7 @@ def test_64_row_steps_equal_isolated_calls(dtype, family, hd):
     for i in range(len(calls)):
         assert got[i] == ref[i], f"{dtype}: call {i} ({sizes[i]} rows) decodes differently inside 64-row steps than alone"
     st = eng.scheduler_stats()
-    assert st["rows_per_step"] > 32.0, f"the steps never reached the 33..64-row forms: {st}"
+    assert st["rows_per_step"] > 32.0, f"the steps never carried more than 32 rows: {st}"
     # 40 utterances in ONE plain call: rows 0..7 are the first call's utterances
     video = torch.cat([c[0] for c in calls[:5]], 0)
     audio = torch.cat([c[1] for c in calls[:5]], 0)
@@ -114,6 +114,28 @@ def test_64_row_steps_equal_isolated_calls(dtype, family, hd):
     ids40, lens40 = eng.generate("audiovisual", video, Tv, audio, Ts, 4, 2, beams=1, max_new=mn, force_len=True)
     torch.cuda.synchronize()
     assert len(Tv) == 39 and ids40[:8].cpu().tolist() == ref[0][0], "39 rows in one decode loop: rows 0..7 differ from the 8-row call"
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("B", [65, 100, 128])
+def test_one_call_of_65_to_128_rows_through_the_scheduler(dtype, B):
+    """the scheduler's default step holds 128 rows and `oavsr_generate_submit` accepts B <= max_rows: a single call that brings more than 64
+    rows (round 4 refused it in admission: sched_init_slots checked B <= 64) decodes, and its first 8 rows are the ids of those 8 utterances
+    submitted as a call of their own"""
+    spec = tiny_spec(family="llama", task_specific=True, shared=True)
+    eng = OmniEngine(spec, dtype=dtype).load_state_dict(synth_state_dict(spec, seed=1234))
+    eng.sched_lanes, eng.sched_rows, eng.sched_slots = 1, 128, 256
+    mn = spec.max_dec_tokens
+    big = clips(B, 900 + B)
+    head = tuple(x[:8] for x in big)
+    ref8 = alone(eng, head, mn, True)
+    s = torch.cuda.Stream()
+    p = submit(eng, big, mn, True, 0, s)
+    p8 = submit(eng, head, mn, True, 1, s)          # joins the same lane when B + 8 <= 128, else the lane makes room first
+    ids, lens = collect(eng, p, s)
+    assert len(ids) == B and all(n == mn for n in lens)
+    assert (ids[:8], lens[:8]) == ref8, f"{dtype}: rows 0..7 of a {B}-row call differ from the 8-row call of the same utterances"
+    assert collect(eng, p8, s) == ref8
 
 
 def test_more_calls_than_rows_per_step_and_oracle_f32():

@@ -272,3 +272,48 @@ def test_shim_forward_matches_engine_and_errors():
         m(batch, is_trainval=False, modality="audiovisual", test_ratio_matry_audio=3, test_ratio_matry_video=2)
     with pytest.raises(NotImplementedError):
         m(batch, is_trainval=True)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_digests_are_the_hashes_of_inputs_embeds_and_first_logits(dtype):
+    """oavsr_workspace_set_digests: per utterance {digest of its spliced inputs_embeds rows, digest of its first-step logits row}.  The values
+    are exactly the host-side hash of what the STAGE entry points return for the same inputs; different clips give different digests; an
+    utterance keeps its digests whatever its position / batch (batch invariance); a call through the decode scheduler reports the same pair."""
+    from gpu_util import digest_words
+    spec, sd, eng, orc = make(dtype)
+    Tv, Ts = [12, 9, 7], [7680, 5000, 4480]
+    video, audio = inputs(B=3, Tv=Tv, Ts=Ts, seed=3)
+    dg = torch.zeros(3, 2, dtype=torch.int64, device="cuda:0")
+    ids, lens = eng.generate("audiovisual", video, Tv, audio, Ts, 4, 2, beams=1, max_new=spec.max_dec_tokens, digests=dg)
+    torch.cuda.synchronize()
+    a_out, na = eng.encode_audio(audio, Ts, 4)
+    v_out, nv = eng.encode_video(video, Tv, 2)
+    emb, S = eng.build_prompt("audiovisual", 3, na, eng.project("audio", 4, a_out), nv, eng.project("video", 2, v_out))
+    logits = eng.prefill("audiovisual", emb, S)
+    torch.cuda.synchronize()
+    off = 0
+    for b in range(3):
+        assert int(dg[b, 0]) == digest_words(emb[off:off + S[b]]), f"utterance {b}: inputs_embeds digest"
+        assert int(dg[b, 1]) == digest_words(logits[b]), f"utterance {b}: first-step logits digest"
+        off += S[b]
+    assert len({int(x) for x in dg[:, 0]}) == 3 and len({int(x) for x in dg[:, 1]}) == 3, "different clips must give different digests"
+    # utterance 1 alone, and as row 0 of another batch: same digests
+    d1 = torch.zeros(1, 2, dtype=torch.int64, device="cuda:0")
+    eng.generate("audiovisual", video[1:2, : Tv[1]], [Tv[1]], audio[1:2, : Ts[1]], [Ts[1]], 4, 2, beams=1, max_new=spec.max_dec_tokens, digests=d1)
+    d2 = torch.zeros(2, 2, dtype=torch.int64, device="cuda:0")
+    eng.generate("audiovisual", video[[1, 0]], [Tv[1], Tv[0]], audio[[1, 0]], [Ts[1], Ts[0]], 4, 2, beams=1, max_new=spec.max_dec_tokens, digests=d2)
+    torch.cuda.synchronize()
+    assert torch.equal(d1[0], dg[1]) and torch.equal(d2[0], dg[1]) and torch.equal(d2[1], dg[0])
+    # through the decode scheduler
+    ds = torch.zeros(3, 2, dtype=torch.int64, device="cuda:0")
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ids_s, lens_s, ticket = eng.submit("audiovisual", video, Tv, audio, Ts, 4, 2, max_new=spec.max_dec_tokens, digests=ds)
+        eng.wait(ticket)
+    st.synchronize()
+    assert torch.equal(ds, dg) and torch.equal(ids_s, ids)
+    # off again: a later call leaves the buffer alone
+    dg2 = dg.clone()
+    eng.generate("audiovisual", video[:1, : Tv[0]], [Tv[0]], audio[:1, : Ts[0]], [Ts[0]], 4, 2, beams=1, max_new=spec.max_dec_tokens)
+    torch.cuda.synchronize()
+    assert torch.equal(dg, dg2)

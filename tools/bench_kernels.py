@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmarks of single kernels through the C ABI (HIP events on torch's current stream).
 Weights are rotated over enough copies to exceed the 256 MiB Infinity Cache, as in the real decode loop where every
-weight byte is read once per step.   python tools/bench_kernels.py [skinny|gemm|attn|all]"""
+weight byte is read once per step.   python tools/bench_kernels.py [decode|gemm|attn|all]"""
 import math
 import os
 import sys
@@ -28,38 +28,11 @@ def timeit(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) / iters * 1e3   # us
 
 
-def bench_skinny(dtype="bf16"):
-    td = torch.bfloat16 if dtype == "bf16" else torch.float32
-    esz = 2 if dtype == "bf16" else 4
-    print(f"--- skinny (decode) GEMMs, {dtype}, M=8 ---")
-    cases = [("lora_dn", 256, 2048, 0, True, False), ("qkv+lora", 3072, 2048, 256, True, False), ("o_proj", 2048, 2048, 0, False, False),
-             ("gate_up+swiglu", 16384, 2048, 0, True, True), ("down", 2048, 8192, 0, False, False), ("lm_head", 128256, 2048, 0, True, False)]
-    for M in (8, 120):
-        for name, N, K, K2, norm, swi in cases:
-            if swi and M > 32:
-                continue
-            ncopy = max(2, int(400e6 // (N * (K + K2) * esz)) + 1)
-            Ws = [torch.randn(N, K, device=DEV, dtype=td) * 0.02 for _ in range(ncopy)]
-            W2s = [torch.randn(N, K2, device=DEV, dtype=td) * 0.02 for _ in range(ncopy)] if K2 else None
-            x = torch.randn(M, K, device=DEV, dtype=td)
-            a2 = torch.randn(M, K2, device=DEV, dtype=td) if K2 else None
-            gain = torch.ones(K, device=DEV)
-            out = torch.empty(M, N // (2 if swi else 1), device=DEV, dtype=torch.float32 if name == "lm_head" else td)
-            res = torch.randn(M, N, device=DEV, dtype=td) if name in ("o_proj", "down") else None
-
-            def run(i):
-                kw = {}
-                if K2:
-                    kw.update(A2=a2, W2=W2s[i % ncopy])
-                if norm:
-                    kw.update(norm_gain=gain, norm_eps=1e-5)
-                if swi:
-                    kw.update(swiglu_pairs=1)
-                gemm(dtype, x, Ws[i % ncopy], skinny=True, residual=res, C_out=out, out_f32=(name == "lm_head"), **kw)
-            us = timeit(run, iters=max(20, ncopy * 2))
-            gb = N * (K + K2) * esz / 1e9
-            print(f"M={M:4d} {name:16s} N={N:6d} K={K:5d}+{K2:3d}: {us:8.1f} us  {gb / us * 1e6:7.0f} GB/s")
-            del Ws, W2s
+def bench_decode():
+    """the decode-shaped launches of a step, per call site (tools/decode_mix.py --time)"""
+    import subprocess
+    for rows, model in ((8, "1b"), (97, "1b"), (97, "8b")):
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "decode_mix.py"), str(rows), model, "1", "--time"], check=False)
 
 
 def bench_gemm(dtype="bf16"):
@@ -104,8 +77,8 @@ def bench_attn(dtype="bf16"):
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
-    if what in ("skinny", "all"):
-        bench_skinny()
+    if what in ("decode", "all"):
+        bench_decode()
     if what in ("gemm", "all"):
         bench_gemm()
     if what in ("attn", "all"):

@@ -22,11 +22,11 @@ for name, M, N, K in [("whisper qkv", 12000, 3072, 1024), ("whisper fc1", 12000,
     us = timeit(lambda: torch.matmul(a, w.t(), out=out))
     ours = timeit(lambda: gemm("bf16", a, w, C_out=out))                  # this repo's dispatcher (gemm2.hip / gemm3.hip)
     try:
-        pp = timeit(lambda: gemm("bf16", a, w, C_out=out, skinny=2))      # the 8-wave ping-pong kernel whatever the dispatcher's rule says
+        pp = timeit(lambda: gemm("bf16", a, w, C_out=out, kernel=2))      # the 8-wave ping-pong kernel whatever the dispatcher's rule says
     except Exception:
         pp = float("nan")
     try:
-        ps = timeit(lambda: gemm("bf16", a, w, C_out=out, skinny=3))      # the persistent ping-pong kernel (round 4; the dispatcher takes it when tiles > CUs)
+        ps = timeit(lambda: gemm("bf16", a, w, C_out=out, kernel=3))      # the persistent ping-pong kernel (round 4; the dispatcher takes it when tiles > CUs)
     except Exception:
         ps = float("nan")
     fl = 2.0 * M * N * K / 1e6

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""The decode-shaped launches of ONE decode step (llm_decode_layers + lm_head, model.hip) at R rows for a model's widths, through the C ABI:
+per layer LoRA-down, QKV (+ LoRA segment, row_scale), o_proj (+ residual, next-norm outputs), gate / up (+ SwiGLU, row_scale), down_proj
+(+ residual, next-norm outputs) -- split-K with the reduce inside the launch exactly as decode_gemm sizes it -- then lm_head (fp32 logits).
+Weight copies rotate beyond the 256 MiB Infinity Cache.  For `rocprofv3 --pmc` / `--kernel-trace` passes over the decode kernels that
+ship (tools/pmc_round.py tags "decode..."), and with `--time` a per-site timing table.
+
+usage: decode_mix.py [rows=97] [model=1b|8b|7b] [steps=2] [--time]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+from omni_avsr_amd import lib as L  # noqa: E402
+from gpu_util import gemm, DEV  # noqa: E402
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+R = int(args[0]) if args else 97
+model = args[1] if len(args) > 1 else "1b"
+steps = int(args[2]) if len(args) > 2 else 2
+timing = "--time" in sys.argv
+# d, nqkv, nq, 2I, lora k2, vocab, layers
+d, nqkv, nq, I2, k2, V, layers = {"1b": (2048, 3072, 2048, 16384, 256, 128261, 16), "8b": (4096, 6144, 4096, 28672, 512, 128261, 32),
+                                  "7b": (3584, 4608, 3584, 37888, 448, 152068, 28)}[model]
+td = torch.bfloat16
+
+
+def split(N, K, min_ks=1):      # model.hip: decode_split
+    ktiles = K // 64
+    ks = 256 // max(1, -(-N // 64))
+    ks = min(ks, max(1, ktiles // 2))
+    ks = max(1, min(ks, 16))
+    return max(ks, min(min_ks, max(1, ktiles)))
+
+
+sites = [("lora_dn", k2, d, 0, 1, False), ("qkv", nqkv, d, k2, 1, False), ("o_proj", d, nq, 0, 2, True), ("gate_up", I2, d, 0, 1, False), ("down", d, I2 // 2, 0, 2, True)]
+ncopy = 3 if model == "1b" else 2
+W = {n: [torch.randn(N, K, device=DEV, dtype=td) * 0.02 for _ in range(ncopy)] for n, N, K, K2, mk, ng in sites}
+W2 = [torch.randn(nqkv, k2, device=DEV, dtype=td) * 0.02 for _ in range(ncopy)]
+Wl = torch.randn(V, d, device=DEV, dtype=td) * 0.02
+x = torch.randn(R, d, device=DEV, dtype=td)
+xg = torch.randn(R, d, device=DEV, dtype=td)
+t = torch.randn(R, k2, device=DEV, dtype=td)
+attn = torch.randn(R, nq, device=DEV, dtype=td)
+act = torch.randn(R, I2 // 2, device=DEV, dtype=td)
+qkv = torch.empty(R, nqkv, device=DEV, dtype=td)
+logits = torch.empty(R, V, device=DEV, dtype=torch.float32)
+rstd = torch.rand(R, device=DEV) + 0.5
+gain = torch.ones(d, device=DEV)
+rowsq = torch.empty((d // 64 + 2) * R, device=DEV)
+part = torch.empty(16 * 128 * max(nqkv, d, k2), device=DEV, dtype=torch.float32)
+sync = torch.zeros(L.GEMM_SYNC_INTS, dtype=torch.int32, device=DEV)
+
+
+def launch(name, i):
+    w = W[name][i % ncopy] if name != "lm_head" else Wl
+    if name == "lora_dn":
+        gemm("bf16", xg, w, C_out=t, ksplit=split(k2, d), partial=part, sync=sync)
+    elif name == "qkv":
+        ks = split(nqkv, d + k2)
+        kw = dict(ksplit=ks, partial=part, sync=sync) if ks > 1 else dict(decode_tiled=1)
+        gemm("bf16", xg, w, A2=t, W2=W2[i % ncopy], row_scale=rstd, C_out=qkv, **kw)
+    elif name == "o_proj":
+        gemm("bf16", attn, w, residual=x, C_out=x, ksplit=split(d, nq, 2), partial=part, sync=sync, ng_out=xg, ng_ld=d, ng_gain=gain, ng_rowsq=rowsq, ng_rstd=rstd, ng_eps=1e-5)
+    elif name == "gate_up":
+        gemm("bf16", xg, w, row_scale=rstd, swiglu_pairs=1, C_out=act, decode_tiled=1)
+    elif name == "down":
+        gemm("bf16", act, w, residual=x, C_out=x, ksplit=split(d, I2 // 2, 2), partial=part, sync=sync, ng_out=xg, ng_ld=d, ng_gain=gain, ng_rowsq=rowsq, ng_rstd=rstd, ng_eps=1e-5)
+    else:
+        gemm("bf16", xg, w, row_scale=rstd, out_f32=True, C_out=logits, decode_tiled=1)
+
+
+if timing:
+    for name in [s[0] for s in sites] + ["lm_head"]:
+        for i in range(3):
+            launch(name, i)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 24
+        e0.record()
+        for i in range(n):
+            launch(name, i)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / n
+        N, K = {"lora_dn": (k2, d), "qkv": (nqkv, d + k2), "o_proj": (d, nq), "gate_up": (I2, d), "down": (d, I2 // 2), "lm_head": (V, d)}[name]
+        print(f"{model} rows={R:3d} {name:8s} N={N:6d} K={K:5d} split={split(N, K, 2 if name in ('o_proj', 'down') else 1) if name not in ('gate_up', 'lm_head') else 1:2d}: {us:7.1f} us  {N * K * 2 / us / 1e3:7.1f} GB/s of weights")
+else:
+    for s in range(steps):
+        for li in range(layers):
+            for name in [s_[0] for s_ in sites]:
+                launch(name, li)
+        launch("lm_head", 0)
+    torch.cuda.synchronize()

@@ -67,10 +67,10 @@ def main():
         if sw:
             kw["swiglu_pairs"] = 1
         # reference bits from the 16-wave kernel; every variant must reproduce them
-        ref = gemm("bf16", sets[0][0], sets[0][1], bias=bias, skinny=5, **kw).clone()
+        ref = gemm("bf16", sets[0][0], sets[0][1], bias=bias, kernel=5, **kw).clone()
         times = {v: [] for v in variants}
         for v in variants:
-            out = gemm("bf16", sets[0][0], sets[0][1], bias=bias, skinny=v[0], grid=v[1], **kw)
+            out = gemm("bf16", sets[0][0], sets[0][1], bias=bias, kernel=v[0], grid=v[1], **kw)
             assert torch.equal(out, ref), f"{name}: variant {v} differs from the 16-wave kernel"
         torch.cuda.synchronize()
         for r in range(a.rounds):
@@ -78,11 +78,11 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 for i in range(2):
                     A, W, Cc = sets[i % nset]
-                    gemm("bf16", A, W, bias=bias, skinny=v[0], grid=v[1], C_out=Cc, **kw)
+                    gemm("bf16", A, W, bias=bias, kernel=v[0], grid=v[1], C_out=Cc, **kw)
                 e0.record()
                 for i in range(a.iters):
                     A, W, Cc = sets[i % nset]
-                    gemm("bf16", A, W, bias=bias, skinny=v[0], grid=v[1], C_out=Cc, **kw)
+                    gemm("bf16", A, W, bias=bias, kernel=v[0], grid=v[1], C_out=Cc, **kw)
                 e1.record()
                 torch.cuda.synchronize()
                 times[v].append(e0.elapsed_time(e1) * 1e3 / a.iters)

@@ -22,25 +22,15 @@ FAMILY = [  # rocprof kernel-name pattern -> bench.py family name
     (r"gemm_8p_kernel", "gemm_8p_256x256_bf16"),
     (r"gemm_dma_kernelIDF16bLi0ELi256ELi256E|gemm_dma_kernel<.*256, 256, 2", "gemm_dma_256x256_bf16"),
     (r"gemm_dma_kernelIDF16bLi0ELi256ELi128E|gemm_dma_kernel<[^>]*0, 256, 128", "gemm_dma_256x128_bf16"),
-    (r"skinny_kernel<[^>]*, 1, false, 8, true, 8>|skinny_kernelIDF16bLi1ELi1ELb0ELi8ELb1ELi8E", "skinny_mt1_nt1_bf16"),
-    (r"skinny_kernel<[^>]*, 1, true, 8, true, 8>|skinny_kernelIDF16bLi1ELi1ELb1ELi8ELb1ELi8E", "skinny_mt1_nt1_norm_bf16"),
-    (r"skinny_kernel<[^>]*, 4, true, 2, true, 8>|skinny_kernelIDF16bLi1ELi4ELb1ELi2ELb1ELi8E", "skinny_mt1_nt4_norm_swiglu_bf16"),
-    (r"skinny_kernel<[^>]*, 4, true, 2, true, 4>|skinny_kernelIDF16bLi1ELi4ELb1ELi2ELb1ELi4E", "skinny_mt1_nt4_norm_bf16"),
-    (r"skinny_persist_kernel<.*, 4, 8, true>|skinny_persist_kernelI.*Li4ELi8ELb1E", "skinny_mt1_nt4_norm_swiglu_bf16"),     # gate / up, <= 8 rows (round 2: persistent)
-    (r"skinny_persist_kernel<.*, 8, 4, false>|skinny_persist_kernelI.*Li8ELi4ELb0E", "skinny_mt1_nt4_norm_bf16"),           # lm_head, <= 8 rows (round 2: persistent)
+    (r"gemm_dma_kernelIDF16bLi0ELi128ELi64E|gemm_dma_kernel<[^>]*0, 128, 64", "decode_gemm_dma_128x64_bf16"),        # (tools/decode_mix.py passes: split-K launches, reduce inside)
+    (r"gemm_dma_kernelIDF16bLi0ELi128ELi256E|gemm_dma_kernel<[^>]*0, 128, 256", "decode_gemm_dma_128x256_bf16"),     # lm_head
+    (r"decode_attn_beam4_kernel", "decode_attention_beam4"),
     (r"decode_attn_kernel", "decode_attention"),
     (r"attn_dma_kernel", "attention_bf16"),
 ]
 
 
 def fam(name):
-    # round 3: the 9..32-row decode kernels (what the decode scheduler's 32-row steps run): family from the template arguments
-    m = re.search(r"skinny_(persist_)?r16_kernel(?:IDF16b|<[^,]*,)\s*(?:Li)?(\d)E?,?\s*(?:Li)?(\d)?E?,?\s*(?:Lb)?(\d|true|false)?", name)
-    if m:
-        persist, a, b, c = m.group(1), m.group(2), m.group(3), m.group(4)
-        if persist:
-            return f"skinny_persist_r16_mt{a}_bf16"
-        return f"skinny_r16_mt{a}_nt{b}{'_norm' if c in ('1', 'true') else ''}_bf16"
     for pat, f in FAMILY:
         if re.search(pat, name):
             return f
@@ -81,8 +71,7 @@ for f in sorted(set(fa) | set(sa)):
     write = wa[f].get("WRITE_SIZE", 0.0) / max(wc[f].get("WRITE_SIZE", 0), 1)
     ns = max(sc[f].get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0), 1)
     mops = sa[f].get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) / ns
-    what = "tools/skinny_mix.py 64 1 8b (64 rows, the scheduler's forms, Llama-3.1-8B widths)" if "skinny64s8b" in tag else \
-        "tools/skinny_mix.py 32 1 (32 rows, the scheduler's forms)" if "skinny32s" in tag else "tools/skinny_mix.py 32" if "skinny32" in tag else "tools/skinny_mix.py 8" if "skinny" in tag else "tools/gemm_mix.py" if "gemm" in tag else \
+    what = "tools/decode_mix.py 97 8b (97 rows, Llama-3.1-8B widths)" if "decode8b" in tag else "tools/decode_mix.py 97 1b (97 rows, Llama-3.2-1B widths)" if "decode" in tag else "tools/gemm_mix.py" if "gemm" in tag else \
         "bench.py --streams 1 --steps 1 --warmup 1 --calls-per-step 2 --no-cpu-baseline --no-roofline"
     d = dict(note="rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*; separate runs, each with --kernel-trace) over `" + what + "`; traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B (gfx950 read-side "
                   "correction; the counters sit on the L2's memory side, Infinity-Cache hits included); mfma flops = SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512; "

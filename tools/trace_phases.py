@@ -12,7 +12,7 @@ for r in rows:
     n = r["Kernel_Name"]
     if "at::native" in n or "rocclr" in n:
         continue
-    dec = any(k in n for k in ("skinny_", "decode_attn", "argmax", "greedy_update", "sched_", "set_ints", "beam_"))
+    dec = any(k in n for k in ("decode_attn", "argmax", "greedy_update", "sched_", "set_ints", "beam_", "rms_prep", "Li128ELi64E", "128, 64"))
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), dec, r.get("Queue_Id", "0"), n))
 ev.sort()
 t0, t1 = ev[0][0], max(e[1] for e in ev)
