@@ -234,6 +234,31 @@ def per_call_leg(eng, args, pre, task, use_a, B, sets, streams, nstream):
             "note": "decode scheduler off: one decode loop per call of the same batches (the round-2 configuration); not `value`"}
 
 
+def latency_leg(eng, args, pre, task, use_a, first_set):
+    """One utterance alone (B = 1), one call at a time, host-synchronised after every call: ms per utterance, median of 10, for greedy decode
+    (32 tokens, EOS suppressed: like `value`) and for HF beam search K = 15 (the reference's default; natural end)."""
+    video, audio, Tvs, Ts = first_set
+    t1 = Tvs[0]
+    v1, a1 = video[: t1].contiguous(), (audio[:1, : 640 * t1].contiguous() if use_a else None)
+    ra, rv = pre["rates"][0]
+    out = {"unit": "ms per utterance", "clip_s": round(t1 / 25.0, 2), "calls": 10,
+           "note": "B = 1, one call at a time on an idle chip, device-synchronised per call, median of 10 (the reference's evaluation protocol, data_module.py:238-242)"}
+    for name, beams in (("greedy", 1), ("beam15", 15)):
+        ts = []
+        for k in range(13):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.generate(task, v1, [t1], a1, [640 * t1] if use_a else None, ra, rv, beams=beams, max_new=args.max_new, force_len=(beams == 1),
+                         video_is_flat=True, slot=6 if beams == 1 else 7)
+            torch.cuda.synchronize()
+            if k >= 3:
+                ts.append((time.perf_counter() - t0) * 1e3)
+        ts.sort()
+        out[name] = round(ts[len(ts) // 2], 3)
+        out[name + "_min"] = round(ts[0], 3)
+    return out
+
+
 def schedule_summary(recs, skip_calls):
     """Occupancy summary of a scheduler trace (OmniEngine.scheduler_trace_read): when were encoder + prefill phases running, when were decode
     steps running, and how fast do steps go beside the phases.  Everything is clipped to the steady window that starts with call
@@ -283,7 +308,7 @@ def schedule_summary(recs, skip_calls):
                      "lanes), un-profiled run; fractions of the steady window; step_ms_beside_phases = burst time / steps of one lane")
 
 
-def testset_run(args, rank, world, local, use_dist):
+def testset_run(args, rank, world, local, use_dist, affinity=None):
     """The reference's evaluation loop (eval_OmniAVSR.py:273-357: one Trainer.test pass over the test set) as this repo runs it: every rank
     owns the utterances `dist.shard_utterances` deals it (duration-sorted round-robin), batches them longest first (`make_batches`), and
     `harness.evaluate(in_flight=3)` keeps three batches in flight through the engine's decode scheduler with host inputs (collation and
@@ -415,11 +440,65 @@ def testset_run(args, rank, world, local, use_dist):
                        "host_ms_per_batch": {k: round(tm[k] / max(1, tm["batches"]) * 1e3, 2) for k in ("wait_collate", "submit", "collect")},
                        "gathered_hypotheses": len(hyp), "wer_counters": {"edits": edits, "words": words, "failed": failed},
                        "dist_backend": (dist.get_backend() if use_dist else None), "setup_s": round(setup_s, 1), "ids_verified": True,
-                       "decode_scheduler": eng.scheduler_stats(), "env": env_snapshot()},
+                       "cpu_affinity": affinity, "decode_scheduler": dict(eng.scheduler_stats(), pool_bytes=eng.scheduler_bytes()), "env": env_snapshot()},
         }
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def pin_rank(local: int, world_local: int):
+    """CPU affinity of this rank, set BEFORE anything touches the GPU (threads created later -- the collation helpers, the runtime's own --
+    inherit it): the cores of the NUMA node the rank's GPU hangs off, shared evenly by the ranks whose GPUs sit on the same node; without
+    NUMA information an even slice of the host's CPUs.  Reads sysfs only.  Returns what it did (for `config`)."""
+    try:
+        allc = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return None
+
+    def cpulist(txt):
+        out = []
+        for part in txt.strip().split(","):
+            if not part:
+                continue
+            a, _, b = part.partition("-")
+            out.extend(range(int(a), int(b or a) + 1))
+        return out
+    gpus = []                                  # (pci address, numa node) of the AMD display / processing accelerators, in bus order = HIP's device order
+    try:
+        for dev in sorted(os.listdir("/sys/bus/pci/devices")):
+            base = os.path.join("/sys/bus/pci/devices", dev)
+            try:
+                if open(os.path.join(base, "vendor")).read().strip() != "0x1002":
+                    continue
+                cls = open(os.path.join(base, "class")).read().strip()
+                if not (cls.startswith("0x0302") or cls.startswith("0x0380") or cls.startswith("0x1200")):
+                    continue
+                gpus.append((dev, int(open(os.path.join(base, "numa_node")).read().strip())))
+            except (OSError, ValueError):
+                continue
+    except OSError:
+        pass
+    node, cpus = -1, None
+    if local < len(gpus) and gpus[local][1] >= 0:
+        node = gpus[local][1]
+        try:
+            ncpus = [c for c in cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read()) if c in set(allc)]
+        except OSError:
+            ncpus = []
+        peers = [i for i in range(min(world_local, len(gpus))) if gpus[i][1] == node]
+        if ncpus and local in peers:
+            k, n = peers.index(local), len(peers)
+            per = max(1, len(ncpus) // n)
+            cpus = ncpus[k * per:(k + 1) * per] or ncpus
+    if cpus is None:                           # no NUMA information: an even slice of what the process may use
+        per = max(1, len(allc) // max(1, world_local))
+        cpus = allc[local * per:(local + 1) * per] or allc
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        return None
+    return {"numa_node": node, "cpus": len(cpus), "first_cpu": cpus[0], "gpus_seen": len(gpus)}
 
 
 def launch_ranks(args):
@@ -454,6 +533,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    affinity = pin_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if world > 1 else None      # before any GPU call (one rank: the whole host is its own)
     if args.gpus > 1 and world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr, flush=True)
         sys.exit(2)
@@ -465,7 +545,7 @@ def main():
     dev = torch.device(f"cuda:{local}")
 
     if args.testset > 0:
-        return testset_run(args, rank, world, local, use_dist)
+        return testset_run(args, rank, world, local, use_dist, affinity)
     from omni_avsr_amd.dist import gather_hypotheses, pack_records
     from omni_avsr_amd.modeling import OmniEngine
     from omni_avsr_amd.synth import synth_state_dict
@@ -521,7 +601,10 @@ def main():
     else:
         streams = [torch.cuda.Stream(device=dev) for _ in range(nstream)]
     pending = []
-    timed = None                                     # inside the timed region: [(call index, ids, lens)] of every call, for the identity check after it
+    timed = None                                     # inside the timed region: [(call index, ids, lens, digests)] of every call, for the identity check after it
+    # per-utterance {inputs_embeds, first-step logits} digests of every timed call (oavsr_workspace_set_digests): allocated up front, two tiny
+    # launches per call inside the timed region
+    dg_pool = torch.zeros(args.steps * max(1, calls // G) + 1, B * G, 2, dtype=torch.int64, device=dev)
     # Without the scheduler the encoder + prefill phases of the calls in flight are chained (only the decode loops overlap them); with it
     # the callers' streams carry nothing but those phases, and letting the tail of one overlap the head of the next is worth 5 %.
     if nstream > 1 and not args.no_stagger and not use_sched:
@@ -531,10 +614,11 @@ def main():
         s = i % nstream
         video, audio, Tvs, Ts = sets[i % nsets]
         ra, rv = pre["rates"][i % len(pre["rates"])]
+        dg = dg_pool[len(timed)] if timed is not None and len(timed) < dg_pool.shape[0] else None
         with torch.cuda.stream(streams[s]):
             if use_sched:
                 ids_, lens_, ticket = eng.submit(task, video, Tvs, audio if use_a else None, Ts if use_a else None, ra, rv, max_new=args.max_new,
-                                                 force_len=True, video_is_flat=True, slot=s)
+                                                 force_len=True, video_is_flat=True, slot=s, digests=dg)
                 pending.append((s, ticket))
                 if len(pending) > 2 * nstream + 8 * args.sched_lanes:            # every step of that call was issued long ago: a stream-side wait, no host sync
                     s0, t0_ = pending.pop(0)
@@ -542,12 +626,13 @@ def main():
                         eng.wait(t0_)
                 results[s] = (ids_, lens_)
                 if timed is not None:
-                    timed.append((i, ids_, lens_))
+                    timed.append((i, ids_, lens_, dg))
             else:
                 results[s] = eng.generate(task, video, Tvs, audio if use_a else None, Ts if use_a else None, ra, rv, beams=args.beams,
-                                          max_new=args.max_new, force_len=(args.beams == 1), video_is_flat=True, slot=s, chunk=B if G > 1 else None)
+                                          max_new=args.max_new, force_len=(args.beams == 1), video_is_flat=True, slot=s, chunk=B if G > 1 else None,
+                                          digests=dg)
                 if timed is not None:
-                    timed.append((i, results[s][0], results[s][1]))
+                    timed.append((i, results[s][0], results[s][1], dg))
         return results[s]
 
     def drain():
@@ -574,6 +659,7 @@ def main():
         host_s += time.perf_counter() - th            # host time inside the call (launches; includes waiting for queue / staging space)
         ncall += 1
     drain()
+    busy = time.perf_counter() - t0               # this rank's own work (before the exchange and the closing barrier)
     n_last = B * G
     # the path's only exchange step, inside the timed region: gather the hypotheses of the last call
     hyp = gather_hypotheses(pack_records([rank * n_last + j for j in range(n_last)], ids, lens, args.max_new), world * n_last)
@@ -581,10 +667,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    rank_busy = [round(busy, 3)]
     if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed, busy], device=dev, dtype=torch.float64)
+        tl = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(tl, t)
+        elapsed = max(float(x[0]) for x in tl)
+        rank_busy = [round(float(x[1]), 3) for x in tl]
     assert len(hyp) == world * n_last
     assert args.beams > 1 or int(lens.min()) == args.max_new
     # ---- identity check (outside the timed region): the input sets and rates rotate, so every timed call must have produced exactly the
@@ -593,32 +682,46 @@ def main():
     timed_calls, timed = timed, None
     torch.cuda.synchronize()
     iso = {}
-    bad = []
-    for i, ids_t, lens_t in timed_calls:
+    bad, bad_dg = [], []
+    for i, ids_t, lens_t, dg_t in timed_calls:
         key = (i % nsets, i % len(pre["rates"]))
         if key not in iso:
             video, audio, Tvs, Ts = sets[key[0]]
             ra, rv = pre["rates"][key[1]]
+            r_dg = torch.zeros(B * G, 2, dtype=torch.int64, device=dev)
             r_ids, r_lens = eng.generate(task, video, Tvs, audio if use_a else None, Ts if use_a else None, ra, rv, beams=args.beams, max_new=args.max_new,
-                                         force_len=(args.beams == 1), video_is_flat=True, slot=0, chunk=B if G > 1 else None)
+                                         force_len=(args.beams == 1), video_is_flat=True, slot=0, chunk=B if G > 1 else None, digests=r_dg)
             torch.cuda.synchronize()
-            iso[key] = (r_ids.clone(), r_lens.clone())
+            iso[key] = (r_ids.clone(), r_lens.clone(), r_dg)
         if not (torch.equal(ids_t, iso[key][0]) and torch.equal(lens_t, iso[key][1])):
             bad.append(i)
-    ok_t = torch.tensor([0 if bad else 1], device=dev, dtype=torch.int32)
+        if dg_t is not None and not torch.equal(dg_t, iso[key][2]):
+            bad_dg.append(i)
+    # the ids of seeded random weights hardly depend on the clip; the digests do: every utterance of every input set must have its own pair,
+    # otherwise "equal to the isolated call" could not tell a call that was handed another call's inputs, KV rows or logits
+    alld = torch.cat([v[2] for v in iso.values()])
+    distinct = len({int(x) for x in alld[:, 0]}) == alld.shape[0] and len({int(x) for x in alld[:, 1]}) == alld.shape[0]
+    n_dg = sum(1 for t in timed_calls if t[3] is not None)
+    ok_t = torch.tensor([0 if (bad or bad_dg or not distinct) else 1], device=dev, dtype=torch.int32)
     if use_dist:
         dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
     if bad:
         print(f"bench.py: rank {rank}: {len(bad)} of {len(timed_calls)} timed calls returned ids that differ from an isolated call of the same inputs "
               f"(first: call {bad[0]})", file=sys.stderr, flush=True)
+    if bad_dg:
+        print(f"bench.py: rank {rank}: {len(bad_dg)} of {n_dg} timed calls report input digests that differ from the isolated call's (first: call {bad_dg[0]}): "
+              "the call did not see its own inputs_embeds / first-step logits", file=sys.stderr, flush=True)
+    if not distinct:
+        print(f"bench.py: rank {rank}: the input sets' digests are not pairwise different: the identity check is not input-sensitive", file=sys.stderr, flush=True)
     if int(ok_t.item()) != 1:
         if use_dist:
             dist.destroy_process_group()
         sys.exit(3)
     n_verified = len(timed_calls)
-    del timed_calls, iso
+    del timed_calls, iso, alld
 
     dsched = eng.scheduler_stats() if use_sched else None      # the timed region's (the passes below run more calls)
+    sched_bytes = eng.scheduler_bytes() if use_sched else 0
     schedule = None
     if rank == 0 and use_sched and not args.no_roofline:
         # the same loop for 32 more calls with the scheduler's trace on: what overlaps what (a kernel trace cannot show it: the profiler
@@ -736,6 +839,15 @@ def main():
         except Exception as e:                               # the headline line must not depend on this leg
             grouped = {"error": f"{type(e).__name__}: {e}"[:200]}
 
+    # The reference's own protocol (datamodule/data_module.py:238-242: batch 1, one call at a time): what ONE 16 s utterance costs alone on an
+    # otherwise idle chip, greedy and with the reference's default K = 15 (eval_OmniAVSR.py:215-226), median of 10 calls each
+    latency = None
+    if rank == 0 and world == 1 and not args.no_grouped and args.beams == 1:
+        try:
+            latency = latency_leg(eng, args, pre, task, use_a, sets[0])
+        except Exception as e:                               # the headline line must not depend on this leg
+            latency = {"error": f"{type(e).__name__}: {e}"[:200]}
+
     cpu = None
     if sd_cpu is not None:
         cpu = cpu_baseline(spec, sd_cpu, Tv, args.max_new, task, pre["rates"][0])
@@ -762,10 +874,11 @@ def main():
                        "host_ms_per_call": round(host_s / (args.steps * (calls // G)) * 1e3, 3),
                        "parallelism": f"utterance-sharded dp{world}", "gathered_hypotheses": len(hyp), "dist_backend": (dist.get_backend() if use_dist else None),
                        "streams_per_gpu": nstream, "decode_group": G, "setup_s": round(setup_s, 1),
-                       "ids_verified": True, "ids_verified_calls": n_verified,
-                       "env": env_snapshot(),
-                       "decode_scheduler": (dict(rows_per_step_cap=args.sched_rows, slots=args.sched_slots, lanes=args.sched_lanes, **dsched) if use_sched else None)},
-            "roofline": roofline, "roofline_sides": sides, "schedule": schedule, "cpu_baseline": cpu, "per_call_decode": grouped, "stages": stages,
+                       "ids_verified": True, "ids_verified_calls": n_verified, "digests_verified": n_dg == n_verified and n_dg > 0, "digests_verified_calls": n_dg,
+                       "cpu_affinity": affinity, "rank_busy_s": rank_busy, "env": env_snapshot(),
+                       "decode_scheduler": (dict(rows_per_step_cap=args.sched_rows, slots=args.sched_slots, lanes=args.sched_lanes, pool_bytes=sched_bytes, **dsched) if use_sched else None)},
+            "roofline": roofline, "roofline_sides": sides, "schedule": schedule, "cpu_baseline": cpu, "per_call_decode": grouped, "latency_b1": latency,
+            "stages": stages,
         }
         print(json.dumps(line), flush=True)
     if use_dist:

@@ -258,21 +258,21 @@ typedef struct oavsr_gemm_desc {
   int32_t ksplit;
   float* partial;
   int32_t* sync;
-  /* per-row multiplier of the accumulator, before col_scale / col_bias: the decode path's deferred RMSNorm (Llama_LoRA.py:587-655 computes
-     norm(x) W^T = row_scale[m] * ((x * gain) W^T) with row_scale = 1 / rms(x)) */
-  const float* row_scale;
+  /* the decode path's deferred RMSNorm (Llama_LoRA.py:587-655 computes norm(x) W^T): A holds T(x * gain); the accumulator is multiplied,
+     before col_scale / col_bias, by 1 / rms(x[m]) = rsqrt(sum_{t < row_sumsq_tiles} row_sumsq[t * M + m] / row_dim + row_eps).  NULL: none */
+  const float* row_sumsq;
+  int32_t row_sumsq_tiles, row_dim;
+  float row_eps;
   /* split-K only (optional): "next norm" outputs for the consumer of the residual stream C = x (plain epilogue, C in `dtype`, N a multiple
-     of 64): ng_out[m][n] = T(x[m][n] * ng_gain[n]) (row stride ng_ld), ng_rstd[m] = rsqrt(mean_n x[m][n]^2 + ng_eps); ng_rowsq: scratch
-     of ceil(N / 64) * M floats */
+     of 64): ng_out[m][n] = T(x[m][n] * ng_gain[n]) (row stride ng_ld), ng_rowsq[t * M + m] = sum over column tile t (64 columns) of
+     x[m][n]^2 -- the consumer's row_sumsq with ceil(N / 64) tiles */
   void* ng_out;
   int64_t ng_ld;
   const float* ng_gain;
   float* ng_rowsq;
-  float* ng_rstd;
-  float ng_eps;
   int32_t grid;        /* persistent kernel only: workgroups (multiple of 8); 0 = the launcher's rule */
 } oavsr_gemm_desc;
-#define OAVSR_GEMM_SYNC_INTS (4096 + 64)
+#define OAVSR_GEMM_SYNC_INTS 4096
 int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream);
 
 typedef struct oavsr_attn_desc {
@@ -304,9 +304,9 @@ int oavsr_op_decode_attention(const oavsr_decode_attn_desc* d, oavsr_stream stre
 int oavsr_op_norm(int32_t mode, int32_t dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, const float* b,
                   int32_t rows, int32_t D, float eps, oavsr_stream stream);
 /* Deferred RMSNorm of the decode path (Llama_LoRA.py:587-655 input_layernorm / post_attention_layernorm / model.norm): y = T(x * w),
- * rstd[row] = rsqrt(mean(x[row]^2) + eps); the consumer GEMM takes y as A and rstd as oavsr_gemm_desc.row_scale. */
-int oavsr_op_rms_prep(int32_t dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, float* rstd, int32_t rows, int32_t D,
-                      float eps, oavsr_stream stream);
+ * sumsq[row] = sum_c x[row][c]^2; the consumer GEMM takes y as A and sumsq as oavsr_gemm_desc.row_sumsq (one tile, row_dim = D). */
+int oavsr_op_rms_prep(int32_t dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, float* sumsq, int32_t rows, int32_t D,
+                      oavsr_stream stream);
 /* Fused visual stem: Conv3d(1->64, k (5,7,7), s (1,2,2), p (2,3,3)) + folded BN + PReLU + MaxPool3d((1,3,3), s (1,2,2), p (0,1,1))
  * (reference resnet.py:137-141).  video: f32 [F][88][88] (channels = 0) or uint8 [F][channels][height][width] with the test-time
  * transform fused (oavsr_workspace_set_video_format); frameinfo int32 pairs {t, len} per frame; w [64][256] in the model

@@ -1270,7 +1270,10 @@ int launch_decode_attention(const DecodeAttnArgs& a, hipStream_t st) {
   // than 8-wave ones.  The choice follows the decode MODE (beams > 1), never the row count: the key -> wave partition and with
   // it the fp32 merge order of a row is then the same whether its utterance is decoded alone or inside a batch.
   if (a.head_dim == 64 && a.beams > 1) {
-    // GQA group of 4 (Llama-3.2-1B): four beams of an utterance per workgroup share the prefix K / V tiles (decode_attn_beam4_kernel)
+    // GQA group of 4 (Llama-3.2-1B): four beams of an utterance per workgroup share the prefix K / V tiles (decode_attn_beam4_kernel).
+    // Its tail tile holds <= 64 positions, so it serves workspaces whose max_new is <= 64 (the reference decodes 32 tokens, eval_OmniAVSR.py:
+    // max_dec_tokens); max_tail is the WORKSPACE's max_new and decode_beam insists on max_new == that, so the kernel -- and its fp32 merge
+    // order -- is fixed by (model, max_new), the same for an utterance alone and inside any batch ("what a result may depend on")
     if (a.n_heads == 4 * a.n_kv_heads && a.step && !a.rowmap && a.rows % a.beams == 0 && a.max_tail <= 64) return launch_dec_beam4(a, st);
     return launch_dec_t<bf16_t, 64, 4>(a, st);
   }

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(const GemmArgs p) {
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm * (TM * 16) + i * 16 + fg * 4 + r;
         if (m >= p.M) continue;
-        float y = fmaf(p.row_scale ? acc[i][j][r] * p.row_scale[m] : acc[i][j][r], sc, bi);
+        float y = fmaf(acc[i][j][r], sc, bi);
         float res = R ? to_f32(R[(int64_t)m * p.ldr + ng]) : 0.f;
         if (!p.res_after_act) y += res;
         switch (p.act) {
@@ -314,22 +314,24 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   if (a.amode == A_STEM) OAVSR_REQUIRE(a.frameinfo && a.K == 256 && a.M % 1936 == 0, "gemm/stem: bad geometry");
   OAVSR_REQUIRE(a.act != ACT_PRELU || a.prelu, "gemm: PReLU needs slopes");
   if (a.ksplit > 1) {
-    // split-K: the 128 x 64 LDS-DMA tile only, with the reduce inside the launch (gemm2.hip) -- the decode-shaped GEMMs, <= 128 rows per launch
+    // split-K: the 128 x 64 LDS-DMA tile only -- the decode-shaped GEMMs, <= 128 rows per launch -- with the reduce inside the launch (a.sync:
+    // arrival counters) or as a second launch of the same reduce code (gemm2.hip)
     const int vec_t = a.dtype == DT_F32 ? 4 : 8;
-    OAVSR_REQUIRE(a.partial && a.sync && a.groups == 1 && a.amode == A_DENSE && !a.swiglu_pairs, "gemm: split-K needs slabs, arrival counters, dense A, no groups");
+    OAVSR_REQUIRE(a.partial && a.groups == 1 && a.amode == A_DENSE && !a.swiglu_pairs, "gemm: split-K needs slabs, dense A, no groups");
     OAVSR_REQUIRE(a.M <= 128 && a.N >= 64, "gemm: split-K serves decode-shaped launches (M <= 128, N >= 64), got %d x %d", a.M, a.N);
     OAVSR_REQUIRE(a.N % 16 == 0 && ((uintptr_t)a.partial & 15) == 0 && ((uintptr_t)a.C & 15) == 0 && a.ldc % (a.out_f32 ? 4 : vec_t) == 0 &&
                   (!a.residual || (a.ldr % vec_t == 0 && ((uintptr_t)a.residual & 15) == 0)), "gemm: split-K reduce needs N %% 16 == 0 and 16-byte rows");
     const int bn = 64;
-    const int64_t ntm = 1, ntn = ceil_div(a.N, bn);
-    OAVSR_REQUIRE(ntm * ntn <= kSyncTiles && ntm <= kSyncMTiles, "gemm: split-K launch of %lld x %lld tiles exceeds the arrival counters", (long long)ntm, (long long)ntn);
+    OAVSR_REQUIRE(ceil_div(a.N, bn) <= kSyncInts, "gemm: split-K launch of %d column tiles exceeds the arrival counters", ceil_div(a.N, bn));
     OAVSR_REQUIRE((int64_t)a.ksplit * a.M * a.N * 4 < (1ll << 31), "gemm: split-K slabs exceed 2 GiB");
     if (a.ng_out) {
-      OAVSR_REQUIRE(a.ng_gain && a.ng_rowsq && a.ng_rstd && !a.out_f32 && a.act == ACT_NONE && a.N % bn == 0 && a.ng_ld % vec_t == 0 && ((uintptr_t)a.ng_out & 15) == 0,
+      OAVSR_REQUIRE(a.ng_gain && a.ng_rowsq && !a.out_f32 && a.act == ACT_NONE && a.N % bn == 0 && a.ng_ld % vec_t == 0 && ((uintptr_t)a.ng_out & 15) == 0,
                     "gemm: next-norm outputs need a plain epilogue, whole column tiles and 16-byte rows");
     }
     return launch_gemm_dma(a, st);
   }
+  OAVSR_REQUIRE(!a.row_sumsq || (a.amode == A_DENSE && a.groups == 1 && a.M <= 128 && a.N >= 64 && a.row_sumsq_tiles >= 1 && a.row_dim > 0 && (a.ksplit > 1 || a.decode_tiled)),
+                "gemm: the row factor (row_sumsq) is an epilogue of the decode-shaped launches (dense, M <= 128, N >= 64, decode_tiled)");
   if (a.swiglu_pairs) OAVSR_REQUIRE(gemm_dma_swiglu_ok(a), "gemm: fused SwiGLU epilogue unavailable for this shape (check gemm_dma_swiglu_ok)");
   if (gemm_dma_eligible(a)) return launch_gemm_dma(a, st);
   return a.dtype == DT_F32 ? launch_mode<float>(a, st) : launch_mode<bf16_t>(a, st);

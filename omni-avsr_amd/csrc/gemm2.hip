@@ -112,6 +112,141 @@ __device__ __forceinline__ void dma16(const void* src, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// ---- split-K reduce of ONE 64-column tile strip: rows [m0, m0 + NI * nthr / 4) x columns [n0, n0 + 64) of C.  A thread owns NI segments of
+//      16 columns (segment w = tid + i * nthr -> row w / 4, columns 16 (w % 4)); everything they need is requested before the first use --
+//      the residual rows, then the slabs of ALL its segments four at a time, so a slab group costs one memory round trip -- the slabs are
+//      added in slab order (the result does not depend on who reduces, nor on the row count), then the epilogue: row factor (rs[row in
+//      strip], from the deferred RMSNorm's sums of squares), col_scale / bias, residual, activation, store; optionally the consumer's
+//      RMSNorm operands (GemmArgs::ng_*): T(x * gain) and the row's sum of squares over the tile (16 columns per lane in column order, then a
+//      fixed butterfly over the row's 4 lanes).  Called by the tile's last-arriving workgroup inside the GEMM launch (gemm_dma_kernel) or by
+//      the stand-alone reduce kernel below: the same code, hence the same bits.
+template <typename T, int NI>
+__device__ __forceinline__ void splitk_reduce_tile(const GemmArgs& p, int m0, int n0, int nt_, int tid, int nthr, const float* rs) {
+  constexpr int VEC = TypeInfo<T>::kVec;
+  constexpr int SEG = 4;                                     // 16-column segments of a 64-column tile row: adjacent lanes
+  const __amdgpu_buffer_rsrc_t prs = raw_rsrc2(p.partial);
+  const unsigned KS = (unsigned)p.ksplit, sstride = (unsigned)((int64_t)p.M * p.N * 4);
+  const T* Rr = reinterpret_cast<const T*>(p.residual);
+  const bool want_ng = p.ng_out != nullptr;
+  int mI[NI], ncI[NI], rI[NI];
+  bool liveI[NI];
+  unsigned baseI[NI];
+  Chunk16 rraw[NI][16 / VEC];
+  float y[NI][16];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int w = tid + i * nthr;
+    rI[i] = w / SEG;
+    mI[i] = m0 + rI[i]; ncI[i] = n0 + (w % SEG) * 16;
+    liveI[i] = mI[i] < p.M && ncI[i] < p.N;
+    baseI[i] = liveI[i] ? (unsigned)(((int64_t)mI[i] * p.N + ncI[i]) * 4) : 0u;
+    if (liveI[i] && Rr) {
+#pragma unroll
+      for (int e = 0; e < 16; e += VEC) rraw[i][e / VEC] = *reinterpret_cast<const Chunk16*>(Rr + (int64_t)mI[i] * p.ldr + ncI[i] + e);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) y[i][e] = 0.f;
+  }
+  for (unsigned s = 0; s < KS; s += 4) {                  // four slabs' loads of every segment in flight, added in slab order
+    f32x4 v[NI][4][4];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned sj = s + j < KS ? s + j : KS - 1;      // (past the last slab: a repeated load, not added)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[i][j][q] = liveI[i] ? ld16_sc1f(prs, baseI[i] + sj * sstride + q * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (s + j < KS) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { y[i][4 * q] += v[i][j][q][0]; y[i][4 * q + 1] += v[i][j][q][1]; y[i][4 * q + 2] += v[i][j][q][2]; y[i][4 * q + 3] += v[i][j][q][3]; }
+        }
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int m = mI[i], nc = ncI[i];
+    const bool live = liveI[i];
+    float ss = 0.f;
+    if (live) {
+      float* yy = y[i];
+      if (p.row_sumsq) {
+        const float rsv = rs[rI[i]];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) yy[e] *= rsv;
+      }
+      float res[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) res[e] = 0.f;
+      if (Rr) {
+#pragma unroll
+        for (int e = 0; e < 16; e += VEC) chunk_to_f32<T>(rraw[i][e / VEC], res + e);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float v = fmaf(yy[e], p.col_scale ? p.col_scale[nc + e] : 1.f, p.col_bias ? p.col_bias[nc + e] : 0.f);
+        if (!p.res_after_act) v += res[e];
+        switch (p.act) {
+          case ACT_GELU: v = gelu_act<T>(v); break;
+          case ACT_RELU: v = fmaxf(v, 0.f); break;
+          case ACT_PRELU: v = v >= 0.f ? v : p.prelu[nc + e] * v; break;
+          case ACT_SILU: v = silu(v); break;
+          default: break;
+        }
+        yy[e] = p.res_after_act ? v + res[e] : v;
+      }
+      if (p.out_f32) {
+        float* Cf = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + nc;
+#pragma unroll
+        for (int e = 0; e < 16; e += 4) *reinterpret_cast<f32x4*>(Cf + e) = f32x4{yy[e], yy[e + 1], yy[e + 2], yy[e + 3]};
+      } else {
+        T* Ct = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + nc;
+        Chunk16 oc[16 / VEC];
+#pragma unroll
+        for (int e = 0; e < 16; e += VEC) { oc[e / VEC] = chunk_from_f32<T>(yy + e); *reinterpret_cast<Chunk16*>(Ct + e) = oc[e / VEC]; }
+        if (want_ng) {      // the consumer's RMSNorm: x * gain now (x as stored), the row's sum of squares per column tile
+          float xr[16], xg[16];
+#pragma unroll
+          for (int e = 0; e < 16; e += VEC) chunk_to_f32<T>(oc[e / VEC], xr + e);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { xg[e] = xr[e] * p.ng_gain[nc + e]; ss = fmaf(xr[e], xr[e], ss); }
+          T* Gt = reinterpret_cast<T*>(p.ng_out) + (int64_t)m * p.ng_ld + nc;
+#pragma unroll
+          for (int e = 0; e < 16; e += VEC) *reinterpret_cast<Chunk16*>(Gt + e) = chunk_from_f32<T>(xg + e);
+        }
+      }
+    }
+    if (want_ng) {      // the row's sum of squares over this tile's columns: the SEG adjacent lanes, fixed butterfly
+#pragma unroll
+      for (int o = 1; o < SEG; o <<= 1) ss += __shfl_xor(ss, o, 64);
+      if (live && (tid % SEG) == 0) p.ng_rowsq[(int64_t)nt_ * p.M + m] = ss;
+    }
+  }
+}
+
+// The same reduce as a launch of its own (GemmArgs::sync == nullptr): one workgroup of 128 threads per (column tile, 32 rows).  Above a few
+// dozen rows a tile's last-arriving workgroup becomes a serial tail (8 slabs x 97 rows x 64 columns: 200 KB through one workgroup), which
+// this spreads over ~4 x as many workgroups; model.hip chooses by the row count -- speed only: the arithmetic is splitk_reduce_tile's.
+template <typename T>
+__global__ __launch_bounds__(128) void splitk_reduce_kernel(const GemmArgs p) {
+  __shared__ float rs[32];
+  const int nt_ = blockIdx.x, m0 = blockIdx.y * 32, n0 = nt_ * 64, tid = threadIdx.x;
+  if (p.row_sumsq && tid < 32) {
+    const int m = m0 + tid;
+    float tot = 0.f;
+    if (m < p.M) {
+#pragma unroll 8
+      for (int t = 0; t < p.row_sumsq_tiles; ++t) tot += p.row_sumsq[(int64_t)t * p.M + m];
+    }
+    rs[tid] = rsqrtf(tot / (float)p.row_dim + p.row_eps);
+  }
+  __syncthreads();
+  splitk_reduce_tile<T, 1>(p, m0, n0, nt_, tid, 128, rs);
+}
+
 // BM x BN tile, kStages LDS stages (kStages - 1 k-tiles in flight), NWAVES waves as WAVES_M x (NWAVES / WAVES_M).
 // DW: waves that issue the LDS-DMA loads (segments are dealt over them); the rest only compute (12-wave 256 x 192 tile: 56 segments = 8 x 7)
 template <typename T, int AMODE, int BM, int BN, int kStages, int WAVES_M, int NWAVES, int DW = NWAVES>
@@ -238,6 +373,24 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
 #pragma unroll
   for (int t = 0; t < kStages - 1; ++t)
     if (t < ntot) issue(t);
+  // Decode-shaped launches (the 128-row tiles): the rows' 1 / rms from the producer's partial sums of squares (GemmArgs::row_sumsq), one
+  // row per thread, into LDS behind the k-tile stages -- the loads go out BEHIND the first k-tiles' DMA (already in flight), so waiting for
+  // them costs nothing the first k-tile would not have waited for anyway; the epilogues read the factors after the k loop's barriers.
+  constexpr bool kRowScale = AMODE == A_DENSE && BM == 128;
+  float* rs_lds = reinterpret_cast<float*>(smem + kStages * kStageBytes);
+  if constexpr (kRowScale) {
+    if (p.row_sumsq && tid < BM) {
+      const int m = m0 + tid;
+      float tot = 0.f;
+      if (m < p.M) {
+#pragma unroll 8
+        for (int t = 0; t < p.row_sumsq_tiles; ++t) tot += p.row_sumsq[(int64_t)t * p.M + m];
+      }
+      rs_lds[tid] = rsqrtf(tot / (float)p.row_dim + p.row_eps);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+
   const int frow = lane & 15, fg = lane >> 4;
   for (int t = 0; t < ntot; ++t) {
     // tile t has landed once at most (kStages - 2) younger tiles (NLD loads each) are still outstanding
@@ -293,7 +446,6 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
   const int64_t e_ldc = split ? (int64_t)p.N : p.ldc;
   // the tiles the decode-shaped GEMMs run on (<= 128 rows per launch: 128 x 64 / 128 x 128 / 128 x 256): row_scale, and -- on the one that
   // serves split-K launches -- the reduce inside the launch.  Compiled out of every other instantiation (registers: the 16-wave tile has none to spare).
-  constexpr bool kRowScale = AMODE == A_DENSE && BM == 128;
   constexpr bool kFusedReduce = AMODE == A_DENSE && BM == 128 && BN == 64;
   const bool fused = kFusedReduce && split && p.sync != nullptr;      // the reduce happens below, in this launch: slabs go out write-through
   const __amdgpu_buffer_rsrc_t prs = raw_rsrc2(p.partial);
@@ -326,8 +478,8 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
       }
       continue;
     }
-    if constexpr (kRowScale) if (!split && p.row_scale) {
-      const float rs = p.row_scale[m];
+    if constexpr (kRowScale) if (!split && p.row_sumsq) {
+      const float rs = rs_lds[m - m0];
 #pragma unroll
       for (int e = 0; e < 16; ++e) y[e] *= rs;
     }
@@ -447,115 +599,8 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
       }
       __syncthreads();
       if (!*sflag) return;
-      constexpr int SEG = BN / 16;                           // 16-column segments of a tile row: adjacent lanes
-      const unsigned KS = gridDim.y, sstride = (unsigned)((int64_t)p.M * p.N * 4);
-      const T* Rr = reinterpret_cast<const T*>(p.residual);
-      const bool want_ng = p.ng_out != nullptr;
-      for (int w = tid; w < BM * SEG; w += kThreads) {
-        const int r = w / SEG, sg = w % SEG;
-        const int m = m0 + r, nc = n0 + sg * 16;
-        const bool live = m < p.M && nc < p.N;
-        float ss = 0.f;
-        if (live) {
-          float y[16];
-#pragma unroll
-          for (int e = 0; e < 16; ++e) y[e] = 0.f;
-          const unsigned base = (unsigned)(((int64_t)m * p.N + nc) * 4);
-          unsigned s = 0;
-          for (; s + 4 <= KS; s += 4) {                      // four slabs' loads in flight, added in slab order
-            f32x4 v[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) v[j][q] = ld16_sc1f(prs, base + (s + j) * sstride + q * 16);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) { y[4 * q] += v[j][q][0]; y[4 * q + 1] += v[j][q][1]; y[4 * q + 2] += v[j][q][2]; y[4 * q + 3] += v[j][q][3]; }
-          }
-          for (; s < KS; ++s) {
-            f32x4 v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = ld16_sc1f(prs, base + s * sstride + q * 16);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { y[4 * q] += v[q][0]; y[4 * q + 1] += v[q][1]; y[4 * q + 2] += v[q][2]; y[4 * q + 3] += v[q][3]; }
-          }
-          if (p.row_scale) {
-            const float rs = p.row_scale[m];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) y[e] *= rs;
-          }
-          float res[16];
-#pragma unroll
-          for (int e = 0; e < 16; ++e) res[e] = 0.f;
-          if (Rr) {
-#pragma unroll
-            for (int e = 0; e < 16; e += VEC) chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(Rr + (int64_t)m * p.ldr + nc + e), res + e);
-          }
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            float v = fmaf(y[e], p.col_scale ? p.col_scale[nc + e] : 1.f, p.col_bias ? p.col_bias[nc + e] : 0.f);
-            if (!p.res_after_act) v += res[e];
-            switch (p.act) {
-              case ACT_GELU: v = gelu_act<T>(v); break;
-              case ACT_RELU: v = fmaxf(v, 0.f); break;
-              case ACT_PRELU: v = v >= 0.f ? v : p.prelu[nc + e] * v; break;
-              case ACT_SILU: v = silu(v); break;
-              default: break;
-            }
-            y[e] = p.res_after_act ? v + res[e] : v;
-          }
-          if (p.out_f32) {
-            float* Cf = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + nc;
-#pragma unroll
-            for (int e = 0; e < 16; e += 4) *reinterpret_cast<f32x4*>(Cf + e) = f32x4{y[e], y[e + 1], y[e + 2], y[e + 3]};
-          } else {
-            T* Ct = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + nc;
-            Chunk16 oc[16 / VEC];
-#pragma unroll
-            for (int e = 0; e < 16; e += VEC) { oc[e / VEC] = chunk_from_f32<T>(y + e); *reinterpret_cast<Chunk16*>(Ct + e) = oc[e / VEC]; }
-            if (want_ng) {      // the consumer's RMSNorm: x * gain now (x as stored), 1 / rms(x) once the whole row is known
-              float xr[16], xg[16];
-#pragma unroll
-              for (int e = 0; e < 16; e += VEC) chunk_to_f32<T>(oc[e / VEC], xr + e);
-#pragma unroll
-              for (int e = 0; e < 16; ++e) { xg[e] = xr[e] * p.ng_gain[nc + e]; ss = fmaf(xr[e], xr[e], ss); }
-              T* Gt = reinterpret_cast<T*>(p.ng_out) + (int64_t)m * p.ng_ld + nc;
-#pragma unroll
-              for (int e = 0; e < 16; e += VEC) *reinterpret_cast<Chunk16*>(Gt + e) = chunk_from_f32<T>(xg + e);
-            }
-          }
-        }
-        if (want_ng) {      // the row's sum of squares over this tile's columns: the SEG adjacent lanes, fixed butterfly
-#pragma unroll
-          for (int o = 1; o < SEG; o <<= 1) ss += __shfl_xor(ss, o, 64);
-          if (live && sg == 0)
-            __hip_atomic_store(p.ng_rowsq + (int64_t)nt_ * p.M + m, ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-      if (!want_ng) {
-        if (tid == 0) __hip_atomic_store(p.sync + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-        return;
-      }
-      // second level: the workgroup that completes the M-tile's LAST column tile turns the per-tile sums into 1 / rms per row
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) {
-        __hip_atomic_store(p.sync + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int old = __hip_atomic_fetch_add(p.sync + kSyncTiles + mt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *sflag = old == ntn - 1;
-      }
-      __syncthreads();
-      if (!*sflag) return;
-      for (int r = tid; r < BM; r += kThreads) {
-        const int m = m0 + r;
-        if (m >= p.M) continue;
-        float tot = 0.f;
-#pragma unroll 8
-        for (int t = 0; t < ntn; ++t) tot += __hip_atomic_load(p.ng_rowsq + (int64_t)t * p.M + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        p.ng_rstd[m] = rsqrtf(tot / (float)p.N + p.ng_eps);
-      }
-      if (tid == 0) __hip_atomic_store(p.sync + kSyncTiles + mt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      splitk_reduce_tile<T, BM * (BN / 16) / kThreads>(p, m0, n0, nt_, tid, kThreads, rs_lds);
+      if (tid == 0) __hip_atomic_store(p.sync + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
     }
   }
 }
@@ -563,7 +608,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
 template <typename T, int AMODE, int BM, int BN, int kStages, int WAVES_M, int NWAVES, int DW = NWAVES>
 int launch_dma(const GemmArgs& a, hipStream_t st) {
   auto kern = gemm_dma_kernel<T, AMODE, BM, BN, kStages, WAVES_M, NWAVES, DW>;
-  constexpr int smem = kStages * (BM + BN) * kRowBytes;
+  constexpr int smem = kStages * (BM + BN) * kRowBytes + ((AMODE == A_DENSE && BM == 128) ? 1024 : 0);      // + the rows' 1 / rms (decode-shaped launches)
   static bool attr_set = false;
   if (!attr_set) {
     OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -589,9 +634,12 @@ static bool small_tile_rule(const GemmArgs& a) {
 }
 
 static int dma_tile_choice(const GemmArgs& a) {
-  // 0: not eligible, 1: 256x128, 2: 256x256, 4: the <= 128-row / small-GEMM tiles
+  // 0: not eligible, 1: 256x128, 2: 256x256, 4: the <= 128-row / small-GEMM tiles, 5: grouped conv1d on 128x64 tiles
   // <= 128 rows (the decode-shaped GEMMs, tiny prefills): 128 x 64 tiles stream the weights with 4 x more workgroups per N
   if (a.amode == A_DENSE && a.groups == 1 && a.M <= 128 && (a.M > 32 || a.decode_tiled || a.ksplit > 1) && a.N >= 64) return 4;
+  // grouped token-major conv1d with 64 output channels per group and whole k-tiles per tap (AV-HuBERT's positional convolution,
+  // wav2vec2.py:825-838: 16 groups of 64 channels, 128 taps): 128 x 64 tiles, one column tile per group (round 5; the classic kernel ran it at 0.12 of peak)
+  if (a.amode == A_CONV1D && a.N == 64 && a.groups > 1 && a.ksplit <= 1 && a.M >= 256 && a.Cin % (128 / (a.dtype == DT_F32 ? 4 : 2)) == 0) return 5;
   if (a.ksplit > 1) return 0;      // split-K: decode-shaped launches only (launch_gemm checks)
   if (small_tile_rule(a)) return 4;
   if (a.amode == A_STEM || a.N < 128) return 0;
@@ -637,6 +685,7 @@ int launch_dma_mode(const GemmArgs& a, hipStream_t st) {
     // and what counts there is how many of their workgroups fit beside each other (120.6 -> 125.1 utt/s, round 3).
     return launch_dma<T, A_DENSE, 128, 64, 3, 4, 4>(a, st);
   }
+  if (dma_tile_choice(a) == 5) return launch_dma<T, A_CONV1D, 128, 64, 3, 4, 4>(a, st);
   if (tile160_rule(a)) return launch_dma<T, A_DENSE, 160, 128, 4, 2, 4>(a, st);
   switch (a.amode) {
     case A_DENSE: return launch_dma<T, A_DENSE, 256, 128, 3, 4, 8>(a, st);
@@ -658,7 +707,7 @@ bool gemm_dma_swiglu_ok(const GemmArgs& a) {
 }
 const char* gemm_dma_variant(const GemmArgs& a) {
   const int c = dma_tile_choice(a);
-  if (c == 4) return a.ksplit > 1 ? "dma_splitk_128x64" : "dma_128x64";
+  if (c == 4 || c == 5) return a.ksplit > 1 ? "dma_splitk_128x64" : "dma_128x64";
   if (c == 2 && gemm_8pp_eligible(a)) return "8pp_256x256";
   if (c == 2 && gemm_8p_eligible(a)) return "8p_256x256";
   if (tile160_rule(a)) return "dma_160x128";
@@ -666,7 +715,14 @@ const char* gemm_dma_variant(const GemmArgs& a) {
 }
 
 int launch_gemm_dma(const GemmArgs& a, hipStream_t st) {
-  return a.dtype == DT_F32 ? launch_dma_mode<float>(a, st) : launch_dma_mode<bf16_t>(a, st);
+  OAVSR_TRY(a.dtype == DT_F32 ? launch_dma_mode<float>(a, st) : launch_dma_mode<bf16_t>(a, st));
+  if (a.ksplit > 1 && !a.sync) {      // split-K without arrival counters: the slabs were stored plainly; the reduce is a launch of its own
+    const dim3 grid(ceil_div(a.N, 64), ceil_div(a.M, 32));
+    if (a.dtype == DT_F32) hipLaunchKernelGGL(splitk_reduce_kernel<float>, grid, dim3(128), 0, st, a);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, grid, dim3(128), 0, st, a);
+    OAVSR_CHECK_HIP(hipGetLastError());
+  }
+  return 0;
 }
 
 }  // namespace oavsr

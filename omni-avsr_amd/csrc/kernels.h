@@ -36,17 +36,20 @@ struct GemmArgs {
   // A_STEM: input f32 video [frame][88][88]; frameinfo[frame] = {t, len}; M = frames*44*44, K = 256 (245 valid)
   const int2* frameinfo = nullptr;
   int swiglu_pairs = 0;          // fused SwiGLU epilogue: gate / up weight rows interleaved in blocks of 16 (LDS-DMA kernels)
-  // split-K over blockIdx.y: fp32 partial slabs [ksplit][M][N], summed in slab order (deterministic) by the LAST workgroup to arrive at the
-  // output tile, inside the GEMM launch (gemm2.hip: sync = the workspace's arrival counters, self-resetting); the decode GEMMs only
+  // split-K over blockIdx.y (decode-shaped GEMMs only): fp32 partial slabs [ksplit][M][N], summed in slab order (deterministic) -- by the
+  // LAST workgroup to arrive at the output tile, inside the GEMM launch (sync != nullptr: the workspace's arrival counters, zero between
+  // launches), or by a reduce launch of its own running the SAME code (sync == nullptr): same bits, the caller picks by the row count
   int ksplit = 1; float* partial = nullptr;
-  // per-row multiplier of the accumulator, applied before col_scale / col_bias: the decode path's deferred RMSNorm -- the producer of A
-  // stored bf16(x * gain) and 1 / rms(x) per row (ng_* below), so  norm(x) W^T = row_scale[m] * (A W^T)
-  const float* row_scale = nullptr;
-  // "next norm" outputs of the split-K reduce (C = the residual stream x; !out_f32, no activation): ng_out[m][n] = T(x[m][n] * ng_gain[n]),
-  // ng_rowsq[nt][m] = sum over column tile nt of x[m][n]^2 (x as rounded to T); the workgroup that finishes an M-tile's last column tile
-  // writes ng_rstd[m] = rsqrt(sum_nt ng_rowsq[nt][m] / N + ng_eps).  Every sum in a fixed order: a row's bits never depend on the row count.
-  void* ng_out = nullptr; int64_t ng_ld = 0; const float* ng_gain = nullptr; float* ng_rowsq = nullptr; float* ng_rstd = nullptr; float ng_eps = 0.f;
-  int* sync = nullptr;       // [kSyncInts] arrival counters: one per output tile, then one per M-tile (zero between launches)
+  // Deferred RMSNorm of the decode path: the producer of A stored T(x * gain) and, per row, partial sums of x^2 (ng_* below, or
+  // launch_rms_prep); this launch multiplies its accumulator, before col_scale / col_bias, by
+  //   1 / rms(x[m]) = rsqrt(sum_{t < row_sumsq_tiles} row_sumsq[t * M + m] / row_dim + row_eps)      (norm(x) W^T = that x (A W^T))
+  // computed once per workgroup while its first k-tiles are in flight.  nullptr: no row factor.
+  const float* row_sumsq = nullptr; int row_sumsq_tiles = 0, row_dim = 0; float row_eps = 0.f;
+  // "next norm" outputs of the split-K reduce (C = the residual stream x; !out_f32, no activation, whole 64-column tiles):
+  // ng_out[m][n] = T(x[m][n] * ng_gain[n]), ng_rowsq[nt * M + m] = sum over column tile nt of x[m][n]^2 (x as rounded to T; 16 columns per
+  // lane in column order, then a fixed butterfly over the row's 4 lanes) -- the consumer's row_sumsq with ceil(N / 64) tiles.
+  void* ng_out = nullptr; int64_t ng_ld = 0; const float* ng_gain = nullptr; float* ng_rowsq = nullptr;
+  int* sync = nullptr;       // [kSyncInts] arrival counters, one per output tile (zero between launches)
   // LDS-DMA kernels: order in which an XCD's contiguous range of workgroups walks the output tiles.  0: row-major (or column-major when
   // M < N); 1: blocks of 8 M-tiles x 4 N-tiles, so the 32 tiles an XCD's CUs work on at one time share 8 A panels and 4 W panels in
   // its L2 (12 panel fetches per k-step for 64 panel reads).  Speed only, never results.  Set by the launcher.
@@ -55,7 +58,7 @@ struct GemmArgs {
   int force_tile = 0;
   int decode_tiled = 0;      // decode-shaped launch (M <= 128): the 128-row LDS-DMA tiles at ANY row count (speed only: the tile shape never changes a bit)
 };
-constexpr int kSyncTiles = 4096, kSyncMTiles = 64, kSyncInts = kSyncTiles + kSyncMTiles;      // GemmArgs::sync
+constexpr int kSyncInts = 4096;      // GemmArgs::sync
 // (mt, nt) of linear tile index bid in the blocked order above; bijective for any ntm x ntn
 __host__ __device__ inline void blocked_tile(int bid, int ntm, int ntn, int& mt, int& nt) {
   constexpr int GM = 8, GN = 4;
@@ -143,8 +146,8 @@ int launch_layernorm_zero_prefix(int dtype, const void* x, int64_t ldx, void* y,
                                  const float* b, int rows, int D, float eps, hipStream_t st);
 int launch_rmsnorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, int rows, int D,
                    float eps, hipStream_t st);
-// decode path's deferred RMSNorm for rows no GEMM produced: y = T(x * w), rstd[row] = 1 / rms(x[row])  (ops.hip: rms_prep_kernel)
-int launch_rms_prep(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, float* rstd, int rows, int D, float eps, hipStream_t st);
+// decode path's deferred RMSNorm for rows no GEMM produced: y = T(x * w), sumsq[row] = sum_c x[row][c]^2  (ops.hip: rms_prep_kernel)
+int launch_rms_prep(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, float* sumsq, int rows, int D, hipStream_t st);
 // Fused visual stem (stem.hip): Conv3d(1->64, 5x7x7, s (1,2,2)) + BN + PReLU + MaxPool(3x3, s2) on f32 video [F][88][88];
 // frameinfo[f] = {t, len}; wp = weights repacked by launch_stem_repack ([64][256] -> [64][288]); out [F][22][22][64].
 int launch_stem_repack(int dtype, const void* w, void* wp, hipStream_t st);

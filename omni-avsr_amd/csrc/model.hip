@@ -40,6 +40,7 @@ struct KnobDef { const char* name; int dflt; const char* what; };
 static const KnobDef kKnobs[] = {
     {"OAVSR_PROF_SHAPES", 0, "profiling hook: one family per GEMM shape instead of per kernel"},
     {"OAVSR_DECODE_GRAPH", 1, "0: decode steps are launched eagerly instead of replayed from hipGraphs (same kernels, same bits)"},
+    {"OAVSR_FUSED_REDUCE_ROWS", 32, "decode-shaped GEMMs with at most this many rows reduce their split-K slabs inside the launch, others in a second launch (same code, same bits)"},
 };
 int knob(const char* name) {
   for (const KnobDef& k : kKnobs)
@@ -150,10 +151,10 @@ struct Projector { const void *fc1w, *fc2w; const float *fc1b, *fc2b, *lnw, *lnb
 
 using namespace oavsr;
 
-// caller streams handed out by oavsr_scheduler_caller_stream: created with the process's FIRST scheduler, before that scheduler's lanes
-// (hardware-queue binding order); process lifetime
+// caller streams handed out by oavsr_scheduler_caller_stream: per DEVICE, created with the first scheduler on that device, before that
+// scheduler's lanes (hardware-queue binding order); process lifetime (a host framework that has seen them never holds a dangling stream)
 static constexpr int kCallerStreams = 8;
-static std::vector<hipStream_t> g_caller_streams;
+static std::unordered_map<int, std::vector<hipStream_t>> g_caller_streams;      // device id -> its eight streams
 static std::mutex g_caller_mu;
 
 struct oavsr_model {
@@ -221,7 +222,7 @@ struct oavsr_workspace {
   int *pos, *slot, *cpos, *cu_s, *prefix_len, *last_rows;
   int *amax; void* amax_scratch; GreedyState gs;
   // decode-shaped GEMMs: arrival counters of the split-K reduce (GemmArgs::sync), the deferred RMSNorm's 1 / rms per row and its per-tile sums
-  int* gsync = nullptr; float *rstd = nullptr, *rowsq = nullptr;
+  int* gsync = nullptr; float* rowsq = nullptr;
   // beam search state
   float *beam_scores, *cand_val, *partial; int *cand_tok, *topk_flag, *hyp_n, *hyp_len, *hyp_tok, *seq[2], *anc[2]; double* hyp_score; size_t partial_bytes = 0;
   int max_tok_enc = 0, max_S_total = 0;
@@ -251,7 +252,7 @@ struct oavsr_workspace {
 // Decode scheduler: continuous batching of the greedy decode phase across independent generate calls (include/omni_avsr.h).
 //
 // The reference decodes one utterance at a time (eval_OmniAVSR.py:18-24, datamodule/data_module.py:238-242); a decode step is bound by
-// streaming the LLM weights once, whatever the number of rows (<= 32) it serves.  Calls therefore keep arriving on their own streams
+// streaming the LLM weights once, whatever the number of rows (<= 128) it serves.  Calls therefore keep arriving on their own streams
 // (encoders + prefill per call, unchanged), but their decode rows live in ROW SLOTS of one pool per model -- prefix KV written there by
 // the call's prefill, tail KV, position / step / hypothesis per slot -- and ONE step loop on the scheduler's own stream serves every
 // admitted row: rows join after their prefill (event) and leave after their own max_new tokens, at step granularity.
@@ -262,8 +263,8 @@ struct oavsr_workspace {
 // with n = (max_new - 1) / k, k = row capacity / rows of the call (plus whatever steps make room for the call's rows): the loop advances by 1/k of a hypothesis per admission, so in the
 // steady state k calls share every weight pass and the n steps run beside the next call's MFMA-bound phase.  Steps not yet issued when
 // the caller asks for a result are issued then (oavsr_generate_wait / oavsr_scheduler_flush).
-// Results do not depend on the schedule: the <= 32-row decode kernels give a row the same bits wherever it sits and whatever shares the
-// step (tests/test_invariance_gpu.py, tests/test_scheduler_gpu.py).
+// Results do not depend on the schedule: the decode-shaped GEMMs give a row the same bits wherever it sits and whatever shares the
+// step, at every row count (tests/test_invariance_gpu.py, tests/test_scheduler_gpu.py).
 // ------------------------------------------------------------------------------------------------
 struct SchedCall {
   int64_t ticket = -1;
@@ -281,8 +282,8 @@ struct SchedCall {
 struct SchedLane {
   hipStream_t st = nullptr;
   oavsr_workspace* dws = nullptr;              // activation scratch of a step (lx ... logits) + the pool's pointers (shared by all lanes)
-  int* rowmap = nullptr;                       // device [32]
-  void* partials = nullptr;                    // [32][64] float2 arg-max partials
+  int* rowmap = nullptr;                       // device [128]
+  void* partials = nullptr;                    // [rows][64] float2 arg-max partials
   std::vector<int> active;                     // ring indices in admission order
   bool map_dirty = true;                       // membership changed since the last step: rowmap + input rows must be rebuilt
   int cur_R = 0;
@@ -296,6 +297,7 @@ struct oavsr_scheduler {
   oavsr_workspace* pool = nullptr;             // kpre / vpre / ktail / vtail, prefix_len: indexed by row slot
   char* arena = nullptr; size_t arena_bytes = 0;
   int n_slots = 0, max_rows = 0, max_prefix = 0, max_new = 0;
+  int device = 0;                              // the device the pool and the lanes' streams live on
   SchedState ss;
   float* logits_pre = nullptr;                 // [n_slots][vocab] last-prompt-position logits, written by the calls' prefills
   std::vector<int64_t> slot_owner;             // ticket that last owned the slot (-1: never used)
@@ -813,23 +815,33 @@ static int build_prompt_impl(const oavsr_model* m, oavsr_workspace* ws, int task
 // RMSNorm is DEFERRED (Llama_LoRA.py:587-655 computes norm(x) W^T): the GEMM that produces the residual stream x (o_proj, down_proj) also
 // stores bf16(x * gain_next) and 1 / rms(x) per row (GemmArgs::ng_*); the consumer takes the former as its A operand and multiplies its
 // fp32 accumulator by the latter (row_scale) -- six launches per layer (LoRA-down, QKV, attention, o_proj, gate/up + SwiGLU, down_proj).
-constexpr int kDecodeSplitTarget = 256;      // workgroups per launch the split is sized for: part of the regime's summation order
+// Split factor of a decode-shaped GEMM: a function of N and K ONLY (part of the regime's summation order).  As many k-slices as give <= 256
+// workgroups (one per CU) with at least EIGHT k-tiles each: below that the fp32 slabs -- written through to memory and read back by the tile's
+// last workgroup -- cost more than the extra workgroups stream (tools/decode_split_scan.py, 97 rows: o_proj 2048 x 2048 17.8 us at 4 slices,
+// 22.9 at 8, 33.8 at 16; QKV 3072 x 2304 20.0 / 32.3 / 56.3; 8 rows: within 1 us of the best choice everywhere).
+constexpr int kDecodeSplitTarget = 256, kDecodeMinKtiles = 8;
 static int decode_split(int N, int Ktot, int esz, int min_ks = 1) {
   const int ktiles = Ktot / (128 / esz);
   int ks = kDecodeSplitTarget / std::max(1, ceil_div(N, 64));
-  ks = std::min(ks, std::max(1, ktiles / 2));
+  ks = std::min(ks, std::max(1, ktiles / kDecodeMinKtiles));
   ks = std::max(1, std::min(ks, 16));
   return std::max(ks, std::min(min_ks, std::max(1, ktiles)));
 }
 
+// ws->rowsq: per 128-row chunk of the decode rows, [column tile of the producer][row in chunk] partial sums of x^2
+static size_t rowsq_chunk(int d) { return (size_t)(ceil_div(d, 64) + 1) * 128; }
+
 // One decode-shaped GEMM over g.M rows, 128 rows (one M-tile of the 128-row tiles) per launch -- every kernel on this path then has the
-// row_scale epilogue and the in-launch reduce, whatever the row count (beam search with B x K > 128 rows: two launches).
-// next_gain: the GEMM's output is the residual stream; also write T(x * next_gain) to `ng_out` and 1 / rms(x) to `ng_rstd`.
-static int decode_gemm(const oavsr_model* m, oavsr_workspace* ws, const GemmArgs& g0, hipStream_t st, const float* next_gain = nullptr, void* ng_out = nullptr,
-                       float* ng_rstd = nullptr) {
+// row-factor epilogue and the in-launch reduce, whatever the row count (beam search with B x K > 128 rows: two launches).
+// sq_tiles > 0: A is T(x * gain) of a deferred RMSNorm; the accumulator is multiplied by 1 / rms(x) from the `sq_tiles` partial sums per row
+//   that the producer of A left in ws->rowsq (rms_prep: 1; the reduce of o_proj / down_proj: d / 64).
+// next_gain: the GEMM's output is the residual stream; also write T(x * next_gain) to `ng_out` and the rows' partial sums to ws->rowsq.
+static int decode_gemm(const oavsr_model* m, oavsr_workspace* ws, const GemmArgs& g0, hipStream_t st, int sq_tiles = 0, const float* next_gain = nullptr,
+                       void* ng_out = nullptr) {
   const size_t e = m->esz;
+  const int d = m->cfg.llm_hidden;
   const int ks = g0.swiglu_pairs ? 1 : decode_split(g0.N, g0.K + g0.K2, (int)e, next_gain ? 2 : 1);
-  OAVSR_REQUIRE(!next_gain || ks > 1, "decode GEMM %d x %d x %d: the next-norm outputs need a split-K launch", g0.M, g0.N, g0.K + g0.K2);
+  OAVSR_REQUIRE(!next_gain || (ks > 1 && g0.N == d), "decode GEMM %d x %d x %d: the next-norm outputs need a split-K launch over the hidden width", g0.M, g0.N, g0.K + g0.K2);
   for (int r0 = 0; r0 < g0.M; r0 += 128) {
     GemmArgs g = g0;
     g.M = std::min(128, g0.M - r0);
@@ -837,58 +849,71 @@ static int decode_gemm(const oavsr_model* m, oavsr_workspace* ws, const GemmArgs
     auto adv = [&](const void* p, int64_t ld, size_t es) -> const void* { return p ? (const char*)p + (size_t)r0 * ld * es : nullptr; };
     g.A = adv(g0.A, g0.lda, e); g.A2 = adv(g0.A2, g0.lda2, e); g.residual = adv(g0.residual, g0.ldr, e);
     g.C = (void*)adv(g0.C, g0.ldc, g0.out_f32 ? 4 : e);
-    if (g0.row_scale) g.row_scale = g0.row_scale + r0;
+    float* sq = ws->rowsq + (size_t)(r0 / 128) * rowsq_chunk(d);
+    if (sq_tiles > 0) { g.row_sumsq = sq; g.row_sumsq_tiles = sq_tiles; g.row_dim = d; g.row_eps = m->cfg.llm_rms_eps; }
     OAVSR_REQUIRE(gemm_dma_eligible(g), "decode GEMM %d x %d x %d: no LDS-DMA tile (N >= 64 needed)", g.M, g.N, g.K + g.K2);
     if (ks > 1) {
       OAVSR_REQUIRE((size_t)ks * g.M * g.N * 4 <= ws->partial_bytes, "decode GEMM: split-K slabs (%d x %d x %d) exceed the workspace", ks, g.M, g.N);
-      g.ksplit = ks; g.partial = ws->partial; g.sync = ws->gsync;
-      if (next_gain) {
-        g.ng_out = (char*)ng_out + (size_t)r0 * g.N * e; g.ng_ld = g.N; g.ng_gain = next_gain; g.ng_rowsq = ws->rowsq; g.ng_rstd = ng_rstd + r0;
-        g.ng_eps = m->cfg.llm_rms_eps;
-      }
+      // up to kFusedRows rows the tile's last-arriving workgroup reduces the slabs inside the launch (one launch instead of two: what
+      // counts when a launch is mostly fixed cost); above, that workgroup would be a serial tail -- the same reduce runs as a launch of
+      // its own over ~4 x the workgroups.  Same code either way: never a different bit (tests compare them).
+      static const int kFusedRows = knob("OAVSR_FUSED_REDUCE_ROWS");
+      g.ksplit = ks; g.partial = ws->partial; g.sync = g.M <= kFusedRows ? ws->gsync : nullptr;
+      if (next_gain) { g.ng_out = (char*)ng_out + (size_t)r0 * g.N * e; g.ng_ld = g.N; g.ng_gain = next_gain; g.ng_rowsq = sq; }
     }
     OAVSR_TRY(run_gemm(g, st));
   }
   return 0;
 }
 
+// the deferred RMSNorm of rows no GEMM produced (a decode step's input embeddings): xg = T(x * gain), one partial sum of squares per row
+static int decode_rms_prep(const oavsr_model* m, oavsr_workspace* ws, const void* x, void* xg, const float* gain, int rows, hipStream_t st) {
+  const int d = m->cfg.llm_hidden;
+  ProfScope ps("decode_rms_prep", 0, 2.0 * rows * d * m->esz, st);
+  for (int r0 = 0; r0 < rows; r0 += 128)
+    OAVSR_TRY(launch_rms_prep(m->dtype, (const char*)x + (size_t)r0 * d * m->esz, d, (char*)xg + (size_t)r0 * d * m->esz, d, gain,
+                              ws->rowsq + (size_t)(r0 / 128) * rowsq_chunk(d), std::min(128, rows - r0), d, st));
+  return 0;
+}
+
 // Everything of a decoder layer behind the attention, on decode-shaped rows: o_proj (+ residual; prepares ln2), gate / up + SwiGLU,
-// down_proj (+ residual; prepares `next_gain`: the next layer's ln1 or the final norm).  xres: residual stream rows (in place); xg / rstd:
-// where the two norms' operands go (and come from).
+// down_proj (+ residual; prepares `next_gain`: the next layer's ln1 or the final norm).  xres: residual stream rows (in place); xg: where the
+// two norms' operands T(x * gain) go (and come from); the rows' sums of squares travel in ws->rowsq.
 static int decode_layer_tail(const oavsr_model* m, oavsr_workspace* ws, const LlmLayer& L, int rows, void* xres, const void* attn_r, void* act_r,
-                             void* xg, float* rstd, const float* next_gain, hipStream_t st) {
+                             void* xg, const float* next_gain, hipStream_t st) {
   const oavsr_config& c = m->cfg;
   const int dt = m->dtype, d = c.llm_hidden, nq = c.llm_heads * c.llm_head_dim, I = c.llm_mlp;
+  const int dtiles = ceil_div(d, 64);
   GemmArgs g; g.dtype = dt; g.M = rows; g.N = d; g.K = nq; g.A = attn_r; g.lda = nq; g.W = L.ow; g.ldw = nq;
   g.residual = xres; g.ldr = d; g.C = xres; g.ldc = d;
-  OAVSR_TRY(decode_gemm(m, ws, g, st, L.ln2w, xg, rstd));
-  g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 2 * I; g.K = d; g.A = xg; g.lda = d; g.W = L.guw; g.ldw = d; g.row_scale = rstd;
+  OAVSR_TRY(decode_gemm(m, ws, g, st, 0, L.ln2w, xg));
+  g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 2 * I; g.K = d; g.A = xg; g.lda = d; g.W = L.guw; g.ldw = d;
   GemmArgs gf = g; gf.swiglu_pairs = 1; gf.C = act_r; gf.ldc = I; gf.decode_tiled = 1;
   // SwiGLU in the GEMM epilogue when the 128 x 64 tiles fill the chip without a split (every real model: 2 I / 64 >= 256 column tiles)
   GemmArgs gp = gf; gp.M = std::min(rows, 128);
   if (decode_split(g.N, g.K, (int)m->esz) == 1 && gemm_dma_swiglu_ok(gp)) {
-    OAVSR_TRY(decode_gemm(m, ws, gf, st));
+    OAVSR_TRY(decode_gemm(m, ws, gf, st, dtiles));
   } else {
     g.C = ws->lgu; g.ldc = 2 * I;
-    OAVSR_TRY(decode_gemm(m, ws, g, st));
+    OAVSR_TRY(decode_gemm(m, ws, g, st, dtiles));
     ProfScope ps("decode_swiglu", 0, 3.0 * rows * I * m->esz, st);
     OAVSR_TRY(launch_swiglu(dt, ws->lgu, 2 * I, act_r, I, rows, I, 1, st));
   }
   g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = d; g.K = I; g.A = act_r; g.lda = I; g.W = L.downw; g.ldw = I;
   g.residual = xres; g.ldr = d; g.C = xres; g.ldc = d;
-  return decode_gemm(m, ws, g, st, next_gain, xg, rstd);
+  return decode_gemm(m, ws, g, st, 0, next_gain, xg);
 }
 
 // One decode step through every layer.  In: ws->lx = the rows' input embeddings.  Out: ws->lx = final hidden rows, ws->lh = T(x * norm.w),
-// ws->rstd = 1 / rms(x): lm_head's operands (lm_head_rows with normed = true).
+// ws->rowsq = the rows' sums of squares: lm_head's operands (lm_head_rows).
 static int llm_decode_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int rows, int beams, int max_S, const int* pos, const int* cpos,
                              const int* anc, const int* step, hipStream_t st, const float2* rope_cs = nullptr) {
   const oavsr_config& c = m->cfg;
   const int dt = m->dtype, d = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, hd = c.llm_head_dim;
   const int nq = H * hd, nqkv = (H + 2 * KV) * hd;
   const int tl = c.lora_task_specific ? task : 0;
-  { ProfScope ps("decode_rms_prep", 0, 2.0 * rows * d * m->esz, st);
-    OAVSR_TRY(launch_rms_prep(dt, ws->lx, d, ws->lh, d, m->llayers[0].ln1w, ws->rstd, rows, d, c.llm_rms_eps, st)); }
+  OAVSR_TRY(decode_rms_prep(m, ws, ws->lx, ws->lh, m->llayers[0].ln1w, rows, st));
+  int sq_tiles = 1;                            // partial sums per row in ws->rowsq: 1 behind rms_prep, d / 64 behind a reduce
   for (int li = 0; li < c.llm_layers; ++li) {
     const LlmLayer& L = m->llayers[li];
     GemmArgs g;
@@ -898,8 +923,8 @@ static int llm_decode_layers(const oavsr_model* m, oavsr_workspace* ws, int task
     }
     g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = nqkv; g.K = d; g.A = ws->lh; g.lda = d; g.W = L.qkvw; g.ldw = d; g.col_bias = L.qkvb;
     if (c.lora_k2 > 0) { g.A2 = ws->llora; g.lda2 = c.lora_k2; g.W2 = L.lora_up[tl]; g.ldw2 = c.lora_k2; g.K2 = c.lora_k2; }
-    g.row_scale = ws->rstd; g.C = ws->lqkv; g.ldc = nqkv;
-    OAVSR_TRY(decode_gemm(m, ws, g, st));
+    g.C = ws->lqkv; g.ldc = nqkv;
+    OAVSR_TRY(decode_gemm(m, ws, g, st, sq_tiles));
     // RoPE + cache append are fused into the decode-attention kernel
     DecodeAttnArgs a; a.dtype = dt; a.head_dim = hd; a.n_heads = H; a.n_kv_heads = KV; a.rows = rows; a.beams = beams;
     a.Q = ws->lqkv; a.ldq = nqkv; a.O = ws->lattn; a.ldo = nq;
@@ -910,7 +935,8 @@ static int llm_decode_layers(const oavsr_model* m, oavsr_workspace* ws, int task
     { ProfScope ps("decode_attention", 0, 2.0 * rows * max_S * KV * hd * m->esz, st);
       OAVSR_TRY(launch_decode_attention(a, st)); }
     const float* next_gain = li + 1 < c.llm_layers ? m->llayers[li + 1].ln1w : m->norm_w;
-    OAVSR_TRY(decode_layer_tail(m, ws, L, rows, ws->lx, ws->lattn, ws->lact, ws->lh, ws->rstd, next_gain, st));
+    OAVSR_TRY(decode_layer_tail(m, ws, L, rows, ws->lx, ws->lattn, ws->lact, ws->lh, next_gain, st));
+    sq_tiles = ceil_div(d, 64);
   }
   return 0;
 }
@@ -920,7 +946,7 @@ static int llm_decode_layers(const oavsr_model* m, oavsr_workspace* ws, int task
 // (the reference materialises all positions, Llama_LoRA.py:372-373), so in the LAST layer everything after the KV append -- attention
 // queries, o_proj, the MLP -- runs on the B gathered rows (compact residual stream ws->lastx) through the decode-shaped path above, 128
 // rows at a time: an utterance's first-token logits do not depend on its batch.  On return ws->lastx holds the final hidden rows, ws->lh /
-// ws->rstd the final norm's operands for lm_head_rows(normed = true).
+// ws->rowsq the final norm's operands for lm_head_rows.
 static int llm_prefill_layers(const oavsr_model* m, oavsr_workspace* ws, int task, int rows, int B, int max_S, const int* pos, const int* cpos,
                               const int* last_rows, const int* cu_last, hipStream_t st) {
   const oavsr_config& c = m->cfg;
@@ -958,7 +984,7 @@ static int llm_prefill_layers(const oavsr_model* m, oavsr_workspace* ws, int tas
     { ProfScope ps(dt == DT_F32 ? "attention_f32" : "attention_bf16", 2.0 * (prune ? B : rows) * max_S * nq, 4.0 * (prune ? B : rows) * nq * m->esz, st);
       OAVSR_TRY(launch_attention(a, st)); }
     if (prune) {      // (ws->lh held the gathered queries: free again)
-      OAVSR_TRY(decode_layer_tail(m, ws, L, B, ws->lastx, ws->lattn, ws->lact, ws->lh, ws->rstd, m->norm_w, st));
+      OAVSR_TRY(decode_layer_tail(m, ws, L, B, ws->lastx, ws->lattn, ws->lact, ws->lh, m->norm_w, st));
       break;
     }
     g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = d; g.K = nq; g.A = ws->lattn; g.lda = nq; g.W = L.ow; g.ldw = nq;
@@ -983,14 +1009,14 @@ static int llm_prefill_layers(const oavsr_model* m, oavsr_workspace* ws, int tas
 }
 
 // logits[rows][vocab] (fp32, Llama_LoRA.py:372-373) of decode-shaped rows: A = ws->lh rows (T(x * norm.w), written by the last
-// down_proj's reduce), accumulator x ws->rstd
+// down_proj's reduce), accumulator x 1 / rms(x) from the same reduce's sums of squares
 static int lm_head_rows(const oavsr_model* m, oavsr_workspace* ws, int rows, float* logits, hipStream_t st) {
   const oavsr_config& c = m->cfg;
   const int d = c.llm_hidden;
   GemmArgs g; g.dtype = m->dtype; g.M = rows; g.N = c.llm_vocab; g.K = d; g.W = m->lm_head; g.ldw = d;
-  g.A = ws->lh; g.lda = d; g.row_scale = ws->rstd; g.C = logits; g.ldc = c.llm_vocab; g.out_f32 = 1; g.swiglu_pairs = 0;
+  g.A = ws->lh; g.lda = d; g.C = logits; g.ldc = c.llm_vocab; g.out_f32 = 1;
   // (N = the vocabulary: the column tiles alone fill the chip; decode_split gives 1)
-  return decode_gemm(m, ws, g, st);
+  return decode_gemm(m, ws, g, st, ceil_div(d, 64));
 }
 
 // Where a prefill puts what the decode loop needs: the row slots slot0.. of a decode scheduler's pool instead of the workspace's own caches.
@@ -1332,7 +1358,7 @@ int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, 
   WANT(ktail, ws->ktail_layer * c.llm_layers); WANT(vtail, ws->ktail_layer * c.llm_layers);
   WANT(pos, Rl * 4); WANT(slot, Rl * 4); WANT(cpos, Rl * 4); WANT(cu_s, (max_B + 1) * 4); WANT(prefix_len, max_B * 4); WANT(last_rows, max_B * 4);
   WANT(amax, rows_dec * 4); WANT(amax_scratch, rows_dec * 64 * 8);
-  WANT(gsync, kSyncInts * 4); WANT(rstd, Rl * 4); WANT(rowsq, ((size_t)ceil_div(d, 64) + 2) * Rl * 4);
+  WANT(gsync, kSyncInts * 4); WANT(rowsq, rowsq_chunk(d) * ceil_div64((int64_t)Rl, 128) * 4);
   WANT(gs.tok, rows_dec * 4); WANT(gs.finished, rows_dec * 4); WANT(gs.out_ids, rows_dec * (size_t)max_new * 4); WANT(gs.out_len, rows_dec * 4);
   WANT(gs.step, 256); WANT(gs.pos, rows_dec * 4); WANT(gs.cpos, rows_dec * 4); WANT(gs.rope_cs, rows_dec * (size_t)(hd / 2) * sizeof(float2));
   {   // split-K partial slabs of the decode-shaped GEMMs: ks(N, K) x rows x N fp32 per call site (decode_split; o_proj / down_proj split >= 2)
@@ -1664,7 +1690,7 @@ int oavsr_scheduler_create(const oavsr_model* m, int32_t n_slots, int32_t max_ro
       for (auto& s2 : sites) if (s2[0] > 0) pb = std::max(pb, (size_t)decode_split(s2[0], s2[1], (int)e, s2[2]) * 128 * s2[0] * 4);
       lw->partial_bytes = pb;
       WANT(lw->partial, std::max<size_t>(pb, 256)); WANT(lw->lgu, R * 2 * (size_t)I * e);
-      WANT(lw->gsync, kSyncInts * 4); WANT(lw->rstd, R * 4); WANT(lw->rowsq, ((size_t)ceil_div(d, 64) + 2) * R * 4);
+      WANT(lw->gsync, kSyncInts * 4); WANT(lw->rowsq, rowsq_chunk(d) * 4);
     }
   }
 #undef WANT
@@ -1692,11 +1718,16 @@ int oavsr_scheduler_create(const oavsr_model* m, int32_t n_slots, int32_t max_ro
   // were measured in round 3 and removed in round 4: profiles/r03_sched_scan.txt.)
   // (they belong to the PROCESS -- one process per GPU: created once, with the first scheduler, and never destroyed, so that a host
   // framework that has seen them, e.g. PyTorch's caching allocator after record_stream, never holds a dangling stream)
+  if (hipGetDevice(&s->device) != hipSuccess) return fail("hipGetDevice failed");
   { std::lock_guard<std::mutex> lk(g_caller_mu);
-    while ((int)g_caller_streams.size() < kCallerStreams) {
-      hipStream_t cs = nullptr;
-      if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return fail("stream creation failed");
-      g_caller_streams.push_back(cs);
+    if (!g_caller_streams.count(s->device)) {      // all eight or none: a failure half way leaves no partial table behind
+      std::vector<hipStream_t> v;
+      for (int i = 0; i < kCallerStreams; ++i) {
+        hipStream_t cs = nullptr;
+        if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { for (hipStream_t x : v) hipStreamDestroy(x); return fail("stream creation failed"); }
+        v.push_back(cs);
+      }
+      g_caller_streams[s->device] = v;
     } }
   for (auto& l : s->lanes) {
     oavsr_workspace* lw = l.dws;      // the lane's view: its own scratch, the shared pool
@@ -1731,8 +1762,10 @@ void oavsr_scheduler_destroy(oavsr_scheduler* s) {
 uint64_t oavsr_scheduler_bytes(const oavsr_scheduler* s) { return s ? s->arena_bytes : 0; }
 oavsr_stream oavsr_scheduler_caller_stream(oavsr_scheduler* s, int32_t i) {
   std::lock_guard<std::mutex> lk(g_caller_mu);
-  if (!s || i < 0 || i >= (int)g_caller_streams.size()) { set_last_error("scheduler_caller_stream: index %d out of range (0..%d)", (int)i, kCallerStreams - 1); return nullptr; }
-  return (oavsr_stream)g_caller_streams[i];
+  if (!s || i < 0 || i >= kCallerStreams) { set_last_error("scheduler_caller_stream: index %d out of range (0..%d)", (int)i, kCallerStreams - 1); return nullptr; }
+  auto it = g_caller_streams.find(s->device);      // the streams of the device THIS scheduler lives on
+  if (it == g_caller_streams.end()) { set_last_error("scheduler_caller_stream: no streams for device %d", s->device); return nullptr; }
+  return (oavsr_stream)it->second[i];
 }
 
 int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_workspace* ws, int32_t task, const void* video_dev, const int32_t* Tv_host,
@@ -1960,11 +1993,12 @@ int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream) {
   g.H = d->H; g.Wd = d->W_; g.Cin = d->Cin; g.OH = d->OH; g.OW = d->OW; g.stride = d->stride; g.pad = d->pad; g.ksize = d->ksize;
   g.rowinfo = (const int4*)d->rowinfo; g.taps = d->taps; g.Kvalid = d->Kvalid; g.frameinfo = (const int2*)d->frameinfo;
   g.swiglu_pairs = d->swiglu_pairs; g.decode_tiled = d->decode_tiled != 0;
-  g.ksplit = d->ksplit < 1 ? 1 : d->ksplit; g.partial = d->partial; g.sync = d->sync; g.row_scale = d->row_scale;
-  g.ng_out = d->ng_out; g.ng_ld = d->ng_ld; g.ng_gain = d->ng_gain; g.ng_rowsq = d->ng_rowsq; g.ng_rstd = d->ng_rstd; g.ng_eps = d->ng_eps;
+  g.ksplit = d->ksplit < 1 ? 1 : d->ksplit; g.partial = d->partial; g.sync = d->sync;
+  g.row_sumsq = d->row_sumsq; g.row_sumsq_tiles = d->row_sumsq_tiles; g.row_dim = d->row_dim; g.row_eps = d->row_eps;
+  g.ng_out = d->ng_out; g.ng_ld = d->ng_ld; g.ng_gain = d->ng_gain; g.ng_rowsq = d->ng_rowsq;
   OAVSR_REQUIRE(!g.ng_out || g.ksplit > 1, "op_gemm: the next-norm outputs need split-K (ksplit > 1)");
-  OAVSR_REQUIRE(!g.row_scale || (g.M <= 128 && g.amode == A_DENSE && g.groups == 1 && g.N >= 64 && d->kernel == 0), "op_gemm: row_scale is an epilogue of the decode-shaped launches (dense, M <= 128, N >= 64)");
-  if (g.row_scale) g.decode_tiled = 1;
+  OAVSR_REQUIRE(!g.row_sumsq || d->kernel == 0, "op_gemm: the row factor is an epilogue of the decode-shaped launches (kernel selector 0)");
+  if (g.row_sumsq) g.decode_tiled = 1;
   if (d->kernel == 2) {      // tests: the 8-wave ping-pong 256 x 256 kernel whatever the dispatcher's rule says
     OAVSR_REQUIRE(gemm_8p_supported(g), "op_gemm: shape / layout not supported by the ping-pong kernel");
     return launch_gemm_8p(g, (hipStream_t)stream);
@@ -2029,10 +2063,10 @@ int oavsr_op_norm(int32_t mode, int32_t dtype, const void* x, int64_t ldx, void*
   set_last_error("op_norm: bad mode %d", mode);
   return -1;
 }
-int oavsr_op_rms_prep(int32_t dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, float* rstd, int32_t rows, int32_t D, float eps,
+int oavsr_op_rms_prep(int32_t dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, float* sumsq, int32_t rows, int32_t D,
                       oavsr_stream stream) {
-  OAVSR_REQUIRE(x && y && w && rstd, "op_rms_prep: null argument");
-  return launch_rms_prep(dtype, x, ldx, y, ldy, w, rstd, rows, D, eps, (hipStream_t)stream);
+  OAVSR_REQUIRE(x && y && w && sumsq, "op_rms_prep: null argument");
+  return launch_rms_prep(dtype, x, ldx, y, ldy, w, sumsq, rows, D, (hipStream_t)stream);
 }
 int oavsr_op_maxpool3x3s2(int32_t dtype, const void* x, void* y, int32_t imgs, int32_t H, int32_t W, int32_t C, oavsr_stream stream) {
   return launch_maxpool3x3s2(dtype, x, y, imgs, H, W, C, (hipStream_t)stream);

@@ -169,12 +169,12 @@ int launch_norm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, con
 }
 
 // Deferred RMSNorm of the decode path (Llama_LoRA.py:587-655: input_layernorm / post_attention_layernorm / model.norm): the consumer GEMM
-// takes y = T(x * gain) as its A operand and multiplies its accumulator by rstd[row] = 1 / rms(x) (GemmArgs::row_scale).  This kernel
-// prepares the pair for rows that no GEMM produced (the embedding rows at the start of a decode step); inside a step the split-K reduce
-// of o_proj / down_proj writes it (gemm2.hip).  One wave per row; sum of squares per lane in column order, then wave_sum.
+// takes y = T(x * gain) as its A operand and multiplies its accumulator by 1 / rms(x), which it derives from the row's sum of squares
+// (GemmArgs::row_sumsq).  This kernel prepares the pair for rows that no GEMM produced (the embedding rows at the start of a decode step);
+// inside a step the split-K reduce of o_proj / down_proj writes it (gemm2.hip).  One wave per row; sum per lane in column order, then wave_sum.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void rms_prep_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy,
-                                                             const float* __restrict__ w, float* __restrict__ rstd, int rows, int D, float eps) {
+                                                             const float* __restrict__ w, float* __restrict__ sumsq, int rows, int D) {
   constexpr int VEC = TypeInfo<T>::kVec;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * kWavesPerBlock + wave;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kThreads) void rms_prep_kernel(const T* __restrict_
     *reinterpret_cast<Chunk16*>(yr + c) = chunk_from_f32<T>(o);
   }
   s2 = wave_sum(s2);
-  if (lane == 0) rstd[row] = rsqrtf(s2 / (float)D + eps);
+  if (lane == 0) sumsq[row] = s2;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -586,13 +586,13 @@ int launch_rmsnorm(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, 
   return launch_norm<1>(dtype, x, ldx, y, ldy, w, nullptr, rows, D, eps, st);
 }
 
-int launch_rms_prep(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, float* rstd, int rows, int D, float eps, hipStream_t st) {
+int launch_rms_prep(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, const float* w, float* sumsq, int rows, int D, hipStream_t st) {
   if (rows <= 0) return 0;
   const int vec = dtype == DT_F32 ? 4 : 8;
   OAVSR_REQUIRE(D % vec == 0 && ldx % vec == 0 && ldy % vec == 0, "rms_prep: D=%d must be a multiple of %d", D, vec);
   dim3 grid(ceil_div(rows, kWavesPerBlock));
-  if (dtype == DT_F32) hipLaunchKernelGGL(rms_prep_kernel<float>, grid, dim3(kThreads), 0, st, (const float*)x, ldx, (float*)y, ldy, w, rstd, rows, D, eps);
-  else hipLaunchKernelGGL(rms_prep_kernel<bf16_t>, grid, dim3(kThreads), 0, st, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, w, rstd, rows, D, eps);
+  if (dtype == DT_F32) hipLaunchKernelGGL(rms_prep_kernel<float>, grid, dim3(kThreads), 0, st, (const float*)x, ldx, (float*)y, ldy, w, sumsq, rows, D);
+  else hipLaunchKernelGGL(rms_prep_kernel<bf16_t>, grid, dim3(kThreads), 0, st, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, w, sumsq, rows, D);
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("OAVSR_LIB") or os.path.join(_HERE, "libomniavsr_hip.s
 
 ABI_VERSION = 3      # OAVSR_ABI_VERSION of include/omni_avsr.h this binding's structures and argument lists follow
 MAX_RATES = 8
-GEMM_SYNC_INTS = 4096 + 64      # OAVSR_GEMM_SYNC_INTS: zeroed ints a split-K oavsr_op_gemm launch needs (GemmDesc.sync)
+GEMM_SYNC_INTS = 4096      # OAVSR_GEMM_SYNC_INTS: zeroed ints a split-K oavsr_op_gemm launch needs (GemmDesc.sync)
 DT_F32, DT_BF16 = 0, 1
 TASK_ID = {"audio": 0, "video": 1, "audiovisual": 2}
 
@@ -62,8 +62,9 @@ class GemmDesc(C.Structure):
         ("stride", C.c_int32), ("pad", C.c_int32), ("ksize", C.c_int32),
         ("rowinfo", C.c_void_p), ("taps", C.c_int32), ("Kvalid", C.c_int32), ("frameinfo", C.c_void_p),
         ("kernel", C.c_int32), ("swiglu_pairs", C.c_int32), ("decode_tiled", C.c_int32),
-        ("ksplit", C.c_int32), ("partial", C.c_void_p), ("sync", C.c_void_p), ("row_scale", C.c_void_p),
-        ("ng_out", C.c_void_p), ("ng_ld", C.c_int64), ("ng_gain", C.c_void_p), ("ng_rowsq", C.c_void_p), ("ng_rstd", C.c_void_p), ("ng_eps", C.c_float),
+        ("ksplit", C.c_int32), ("partial", C.c_void_p), ("sync", C.c_void_p),
+        ("row_sumsq", C.c_void_p), ("row_sumsq_tiles", C.c_int32), ("row_dim", C.c_int32), ("row_eps", C.c_float),
+        ("ng_out", C.c_void_p), ("ng_ld", C.c_int64), ("ng_gain", C.c_void_p), ("ng_rowsq", C.c_void_p),
         ("grid", C.c_int32),
     ]
 
@@ -130,7 +131,7 @@ SYMBOLS = {
     "oavsr_op_attention": (C.c_int, [C.POINTER(AttnDesc), _P]),
     "oavsr_op_decode_attention": (C.c_int, [C.POINTER(DecodeAttnDesc), _P]),
     "oavsr_op_norm": (C.c_int, [_I, _I, _P, _L, _P, _L, _P, _P, _I, _I, _F, _P]),
-    "oavsr_op_rms_prep": (C.c_int, [_I, _P, _L, _P, _L, _P, _P, _I, _I, _F, _P]),
+    "oavsr_op_rms_prep": (C.c_int, [_I, _P, _L, _P, _L, _P, _P, _I, _I, _P]),
     "oavsr_op_stem_pool": (C.c_int, [_I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "oavsr_op_conv3x3_c64": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "oavsr_op_beam_topk": (C.c_int, [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P]),

@@ -342,10 +342,25 @@ class OmniEngine:
             self._sched = C.c_void_p(None)
             max_prefix, max_new = max(max_prefix, key[0]), max(max_new, key[1])
         max_prefix = (max_prefix + 63) // 64 * 64
-        L.check(self.lib.oavsr_scheduler_create(self._model, self.sched_slots, self.sched_rows, self.sched_lanes, max_prefix, max_new, C.byref(self._sched)))
+        slots = self._fit_slots(max_prefix, max_new)
+        L.check(self.lib.oavsr_scheduler_create(self._model, slots, self.sched_rows, self.sched_lanes, max_prefix, max_new, C.byref(self._sched)))
         self._sched_key = (max_prefix, max_new, self.sched_rows, self.sched_slots, self.sched_lanes)
         self._sched_gen += 1
         self._stride_set = 0
+
+    def _fit_slots(self, max_prefix: int, max_new: int) -> int:
+        """Row slots the pool is built with: `sched_slots`, cut down (never below one step's rows) so that the pool -- per slot the prefix and tail
+        KV rows of every layer plus one fp32 logits row -- stays under a quarter of the device's memory (Llama-3.1-8B, 16 s clips: ~42 MB per
+        slot, 512 slots = 21 GB: fine on 288 GB, not on a small board or with several engines per process)."""
+        l = self.spec.llm
+        esz = 2 if self.dtype == "bf16" else 4
+        per_slot = 2 * l.layers * l.kv_heads * l.head_dim * (max_prefix + max_new) * esz + l.vocab * 4
+        cap = torch.cuda.get_device_properties(self.device).total_memory // 4
+        return int(max(self.sched_rows, min(self.sched_slots, cap // max(1, per_slot))))
+
+    def scheduler_bytes(self) -> int:
+        """Device bytes of the decode scheduler's pool (row slots' KV + logits, the lanes' step scratch); 0 before the first submit."""
+        return int(self.lib.oavsr_scheduler_bytes(self._sched)) if self._sched else 0
 
     def reserve_scheduler(self, task: str, tv_max: int, ts_max: int, rate_a: Optional[int] = None, rate_v: Optional[int] = None,
                           max_new: Optional[int] = None):

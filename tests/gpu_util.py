@@ -53,7 +53,7 @@ def gemm(dtype, A, W, *, A2=None, W2=None, scale=None, bias=None, prelu=None, ac
     d.groups = groups
     d.kernel = int(kernel)
     for k, v in geom.items():
-        if k in ("rowinfo", "frameinfo", "partial", "sync", "row_scale", "ng_out", "ng_gain", "ng_rowsq", "ng_rstd"):
+        if k in ("rowinfo", "frameinfo", "partial", "sync", "row_sumsq", "ng_out", "ng_gain", "ng_rowsq"):
             setattr(d, k, P(v))
         elif k != "groups":
             setattr(d, k, v)

@@ -51,35 +51,41 @@ def test_gemm_dense(dtype, M, N, K):
                                         (8, 1024, 4096, 0, 2), (1, 64, 2048, 0, 8), (128, 1024 + 16, 1024, 128, 3), (97, 128, 512, 0, 5), (33, 2048, 2048, 0, 13)])
 def test_gemm_splitk_reduced_inside_the_launch(dtype, M, N, K, K2, S):
     """Split-K of the decode-shaped GEMMs (M <= 128): fp32 partial slabs, summed in slab order by the tile's last-arriving workgroup inside
-    the GEMM launch (gemm2.hip), with the fused epilogue (row_scale, bias, residual).  Against fp32 torch; repeated launches on the same
+    the GEMM launch (gemm2.hip), with the fused epilogue (the deferred RMSNorm's row factor from partial sums of squares, bias, residual).  Against fp32 torch; repeated launches on the same
     counters and slabs give the same bits (the counters are zero again when a launch ends; the sum never depends on who came last)."""
     a, ar = q(rnd(M, K, seed=1), dtype)
     w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
     r, rr = q(rnd(M, N, seed=5), dtype)
-    rs = (rnd(M, seed=8).abs() + 0.5)
+    D, eps = 256, 1e-5
+    sq = (rnd(3, M, seed=8).abs() + 0.2) * D / 3          # three partial sums of squares per row -> 1 / rms per row
+    rs = torch.rsqrt(sq.sum(0) / D + eps)
+    rskw = dict(row_sumsq=sq.to(DEV).contiguous(), row_sumsq_tiles=3, row_dim=D, row_eps=eps)
     bias = rnd(N, seed=9)
-    kw, ref = {}, ar @ wr.T
+    kw, ref = dict(rskw), ar @ wr.T
     if K2:
         a2, a2r = q(rnd(M, K2, seed=3), dtype)
         w2, w2r = q(rnd(N, K2, seed=4) / math.sqrt(K2), dtype)
-        kw = dict(A2=a2, W2=w2)
+        kw.update(A2=a2, W2=w2)
         ref = ref + a2r @ w2r.T
     part = torch.empty(S * M * N, dtype=torch.float32, device=DEV)
     sync = torch.zeros(L.GEMM_SYNC_INTS, dtype=torch.int32, device=DEV)
-    out = gemm(dtype, a, w, residual=r, bias=bias.to(DEV), row_scale=rs.to(DEV), ksplit=S, partial=part, sync=sync, **kw).clone()
+    out = gemm(dtype, a, w, residual=r, bias=bias.to(DEV), ksplit=S, partial=part, sync=sync, **kw).clone()
     close(out, ref * rs[:, None] + bias + rr, tol(dtype) * 2, rtol=(8e-3 if dtype == "bf16" else 1e-5), what="gemm split-K")
     for _ in range(3):
-        again = gemm(dtype, a, w, residual=r, bias=bias.to(DEV), row_scale=rs.to(DEV), ksplit=S, partial=part, sync=sync, **kw)
+        again = gemm(dtype, a, w, residual=r, bias=bias.to(DEV), ksplit=S, partial=part, sync=sync, **kw)
         assert torch.equal(again, out), "repeated split-K launches differ"
     torch.cuda.synchronize()
     assert int(sync.abs().sum()) == 0, "the arrival counters are not zero after the launch"
+    # the same reduce as a launch of its own (no arrival counters: what the engine runs above a few dozen rows): same code, same bits
+    sep = gemm(dtype, a, w, residual=r, bias=bias.to(DEV), ksplit=S, partial=part, **kw)
+    assert torch.equal(sep, out), "the stand-alone reduce launch differs from the reduce inside the GEMM launch"
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K,S", [(120, 2048, 8192, 16), (120, 2048, 2048, 8), (45, 4096, 1024, 4), (33, 3584, 512, 2), (8, 256, 256, 2), (128, 512, 384, 3)])
 def test_gemm_splitk_next_norm_outputs(dtype, M, N, K, S):
     """The decode path's deferred RMSNorm (Llama_LoRA.py:587-655: residual add, then the next RMSNorm): the split-K reduce of o_proj /
-    down_proj also writes T(x * gain) and 1 / rms(x) per row for the consumer.  C is bit-identical to the launch without those outputs;
+    down_proj also writes T(x * gain) and, per 64-column tile, the rows' sums of squares for the consumer.  C is bit-identical to the launch without those outputs;
     they are checked against fp32 torch on the rounded C; in place on the residual rows, as the decoder uses it."""
     a, _ = q(rnd(M, K, seed=1), dtype)
     w, _ = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
@@ -91,18 +97,24 @@ def test_gemm_splitk_next_norm_outputs(dtype, M, N, K, S):
     rowsq = torch.empty((N + 63) // 64 * M, dtype=torch.float32, device=DEV)
     for _ in range(2):
         xg = torch.full((M, N), float("nan"), dtype=tdt(dtype), device=DEV)
-        rstd = torch.full((M,), float("nan"), dtype=torch.float32, device=DEV)
-        out = gemm(dtype, a, w, residual=r, ksplit=S, partial=part, sync=sync, ng_out=xg, ng_ld=N, ng_gain=gain, ng_rowsq=rowsq, ng_rstd=rstd, ng_eps=1e-5)
+        rowsq.fill_(float("nan"))
+        out = gemm(dtype, a, w, residual=r, ksplit=S, partial=part, sync=sync, ng_out=xg, ng_ld=N, ng_gain=gain, ng_rowsq=rowsq)
         assert torch.equal(out, ref_c), "C differs from the launch without the next-norm outputs"
         x = out.float()
         close(xg, (x * gain).cpu(), tol(dtype) if dtype == "bf16" else 1e-6, what="x * gain")
-        close(rstd, torch.rsqrt((x * x).mean(-1) + 1e-5).cpu(), 1e-5, rtol=1e-5, what="1 / rms")
+        sq = rowsq.view(-1, M)                              # [column tile][row]
+        close(sq, (x * x).view(M, -1, 64).sum(-1).T.cpu(), 1e-3, rtol=1e-5, what="per-tile sums of squares")
+        sq1 = sq.clone()
     r2 = r.clone()
-    xg2, rstd2 = torch.empty_like(xg), torch.empty_like(rstd)
-    gemm(dtype, a, w, residual=r2, ksplit=S, partial=part, sync=sync, C_out=r2, ng_out=xg2, ng_ld=N, ng_gain=gain, ng_rowsq=rowsq, ng_rstd=rstd2, ng_eps=1e-5)
-    assert torch.equal(r2, ref_c) and torch.equal(xg2, xg) and torch.equal(rstd2, rstd)
+    xg2 = torch.empty_like(xg)
+    gemm(dtype, a, w, residual=r2, ksplit=S, partial=part, sync=sync, C_out=r2, ng_out=xg2, ng_ld=N, ng_gain=gain, ng_rowsq=rowsq)
+    assert torch.equal(r2, ref_c) and torch.equal(xg2, xg) and torch.equal(rowsq.view(-1, M), sq1)
     torch.cuda.synchronize()
     assert int(sync.abs().sum()) == 0
+    # reduce as a launch of its own: same C, same T(x * gain), same sums of squares
+    xg3, rowsq3 = torch.empty_like(xg), torch.full_like(rowsq, float("nan"))
+    c3 = gemm(dtype, a, w, residual=r, ksplit=S, partial=part, ng_out=xg3, ng_ld=N, ng_gain=gain, ng_rowsq=rowsq3)
+    assert torch.equal(c3, ref_c) and torch.equal(xg3, xg) and torch.equal(rowsq3.view(-1, M), sq1)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -113,7 +125,7 @@ def test_decode_shaped_gemm_rows_do_not_depend_on_the_row_count(dtype):
     a, _ = q(rnd(128, K, seed=1), dtype)
     w, _ = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
     r, _ = q(rnd(128, N, seed=5), dtype)
-    rs = (rnd(128, seed=8).abs() + 0.5).to(DEV)
+    sq_all = ((rnd(128, seed=8).abs() + 0.5) * K).to(DEV)       # one partial sum of squares per row (as rms_prep leaves it)
     gain = (rnd(N, seed=6) * 0.1 + 1).to(DEV)
     part = torch.empty(S * 128 * N, dtype=torch.float32, device=DEV)
     sync = torch.zeros(L.GEMM_SYNC_INTS, dtype=torch.int32, device=DEV)
@@ -122,35 +134,35 @@ def test_decode_shaped_gemm_rows_do_not_depend_on_the_row_count(dtype):
     full = {}
     for M in (128, 33, 8, 1):
         xg = torch.empty(M, N, dtype=tdt(dtype), device=DEV)
-        rstd = torch.empty(M, dtype=torch.float32, device=DEV)
-        c = gemm(dtype, a[:M], w, residual=r[:M].clone(), row_scale=rs[:M], ksplit=S, partial=part, sync=sync, ng_out=xg, ng_ld=N, ng_gain=gain,
-                 ng_rowsq=rowsq, ng_rstd=rstd, ng_eps=1e-5)
-        lg = gemm(dtype, a[:M], wl, row_scale=rs[:M], out_f32=True, decode_tiled=1)
-        sg = gemm(dtype, a[:M], wl, row_scale=rs[:M], swiglu_pairs=1, decode_tiled=1)
-        got = [t.clone() for t in (c, xg, rstd, lg, sg)]
+        rskw = dict(row_sumsq=sq_all[:M].contiguous(), row_sumsq_tiles=1, row_dim=K, row_eps=1e-5)
+        c = gemm(dtype, a[:M], w, residual=r[:M].clone(), ksplit=S, partial=part, sync=sync, ng_out=xg, ng_ld=N, ng_gain=gain, ng_rowsq=rowsq, **rskw)
+        sq = rowsq[: N // 64 * M].view(-1, M).T.clone()     # [row][column tile]
+        lg = gemm(dtype, a[:M], wl, out_f32=True, decode_tiled=1, **rskw)
+        sg = gemm(dtype, a[:M], wl, swiglu_pairs=1, decode_tiled=1, **rskw)
+        got = [t.clone() for t in (c, xg, sq, lg, sg)]
         if M == 128:
             full = got
         else:
-            for t, f, what in zip(got, full, ("C", "x * gain", "1 / rms", "fp32 logits", "SwiGLU")):
+            for t, f, what in zip(got, full, ("C", "x * gain", "sums of squares", "fp32 logits", "SwiGLU")):
                 assert torch.equal(t, f[:M]), f"{dtype}: {what} of rows 0..{M - 1} depends on the row count ({M} vs 128)"
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_rms_prep_and_row_scale_equal_rmsnorm_then_gemm(dtype):
-    """oavsr_op_norm mode 3 (the rows of a decode step's first layer: y = T(x * gain), rstd = 1 / rms(x)) followed by a row_scale GEMM computes
-    RMSNorm(x) W^T (Llama_LoRA.py:587-655) -- against fp32 torch."""
+    """oavsr_op_rms_prep (the rows of a decode step's first layer: y = T(x * gain), the row's sum of squares) followed by a GEMM with the row
+    factor computes RMSNorm(x) W^T (Llama_LoRA.py:587-655) -- against fp32 torch."""
     M, N, K = 24, 256, 512
     x, xr = q(rnd(M, K, seed=1) * 1.7, dtype)
     w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
     gain = rnd(K, seed=3) * 0.1 + 1
     lib = L.load()
     y = torch.empty(M, K, dtype=tdt(dtype), device=DEV)
-    rstd = torch.empty(M, dtype=torch.float32, device=DEV)
+    sumsq = torch.empty(M, dtype=torch.float32, device=DEV)
     gd = gain.to(DEV)
-    L.check(lib.oavsr_op_rms_prep(dcode(dtype), P(x), K, P(y), K, P(gd), P(rstd), M, K, 1e-5, stream()))
-    close(rstd, torch.rsqrt(xr.pow(2).mean(-1) + 1e-5), 1e-5, rtol=1e-5, what="rstd")
+    L.check(lib.oavsr_op_rms_prep(dcode(dtype), P(x), K, P(y), K, P(gd), P(sumsq), M, K, stream()))
+    close(sumsq, xr.pow(2).sum(-1), 1e-2, rtol=1e-5, what="sum of squares")
     close(y, xr * gain, tol(dtype) if dtype == "bf16" else 1e-6, what="x * gain")
-    out = gemm(dtype, y, w, row_scale=rstd, decode_tiled=1)
+    out = gemm(dtype, y, w, row_sumsq=sumsq, row_sumsq_tiles=1, row_dim=K, row_eps=1e-5, decode_tiled=1)
     ref = (gain * xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5)) @ wr.T
     close(out, ref, tol(dtype) * 2, what="deferred rmsnorm gemm")
 
@@ -321,11 +333,11 @@ def _rowinfo(cu_out, cu_in, stride):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_conv1d_posconv_grouped_varlen(dtype):
-    """AV-HuBERT positional conv: groups, even kernel with SamePad, GELU, residual, per-utterance zero halo."""
-    D, G, taps = 128, 4, 16
+@pytest.mark.parametrize("D,G,taps,lens", [(128, 4, 16, [37, 5, 64]), (256, 4, 32, [200, 61, 129, 3])])
+def test_conv1d_posconv_grouped_varlen(dtype, D, G, taps, lens):
+    """AV-HuBERT positional conv: groups, even kernel with SamePad, GELU, residual, per-utterance zero halo.  The second shape has AV-HuBERT-
+    Large's 64 channels per group and >= 256 rows: the grouped 128 x 64 LDS-DMA conv1d tile (round 5)."""
     Cg = D // G
-    lens = [37, 5, 64]
     cu = [0]
     for n in lens:
         cu.append(cu[-1] + n)

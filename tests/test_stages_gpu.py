@@ -306,6 +306,7 @@ def test_digests_are_the_hashes_of_inputs_embeds_and_first_logits(dtype):
     assert torch.equal(d1[0], dg[1]) and torch.equal(d2[0], dg[1]) and torch.equal(d2[1], dg[0])
     # through the decode scheduler
     ds = torch.zeros(3, 2, dtype=torch.int64, device="cuda:0")
+    torch.cuda.synchronize()              # (the zero fill ran on the default stream)
     st = torch.cuda.Stream()
     with torch.cuda.stream(st):
         ids_s, lens_s, ticket = eng.submit("audiovisual", video, Tv, audio, Ts, 4, 2, max_new=spec.max_dec_tokens, digests=ds)

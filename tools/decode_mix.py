@@ -30,7 +30,7 @@ td = torch.bfloat16
 def split(N, K, min_ks=1):      # model.hip: decode_split
     ktiles = K // 64
     ks = 256 // max(1, -(-N // 64))
-    ks = min(ks, max(1, ktiles // 2))
+    ks = min(ks, max(1, ktiles // 8))
     ks = max(1, min(ks, 16))
     return max(ks, min(min_ks, max(1, ktiles)))
 
@@ -47,9 +47,9 @@ attn = torch.randn(R, nq, device=DEV, dtype=td)
 act = torch.randn(R, I2 // 2, device=DEV, dtype=td)
 qkv = torch.empty(R, nqkv, device=DEV, dtype=td)
 logits = torch.empty(R, V, device=DEV, dtype=torch.float32)
-rstd = torch.rand(R, device=DEV) + 0.5
 gain = torch.ones(d, device=DEV)
-rowsq = torch.empty((d // 64 + 2) * R, device=DEV)
+rowsq = torch.rand((d // 64 + 2) * 128, device=DEV) * 64
+RS = dict(row_sumsq=rowsq, row_sumsq_tiles=d // 64, row_dim=d, row_eps=1e-5)
 part = torch.empty(16 * 128 * max(nqkv, d, k2), device=DEV, dtype=torch.float32)
 sync = torch.zeros(L.GEMM_SYNC_INTS, dtype=torch.int32, device=DEV)
 
@@ -61,15 +61,15 @@ def launch(name, i):
     elif name == "qkv":
         ks = split(nqkv, d + k2)
         kw = dict(ksplit=ks, partial=part, sync=sync) if ks > 1 else dict(decode_tiled=1)
-        gemm("bf16", xg, w, A2=t, W2=W2[i % ncopy], row_scale=rstd, C_out=qkv, **kw)
+        gemm("bf16", xg, w, A2=t, W2=W2[i % ncopy], C_out=qkv, **RS, **kw)
     elif name == "o_proj":
-        gemm("bf16", attn, w, residual=x, C_out=x, ksplit=split(d, nq, 2), partial=part, sync=sync, ng_out=xg, ng_ld=d, ng_gain=gain, ng_rowsq=rowsq, ng_rstd=rstd, ng_eps=1e-5)
+        gemm("bf16", attn, w, residual=x, C_out=x, ksplit=split(d, nq, 2), partial=part, sync=sync, ng_out=xg, ng_ld=d, ng_gain=gain, ng_rowsq=rowsq)
     elif name == "gate_up":
-        gemm("bf16", xg, w, row_scale=rstd, swiglu_pairs=1, C_out=act, decode_tiled=1)
+        gemm("bf16", xg, w, swiglu_pairs=1, C_out=act, decode_tiled=1, **RS)
     elif name == "down":
-        gemm("bf16", act, w, residual=x, C_out=x, ksplit=split(d, I2 // 2, 2), partial=part, sync=sync, ng_out=xg, ng_ld=d, ng_gain=gain, ng_rowsq=rowsq, ng_rstd=rstd, ng_eps=1e-5)
+        gemm("bf16", act, w, residual=x, C_out=x, ksplit=split(d, I2 // 2, 2), partial=part, sync=sync, ng_out=xg, ng_ld=d, ng_gain=gain, ng_rowsq=rowsq)
     else:
-        gemm("bf16", xg, w, row_scale=rstd, out_f32=True, C_out=logits, decode_tiled=1)
+        gemm("bf16", xg, w, out_f32=True, C_out=logits, decode_tiled=1, **RS)
 
 
 if timing:
