@@ -177,10 +177,10 @@ uint64_t oavsr_scheduler_bytes(const oavsr_scheduler* s);
 /* Caller stream i (0 .. 7) of the scheduler: a HIP stream the ENGINE created, before its lanes' streams, for submitting calls on.  ROCm
  * binds a stream to one of its few hardware queues at creation, and which caller stream shares a queue with which lane decides how encoder
  * phases and decode bursts take turns: with streams of the caller's own making the same loop ran at 226-229 or at 255-260 utt/s depending
- * on when they were created (round 3).  Streams handed out here are in the fast order by construction; they belong to the PROCESS
- * (one process per GPU: created with the first scheduler, shared by every scheduler created later, never destroyed -- a host framework
- * that has recorded them, e.g. PyTorch's caching allocator, never holds a dangling stream).  Any other stream
- * still works (speed only, never results).  NULL: index out of range. */
+ * on when they were created (round 3).  Streams handed out here are in the fast order by construction; they belong to the PROCESS and to
+ * the DEVICE the scheduler lives on (eight per device: created with the first scheduler on that device, shared by every scheduler created
+ * there later, never destroyed -- a host framework that has recorded them, e.g. PyTorch's caching allocator, never holds a dangling stream).
+ * Any other stream still works (speed only, never results).  NULL: index out of range. */
 oavsr_stream oavsr_scheduler_caller_stream(oavsr_scheduler* s, int32_t i);
 /* oavsr_generate(beams = 1) split in two: submit queues encoders + prefill on `stream` (workspace ws, as oavsr_generate) and the
  * admission of the B rows on the scheduler's stream; it returns a ticket.  out_ids_dev / out_len_dev ([B][max_new] / [B] int32) are
@@ -253,8 +253,9 @@ typedef struct oavsr_gemm_desc {
                                5 16-wave 256 x 256, 6 160 x 128, 7 256 x 128 */
   int32_t swiglu_pairs;     /* fused SwiGLU epilogue (gate / up weight rows interleaved by 16) */
   int32_t decode_tiled;     /* 1: decode-shaped launch (M <= 128): the 128-row LDS-DMA tiles at any row count */
-  /* decode-shaped launches (M <= 128): split-K with fp32 partial slabs [ksplit][M][N], summed in slab order by the tile's last-arriving
-     workgroup INSIDE the launch; `sync`: OAVSR_GEMM_SYNC_INTS zeroed ints (arrival counters; they are zero again when the launch ends) */
+  /* decode-shaped launches (M <= 128): split-K with fp32 partial slabs [ksplit][M][N], summed in slab order -- by the tile's last-arriving
+     workgroup INSIDE the launch (`sync`: OAVSR_GEMM_SYNC_INTS zeroed ints, the arrival counters; zero again when the launch ends) or, with
+     sync == NULL, by a reduce launch of its own that runs the same code (same bits) */
   int32_t ksplit;
   float* partial;
   int32_t* sync;

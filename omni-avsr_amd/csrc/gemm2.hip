@@ -112,6 +112,92 @@ __device__ __forceinline__ void dma16(const void* src, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// The epilogue of ONE finished 16-column row segment of a decode-shaped GEMM (yy: the fp32 sums): row factor, col_scale / bias, residual,
+// activation, store; optionally the consumer's RMSNorm operands (GemmArgs::ng_*).  The four lanes tid % 4 = 0..3 hold the four segments of
+// one row of a 64-column tile; every lane of the wave must call (the sum of squares crosses those lanes).  The one place where the results
+// of a split decode-shaped GEMM are formed (the reduce inside the GEMM launch and the stand-alone reduce kernel both end here).
+template <typename T>
+__device__ __forceinline__ void segment_finish(const GemmArgs& p, int m, int nc, int nt_, bool live, float (&yy)[16],
+                                               const Chunk16 (&rraw)[16 / TypeInfo<T>::kVec], float rsv, int tid) {
+  constexpr int VEC = TypeInfo<T>::kVec;
+  constexpr int SEG = 4;
+  const T* Rr = reinterpret_cast<const T*>(p.residual);
+  const bool want_ng = p.ng_out != nullptr;
+  float ss = 0.f;
+  if (live) {
+    if (p.row_sumsq) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) yy[e] *= rsv;
+    }
+    float res[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) res[e] = 0.f;
+    if (Rr) {
+#pragma unroll
+      for (int e = 0; e < 16; e += VEC) chunk_to_f32<T>(rraw[e / VEC], res + e);
+    }
+    const bool whole = nc + 16 <= p.N;                        // (a ragged last segment: un-split launches only, e.g. lm_head's vocabulary)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const bool in = whole || nc + e < p.N;
+      float v = fmaf(yy[e], (p.col_scale && in) ? p.col_scale[nc + e] : 1.f, (p.col_bias && in) ? p.col_bias[nc + e] : 0.f);
+      if (!p.res_after_act) v += res[e];
+      switch (p.act) {
+        case ACT_GELU: v = gelu_act<T>(v); break;
+        case ACT_RELU: v = fmaxf(v, 0.f); break;
+        case ACT_PRELU: v = v >= 0.f ? v : (in ? p.prelu[nc + e] : 0.f) * v; break;
+        case ACT_SILU: v = silu(v); break;
+        default: break;
+      }
+      yy[e] = p.res_after_act ? v + res[e] : v;
+    }
+    if (p.out_f32) {
+      float* Cf = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + nc;
+      if (whole && (p.ldc % 4) == 0 && ((uintptr_t)p.C & 15) == 0 && (nc % 4) == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; e += 4) *reinterpret_cast<f32x4*>(Cf + e) = f32x4{yy[e], yy[e + 1], yy[e + 2], yy[e + 3]};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) if (nc + e < p.N) Cf[e] = yy[e];
+      }
+    } else if (!(whole && (p.ldc % VEC) == 0 && ((uintptr_t)p.C & 15) == 0)) {
+      T* Ct = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + nc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) if (nc + e < p.N) Ct[e] = from_f32<T>(yy[e]);
+    } else {
+      T* Ct = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + nc;
+      Chunk16 oc[16 / VEC];
+#pragma unroll
+      for (int e = 0; e < 16; e += VEC) { oc[e / VEC] = chunk_from_f32<T>(yy + e); *reinterpret_cast<Chunk16*>(Ct + e) = oc[e / VEC]; }
+      if (want_ng) {      // the consumer's RMSNorm: x * gain now (x as stored), the row's sum of squares per column tile
+        float xr[16], xg[16];
+#pragma unroll
+        for (int e = 0; e < 16; e += VEC) chunk_to_f32<T>(oc[e / VEC], xr + e);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { xg[e] = xr[e] * p.ng_gain[nc + e]; ss = fmaf(xr[e], xr[e], ss); }
+        T* Gt = reinterpret_cast<T*>(p.ng_out) + (int64_t)m * p.ng_ld + nc;
+#pragma unroll
+        for (int e = 0; e < 16; e += VEC) *reinterpret_cast<Chunk16*>(Gt + e) = chunk_from_f32<T>(xg + e);
+      }
+    }
+  }
+  if (want_ng) {      // the row's sum of squares over this tile's 64 columns: the row's four adjacent lanes, fixed butterfly
+#pragma unroll
+    for (int o = 1; o < SEG; o <<= 1) ss += __shfl_xor(ss, o, 64);
+    if (live && (tid % SEG) == 0) p.ng_rowsq[(int64_t)nt_ * p.M + m] = ss;
+  }
+}
+
+// 1 / rms of a row from the producer's per-tile sums of squares (GemmArgs::row_sumsq), tile by tile, in order
+__device__ __forceinline__ float row_factor(const GemmArgs& p, int m) {
+  float tot = 0.f;
+  if (m < p.M) {
+#pragma unroll 8
+    for (int t = 0; t < p.row_sumsq_tiles; ++t) tot += p.row_sumsq[(int64_t)t * p.M + m];
+  }
+  return rsqrtf(tot / (float)p.row_dim + p.row_eps);
+}
+
 // ---- split-K reduce of ONE 64-column tile strip: rows [m0, m0 + NI * nthr / 4) x columns [n0, n0 + 64) of C.  A thread owns NI segments of
 //      16 columns (segment w = tid + i * nthr -> row w / 4, columns 16 (w % 4)); everything they need is requested before the first use --
 //      the residual rows, then the slabs of ALL its segments four at a time, so a slab group costs one memory round trip -- the slabs are
@@ -167,64 +253,7 @@ __device__ __forceinline__ void splitk_reduce_tile(const GemmArgs& p, int m0, in
         }
   }
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int m = mI[i], nc = ncI[i];
-    const bool live = liveI[i];
-    float ss = 0.f;
-    if (live) {
-      float* yy = y[i];
-      if (p.row_sumsq) {
-        const float rsv = rs[rI[i]];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) yy[e] *= rsv;
-      }
-      float res[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) res[e] = 0.f;
-      if (Rr) {
-#pragma unroll
-        for (int e = 0; e < 16; e += VEC) chunk_to_f32<T>(rraw[i][e / VEC], res + e);
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        float v = fmaf(yy[e], p.col_scale ? p.col_scale[nc + e] : 1.f, p.col_bias ? p.col_bias[nc + e] : 0.f);
-        if (!p.res_after_act) v += res[e];
-        switch (p.act) {
-          case ACT_GELU: v = gelu_act<T>(v); break;
-          case ACT_RELU: v = fmaxf(v, 0.f); break;
-          case ACT_PRELU: v = v >= 0.f ? v : p.prelu[nc + e] * v; break;
-          case ACT_SILU: v = silu(v); break;
-          default: break;
-        }
-        yy[e] = p.res_after_act ? v + res[e] : v;
-      }
-      if (p.out_f32) {
-        float* Cf = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + nc;
-#pragma unroll
-        for (int e = 0; e < 16; e += 4) *reinterpret_cast<f32x4*>(Cf + e) = f32x4{yy[e], yy[e + 1], yy[e + 2], yy[e + 3]};
-      } else {
-        T* Ct = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + nc;
-        Chunk16 oc[16 / VEC];
-#pragma unroll
-        for (int e = 0; e < 16; e += VEC) { oc[e / VEC] = chunk_from_f32<T>(yy + e); *reinterpret_cast<Chunk16*>(Ct + e) = oc[e / VEC]; }
-        if (want_ng) {      // the consumer's RMSNorm: x * gain now (x as stored), the row's sum of squares per column tile
-          float xr[16], xg[16];
-#pragma unroll
-          for (int e = 0; e < 16; e += VEC) chunk_to_f32<T>(oc[e / VEC], xr + e);
-#pragma unroll
-          for (int e = 0; e < 16; ++e) { xg[e] = xr[e] * p.ng_gain[nc + e]; ss = fmaf(xr[e], xr[e], ss); }
-          T* Gt = reinterpret_cast<T*>(p.ng_out) + (int64_t)m * p.ng_ld + nc;
-#pragma unroll
-          for (int e = 0; e < 16; e += VEC) *reinterpret_cast<Chunk16*>(Gt + e) = chunk_from_f32<T>(xg + e);
-        }
-      }
-    }
-    if (want_ng) {      // the row's sum of squares over this tile's columns: the SEG adjacent lanes, fixed butterfly
-#pragma unroll
-      for (int o = 1; o < SEG; o <<= 1) ss += __shfl_xor(ss, o, 64);
-      if (live && (tid % SEG) == 0) p.ng_rowsq[(int64_t)nt_ * p.M + m] = ss;
-    }
-  }
+  for (int i = 0; i < NI; ++i) segment_finish<T>(p, mI[i], ncI[i], nt_, liveI[i], y[i], rraw[i], p.row_sumsq ? rs[rI[i]] : 1.f, tid);
 }
 
 // The same reduce as a launch of its own (GemmArgs::sync == nullptr): one workgroup of 128 threads per (column tile, 32 rows).  Above a few
@@ -234,15 +263,7 @@ template <typename T>
 __global__ __launch_bounds__(128) void splitk_reduce_kernel(const GemmArgs p) {
   __shared__ float rs[32];
   const int nt_ = blockIdx.x, m0 = blockIdx.y * 32, n0 = nt_ * 64, tid = threadIdx.x;
-  if (p.row_sumsq && tid < 32) {
-    const int m = m0 + tid;
-    float tot = 0.f;
-    if (m < p.M) {
-#pragma unroll 8
-      for (int t = 0; t < p.row_sumsq_tiles; ++t) tot += p.row_sumsq[(int64_t)t * p.M + m];
-    }
-    rs[tid] = rsqrtf(tot / (float)p.row_dim + p.row_eps);
-  }
+  if (p.row_sumsq && tid < 32) rs[tid] = row_factor(p, m0 + tid);
   __syncthreads();
   splitk_reduce_tile<T, 1>(p, m0, n0, nt_, tid, 128, rs);
 }
@@ -380,13 +401,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
   float* rs_lds = reinterpret_cast<float*>(smem + kStages * kStageBytes);
   if constexpr (kRowScale) {
     if (p.row_sumsq && tid < BM) {
-      const int m = m0 + tid;
-      float tot = 0.f;
-      if (m < p.M) {
-#pragma unroll 8
-        for (int t = 0; t < p.row_sumsq_tiles; ++t) tot += p.row_sumsq[(int64_t)t * p.M + m];
-      }
-      rs_lds[tid] = rsqrtf(tot / (float)p.row_dim + p.row_eps);
+      rs_lds[tid] = row_factor(p, m0 + tid);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }

@@ -232,6 +232,7 @@ struct oavsr_workspace {
   void *pf_k = nullptr, *pf_v = nullptr; size_t pf_layer = 0; int pf_max_prefix = 0;
   const int* rowmap = nullptr;                 // decode scheduler only: activation row -> row slot (DecodeAttnArgs::rowmap)
   StemSrc vsrc;                                // what `video_dev` of the calls on this workspace holds (oavsr_workspace_set_video_format)
+  hipStream_t own_stream = nullptr; hipEvent_t own_in = nullptr, own_out = nullptr;      // calls made on the legacy default stream run here (generate_impl)
   uint64_t* digests = nullptr;                 // optional [utterance][2]: {inputs_embeds, first-step logits} digests of the calls on this workspace (oavsr_workspace_set_digests)
 
   void* take(size_t bytes) {
@@ -1406,6 +1407,9 @@ int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, 
 void oavsr_workspace_destroy(oavsr_workspace* ws) {
   if (!ws) return;
   for (auto& e : ws->graphs) hipGraphExecDestroy(e.second);
+  if (ws->own_stream) { hipStreamSynchronize(ws->own_stream); hipStreamDestroy(ws->own_stream); }
+  if (ws->own_in) hipEventDestroy(ws->own_in);
+  if (ws->own_out) hipEventDestroy(ws->own_out);
   if (ws->arena) hipFree(ws->arena);
   if (ws->host_base) hipHostFree(ws->host_base);
   for (int i = 0; i < 2; ++i) if (ws->host_ev[i]) hipEventDestroy(ws->host_ev[i]);
@@ -1527,11 +1531,32 @@ static int generate_impl(const oavsr_model* m, oavsr_workspace* ws, int32_t task
   OAVSR_REQUIRE(beams >= 1 && !(beams > 1 && force_len), "generate: bad num_beams / force_len");
   OAVSR_REQUIRE(B >= 1 && B <= ws->max_B, "generate: B=%d exceeds workspace (%d)", B, ws->max_B);
   OAVSR_REQUIRE(chunk_B >= 1, "generate: chunk_B must be >= 1");
-  CallScope cs(ws, st);
-  // ONE decode loop then serves all B rows: the LLM weights are streamed once per step for the whole group instead of once per chunk.
-  OAVSR_TRY(encode_prefill(m, ws, task, video_dev, Tv_host, wav_dev, wav_ld, Ts_host, keep_host, B, chunk_B, rate_audio, rate_video, st, nullptr, nullptr));
-  if (beams > 1) return decode_beam(m, ws, task, B, beams, max_new, out_ids_dev, out_len_dev, st);
-  return decode_greedy(m, ws, task, B, max_new, force_len, out_ids_dev, out_len_dev, st);
+  // The legacy default stream (what a caller who swaps the class and keeps the reference's one-call-at-a-time loop passes: torch's
+  // current stream is the null stream) cannot be captured, so its decode steps would be ~100 eager launches each.  The call then runs on a
+  // stream of the workspace's own, ordered behind everything queued on the null stream so far and ahead of everything queued after it --
+  // for the caller the same stream semantics, with the hipGraph-replayed decode loop (sequential evaluation: 61 -> see DESIGN.md section 5).
+  hipStream_t caller = st;
+  if (!st) {
+    if (!ws->own_stream) {
+      OAVSR_CHECK_HIP(hipStreamCreateWithFlags(&ws->own_stream, hipStreamNonBlocking));
+      OAVSR_CHECK_HIP(hipEventCreateWithFlags(&ws->own_in, hipEventDisableTiming));
+      OAVSR_CHECK_HIP(hipEventCreateWithFlags(&ws->own_out, hipEventDisableTiming));
+    }
+    OAVSR_CHECK_HIP(hipEventRecord(ws->own_in, nullptr));
+    OAVSR_CHECK_HIP(hipStreamWaitEvent(ws->own_stream, ws->own_in, 0));
+    st = ws->own_stream;
+  }
+  int rc;
+  { CallScope cs(ws, st);
+    // ONE decode loop then serves all B rows: the LLM weights are streamed once per step for the whole group instead of once per chunk.
+    rc = encode_prefill(m, ws, task, video_dev, Tv_host, wav_dev, wav_ld, Ts_host, keep_host, B, chunk_B, rate_audio, rate_video, st, nullptr, nullptr);
+    if (rc == 0) rc = beams > 1 ? decode_beam(m, ws, task, B, beams, max_new, out_ids_dev, out_len_dev, st)
+                                : decode_greedy(m, ws, task, B, max_new, force_len, out_ids_dev, out_len_dev, st); }
+  if (!caller) {      // whatever was queued -- also after a refused input -- is ordered in front of the caller's next work
+    OAVSR_CHECK_HIP(hipEventRecord(ws->own_out, ws->own_stream));
+    OAVSR_CHECK_HIP(hipStreamWaitEvent(nullptr, ws->own_out, 0));
+  }
+  return rc;
 }
 
 int oavsr_generate(const oavsr_model* m, oavsr_workspace* ws, int32_t task, const void* video_dev, const int32_t* Tv_host, const float* wav_dev,

@@ -298,16 +298,30 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
             flat = FlatCollator(max(len(b) for b in batches), max(int(samples[i][0]["video_u8"].shape[0]) for i in owned),
                                 max([int(samples[i][0]["audio"].shape[0]) for i in owned if "audio" in samples[i][0]] or [1]),
                                 u8_shape=tuple(samples[owned[0]][0]["video_u8"].shape[1:]))
-        for idxs in batches:
-            batch = flat([samples[i][0] for i in idxs], modality, bos_id) if raw else collate_test([samples[i][0] for i in idxs], modality, bos_id)
-            try:
-                ids = model(batch, is_trainval=False, modality=kw_mod, **forward_kw)
-            except (RuntimeError, ValueError) as e:
-                skip(idxs, e)
-                continue
-            score(idxs, ids)
-        if decode_group > 1:
-            model.encoder_chunk = chunk_prev
+        # one call at a time, like the reference's loop -- whose DataLoader workers prepare the next batch meanwhile (data_module.py:238-242:
+        # num_workers): the next batch is collated on a helper thread while the model runs the current one (the flat collator's staging
+        # buffers are single: it collates in line)
+        from concurrent.futures import ThreadPoolExecutor
+        make = (lambda idxs: flat([samples[i][0] for i in idxs], modality, bos_id)) if raw else \
+            (lambda idxs: collate_test([samples[i][0] for i in idxs], modality, bos_id))
+        pool = None if raw else ThreadPoolExecutor(1)
+        try:
+            nxt = pool.submit(make, batches[0]) if pool else None
+            for n, idxs in enumerate(batches):
+                batch = nxt.result() if pool else make(idxs)
+                if pool and n + 1 < len(batches):
+                    nxt = pool.submit(make, batches[n + 1])
+                try:
+                    ids = model(batch, is_trainval=False, modality=kw_mod, **forward_kw)
+                except (RuntimeError, ValueError) as e:
+                    skip(idxs, e)
+                    continue
+                score(idxs, ids)
+        finally:
+            if pool:
+                pool.shutdown(wait=True)
+            if decode_group > 1:
+                model.encoder_chunk = chunk_prev
         return meter
 
     eng = model.engine

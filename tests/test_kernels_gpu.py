@@ -94,7 +94,7 @@ def test_gemm_splitk_next_norm_outputs(dtype, M, N, K, S):
     part = torch.empty(S * M * N, dtype=torch.float32, device=DEV)
     sync = torch.zeros(L.GEMM_SYNC_INTS, dtype=torch.int32, device=DEV)
     ref_c = gemm(dtype, a, w, residual=r, ksplit=S, partial=part, sync=sync).clone()
-    rowsq = torch.empty((N + 63) // 64 * M, dtype=torch.float32, device=DEV)
+    rowsq = torch.empty(N // 64 * M, dtype=torch.float32, device=DEV)
     for _ in range(2):
         xg = torch.full((M, N), float("nan"), dtype=tdt(dtype), device=DEV)
         rowsq.fill_(float("nan"))
@@ -125,25 +125,27 @@ def test_decode_shaped_gemm_rows_do_not_depend_on_the_row_count(dtype):
     a, _ = q(rnd(128, K, seed=1), dtype)
     w, _ = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
     r, _ = q(rnd(128, N, seed=5), dtype)
-    sq_all = ((rnd(128, seed=8).abs() + 0.5) * K).to(DEV)       # one partial sum of squares per row (as rms_prep leaves it)
+    sq_row = ((rnd(128, seed=8).abs() + 0.5) * K).to(DEV)       # one sum of squares per row (as rms_prep leaves it)
     gain = (rnd(N, seed=6) * 0.1 + 1).to(DEV)
     part = torch.empty(S * 128 * N, dtype=torch.float32, device=DEV)
     sync = torch.zeros(L.GEMM_SYNC_INTS, dtype=torch.int32, device=DEV)
     rowsq = torch.empty(N // 64 * 128, dtype=torch.float32, device=DEV)
     wl, _ = q(rnd(4096 + 64, K, seed=3) / math.sqrt(K), dtype)          # "lm_head" / gate-up shaped: no split
+    wr, _ = q(rnd(1000 + 5, K, seed=4) / math.sqrt(K), dtype)           # a ragged vocabulary (N % 16 != 0, odd row stride of the logits)
     full = {}
-    for M in (128, 33, 8, 1):
+    for M in (128, 33, 17, 16, 8, 1):
         xg = torch.empty(M, N, dtype=tdt(dtype), device=DEV)
-        rskw = dict(row_sumsq=sq_all[:M].contiguous(), row_sumsq_tiles=1, row_dim=K, row_eps=1e-5)
+        rskw = dict(row_sumsq=sq_row[:M].contiguous(), row_sumsq_tiles=1, row_dim=K, row_eps=1e-5)
         c = gemm(dtype, a[:M], w, residual=r[:M].clone(), ksplit=S, partial=part, sync=sync, ng_out=xg, ng_ld=N, ng_gain=gain, ng_rowsq=rowsq, **rskw)
         sq = rowsq[: N // 64 * M].view(-1, M).T.clone()     # [row][column tile]
         lg = gemm(dtype, a[:M], wl, out_f32=True, decode_tiled=1, **rskw)
         sg = gemm(dtype, a[:M], wl, swiglu_pairs=1, decode_tiled=1, **rskw)
-        got = [t.clone() for t in (c, xg, sq, lg, sg)]
+        rg = gemm(dtype, a[:M], wr, out_f32=True, decode_tiled=1, **rskw)
+        got = [t.clone() for t in (c, xg, sq, lg, sg, rg)]
         if M == 128:
             full = got
         else:
-            for t, f, what in zip(got, full, ("C", "x * gain", "sums of squares", "fp32 logits", "SwiGLU")):
+            for t, f, what in zip(got, full, ("C", "x * gain", "sums of squares", "fp32 logits", "SwiGLU", "ragged logits")):
                 assert torch.equal(t, f[:M]), f"{dtype}: {what} of rows 0..{M - 1} depends on the row count ({M} vs 128)"
 
 

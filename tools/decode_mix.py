@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The decode-shaped launches of ONE decode step (llm_decode_layers + lm_head, model.hip) at R rows for a model's widths, through the C ABI:
 per layer LoRA-down, QKV (+ LoRA segment, row_scale), o_proj (+ residual, next-norm outputs), gate / up (+ SwiGLU, row_scale), down_proj
-(+ residual, next-norm outputs) -- split-K with the reduce inside the launch exactly as decode_gemm sizes it -- then lm_head (fp32 logits).
+(+ residual, next-norm outputs) -- split-K exactly as decode_gemm sizes it (reduce inside the launch up to 32 rows, as a second launch above) --, the
+decode attention on the same rows, then lm_head (fp32 logits).
 Weight copies rotate beyond the 256 MiB Infinity Cache.  For `rocprofv3 --pmc` / `--kernel-trace` passes over the decode kernels that
 ship (tools/pmc_round.py tags "decode..."), and with `--time` a per-site timing table.
 
@@ -12,9 +13,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ctypes as C  # noqa: E402
+import math  # noqa: E402
 import torch  # noqa: E402
 from omni_avsr_amd import lib as L  # noqa: E402
-from gpu_util import gemm, DEV  # noqa: E402
+from omni_avsr_amd.weights import rope_inv_freq  # noqa: E402
+from gpu_util import gemm, DEV, stream  # noqa: E402
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 R = int(args[0]) if args else 97
@@ -51,10 +55,36 @@ gain = torch.ones(d, device=DEV)
 rowsq = torch.rand((d // 64 + 2) * 128, device=DEV) * 64
 RS = dict(row_sumsq=rowsq, row_sumsq_tiles=d // 64, row_dim=d, row_eps=1e-5)
 part = torch.empty(16 * 128 * max(nqkv, d, k2), device=DEV, dtype=torch.float32)
-sync = torch.zeros(L.GEMM_SYNC_INTS, dtype=torch.int32, device=DEV)
+sync = torch.zeros(L.GEMM_SYNC_INTS, dtype=torch.int32, device=DEV) if R <= 32 else None      # model.hip: OAVSR_FUSED_REDUCE_ROWS
+
+
+# decode attention (RoPE + KV append fused) on the same rows: 313 prompt keys (a 16 s AVSR clip at rates 4 / 4), step 10, one KV copy per layer slot
+hd = 64 if model == "1b" else 128
+Hh, KVh = nq // hd, (nqkv - nq) // (2 * hd)
+nkv = 4 if model == "1b" else 2
+kp = [torch.randn(R, KVh, 320, hd, device=DEV, dtype=td) for _ in range(nkv)]
+vp = [torch.randn_like(kp[0]) for _ in range(nkv)]
+kt = torch.randn(R, KVh, 32, hd, device=DEV, dtype=td)
+vt = torch.randn_like(kt)
+inv = rope_inv_freq(hd, 500000.0, None).to(DEV)
+pl = torch.full((R,), 313, dtype=torch.int32, device=DEV)
+pos = (pl + 9).to(torch.int32)
+cpos = torch.full((R,), 9, dtype=torch.int32, device=DEV)
+stp = torch.tensor([10], dtype=torch.int32, device=DEV)
+ad = L.DecodeAttnDesc()
+ad.dtype, ad.head_dim, ad.n_heads, ad.n_kv_heads, ad.rows, ad.beams, ad.max_prefix, ad.max_tail = L.DT_BF16, hd, Hh, KVh, R, 1, 320, 32
+ad.Q, ad.Kt, ad.Vt, ad.O = qkv.data_ptr(), kt.data_ptr(), vt.data_ptr(), attn.data_ptr()
+ad.ldq, ad.ldo = nqkv, nq
+ad.prefix_len, ad.step, ad.anc, ad.scale = pl.data_ptr(), stp.data_ptr(), None, 1.0 / math.sqrt(hd)
+ad.inv_freq, ad.pos, ad.cpos = inv.data_ptr(), pos.data_ptr(), cpos.data_ptr()
+lib = L.load()
 
 
 def launch(name, i):
+    if name == "attention":
+        ad.Kp, ad.Vp = kp[i % nkv].data_ptr(), vp[i % nkv].data_ptr()
+        L.check(lib.oavsr_op_decode_attention(C.byref(ad), stream()))
+        return
     w = W[name][i % ncopy] if name != "lm_head" else Wl
     if name == "lora_dn":
         gemm("bf16", xg, w, C_out=t, ksplit=split(k2, d), partial=part, sync=sync)
@@ -73,7 +103,7 @@ def launch(name, i):
 
 
 if timing:
-    for name in [s[0] for s in sites] + ["lm_head"]:
+    for name in [s[0] for s in sites] + ["attention", "lm_head"]:
         for i in range(3):
             launch(name, i)
         torch.cuda.synchronize()
@@ -85,12 +115,16 @@ if timing:
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / n
+        if name == "attention":
+            kvb = R * 322 * KVh * hd * 2 * 2
+            print(f"{model} rows={R:3d} attention {Hh}/{KVh} x {hd}, 313 + 9 keys: {us:7.1f} us  {kvb / us / 1e3:7.1f} GB/s of K / V")
+            continue
         N, K = {"lora_dn": (k2, d), "qkv": (nqkv, d + k2), "o_proj": (d, nq), "gate_up": (I2, d), "down": (d, I2 // 2), "lm_head": (V, d)}[name]
         print(f"{model} rows={R:3d} {name:8s} N={N:6d} K={K:5d} split={split(N, K, 2 if name in ('o_proj', 'down') else 1) if name not in ('gate_up', 'lm_head') else 1:2d}: {us:7.1f} us  {N * K * 2 / us / 1e3:7.1f} GB/s of weights")
 else:
     for s in range(steps):
         for li in range(layers):
-            for name in [s_[0] for s_ in sites]:
+            for name in ["lora_dn", "qkv", "attention", "o_proj", "gate_up", "down"]:
                 launch(name, li)
         launch("lm_head", 0)
     torch.cuda.synchronize()
