@@ -469,6 +469,38 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
   const int ngb = g * p.N + nb;
   const bool vec_ok = nb + 16 <= p.N && (e_ldc % VEC) == 0 && ((uintptr_t)e_C & 15) == 0 && (ngb % 16) == 0 &&
                       (!R || ((p.ldr % VEC) == 0 && ((uintptr_t)R & 15) == 0));
+  // (round 5) tiles with registers to spare (<= 8 waves, 2-byte elements) request what the slabs need from global memory -- the residual
+  // segments of ALL their rows, the lane's 16 per-column scales / biases -- BEFORE the first slab instead of inside each (one exposed
+  // load latency per tile instead of one per slab and array)
+  constexpr bool kPre = sizeof(T) == 2 && NWAVES <= 8;
+  const bool pfull = nb + 16 <= p.N;
+  auto load4 = [&](const float* arr, int e, float dflt) -> f32x4 {
+    if (!arr) return f32x4{dflt, dflt, dflt, dflt};
+    if (pfull && (((uintptr_t)(arr + ngb)) & 15) == 0) return *reinterpret_cast<const f32x4*>(arr + ngb + e);
+    f32x4 t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = nb + e + q < p.N ? arr[ngb + e + q] : dflt;
+    return t;
+  };
+  Chunk16 rpre[kPre ? TM : 1][2];
+  f32x4 cpre[kPre ? 4 : 1][2];
+  const bool pre_r = kPre && R && vec_ok && !(kFusedReduce && fused);
+  if constexpr (kPre) {
+    if (pre_r) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mi = m0 + wm * (TM * 16) + i * 16 + rr;
+        if (mi < p.M) {
+          rpre[i][0] = *reinterpret_cast<const Chunk16*>(R + (int64_t)mi * p.ldr + ngb);
+          rpre[i][1] = *reinterpret_cast<const Chunk16*>(R + (int64_t)mi * p.ldr + ngb + 8);
+        }
+      }
+    }
+    if (!(kFusedReduce && fused)) {
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) { cpre[e4][0] = load4(e_scale, e4 * 4, 1.f); cpre[e4][1] = load4(e_bias, e4 * 4, 0.f); }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -502,7 +534,10 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
 #pragma unroll
     for (int e = 0; e < 16; ++e) res[e] = 0.f;
     if (R) {
-      if (vec_ok) {
+      if (kPre && pre_r) {
+        chunk_to_f32<T>(rpre[kPre ? i : 0][0], res);
+        chunk_to_f32<T>(rpre[kPre ? i : 0][1], res + 8);
+      } else if (vec_ok) {
 #pragma unroll
         for (int e = 0; e < 16; e += VEC) chunk_to_f32<T>(*reinterpret_cast<const Chunk16*>(R + (int64_t)m * p.ldr + ngb + e), res + e);
       } else {
@@ -510,49 +545,58 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
         for (int e = 0; e < 16; ++e) if (nb + e < p.N) res[e] = to_f32(R[(int64_t)m * p.ldr + ngb + e]);
       }
     }
-    // per-column parameters are re-read per slab (L1 hits), four columns at a time to keep registers free: one 16-byte vector per
-    // array when the lane's 16 columns are all inside N and the array is 16-byte aligned there, scalar loads on the ragged edge
-    const bool pfull = nb + 16 <= p.N;
-    auto load4 = [&](const float* arr, int e, float dflt) -> f32x4 {
-      if (!arr) return f32x4{dflt, dflt, dflt, dflt};
-      if (pfull && (((uintptr_t)(arr + ngb)) & 15) == 0) return *reinterpret_cast<const f32x4*>(arr + ngb + e);
-      f32x4 t;
+    // per-column parameters: held in registers by the tiles that prefetched them, otherwise re-read per slab (L1 hits), four columns at a
+    // time to keep registers free: one 16-byte vector per array when the lane's 16 columns are all inside N and the array is 16-byte
+    // aligned there, scalar loads on the ragged edge.
+    // No activation (or ReLU after the residual): one path without the run-time selections below -- with nothing between them the order
+    // of residual and activation does not matter, fma(y, scale, bias) + res is what both orders compute (res = 0.f without a residual:
+    // the `+ 0.f` of the generic form) -- 2-3 VALU instructions per element instead of ~8
+    const bool relu_after_res = e_act == ACT_RELU && !p.res_after_act;
+    if (kPre && (e_act == ACT_NONE || relu_after_res)) {      // (the 16-wave tile has no registers for a second path)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) t[q] = nb + e + q < p.N ? arr[ngb + e + q] : dflt;
-      return t;
-    };
+      for (int e4 = 0; e4 < 16; e4 += 4) {
+        const f32x4 csc = kPre ? cpre[kPre ? e4 / 4 : 0][0] : load4(e_scale, e4, 1.f), cbi = kPre ? cpre[kPre ? e4 / 4 : 0][1] : load4(e_bias, e4, 0.f);
 #pragma unroll
-    for (int e4 = 0; e4 < 16; e4 += 4) {
-      const f32x4 csc = load4(e_scale, e4, 1.f), cbi = load4(e_bias, e4, 0.f);
-      float v[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        // one explicit FMA, identical in every GEMM variant, so an element has the same bits whichever tile shape computed it
-        v[q] = fmaf(y[e4 + q], csc[q], cbi[q]);
-        if (!p.res_after_act) v[q] += res[e4 + q];
+        for (int q = 0; q < 4; ++q) y[e4 + q] = fmaf(y[e4 + q], csc[q], cbi[q]) + res[e4 + q];
       }
-      switch (e_act) {                            // one uniform branch per four columns
-        case ACT_GELU:
-          gelu_act4<T>(v);
-          break;
-        case ACT_RELU:
+      if (relu_after_res) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-          break;
-        case ACT_PRELU: {
-          const f32x4 csl = load4(p.prelu, e4, 0.f);
+        for (int e = 0; e < 16; ++e) y[e] = fmaxf(y[e], 0.f);
+      }
+    } else {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = v[q] >= 0.f ? v[q] : csl[q] * v[q];
-          break;
+      for (int e4 = 0; e4 < 16; e4 += 4) {
+        const f32x4 csc = kPre ? cpre[kPre ? e4 / 4 : 0][0] : load4(e_scale, e4, 1.f), cbi = kPre ? cpre[kPre ? e4 / 4 : 0][1] : load4(e_bias, e4, 0.f);
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          // one explicit FMA, identical in every GEMM variant, so an element has the same bits whichever tile shape computed it
+          v[q] = fmaf(y[e4 + q], csc[q], cbi[q]);
+          if (!p.res_after_act) v[q] += res[e4 + q];
         }
-        case ACT_SILU:
+        switch (e_act) {                            // one uniform branch per four columns
+          case ACT_GELU:
+            gelu_act4<T>(v);
+            break;
+          case ACT_RELU:
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
-          break;
-        default: break;
+            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+            break;
+          case ACT_PRELU: {
+            const f32x4 csl = load4(p.prelu, e4, 0.f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = v[q] >= 0.f ? v[q] : csl[q] * v[q];
+            break;
+          }
+          case ACT_SILU:
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
+            break;
+          default: break;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) y[e4 + q] = p.res_after_act ? v[q] + res[e4 + q] : v[q];
       }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) y[e4 + q] = p.res_after_act ? v[q] + res[e4 + q] : v[q];
     }
     if (p.swiglu_pairs && !split) {
       // gate / up weight rows are interleaved in blocks of 16: the lanes with an even (lane & 3) hold a gate block, their right

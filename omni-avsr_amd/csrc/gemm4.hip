@@ -13,11 +13,19 @@
 //     tiles (2 x 16-byte stores per 16-row slab: 16 per wave; fused SwiGLU: 8) -- and the stores drain behind ~2 us of MFMA work.  Edge tiles
 //     (ragged M / N: row-guarded stores, unknown count) fall back to the plain counts, i.e. they wait for their stores: slower, never wrong
 //     (assuming FEWER outstanding operations than there are is the safe direction);
-//   * bias + activation (+ SwiGLU: gate and up columns of a pair sit in the same lane) and the rounding to bf16 are applied in the MFMA C
-//     layout; the transposition that turns the results into 16-byte row-segment stores goes through LDS of its own (per wave 8 packed row
-//     pairs x 64 columns, XOR-swizzled instead of padded), because the two k-tile buffers already hold the next tile; the bias arrives by
-//     LDS-DMA during the tile's last k-tile (no ordinary global load anywhere in the loop: the compiler would drain vmcnt for it);
-//   * the two wave groups re-synchronise for the epilogue (waves 4-7 run one barrier behind in the k loop, see gemm3.hip) and re-stagger after.
+//   * (round 5) the MFMAs run with the operands swapped -- weights as the A operand, their rows permuted on the way into LDS (free: the
+//     DMA's scalar / per-lane row offsets) -- so a lane's accumulators of a 16-row slab ARE 16 consecutive output columns of one row: bias,
+//     activation, SwiGLU (gate and up of a column in the same lane), residual and rounding happen in registers and go out as 16-byte row
+//     segments, without the LDS transposition of round 4 (measured equal alone; it frees 32 KiB of LDS and half the epilogue's code).  The
+//     bias arrives by LDS-DMA during the tile's last k-tile (no ordinary global load anywhere in the loop: the compiler would drain vmcnt);
+//   * the epilogue is instantiated per activation (template ACT): with the run-time selections of the generic form (activation switch,
+//     residual-before / after-activation, the `+ 0.f` of the other kernels) a plain bias epilogue cost ~6 VALU instructions per element --
+//     2.6 us per tile on the two waves of a SIMD; specialised: fc1 (GELU) 114 -> 102 us, gate / up (SwiGLU) 156 -> 145 us, AV-HuBERT fc1
+//     40 -> 36 us, same bits (profiles/r05_gemm_epilogue_probe.txt: what the time between two k loops consists of);
+//   * the two wave groups re-synchronise for the epilogue (waves 4-7 run one barrier behind in the k loop, see gemm3.hip) and re-stagger
+//     after.  Nothing in the register-only epilogue needs that -- letting the stagger run through it (kSyncEpi = false: each group's epilogue
+//     under ONE quadrant of the other's MFMAs, the two epilogues one after the other) measured 3-6 % SLOWER on fc1 / gate-up: two waves of a
+//     SIMD hide each other's latencies better than 16 MFMAs hide an epilogue.
 // Same accumulation order (k ascending, 32 per MFMA) and the same epilogue expressions as gemm2.hip / gemm3.hip: bit-identical to them
 // (tests/test_kernels_gpu.py).  No second K segment, no per-column scale / PReLU, bf16 output.  The dispatcher takes it for every dense
 // 256 x 256-tile launch it supports: with one tile per workgroup it still beats the 16-wave and the ping-pong kernel (leaner prologue and
@@ -31,7 +39,7 @@ namespace {
 
 constexpr int kHalf4 = 16384;                 // one half-tile: 128 rows x 128 B
 constexpr int kBuf4 = 4 * kHalf4;             // A0 | A1 | B0 | B1
-constexpr int kPatch4 = 2 * kBuf4;            // 8 waves x 4 KiB: epilogue patches; also where the dummy DMAs of a workgroup's LAST tile land
+constexpr int kPatch4 = 2 * kBuf4;            // 8 waves x 4 KiB: where the dummy DMAs of a workgroup's LAST tile land (lower half) and the tile's bias (upper half)
 constexpr int kSmem8pp = 2 * kBuf4 + 8 * 4096;   // 160 KiB: the whole LDS of a CU
 
 __device__ __forceinline__ void mma4(const Chunk16& a, const Chunk16& b, f32x4& c) {
@@ -39,17 +47,19 @@ __device__ __forceinline__ void mma4(const Chunk16& a, const Chunk16& b, f32x4& 
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+constexpr bool kSyncEpi = true;
 #define PP_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define PP_BARRIER() do { PP_FENCE(); __builtin_amdgcn_s_barrier(); PP_FENCE(); } while (0)
 
-// SWIGLU: fused SwiGLU epilogue (gate / up rows interleaved by 16).  RES: residual rows (o_proj, fc2, down_proj): the residual lives in the
-// row layout, so that variant transposes fp32 sums (bias already added in the C layout) and finishes -- residual, activation, rounding --
-// after the transposition, with the bias and ALL residual rows of the tile requested before the first store (ordinary loads: the
-// compiler waits for everything in flight at their first use, which costs nothing in the single-round launches this variant serves).
-template <bool SWIGLU, bool RES>
+// SWIGLU: fused SwiGLU epilogue (gate / up rows interleaved by 16).  RES: residual rows (o_proj, fc2, down_proj), with the bias and ALL
+// residual rows of the tile requested before the first store (ordinary loads: the compiler waits for everything in flight at their first
+// use, which costs nothing in the single-round launches this variant serves).  ACT: -1 = generic epilogue (run-time activation /
+// residual order), ACT_NONE / ACT_GELU = the specialised forms the launcher picks when they apply (same bits).
+template <bool SWIGLU, bool RES, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, const int ntiles) {
   typedef bf16_t T;
   constexpr int BKE = 64, VEC = 8;
+  constexpr bool kSpec = ACT >= 0;              // epilogue specialised for a compile-time activation (launcher: ACT_NONE, or ACT_GELU without a residual)
   constexpr int S = SWIGLU ? 8 : 16;            // store instructions a wave issues for one FULL tile: 8 slabs x 2 (SwiGLU: 8 slabs x 1)
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -92,13 +102,19 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
   const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
   const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)(((int64_t)p.M - 1) * p.lda * 2 + (int64_t)p.K * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, (int)(((int64_t)p.N - 1) * p.ldw * 2 + (int64_t)p.K * 2), 0x00020000);
-  const int avo = (lrow * (int)p.lda + lchunk * VEC) * 2, wvo = (lrow * (int)p.ldw + lchunk * VEC) * 2;
+  // Weight rows are PERMUTED on their way into LDS (free: a segment's 8 rows are separate 128-byte pieces either way) so that, with the
+  // weights as the MFMA's A operand, a lane's accumulators are consecutive output columns (see the epilogue): LDS row j*16 + fg*4 + r of a
+  // wave's 64 columns holds global row fg*16 + j*4 + r -- SwiGLU (gate / up interleaved in blocks of 16): (fg>>1)*32 + (j&1)*16 + (fg&1)*8 +
+  // (j>>1)*4 + r.  Segment `wave` = LDS rows wave*8 + lrow: j = wave >> 1, fg = (wave & 1)*2 + (lrow >> 2), r = lrow & 3.
+  const int wrow_v = SWIGLU ? (lrow >> 2) * 8 + (lrow & 3) : (lrow >> 2) * 16 + (lrow & 3);
+  const int wrow_s = SWIGLU ? (wave & 1) * 32 + ((wave >> 1) & 1) * 16 + (wave >> 2) * 4 : (wave & 1) * 32 + (wave >> 1) * 4;
+  const int avo = (lrow * (int)p.lda + lchunk * VEC) * 2, wvo = (wrow_v * (int)p.ldw + lchunk * VEC) * 2;
   const int a64 = 64 * (int)p.lda * 2, w64 = 64 * (int)p.ldw * 2;      // segment `wave + 8` starts 64 rows below segment `wave`
   int so[4];                                    // scalar byte offset of segment `wave` of the k-tile each kind issues next
   auto set_src = [&](auto hc, int m0x, int n0x) __attribute__((always_inline)) {
     constexpr int h = decltype(hc)::value;
     if (h < 2) so[h] = (m0x + (h & 1) * 128 + wave * 8) * (int)p.lda * 2;
-    else so[h] = (n0x + (h & 1) * 128 + wave * 8) * (int)p.ldw * 2;
+    else so[h] = (n0x + (h & 1) * 128 + wrow_s) * (int)p.ldw * 2;
   };
   const std::integral_constant<int, 0> kA0; const std::integral_constant<int, 1> kA1;
   const std::integral_constant<int, 2> kB0; const std::integral_constant<int, 3> kB1;
@@ -180,7 +196,7 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) mma4(af[i][kb], bf[j][kb], c[i][j]);
+        for (int j = 0; j < 4; ++j) mma4(bf[j][kb], af[i][kb], c[i][j]);      // weights = A operand: D rows = weight rows
     __builtin_amdgcn_s_setprio(0);
   };
   // counted wait of a tile's first phases: `se` != 0 -> the S stores of the previous (full) tile may still be outstanding
@@ -242,22 +258,19 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
   PP_BARRIER();
   if (late) PP_BARRIER();
 
-  // epilogue geometry.  Bias and activation are applied in the MFMA C layout (a lane: rows fg*4 + r, column j*16 + frow) and the results are
-  // rounded to bf16 there; each 16 x 64 (SwiGLU: 16 x 32) slab is then transposed through this wave's LDS patch as PACKED ROW PAIRS -- one
-  // dword = (row 2q, row 2q+1) of one column, 8 row pairs x 64 columns, XOR-swizzled -- so that a lane ends up with 16 (8) consecutive
-  // columns of one row and every store is a 16-byte vector, four lanes per 128-byte (64-byte) row segment.  (Half the LDS write traffic of
-  // an fp32 patch: ds_write_b32 is the slowest LDS instruction, 64 B/clk per CU.)
-  unsigned* sw = reinterpret_cast<unsigned*>(smem + kPatch4 + wave * 4096);
+  // epilogue geometry.  The MFMAs run with the operands SWAPPED (weights = A operand, activations = B operand), so a lane's four
+  // accumulator registers of n-block j are four consecutive weight rows of ONE activation row (lane: m = i*16 + frow, LDS weight rows
+  // j*16 + fg*4 + r), and the DMA above placed global weight row `perm` into that LDS row such that a lane's 16 registers of a 16-row slab
+  // ARE 16 consecutive output columns fg*16 .. fg*16 + 15 of its row (SwiGLU: gate and up of the 8 output columns fg*8 .. fg*8 + 7).  Bias,
+  // activation (SwiGLU), residual and rounding all happen in registers and every store is a 16-byte vector, four lanes per 128-byte
+  // (64-byte) row segment: no transposition through LDS, nothing shared between waves -- so nobody synchronises for the epilogue: the
+  // stagger of the k loop simply continues (waves 0-3 run their epilogue while waves 4-7 issue their last quadrant's MFMAs, waves 4-7 theirs
+  // under the next tile's first quadrant of waves 0-3).
   const bool c_vec = (p.ldc % VEC) == 0 && ((uintptr_t)p.C & 15) == 0;
-  // patch dword (row pair q, col) lives at index q*64 + (col ^ ((q & 3) << 2)).  A lane writes pairs q = fg*2 + h (its rows r = 2h, 2h+1), column
-  // j*16 + frow: wr_pair[h] + j*16; it reads row rr = lane >> 2 (pair rr >> 1, half rr & 1), columns c0 .. c0 + 15 (7)
-  int wr_pair[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) wr_pair[h] = (fg * 2 + h) * 64 + (frow ^ ((((fg & 1) << 1) + h) << 2));
-  const int rr = lane >> 2;
-  const int rd_pair = (rr >> 1) * 64, rd_x = ((rr >> 1) & 3) << 2;
-  const unsigned half_sel = (rr & 1) ? 0x07060302u : 0x05040100u;      // v_perm_b32: the high / low bf16 of two dwords
-  auto pack2 = [](float a, float b) -> unsigned { return __builtin_bit_cast(unsigned, bf16x2{(bf16_t)a, (bf16_t)b}); };
+  // float offset of the bias of registers [j][0..3] inside the wave's 64 columns
+  auto boff = [&](int j) __attribute__((always_inline)) -> int {
+    return SWIGLU ? 32 * (fg >> 1) + 16 * (j & 1) + 8 * (fg & 1) + 4 * (j >> 1) : fg * 16 + j * 4;
+  };
 
   int se = 0;                                   // S if the previous tile of this workgroup issued exactly S stores per wave, else 0
   for (;;) {
@@ -276,24 +289,11 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
 
     // ---- tile boundary
     if (!has_next) wait_vm<0>();                // the dummy DMAs of the last phases land in this wave's patch
-    if (!late) PP_BARRIER();                    // waves 0-3 wait for the last quadrant of waves 4-7: both groups run the epilogue together
+    if (kSyncEpi && !late) PP_BARRIER();        // waves 0-3 wait for the last quadrant of waves 4-7: both groups run the epilogue together
     PP_FENCE();
 
     const bool full = m0 + 256 <= p.M && n0 + 256 <= p.N && c_vec;
-    // bias of the lane's 2 x 4 columns (C layout), from the LDS copy the last k-tile's DMA made (RES: from global memory)
-    float cb[2][4];
-#pragma unroll
-    for (int nh = 0; nh < 2; ++nh)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (RES) {
-          const int n = n0 + nh * 128 + Cw * 64 + j * 16 + frow;
-          cb[nh][j] = (p.col_bias && n < p.N) ? p.col_bias[n] : 0.f;
-        } else {
-          cb[nh][j] = p.col_bias ? sbias[nh * 64 + j * 16 + frow] : 0.f;
-        }
-      }
-    // RES: the residual row segments of the wave's eight slabs (row layout: a lane's 16 columns of row rr), raw bf16, requested up front
+    // RES: the residual row segments of the wave's eight slabs (a lane's 16 columns of row frow), raw bf16, requested up front
     Chunk16 rsd[RES ? 2 : 1][RES ? 2 : 1][RES ? 2 : 1][2];
     if constexpr (RES) {
       const T* Rp = reinterpret_cast<const T*>(p.residual);
@@ -304,8 +304,8 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
         for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            const int m = m0 + mh * 128 + R * 32 + i * 16 + rr;
-            const int nb = n0 + nh * 128 + Cw * 64 + (lane & 3) * 16;
+            const int m = m0 + mh * 128 + R * 32 + i * 16 + frow;
+            const int nb = n0 + nh * 128 + Cw * 64 + fg * 16;
             if (m < p.M && nb + 16 <= p.N && r_vec) {
               rsd[mh][nh][i][0] = *reinterpret_cast<const Chunk16*>(Rp + (int64_t)m * p.ldr + nb);
               rsd[mh][nh][i][1] = *reinterpret_cast<const Chunk16*>(Rp + (int64_t)m * p.ldr + nb + 8);
@@ -319,123 +319,87 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
           }
     }
     auto epi = [&](f32x4 (&cq)[2][4], int mh, int nh) __attribute__((always_inline)) {
-      if constexpr (RES) {
-        float* swf = reinterpret_cast<float*>(sw);          // fp32 patch: element (row, col) at row*64 + (col ^ ((row & 3) << 2))
+      // bias of the lane's registers [j][r], from the LDS copy the last k-tile's DMA made (RES: from global memory)
+      float cb[4][4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+      for (int j = 0; j < 4; ++j) {
+        if (RES) {
+          const int n = n0 + nh * 128 + Cw * 64 + boff(j);
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+          for (int r = 0; r < 4; ++r) cb[j][r] = (p.col_bias && n + r < p.N) ? p.col_bias[n + r] : 0.f;
+        } else if (p.col_bias) {
+          const f32x4 t4 = *reinterpret_cast<const f32x4*>(sbias + nh * 64 + boff(j));
+          cb[j][0] = t4[0]; cb[j][1] = t4[1]; cb[j][2] = t4[2]; cb[j][3] = t4[3];
+        } else {
+          cb[j][0] = cb[j][1] = cb[j][2] = cb[j][3] = 0.f;
+        }
+        // specialised forms, no residual: gemm2.hip / gemm3.hip compute (acc + bias) + 0.f (the `+ 0.f` turns -0 into +0); acc + (bias + 0.f)
+        // has the same bits for every input -- the sum can only be -0 when BOTH addends are, and bias + 0.f never is -- at one add per
+        // element instead of two
+        if constexpr (kSpec && !RES) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) swf[((fg * 4 + r) * 64 + j * 16 + frow) ^ (r << 2)] = fmaf(cq[i][j][r], 1.f, cb[nh][j]);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          const int c0 = (lane & 3) * 16;
-          float y[16], res[16];
+          for (int r = 0; r < 4; ++r) cb[j][r] += 0.f;
+        }
+      }
 #pragma unroll
-          for (int e = 0; e < 16; e += 4) {
-            f32x4 t4 = *reinterpret_cast<const f32x4*>(swf + ((rr * 64 + c0 + e) ^ ((rr & 3) << 2)));
-            y[e] = t4[0]; y[e + 1] = t4[1]; y[e + 2] = t4[2]; y[e + 3] = t4[3];
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int i = 0; i < 2; ++i) {
+        const int m = m0 + mh * 128 + R * 32 + i * 16 + frow;
+        float res[16];
+        if constexpr (RES) {
           chunk_to_f32<T>(rsd[mh][nh][i][0], res);
           chunk_to_f32<T>(rsd[mh][nh][i][1], res + 8);
-          // gemm2.hip / gemm3.hip expression for expression (y already is fmaf(acc, 1, bias))
+        }
 #pragma unroll
-          for (int e4 = 0; e4 < 16; e4 += 4) {
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (kSpec) {
+            // ACT is a compile-time constant (no activation, or GELU without a residual): the generic form below with its run-time
+            // selections folded away -- ~6 VALU instructions per element down to 1 (+ the activation)
             float v[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              v[q] = y[e4 + q];
-              if (!p.res_after_act) v[q] += res[e4 + q];
+            for (int r = 0; r < 4; ++r) {
+              v[r] = cq[i][j][r] + cb[j][r];
+              if constexpr (RES) v[r] += res[j * 4 + r];
             }
-            switch (p.act) {
+            if constexpr (ACT == ACT_GELU) gelu_act4<T>(v);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cq[i][j][r] = v[r];
+          } else {
+            // per-element arithmetic: gemm2.hip / gemm3.hip expression for expression with col_scale = 1 (without a residual the `+ 0.f`
+            // is theirs too)
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = fmaf(cq[i][j][r], 1.f, cb[j][r]);
+              if (!p.res_after_act) v[r] += RES ? res[j * 4 + r] : 0.f;
+            }
+            switch (p.act) {                      // one uniform branch per four elements
               case ACT_GELU:
                 gelu_act4<T>(v);
                 break;
               case ACT_RELU:
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                 break;
               case ACT_SILU:
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
+                for (int r = 0; r < 4; ++r) v[r] = silu(v[r]);
                 break;
               default: break;
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) y[e4 + q] = p.res_after_act ? v[q] + res[e4 + q] : v[q];
-          }
-          const int m = m0 + mh * 128 + R * 32 + i * 16 + rr;
-          const int nb = n0 + nh * 128 + Cw * 64 + c0;
-          T* Ct = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + nb;
-          if (full) {
-            *reinterpret_cast<Chunk16*>(Ct) = chunk_from_f32<T>(y);
-            *reinterpret_cast<Chunk16*>(Ct + 8) = chunk_from_f32<T>(y + 8);
-          } else if (m < p.M && nb < p.N) {
-            if (c_vec && nb + 16 <= p.N) {
-              *reinterpret_cast<Chunk16*>(Ct) = chunk_from_f32<T>(y);
-              *reinterpret_cast<Chunk16*>(Ct + 8) = chunk_from_f32<T>(y + 8);
-            } else {
-#pragma unroll
-              for (int e = 0; e < 16; ++e) if (nb + e < p.N) Ct[e] = from_f32<T>(y[e]);
-            }
+            for (int r = 0; r < 4; ++r) cq[i][j][r] = p.res_after_act ? v[r] + (RES ? res[j * 4 + r] : 0.f) : v[r];
           }
         }
-        return;
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        // per-element arithmetic: gemm2.hip / gemm3.hip expression for expression with col_scale = 1 and a zero residual (the `+ 0.f` is
-        // theirs too: it turns -0 into +0)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[r] = fmaf(cq[i][j][r], 1.f, cb[nh][j]);
-            if (!p.res_after_act) v[r] += 0.f;
-          }
-          switch (p.act) {                      // one uniform branch per four elements
-            case ACT_GELU:
-              gelu_act4<T>(v);
-              break;
-            case ACT_RELU:
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-              break;
-            case ACT_SILU:
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = silu(v[r]);
-              break;
-            default: break;
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) cq[i][j][r] = p.res_after_act ? v[r] + 0.f : v[r];
-        }
-        const int m = m0 + mh * 128 + R * 32 + i * 16 + rr;
         if (SWIGLU) {
-          // gate / up weight rows are interleaved in blocks of 16: n-tiles 0, 2 hold gate columns, 1, 3 the matching up columns -- in the C
-          // layout both sit in the same lane.  Both are rounded to T first (what the unfused GEMM -> swiglu_kernel sequence reads back).
+          // gate / up weight rows are interleaved in blocks of 16; the DMA permutation put gate (j even) and up (j odd) of the lane's 8 output
+          // columns into the same lane.  Both are rounded to T first (what the unfused GEMM -> swiglu_kernel sequence reads back).
+          float o[8];
 #pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            float o[4];
+          for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = silu(to_f32(from_f32<T>(cq[i][2 * jj][r]))) * to_f32(from_f32<T>(cq[i][2 * jj + 1][r]));
-#pragma unroll
-            for (int h = 0; h < 2; ++h) sw[wr_pair[h] + jj * 16] = pack2(o[2 * h], o[2 * h + 1]);
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          const int c0 = (lane & 3) * 8;          // 8 of the slab's 32 output columns
-          u32x4 d[2];
-#pragma unroll
-          for (int e = 0; e < 2; ++e) d[e] = *reinterpret_cast<const u32x4*>(sw + ((rd_pair + c0 + 4 * e) ^ rd_x));
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          Chunk16 out;
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            out.v[2 * e] = __builtin_amdgcn_perm(d[e][1], d[e][0], half_sel);
-            out.v[2 * e + 1] = __builtin_amdgcn_perm(d[e][3], d[e][2], half_sel);
-          }
-          const int nb = ((n0 + nh * 128 + Cw * 64) >> 1) + c0;     // output column (N / 2 columns in all)
+            for (int r = 0; r < 4; ++r) o[jj * 4 + r] = silu(to_f32(from_f32<T>(cq[i][2 * jj][r]))) * to_f32(from_f32<T>(cq[i][2 * jj + 1][r]));
+          const Chunk16 out = chunk_from_f32<T>(o);
+          const int nb = ((n0 + nh * 128 + Cw * 64) >> 1) + fg * 8;     // output column (N / 2 columns in all)
           T* Ct = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + nb;
           if (full) {
             *reinterpret_cast<Chunk16*>(Ct) = out;
@@ -448,40 +412,30 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
             }
           }
         } else {
+          float y[16];
 #pragma unroll
           for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) sw[wr_pair[h] + j * 16] = pack2(cq[i][j][2 * h], cq[i][j][2 * h + 1]);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          const int c0 = (lane & 3) * 16;
-          u32x4 d[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) d[e] = *reinterpret_cast<const u32x4*>(sw + ((rd_pair + c0 + 4 * e) ^ rd_x));
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          Chunk16 out[2];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            out[e >> 1].v[2 * (e & 1)] = __builtin_amdgcn_perm(d[e][1], d[e][0], half_sel);
-            out[e >> 1].v[2 * (e & 1) + 1] = __builtin_amdgcn_perm(d[e][3], d[e][2], half_sel);
-          }
-          const int nb = n0 + nh * 128 + Cw * 64 + c0;          // first of this lane's 16 columns
+            for (int r = 0; r < 4; ++r) y[j * 4 + r] = cq[i][j][r];
+          const Chunk16 out0 = chunk_from_f32<T>(y), out1 = chunk_from_f32<T>(y + 8);
+          const int nb = n0 + nh * 128 + Cw * 64 + fg * 16;          // first of this lane's 16 columns
           T* Ct = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + nb;
           if (full) {
-            *reinterpret_cast<Chunk16*>(Ct) = out[0];
-            *reinterpret_cast<Chunk16*>(Ct + 8) = out[1];
+            *reinterpret_cast<Chunk16*>(Ct) = out0;
+            *reinterpret_cast<Chunk16*>(Ct + 8) = out1;
           } else if (m < p.M && nb < p.N) {
             if (c_vec && nb + 16 <= p.N) {
-              *reinterpret_cast<Chunk16*>(Ct) = out[0];
-              *reinterpret_cast<Chunk16*>(Ct + 8) = out[1];
+              *reinterpret_cast<Chunk16*>(Ct) = out0;
+              *reinterpret_cast<Chunk16*>(Ct + 8) = out1;
             } else {
 #pragma unroll
-              for (int e = 0; e < 16; ++e) if (nb + e < p.N) Ct[e] = __builtin_bit_cast(bf16x8, out[e >> 3].v)[e & 7];
+              for (int e = 0; e < 16; ++e) if (nb + e < p.N) Ct[e] = from_f32<T>(y[e]);
             }
           }
         }
       }
     };
-    epi(acc[0][0], 0, 0); epi(acc[0][1], 0, 1); epi(acc[1][0], 1, 0); epi(acc[1][1], 1, 1);
+    epi(acc[0][0], 0, 0); epi(acc[1][0], 1, 0); epi(acc[1][1], 1, 1); epi(acc[0][1], 0, 1);
     PP_FENCE();
 
     if (!has_next) break;
@@ -490,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
     m0 = m0n; n0 = n0n;
     ++round;
     has_next = tile_at(round + 1, m0n, n0n);
-    if (late) PP_BARRIER();                     // re-stagger: waves 4-7 fall one barrier behind again
+    if (kSyncEpi && late) PP_BARRIER();         // re-stagger: waves 4-7 fall one barrier behind again
   }
 }
 
@@ -547,8 +501,14 @@ int launch_gemm_8pp(const GemmArgs& a, hipStream_t st, int grid) {
     OAVSR_CHECK_HIP(hipGetLastError());
     return 0;
   };
-  if (a.residual) return go(gemm_8pp_kernel<false, true>);
-  return a.swiglu_pairs ? go(gemm_8pp_kernel<true, false>) : go(gemm_8pp_kernel<false, false>);
+  // epilogue specialisations (same bits as the generic form, see the kernel): no activation -- whatever res_after_act says, there is
+  // nothing to order --, and GELU without a residual (fc1)
+  const bool none = a.act == ACT_NONE;
+  if (a.residual) return none ? go(gemm_8pp_kernel<false, true, ACT_NONE>) : go(gemm_8pp_kernel<false, true, -1>);
+  if (a.swiglu_pairs) return none ? go(gemm_8pp_kernel<true, false, ACT_NONE>) : go(gemm_8pp_kernel<true, false, -1>);
+  if (none) return go(gemm_8pp_kernel<false, false, ACT_NONE>);
+  if (a.act == ACT_GELU && !a.res_after_act) return go(gemm_8pp_kernel<false, false, ACT_GELU>);
+  return go(gemm_8pp_kernel<false, false, -1>);
 }
 
 }  // namespace oavsr

@@ -545,8 +545,10 @@ __global__ __launch_bounds__(kThreads) void digest_kernel(const unsigned* __rest
   const long long r0 = cu ? cu[b] : b, r1 = cu ? cu[b + 1] : b + 1;
   const unsigned* p = base + r0 * words_per_row;
   const long long n = (r1 - r0) * words_per_row;
+  // blockIdx.y owns one contiguous share of the utterance's words; the shares meet in an integer atomic add (any order: same value)
+  const long long per = (n + gridDim.y - 1) / gridDim.y, i0 = blockIdx.y * per, i1 = i0 + per < n ? i0 + per : n;
   unsigned long long acc = 0;
-  for (long long i = threadIdx.x; i < n; i += kThreads) acc += mix64((unsigned long long)p[i] | ((unsigned long long)(i + 1) << 32));
+  for (long long i = i0 + threadIdx.x; i < i1; i += kThreads) acc += mix64((unsigned long long)p[i] | ((unsigned long long)(i + 1) << 32));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const unsigned lo = __shfl_xor((unsigned)acc, o, 64), hi = __shfl_xor((unsigned)(acc >> 32), o, 64);
@@ -557,7 +559,7 @@ __global__ __launch_bounds__(kThreads) void digest_kernel(const unsigned* __rest
   if (threadIdx.x == 0) {
     unsigned long long t = 0;
     for (int w = 0; w < kWavesPerBlock; ++w) t += part[w];
-    out[(long long)b * out_stride + out_col] = t;
+    atomicAdd(out + (long long)b * out_stride + out_col, t);
   }
 }
 
@@ -748,7 +750,9 @@ int launch_greedy_update(const int* amax, GreedyState s, int B, int max_new, int
 
 int launch_digest(const void* base, const int* cu, int64_t words_per_row, int n_utts, uint64_t* out, int out_stride, int out_col, hipStream_t st) {
   if (n_utts <= 0) return 0;
-  hipLaunchKernelGGL(digest_kernel, dim3(n_utts), dim3(kThreads), 0, st, (const unsigned*)base, cu, (long long)words_per_row, (unsigned long long*)out, out_stride, out_col);
+  // the utterances' slots of this column start from zero (a strided 8-byte clear), then 64 shares per utterance add into them
+  OAVSR_CHECK_HIP(hipMemset2DAsync(out + out_col, (size_t)out_stride * 8, 0, 8, (size_t)n_utts, st));
+  hipLaunchKernelGGL(digest_kernel, dim3(n_utts, 64), dim3(kThreads), 0, st, (const unsigned*)base, cu, (long long)words_per_row, (unsigned long long*)out, out_stride, out_col);
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -16,6 +16,8 @@ from gpu_util import gemm, DEV  # noqa: E402
 SHAPES = {"qkv": (12000, 3072, 1024, 0, 0, 0), "fc1": (12000, 4096, 1024, 1, 0, 0), "gateup": (2504, 16384, 2048, 0, 1, 0), "fc2+res": (12000, 1024, 4096, 0, 0, 1),
           "o+res": (12000, 1024, 1024, 0, 0, 1), "sq4k": (4096, 4096, 4096, 0, 0, 0), "sq8k": (8192, 8192, 8192, 0, 0, 0)}
 VARIANTS = {0: "shipped", 1: "no global stores", 2: "no epilogue", 4: "stores waited for"}
+if os.environ.get("PROBE_SET") == "2":       # build_ab/csrc_epi2: the register-only epilogue (weights as the A operand, permuted weight rows)
+    VARIANTS = {0: "shipped", 1: "no global stores", 2: "unpermuted W rows", 3: "both", 4: "stores waited for"}
 
 
 def main():
