@@ -54,3 +54,21 @@ def test_gather_reports_failed_utterances_instead_of_asserting():
 def test_whisper_keep_clamps_at_the_encoder_length():
     assert whisper_keep_tokens(480000) == 1500 and whisper_keep_tokens(600000) == 1500 and whisper_keep_tokens(16000) == 50
     assert whisper_keep_tokens(100) == 25
+
+
+def test_rank_pinning_gives_each_local_rank_its_own_cpus():
+    """bench.py: pin_rank (multi-GPU runs pin every rank before it touches the GPU).  In a child process each -- the affinity sticks to the caller."""
+    code = ("import json, os, sys; sys.path.insert(0, %r); import bench; r = bench.pin_rank(int(sys.argv[1]), 2); "
+            "print(json.dumps({'ret': r, 'aff': sorted(os.sched_getaffinity(0))}))") % ROOT
+    before = sorted(os.sched_getaffinity(0))
+    outs = []
+    for local in (0, 1):
+        p = subprocess.run([sys.executable, "-c", code, str(local)], capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    for o in outs:
+        assert o["ret"] is not None and o["ret"]["cpus"] == len(o["aff"]) >= 1
+        assert set(o["aff"]) <= set(before)
+    if len(before) >= 2:                       # without NUMA information about GPUs (this container): disjoint even slices
+        assert not (set(outs[0]["aff"]) & set(outs[1]["aff"]))
+    assert sorted(os.sched_getaffinity(0)) == before
