@@ -225,6 +225,7 @@ typedef struct oavsr_prof_entry {
   double ms;    /* summed HIP-event duration */
   double flops; /* algorithmic flops (2*M*N*K) */
   double bytes; /* algorithmic bytes */
+  double cu_ms; /* sum of duration x the fraction of the chip's CUs the launch can occupy (GEMMs: by the dispatcher's tile; others: 1): its CU-time */
 } oavsr_prof_entry;
 int oavsr_profile_enable(int32_t on); /* on=1: bracket launches with events (serialises the stream); 0: off */
 int oavsr_profile_reset(void);
@@ -250,7 +251,7 @@ typedef struct oavsr_gemm_desc {
   int32_t taps, Kvalid;
   const int32_t* frameinfo; /* int2 per frame */
   int32_t kernel;           /* kernel selector: 0 dispatcher's choice; parity tests only: 2 ping-pong 256 x 256, 3 persistent ping-pong,
-                               5 16-wave 256 x 256, 6 160 x 128, 7 256 x 128 */
+                               5 16-wave 256 x 256, 7 256 x 128, 8 persistent ping-pong with 192-row tiles */
   int32_t swiglu_pairs;     /* fused SwiGLU epilogue (gate / up weight rows interleaved by 16) */
   int32_t decode_tiled;     /* 1: decode-shaped launch (M <= 128): the 128-row LDS-DMA tiles at any row count */
   /* decode-shaped launches (M <= 128): split-K with fp32 partial slabs [ksplit][M][N], summed in slab order -- by the tile's last-arriving

@@ -4,7 +4,7 @@
 // but built around LDS-DMA (`global_load_lds_dwordx4`): tiles go HBM -> LDS without touching VGPRs, one raw `s_barrier` per
 // k-tile, counted `s_waitcnt vmcnt(N)` where more than one k-tile is in flight.  Wave tile 64 x 64 (4 x 4 MFMA 16x16) throughout;
 // tile shapes (launch_dma_mode): 256 x 256 / 16 waves / 2 stages (the workhorse), 256 x 128 / 8 waves / 3 stages (mid-size grids,
-// conv gathers, split-K), 160 x 128 / 4 waves of 80 x 64 / 4 stages (one ragged round), 128 x 64, 128 x 128 and 128 x 256 / 4-8 waves (<= 128 rows: beam-search decode; small GEMMs).
+// conv gathers, split-K), 128 x 64, 128 x 128 and 128 x 256 / 4-8 waves (<= 128 rows: beam-search decode; small GEMMs).
 //   * the DMA writes LDS linearly (wave-uniform base + lane*16), so the XOR swizzle that makes the ds_read_b128 fragment
 //     reads conflict-free is applied to the per-lane SOURCE address (chunk ^ (row & 7)) and again on the read
 //   * out-of-range rows / conv padding read a 16-byte zero page instead of branching
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
     const char* sB = sA + BM * kRowBytes;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      constexpr int TMH = (TM > 4 && TM % 4 == 0) ? 4 : TM;      // A fragments are consumed in groups of 4 row tiles (register budget); 5 row tiles (the 160-row tiles) in one go
+      constexpr int TMH = (TM > 4 && TM % 4 == 0) ? 4 : TM;      // A fragments are consumed in groups of 4 row tiles (register budget)
       Chunk16 bf[TN];
       const int chunk = kb * 4 + fg;
 #pragma unroll
@@ -704,30 +704,25 @@ static int dma_tile_choice(const GemmArgs& a) {
   if (a.amode == A_STEM || a.N < 128) return 0;
   const int64_t n128 = (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 128) * a.groups;
   const int64_t n256 = (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 256) * a.groups;
-  // measured on MI355X (tools/bench_kernels.py): the 256x256 tile wins as soon as ~60 % of the CUs get a tile.  (256 x 192 / 192 x 256
-  // tiles against the ragged last round were built in round 1 and dropped in round 4: alone on the chip they won 10 %, with several
-  // calls in flight they cost 2 % -- the persistent kernel now takes the multi-round shapes anyway.)
-  if (a.amode == A_DENSE && a.N >= 256 && n256 >= 144) return 2;
+  // The 256 x 256 tile (persistent ping-pong kernel where its forms exist) from 64 tiles on.  Alone on the chip it wins only once ~60 % of
+  // the CUs get a tile (144; tools/bench_kernels.py) -- the LLM prefill's o_proj / down_proj (80 tiles) and QKV (120) finish sooner on finer
+  // tiles that cover more CUs -- but the pipelined job is bound by CU-TIME, not by any one launch's latency: the CUs a coarse launch leaves
+  // free run the other calls' kernels and the decode steps, and the 8-wave 256 x 256 tile does the most work per CU-microsecond.  Same box,
+  // alternating runs (round 5): threshold 144 with round 4's 160 x 128 tile (4 waves of 80 x 64) for the 80-tile launches 319.2 utt/s, 144 without that tile 323.3,
+  // **64: 326.7** -- while the "MFMA side, one call at a time" got 0.8 ms per call WORSE; 48 / 24 / 12 (AV-HuBERT's 52-tile o_proj / fc2 on
+  // 52 CUs as well): 332.6 / 332.9 / 333.3 against 335.3 for 64 on a second box -- there the launch is too long a link in its call's chain.
+  // The 160 x 128 tile is gone with its last caller.
+  // (256 x 192 / 192 x 256 tiles against the ragged last round were built in round 1 and dropped in round 4 for the same reason: alone
+  // they won 10 %, with several calls in flight they cost 2 %; round 5's 192-row form of the persistent kernel repeated the lesson.)
+  if (a.amode == A_DENSE && a.N >= 256 && n256 >= 64) return 2;
   if (n128 >= 144) return 1;
   return 0;
-}
-
-// One round of 256 x 128 tiles that leaves CUs idle (the LLM prefill's o_proj / down_proj, 2504 x 2048: 160 workgroups on 256 CUs): when
-// 160 x 128 tiles (4 waves of 80 x 64, 4 LDS stages = 144 KiB) still fit ONE round, the busiest CU owns 160 rows instead of 256 --
-// down_proj (K = 8192) 126 -> 110 us, o_proj 37.7 -> 35.4 us (tools/gemm_pp_bench.py; the 4-wave tile runs at 0.7 of the 8-wave tile's
-// per-CU rate, so it only pays where it adds CUs).  Same k order, same epilogue: same bits.
-static bool tile160_rule(const GemmArgs& a) {
-  if (a.amode != A_DENSE || a.groups != 1 || a.ksplit > 1 || a.swiglu_pairs || dma_tile_choice(a) != 1) return false;
-  static const int ncu = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
-  const int64_t w256 = (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 128), w160 = (int64_t)ceil_div(a.M, 160) * ceil_div(a.N, 128);
-  return w256 <= ncu && w160 <= ncu && w160 > w256;
 }
 
 template <typename T>
 int launch_dma_mode(const GemmArgs& a, hipStream_t st) {
   // 256x256: 16 waves (4 x 4) of 64 x 64, 2 stages; dense only.  256x128: 8 waves (4 x 2) of 64 x 64, 3 stages.
   if (a.force_tile == 2 && a.amode == A_DENSE && a.groups == 1 && a.ksplit <= 1 && a.N >= 256) return launch_dma<T, A_DENSE, 256, 256, 2, 4, 16>(a, st);
-  if (a.force_tile == 5 && a.amode == A_DENSE && a.groups == 1 && a.ksplit <= 1) return launch_dma<T, A_DENSE, 160, 128, 4, 2, 4>(a, st);
   if (a.force_tile == 8 && a.amode == A_DENSE && a.groups == 1 && a.ksplit <= 1) return launch_dma<T, A_DENSE, 256, 128, 3, 4, 8>(a, st);
   if (dma_tile_choice(a) == 2) {
     if (gemm_8pp_eligible(a)) return launch_gemm_8pp(a, st);      // more tiles than CUs: persistent ping-pong kernel (gemm4.hip), bf16
@@ -745,7 +740,6 @@ int launch_dma_mode(const GemmArgs& a, hipStream_t st) {
     return launch_dma<T, A_DENSE, 128, 64, 3, 4, 4>(a, st);
   }
   if (dma_tile_choice(a) == 5) return launch_dma<T, A_CONV1D, 128, 64, 3, 4, 4>(a, st);
-  if (tile160_rule(a)) return launch_dma<T, A_DENSE, 160, 128, 4, 2, 4>(a, st);
   switch (a.amode) {
     case A_DENSE: return launch_dma<T, A_DENSE, 256, 128, 3, 4, 8>(a, st);
     case A_CONV2D: return launch_dma<T, A_CONV2D, 256, 128, 3, 4, 8>(a, st);
@@ -769,8 +763,31 @@ const char* gemm_dma_variant(const GemmArgs& a) {
   if (c == 4 || c == 5) return a.ksplit > 1 ? "dma_splitk_128x64" : "dma_128x64";
   if (c == 2 && gemm_8pp_eligible(a)) return "8pp_256x256";
   if (c == 2 && gemm_8p_eligible(a)) return "8p_256x256";
-  if (tile160_rule(a)) return "dma_160x128";
   return a.ksplit > 1 ? "dma_splitk_256x128" : c == 2 ? "dma_256x256" : "dma_256x128";
+}
+
+// Fraction of the chip's CUs a launch can occupy (profiling only: duration x share = the launch's CU-time, what a pipelined job pays for
+// it while other calls' kernels run on the rest): workgroups / (workgroups that fit a CU x CUs), by the tile the dispatcher will pick.
+double gemm_cu_share(const GemmArgs& a) {
+  static const int ncu = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
+  const int c = dma_tile_choice(a);
+  const int g = a.groups < 1 ? 1 : a.groups, ks = a.ksplit < 1 ? 1 : a.ksplit;
+  double wgs = 0, per_cu = 1;
+  if (c == 2) {
+    const int64_t n256 = (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 256);
+    wgs = gemm_8pp_eligible(a) ? (double)gemm_8pp_grid(n256) : (double)n256;
+  } else if (c == 4 || c == 5) {
+    const int bn = (c == 4 && ks <= 1 && a.N >= 256 * 256) ? 256 : (c == 4 && ks <= 1 && a.N >= 256 * 128) ? 128 : 64;
+    wgs = (double)ceil_div(a.M, 128) * ceil_div(a.N, bn) * ks * g;
+    per_cu = bn == 64 ? 2 : 1;
+  } else if (c == 1) {
+    wgs = (double)ceil_div(a.M, 256) * ceil_div(a.N, 128) * g;
+  } else {
+    wgs = (double)ceil_div(a.M, 128) * ceil_div(a.N, 128) * g;      // classic kernel: 128 x 128 tiles, four waves
+    per_cu = 2;
+  }
+  const double share = wgs / (per_cu * ncu);
+  return share > 1.0 ? 1.0 : share;
 }
 
 int launch_gemm_dma(const GemmArgs& a, hipStream_t st) {

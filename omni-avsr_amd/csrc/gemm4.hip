@@ -55,12 +55,20 @@ constexpr bool kSyncEpi = true;
 // residual rows of the tile requested before the first store (ordinary loads: the compiler waits for everything in flight at their first
 // use, which costs nothing in the single-round launches this variant serves).  ACT: -1 = generic epilogue (run-time activation /
 // residual order), ACT_NONE / ACT_GELU = the specialised forms the launcher picks when they apply (same bits).
-template <bool SWIGLU, bool RES, int ACT>
+// BM: rows of a tile, 256 or 192.  The 192-row form keeps the whole schedule -- eight waves, four phases per k-tile, the same half-tiles of
+// W -- and shortens the SECOND half-tile of A to 64 rows (one DMA piece per wave instead of two; a wave's quadrants over it are 16 x 64 instead
+// of 32 x 64: 8 MFMAs instead of 16 in phases p1 / p2), so a k-tile is 48 MFMAs per wave instead of 64 and every counted wait sees 7 instead of
+// 8 younger operations.  It exists for launches whose 256-row tiles leave CUs idle (Whisper fc2 / o_proj: 188 tiles -> 252); same bits.
+template <bool SWIGLU, bool RES, int ACT, int BM = 256>
 __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, const int ntiles) {
   typedef bf16_t T;
   constexpr int BKE = 64, VEC = 8;
   constexpr bool kSpec = ACT >= 0;              // epilogue specialised for a compile-time activation (launcher: ACT_NONE, or ACT_GELU without a residual)
-  constexpr int S = SWIGLU ? 8 : 16;            // store instructions a wave issues for one FULL tile: 8 slabs x 2 (SwiGLU: 8 slabs x 1)
+  static_assert(BM == 256 || BM == 192, "tile rows");
+  constexpr int M1 = BM == 256 ? 2 : 1;          // 16-row m-tiles of a wave in the quadrants over the second A half-tile
+  constexpr int NSLAB = 2 * (2 + M1);            // 16-row slabs a wave stores per tile
+  constexpr int S = SWIGLU ? NSLAB : 2 * NSLAB;  // store instructions a wave issues for one FULL tile: 2 per slab (SwiGLU: 1)
+  constexpr int kW = BM == 256 ? 8 : 7;          // vector-memory operations of the four half-tile issues younger than the one a phase waits for
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int R = wave >> 1, Cw = wave & 1;
@@ -68,7 +76,7 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
 
   // ---- tile list of this workgroup.  Workgroups are dealt round-robin over the 8 XCDs (private L2s): in every round the workgroups of
   //      one XCD hold a CONTIGUOUS range of logical tiles (gridDim.x is a multiple of 8; the last, partial round is dealt bijectively).
-  const int ntn = (p.N + 255) / 256, ntm = (p.M + 255) / 256;
+  const int ntn = (p.N + 255) / 256, ntm = (p.M + BM - 1) / BM;
   const int G = gridDim.x, xcd = blockIdx.x & 7, wi = blockIdx.x >> 3;
   const bool nmajor = p.M < p.N;
   auto tile_at = [&](int round, int& m0o, int& n0o) -> bool {
@@ -85,7 +93,7 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
     const int L = base + pos;
     int mt = nmajor ? L % ntm : L / ntn, nt = nmajor ? L / ntm : L - (L / ntn) * ntn;
     if (p.tile_order == 1) blocked_tile(L, ntm, ntn, mt, nt);
-    m0o = mt * 256; n0o = nt * 256;
+    m0o = mt * BM; n0o = nt * 256;
     return true;
   };
   int m0 = 0, n0 = 0, m0n = 0, n0n = 0;
@@ -126,7 +134,7 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
     constexpr int h = decltype(hc)::value;
     if (h < 2) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void*)dst0, 16, avo, soff, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void*)dst1, 16, avo, soff + a64, 0, 0);
+      if (h == 0 || BM == 256) __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void*)dst1, 16, avo, soff + a64, 0, 0);
     } else {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)dst0, 16, wvo, soff, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)dst1, 16, wvo, soff + w64, 0, 0);
@@ -172,14 +180,16 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
   const int frow = lane & 15, fg = lane >> 4;
   const int sw0 = ((fg ^ (frow & 7)) << 4), sw1 = (((4 + fg) ^ (frow & 7)) << 4);
   const int a_off = (R * 32 + frow) * 128, b_off = 2 * kHalf4 + (Cw * 64 + frow) * 128;
+  const int a_off1 = BM == 256 ? a_off : (R * 16 + frow) * 128;      // second A half-tile: 16 rows per wave in the 192-row form
 
   f32x4 acc[2][2][2][4];                        // [mh][nh][m-tile][n-tile]
   Chunk16 af0[2][2], af1[2][2], bf[4][2];
-  auto load_a = [&](const char* buf, int mh, Chunk16 (&af)[2][2]) __attribute__((always_inline)) {
+  auto load_a = [&](const char* buf, auto mhc, Chunk16 (&af)[2][2]) __attribute__((always_inline)) {
+    constexpr int mh = decltype(mhc)::value;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      af[i][0] = *reinterpret_cast<const Chunk16*>(buf + mh * kHalf4 + a_off + i * 2048 + sw0);
-      af[i][1] = *reinterpret_cast<const Chunk16*>(buf + mh * kHalf4 + a_off + i * 2048 + sw1);
+    for (int i = 0; i < (mh ? M1 : 2); ++i) {
+      af[i][0] = *reinterpret_cast<const Chunk16*>(buf + mh * kHalf4 + (mh ? a_off1 : a_off) + i * 2048 + sw0);
+      af[i][1] = *reinterpret_cast<const Chunk16*>(buf + mh * kHalf4 + (mh ? a_off1 : a_off) + i * 2048 + sw1);
     }
   };
   auto load_b = [&](const char* buf, int nh) __attribute__((always_inline)) {
@@ -189,12 +199,13 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
       bf[j][1] = *reinterpret_cast<const Chunk16*>(buf + nh * kHalf4 + b_off + j * 2048 + sw1);
     }
   };
-  auto quad = [&](f32x4 (&c)[2][4], const Chunk16 (&af)[2][2]) __attribute__((always_inline)) {
+  auto quad = [&](f32x4 (&c)[2][4], const Chunk16 (&af)[2][2], auto mic) __attribute__((always_inline)) {
+    constexpr int MI = decltype(mic)::value;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) mma4(bf[j][kb], af[i][kb], c[i][j]);      // weights = A operand: D rows = weight rows
     __builtin_amdgcn_s_setprio(0);
@@ -204,7 +215,9 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
     constexpr int C = decltype(cc)::value;
     if (se) wait_vm<S + C>(); else wait_vm<C>();
   };
-  const std::integral_constant<int, 8> c8;
+  const std::integral_constant<int, kW> c8;
+  const std::integral_constant<int, 0> kMh0; const std::integral_constant<int, 1> kMh1;
+  const std::integral_constant<int, 2> kMi2; const std::integral_constant<int, M1> kMi1;
 
   // One k-tile = four phases (gemm3.hip).  KT 0: steady state.  KT 1: first k-tile of a tile -- the queue still holds the previous tile's
   // stores behind the four half-tiles issued before them, so the counts are larger.  KT 3 / 4: second-to-last / last k-tile -- the
@@ -214,39 +227,39 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
     constexpr int KT = decltype(ktc)::value;
     const char* buf = smem + ((t + par) & 1) * kBuf4;
     // p0
-    load_a(buf, 0, af0);
+    load_a(buf, kMh0, af0);
     load_b(buf, 0);
     if (KT == 4 && !RES) issue_bias();
     if (KT == 4) issue_next(kA1, 0);
     else issue(kA1, t + 1);
-    if (KT == 1) wait_se(c8, se); else wait_vm<8>();
+    if (KT == 1) wait_se(c8, se); else wait_vm<kW>();
     PP_BARRIER();
-    quad(acc[0][0], af0);
+    quad(acc[0][0], af0, kMi2);
     PP_BARRIER();
     // p1
-    load_a(buf, 1, af1);
+    load_a(buf, kMh1, af1);
     if (KT == 4) issue_next(kB1, 0);
     else issue(kB1, t + 1);
-    if (KT == 1) wait_se(c8, se); else wait_vm<8>();
+    if (KT == 1) wait_se(c8, se); else wait_vm<kW>();
     PP_BARRIER();
-    quad(acc[1][0], af1);
+    quad(acc[1][0], af1, kMi1);
     PP_BARRIER();
     // p2
     load_b(buf, 1);
     if (KT == 3) issue_next(kB0, 0);
     else if (KT == 4) issue_next(kB0, 1);
     else issue(kB0, t + 2);
-    if (KT == 1) wait_se(c8, se); else wait_vm<8>();
+    if (KT == 1) wait_se(c8, se); else wait_vm<kW>();
     PP_BARRIER();
-    quad(acc[1][1], af1);
+    quad(acc[1][1], af1, kMi1);
     PP_BARRIER();
     // p3
     if (KT == 3) issue_next(kA0, 0);
     else if (KT == 4) issue_next(kA0, 1);
     else issue(kA0, t + 2);
-    if (KT == 1) wait_se(c8, se); else wait_vm<8>();
+    if (KT == 1) wait_se(c8, se); else wait_vm<kW>();
     PP_BARRIER();
-    quad(acc[0][1], af0);
+    quad(acc[0][1], af0, kMi2);
     PP_BARRIER();
   };
   const std::integral_constant<int, 0> kt_steady; const std::integral_constant<int, 1> kt_first;
@@ -254,7 +267,7 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
 
   // ---- prologue of the workgroup's first tile: the half-tiles the periodic schedule would have issued before its first phase
   issue(kB0, 0); issue(kA0, 0); issue(kA1, 0); issue(kB1, 0); issue(kB0, 1); issue(kA0, 1);
-  wait_vm<8>();                                 // B0(0), A0(0) have landed (this wave's share)
+  wait_vm<kW>();                                // B0(0), A0(0) have landed (this wave's share)
   PP_BARRIER();
   if (late) PP_BARRIER();
 
@@ -292,7 +305,7 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
     if (kSyncEpi && !late) PP_BARRIER();        // waves 0-3 wait for the last quadrant of waves 4-7: both groups run the epilogue together
     PP_FENCE();
 
-    const bool full = m0 + 256 <= p.M && n0 + 256 <= p.N && c_vec;
+    const bool full = m0 + BM <= p.M && n0 + 256 <= p.N && c_vec;
     // RES: the residual row segments of the wave's eight slabs (a lane's 16 columns of row frow), raw bf16, requested up front
     Chunk16 rsd[RES ? 2 : 1][RES ? 2 : 1][RES ? 2 : 1][2];
     if constexpr (RES) {
@@ -303,8 +316,8 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const int m = m0 + mh * 128 + R * 32 + i * 16 + frow;
+          for (int i = 0; i < (mh ? M1 : 2); ++i) {
+            const int m = m0 + mh * 128 + ((mh && BM == 192) ? R * 16 : R * 32) + i * 16 + frow;
             const int nb = n0 + nh * 128 + Cw * 64 + fg * 16;
             if (m < p.M && nb + 16 <= p.N && r_vec) {
               rsd[mh][nh][i][0] = *reinterpret_cast<const Chunk16*>(Rp + (int64_t)m * p.ldr + nb);
@@ -343,7 +356,8 @@ __global__ __launch_bounds__(512, 2) void gemm_8pp_kernel(const GemmArgs p, cons
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int m = m0 + mh * 128 + R * 32 + i * 16 + frow;
+        if (mh && i >= M1) continue;             // 192-row form: one m-tile over the second A half-tile
+        const int m = m0 + mh * 128 + ((mh && BM == 192) ? R * 16 : R * 32) + i * 16 + frow;
         float res[16];
         if constexpr (RES) {
           chunk_to_f32<T>(rsd[mh][nh][i][0], res);
@@ -483,9 +497,27 @@ int gemm_8pp_grid(int64_t ntiles) {
 // 30 us, 4096^3 1.13 -> 1.27 PFLOP/s; profiles/r04_vendor_yardstick.txt)
 bool gemm_8pp_eligible(const GemmArgs& a) { return gemm_8pp_supported(a); }
 
-int launch_gemm_8pp(const GemmArgs& a, hipStream_t st, int grid) {
+// Tile rows.  The 192-row form puts an under-filled launch on more CUs (Whisper fc2 / o_proj: 188 -> 252 tiles, QKV: 192 -> 256 workgroups
+// for three rounds) and finishes it sooner ALONE -- QKV 83 -> 74 us, fc2 91 -> 84, o_proj 31 -> 29 (profiles/r05_gemm_8pp_rows192.txt) -- but a
+// 192-row tile takes 0.89-0.93 of a 256-row tile's time for 0.75 of its work: ~20 % more CU-time per launch.  In the pipelined job the CUs a
+// 256-row launch leaves free are not idle (other calls' kernels, the decode steps), and the headline went 321-322 -> 317-318 utt/s with the
+// finer tiles while the family's own time fell 10.9 -> 10.6 ms per call.  So the launcher keeps 256 rows; OAVSR_GEMM_TILE_ROWS=192 selects
+// the other form where it exists (one call at a time on an otherwise idle chip).  Never a bit: both forms accumulate every element in the
+// same order (tests compare them).
+int gemm_8pp_rows(const GemmArgs& a) {
+  static const int forced = knob("OAVSR_GEMM_TILE_ROWS");
+  const bool has192 = !a.swiglu_pairs && (a.act == ACT_NONE || (a.act == ACT_GELU && !a.res_after_act && !a.residual));
+  return forced == 192 && has192 ? 192 : 256;
+}
+
+int launch_gemm_8pp(const GemmArgs& a, hipStream_t st, int grid, int rows) {
   OAVSR_REQUIRE(gemm_8pp_supported(a), "gemm_8pp: shape / epilogue not supported by the persistent ping-pong kernel");
-  const int64_t ntiles = (int64_t)ceil_div(a.M, 256) * ceil_div(a.N, 256);
+  if (rows == 0) rows = gemm_8pp_rows(a);
+  OAVSR_REQUIRE(rows == 256 || rows == 192, "gemm_8pp: tile rows must be 256 or 192 (got %d)", rows);
+  const bool none = a.act == ACT_NONE;
+  OAVSR_REQUIRE(rows == 256 || (!a.swiglu_pairs && (none || (a.act == ACT_GELU && !a.res_after_act && !a.residual))),
+                "gemm_8pp: the 192-row form serves plain / residual epilogues without activation and bias + GELU");
+  const int64_t ntiles = (int64_t)ceil_div(a.M, rows) * ceil_div(a.N, 256);
   if (grid <= 0) grid = gemm_8pp_grid(ntiles);
   OAVSR_REQUIRE(grid % 8 == 0 && grid >= 8, "gemm_8pp: the grid must be a multiple of 8 (got %d)", grid);
   if ((int64_t)grid > (ntiles + 7) / 8 * 8) grid = (int)((ntiles + 7) / 8 * 8);     // (a ragged single round is dealt over the 8 XCD groups by tile_at)
@@ -503,7 +535,10 @@ int launch_gemm_8pp(const GemmArgs& a, hipStream_t st, int grid) {
   };
   // epilogue specialisations (same bits as the generic form, see the kernel): no activation -- whatever res_after_act says, there is
   // nothing to order --, and GELU without a residual (fc1)
-  const bool none = a.act == ACT_NONE;
+  if (rows == 192) {
+    if (a.residual) return go(gemm_8pp_kernel<false, true, ACT_NONE, 192>);
+    return none ? go(gemm_8pp_kernel<false, false, ACT_NONE, 192>) : go(gemm_8pp_kernel<false, false, ACT_GELU, 192>);
+  }
   if (a.residual) return none ? go(gemm_8pp_kernel<false, true, ACT_NONE>) : go(gemm_8pp_kernel<false, true, -1>);
   if (a.swiglu_pairs) return none ? go(gemm_8pp_kernel<true, false, ACT_NONE>) : go(gemm_8pp_kernel<true, false, -1>);
   if (none) return go(gemm_8pp_kernel<false, false, ACT_NONE>);

@@ -91,8 +91,10 @@ int launch_gemm_8p(const GemmArgs& a, hipStream_t st);
 bool gemm_8pp_eligible(const GemmArgs& a);     // the dispatcher's rule (supported && multi-round)
 bool gemm_8pp_supported(const GemmArgs& a);
 int gemm_8pp_grid(int64_t ntiles);             // workgroups the launcher uses for `ntiles` tiles
-// grid: workgroups (multiple of 8; 0 = gemm_8pp_grid)
-int launch_gemm_8pp(const GemmArgs& a, hipStream_t st, int grid = 0);
+// grid: workgroups (multiple of 8; 0 = gemm_8pp_grid); rows: tile rows, 256 / 192 (0 = gemm_8pp_rows: the cheaper form for the shape; same bits)
+int gemm_8pp_rows(const GemmArgs& a);
+double gemm_cu_share(const GemmArgs& a);     // fraction of the CUs the launch can occupy (profiling: CU-time = duration x share)
+int launch_gemm_8pp(const GemmArgs& a, hipStream_t st, int grid = 0, int rows = 0);
 
 // ---- attention ---------------------------------------------------------------------------------
 struct AttnArgs {

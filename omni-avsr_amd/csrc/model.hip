@@ -41,6 +41,7 @@ static const KnobDef kKnobs[] = {
     {"OAVSR_PROF_SHAPES", 0, "profiling hook: one family per GEMM shape instead of per kernel"},
     {"OAVSR_DECODE_GRAPH", 1, "0: decode steps are launched eagerly instead of replayed from hipGraphs (same kernels, same bits)"},
     {"OAVSR_FUSED_REDUCE_ROWS", 32, "decode-shaped GEMMs with at most this many rows reduce their split-K slabs inside the launch, others in a second launch (same code, same bits)"},
+    {"OAVSR_GEMM_TILE_ROWS", 256, "persistent GEMM: 192 = the 192-row tiles wherever that form exists: shorter launches alone, ~20 % more CU-time (same bits)"},
 };
 int knob(const char* name) {
   for (const KnobDef& k : kKnobs)
@@ -57,7 +58,7 @@ int knob(const char* name) {
 // ------------------------------------------------------------------------------------------------
 struct Profiler {
   bool on = false;
-  struct Rec { int fam; hipEvent_t e0, e1; double flops, bytes; };
+  struct Rec { int fam; hipEvent_t e0, e1; double flops, bytes, cu_share; };
   std::vector<Rec> recs;
   std::vector<Rec> empty;                      // back-to-back event pairs: what a bracket measures with nothing inside
   std::vector<std::string> names;
@@ -83,15 +84,15 @@ static Profiler g_prof;
 
 struct ProfScope {
   hipStream_t st; int idx = -1;
-  ProfScope(const char* name, double flops, double bytes, hipStream_t s) : st(s) {
+  ProfScope(const char* name, double flops, double bytes, hipStream_t s, double cu_share = 1.0) : st(s) {
     if (!g_prof.on) return;
     std::lock_guard<std::mutex> lk(g_prof.mu);
     if (g_prof.empty.size() < 16) {            // calibration: an empty bracket on the same stream, subtracted from every record on read
-      Profiler::Rec c; c.fam = -1; c.e0 = g_prof.get(); c.e1 = g_prof.get(); c.flops = c.bytes = 0;
+      Profiler::Rec c; c.fam = -1; c.e0 = g_prof.get(); c.e1 = g_prof.get(); c.flops = c.bytes = 0; c.cu_share = 1.0;
       hipEventRecord(c.e0, st); hipEventRecord(c.e1, st);
       g_prof.empty.push_back(c);
     }
-    Profiler::Rec r; r.fam = g_prof.family(name); r.e0 = g_prof.get(); r.e1 = g_prof.get(); r.flops = flops; r.bytes = bytes;
+    Profiler::Rec r; r.fam = g_prof.family(name); r.e0 = g_prof.get(); r.e1 = g_prof.get(); r.flops = flops; r.bytes = bytes; r.cu_share = cu_share;
     hipEventRecord(r.e0, st);
     g_prof.recs.push_back(r);
     idx = (int)g_prof.recs.size() - 1;
@@ -126,7 +127,7 @@ static int run_gemm(const GemmArgs& a, hipStream_t st) {
   const double kk = (double)a.K + a.K2;
   const double flops = 2.0 * a.M * a.N * kk * a.groups;
   const double bytes = esz * ((double)a.M * kk + (double)a.N * kk * a.groups) + (a.out_f32 ? 4 : esz) * (double)a.M * a.N * a.groups;
-  ProfScope ps(gemm_family(a), flops, bytes, st);
+  ProfScope ps(gemm_family(a), flops, bytes, st, g_prof.on ? gemm_cu_share(a) : 1.0);
   return launch_gemm(a, st);
 }
 
@@ -2001,7 +2002,7 @@ int oavsr_profile_read(oavsr_prof_entry* out, int32_t max_entries) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
     ms = std::max(0.f, ms - base);
-    agg[r.fam].launches += 1; agg[r.fam].ms += ms; agg[r.fam].flops += r.flops; agg[r.fam].bytes += r.bytes;
+    agg[r.fam].launches += 1; agg[r.fam].ms += ms; agg[r.fam].flops += r.flops; agg[r.fam].bytes += r.bytes; agg[r.fam].cu_ms += ms * r.cu_share;
   }
   int n = std::min(nf, (int)max_entries);
   for (int i = 0; i < n; ++i) out[i] = agg[i];
@@ -2028,13 +2029,14 @@ int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream) {
     OAVSR_REQUIRE(gemm_8p_supported(g), "op_gemm: shape / layout not supported by the ping-pong kernel");
     return launch_gemm_8p(g, (hipStream_t)stream);
   }
-  if (d->kernel == 3) return launch_gemm_8pp(g, (hipStream_t)stream, d->grid);      // tests: the persistent ping-pong kernel on d->grid workgroups
+  if (d->kernel == 3) return launch_gemm_8pp(g, (hipStream_t)stream, d->grid, 256);      // tests: the persistent ping-pong kernel on d->grid workgroups, 256-row tiles
+  if (d->kernel == 8) return launch_gemm_8pp(g, (hipStream_t)stream, d->grid, 192);      // ... its 192-row form
   if (d->kernel == 5) {      // tests / yardsticks: the 16-wave 256 x 256 LDS-DMA kernel whatever the dispatcher's rule says
     g.force_tile = 2;
     return launch_gemm(g, (hipStream_t)stream);
   }
-  if (d->kernel == 6 || d->kernel == 7) {      // tests / yardsticks: the 160 x 128 (6) / 256 x 128 (7) LDS-DMA tiles whatever the dispatcher's rule says
-    g.force_tile = d->kernel == 6 ? 5 : 8;
+  if (d->kernel == 7) {      // tests / yardsticks: the 256 x 128 LDS-DMA tile whatever the dispatcher's rule says
+    g.force_tile = 8;
     return launch_gemm_dma(g, (hipStream_t)stream);
   }
   OAVSR_REQUIRE(d->kernel == 0, "op_gemm: unknown kernel selector %d", d->kernel);

@@ -42,7 +42,7 @@ class OavsrTensor(C.Structure):
 
 
 class OavsrProfEntry(C.Structure):
-    _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint64), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint64), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double), ("cu_ms", C.c_double)]
 
 
 class OavsrTraceRec(C.Structure):

@@ -511,7 +511,7 @@ class OmniEngine:
         arr = (L.OavsrProfEntry * 256)()
         n = self.lib.oavsr_profile_read(arr, 256)
         return [dict(name=arr[i].name.decode(), launches=int(arr[i].launches), ms=float(arr[i].ms), flops=float(arr[i].flops),
-                     bytes=float(arr[i].bytes)) for i in range(max(n, 0))]
+                     bytes=float(arr[i].bytes), cu_ms=float(arr[i].cu_ms)) for i in range(max(n, 0))]
 
 
 class PendingIds:

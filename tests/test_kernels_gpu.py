@@ -1002,12 +1002,18 @@ def test_gemm_8pp_persistent(M, N, K, grid, act):
     for _ in range(3):
         again = gemm(dtype, a, w, bias=bias.to(DEV), act=act, kernel=3, grid=grid)
         assert torch.equal(out, again), "two launches of the persistent GEMM differ (race in the cross-tile schedule)"
+    if act in (0, 1):                 # the 192-row form (second A half-tile of 64 rows; instantiated for no activation and bias + GELU): same bits
+        for _ in range(2):
+            rows192 = gemm(dtype, a, w, bias=bias.to(DEV), act=act, kernel=8, grid=grid)
+            assert torch.equal(out, rows192), f"192-row form differs: max diff {(out.float() - rows192.float()).abs().max().item():.3e}"
 
 
 @pytest.mark.parametrize("M,N,K,grid,act,raa", [
     (12000, 1024, 4096, 0, 0, 0),       # Whisper fc2: 188 tiles, one per workgroup (ragged single round dealt over the XCD groups), residual
     (2048 + 77, 1280 + 40, 320, 16, 1, 1),   # ragged edges, several rounds, GELU then residual
     (3000, 1024, 1024, 8, 4, 0),        # 48 tiles on 8 workgroups: the residual variant across tile boundaries
+    (3000 + 50, 1024, 1024, 8, 0, 0),   # no activation, ragged M, several rounds: also the 192-row form across tile boundaries
+    (12000, 1024, 1024, 0, 0, 1),       # Whisper o_proj
 ])
 def test_gemm_8pp_residual_variant(M, N, K, grid, act, raa):
     """The residual form of the persistent kernel (o_proj / fc2 / down_proj: residual and activation after the transposition, bias before
@@ -1031,6 +1037,12 @@ def test_gemm_8pp_residual_variant(M, N, K, grid, act, raa):
     inplace = r.clone()
     gemm(dtype, a, w, bias=bias.to(DEV), act=act, residual=inplace, res_after_act=raa, kernel=3, grid=grid, C_out=inplace)
     assert torch.equal(inplace, out), "in-place (C == residual) differs"
+    if act == 0:                      # 192-row form of the residual variant (Whisper fc2 / o_proj: 252 tiles instead of 188)
+        rows192 = gemm(dtype, a, w, bias=bias.to(DEV), act=act, residual=r, res_after_act=raa, kernel=8, grid=grid)
+        assert torch.equal(out, rows192), f"192-row residual form differs: max diff {(out.float() - rows192.float()).abs().max().item():.3e}"
+        inplace = r.clone()
+        gemm(dtype, a, w, bias=bias.to(DEV), act=act, residual=inplace, res_after_act=raa, kernel=8, grid=grid, C_out=inplace)
+        assert torch.equal(inplace, out), "192-row form in place (C == residual) differs"
 
 
 def test_gemm_8pp_identity_layout_and_tile_walk():
@@ -1043,6 +1055,8 @@ def test_gemm_8pp_identity_layout_and_tile_walk():
     for grid in (8, 16, 48, 64):
         out = gemm("bf16", a, w, kernel=3, grid=grid)
         close(out, wr.T, 1e-6, what=f"gemm 8pp identity grid {grid}")
+        out = gemm("bf16", a, w, kernel=8, grid=grid)
+        close(out, wr.T, 1e-6, what=f"gemm 8pp (192-row tiles) identity grid {grid}")
 
 
 def test_gemm_8pp_under_load_is_deterministic():
@@ -1091,10 +1105,10 @@ def test_gemm_dispatch_takes_persistent_kernel_for_multi_round_launches():
 
 
 @pytest.mark.parametrize("M,N,K,K2", [(2504, 2048, 2048, 0), (2504, 2048, 8192, 0), (2397, 2048, 1024, 64), (1500, 3072, 512, 0)])
-def test_gemm_160_row_tile_for_one_ragged_round(M, N, K, K2):
-    """One round of 256 x 128 tiles that would leave CUs idle runs on 160 x 128 tiles (gemm2.hip: tile160_rule; the LLM prefill's o_proj /
-    down_proj): the dispatcher's choice, the forced 160 x 128 tile and the forced 256 x 128 tile give the same bits -- residual, bias,
-    a LoRA segment and a ragged last row tile included -- and match the fp32 reference."""
+def test_gemm_under_filled_launches_same_bits_on_every_tile(M, N, K, K2):
+    """The LLM prefill's o_proj / down_proj / QKV (80 .. 120 tiles of 256 x 256: the dispatcher takes the coarse tile from 64 tiles on, for the
+    job's CU-time): the dispatcher's choice and the forced 256 x 128 tile give the same bits -- residual, bias, a LoRA segment and a ragged
+    last row tile included -- and match the fp32 reference."""
     dtype = "bf16"
     a, ar = q(rnd(M, K, seed=1), dtype)
     w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
@@ -1107,10 +1121,9 @@ def test_gemm_160_row_tile_for_one_ragged_round(M, N, K, K2):
         kw = dict(A2=a2, W2=w2)
         ref = ref + a2r @ w2r.T
     auto = gemm(dtype, a, w, bias=bias.to(DEV), residual=r, **kw)
-    t160 = gemm(dtype, a, w, bias=bias.to(DEV), residual=r, kernel=6, **kw)
     t256 = gemm(dtype, a, w, bias=bias.to(DEV), residual=r, kernel=7, **kw)
-    close(auto, ref, tol(dtype) * 2, what="160-row tile gemm")
-    assert torch.equal(t160, t256) and torch.equal(auto, t160)
+    close(auto, ref, tol(dtype) * 2, what="under-filled launch")
+    assert torch.equal(auto, t256)
 
 
 @pytest.mark.parametrize("dtype,M,N,K,K2", [("bf16", 3200, 3072, 1024, 64), ("bf16", 1000, 3072, 1024, 64), ("f32", 700, 384, 128, 32)])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B timing of the 256 x 256 bf16 GEMM kernels on the benchmark's multi-round shapes, all variants interleaved in ONE process
 (guide rule 24): kernel selector 5 = 16-wave LDS-DMA, 2 = ping-pong, 3 = persistent ping-pong,
-6 = 160 x 128 tiles, 7 = 256 x 128, 0 = the dispatcher's choice.  Operand sets rotate so that no set survives in the 256 MiB Infinity Cache between its uses.
+7 = 256 x 128, 8 = persistent ping-pong with 192-row tiles, 0 = the dispatcher's choice.  Operand sets rotate so that no set survives in the 256 MiB Infinity Cache between its uses.
 
 usage: gemm_pp_bench.py [--rounds R] [--shapes qkv,fc1,gateup,fc2,sq4k,sq8k] [--grids 0,256]"""
 import argparse
