@@ -189,6 +189,9 @@ def parse_args():
     ap.add_argument("--decode-group", type=int, default=1,
                     help="G > 1: G consecutive calls share ONE decode loop (encoders / prefill still run per batch of --batch; "
                          "continuous batching of the decode phase).  Opt-in: not the configuration the headline number is quoted on")
+    ap.add_argument("--alone", action="store_true",
+                    help="dispatcher objective 'one call at a time on an idle chip' (oavsr_set_launch_objective(1)) for the timed loop: with --streams 1 --no-scheduler "
+                         "the reference's own protocol at this batch size; never the headline")
     ap.add_argument("--no-scheduler", action="store_true",
                     help="round-2 mode: every call runs its own decode loop on its own stream (default: the engine's decode scheduler merges the "
                          "decode rows of the calls in flight; greedy only)")
@@ -199,7 +202,7 @@ def parse_args():
     ap.add_argument("--no-stagger", action="store_true", help="let the encoder phases of in-flight batches share the chip (default: chained)")
     ap.add_argument("--testset", type=int, default=0,
                     help="N > 0: the test-set-shaped run instead of the step loop (BASELINE.json configs[4] / SURVEY.md 8d C5: N synthetic utterances, "
-                         "lengths U[1 s, 16 s], HOST inputs): duration-sorted sharding over the ranks -> batches -> harness.evaluate(in_flight=3) -> one "
+                         "lengths U[1 s, 16 s], HOST inputs): duration-sorted sharding over the ranks -> batches -> harness.evaluate(in_flight=4) -> one "
                          "all_gather of the hypotheses + all_reduce of the WER counters.  STRONG scaling: value = N / wall time of the whole set")
     ap.add_argument("--streams", type=int, default=None,
                     help="caller streams = batches whose encoder phases (and, without the scheduler, decode loops) may be in flight; default 4; "
@@ -243,6 +246,7 @@ def latency_leg(eng, args, pre, task, use_a, first_set):
     ra, rv = pre["rates"][0]
     out = {"unit": "ms per utterance", "clip_s": round(t1 / 25.0, 2), "calls": 10,
            "note": "B = 1, one call at a time on an idle chip, device-synchronised per call, median of 10 (the reference's evaluation protocol, data_module.py:238-242)"}
+    eng.launch_objective(True)              # one call at a time on an idle chip: the dispatcher's latency rule (same bits)
     for name, beams in (("greedy", 1), ("beam15", 15)):
         ts = []
         for k in range(13):
@@ -256,6 +260,7 @@ def latency_leg(eng, args, pre, task, use_a, first_set):
         ts.sort()
         out[name] = round(ts[len(ts) // 2], 3)
         out[name + "_min"] = round(ts[0], 3)
+    eng.launch_objective(False)
     return out
 
 
@@ -311,7 +316,7 @@ def schedule_summary(recs, skip_calls):
 def testset_run(args, rank, world, local, use_dist, affinity=None):
     """The reference's evaluation loop (eval_OmniAVSR.py:273-357: one Trainer.test pass over the test set) as this repo runs it: every rank
     owns the utterances `dist.shard_utterances` deals it (duration-sorted round-robin), batches them longest first (`make_batches`), and
-    `harness.evaluate(in_flight=3)` keeps three batches in flight through the engine's decode scheduler with host inputs (collation and
+    `harness.evaluate(in_flight=4)` keeps four batches in flight through the engine's decode scheduler with host inputs (collation and
     host-to-device copies inside the timed region).  The only exchange: one all_gather of {utt_id, n, ids} records and one all_reduce of
     the WER counters, inside the timed region before the closing barrier.  Strong scaling: the set is fixed, `value` = N / wall."""
     import torch.distributed as dist
@@ -373,9 +378,9 @@ def testset_run(args, rank, world, local, use_dist, affinity=None):
         to_text.rows.extend(ids.tolist())
         return out
     to_text.rows = []
-    kw = dict(batch_size=B, bos_id=spec.ids["bos"], rank=rank, world=world, in_flight=3, test_ratio_matry_audio=ra, test_ratio_matry_video=rv)
+    kw = dict(batch_size=B, bos_id=spec.ids["bos"], rank=rank, world=world, in_flight=4, test_ratio_matry_audio=ra, test_ratio_matry_video=rv)
     # warm-up: the first batches of this rank's own shard (workspaces, scheduler pool, step graphs, pinned staging)
-    H.evaluate(model, [samples[i] for i in sorted(owned, key=lambda i: -Tvs[i])[: 4 * B]], task, to_text, batch_size=B, bos_id=spec.ids["bos"], in_flight=3,
+    H.evaluate(model, [samples[i] for i in sorted(owned, key=lambda i: -Tvs[i])[: 4 * B]], task, to_text, batch_size=B, bos_id=spec.ids["bos"], in_flight=4,
                test_ratio_matry_audio=ra, test_ratio_matry_video=rv)
     to_text.rows = []
     torch.cuda.synchronize()
@@ -592,6 +597,7 @@ def main():
     if args.sched_slots is None:
         args.sched_slots = eng.sched_slots if args.sched_rows == eng.sched_rows else max(192, 4 * args.sched_rows)
     use_sched = not args.no_scheduler and args.beams == 1 and G == 1 and B <= args.sched_rows
+    eng.launch_objective(bool(args.alone))
     eng.sched_rows, eng.sched_slots, eng.sched_stride, eng.sched_lanes = args.sched_rows, args.sched_slots, args.sched_stride, args.sched_lanes
     if use_sched and nstream <= 8:
         # the ENGINE's caller streams (created before its lanes' streams: the hardware-queue binding order no longer depends on the caller)
@@ -768,6 +774,11 @@ def main():
             roofline = dict(bound="mfma", kernel=dom["name"], achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
                             traffic=traffic, avg_launch_ms=round(dom["ms"] / dom["launches"], 4), launches=dom["launches"],
                             share_of_step=round(dom["ms"] / tot_ms, 3))
+            # the same flops over the family's CU-time (duration x fraction of the CUs a launch occupies): the dispatcher runs launches of
+            # 64 .. 255 tiles on as many CUs as they have tiles -- the rest of the chip belongs to the other calls in flight -- so `frac`
+            # (whole-chip peak, one call at a time) understates what a CU delivers while it works on this family
+            if dom.get("cu_ms", 0) > 0:
+                roofline["cu_frac"] = round(dom["flops"] / dom["cu_ms"] / 1e9 / peak, 4)
         else:
             ach = dom["bytes"] / dom["ms"] / 1e6
             roofline = dict(bound="hbm", kernel=dom["name"], achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),

@@ -78,6 +78,11 @@ const char* oavsr_last_error(void);
  * returns how many there are.  The library's own switches (csrc/model.hip: kKnobs) only pick between kernel forms that produce the same
  * bits or turn diagnostics on -- no environment variable changes a result; bench.py records this string in `config.env`. */
 int oavsr_env_report(char* buf, int32_t nbytes);
+/* What the GEMM dispatcher optimises, process-wide (default 0).  0: the calls in flight share the chip (oavsr_generate_submit pipelines,
+ * several streams) -- launches of 64 .. 255 coarse tiles stay on as many CUs as they have tiles, because the job is bound by CU-time and the
+ * other CUs are not idle.  1: ONE call at a time on an otherwise idle chip (the reference's evaluation protocol, data_module.py:238-242) --
+ * such launches take finer tiles that cover more CUs and finish sooner.  Never a bit: every tile shape accumulates in the same order. */
+int oavsr_set_launch_objective(int32_t alone);
 
 /* weights: one device blob + manifest (replaces AVSR_LLMs.load_state_dict, lightning_OmniAVSR.py:148-150) */
 int oavsr_model_create(const oavsr_config* cfg, const void* blob_dev, uint64_t blob_bytes, const oavsr_tensor* tensors,

@@ -501,13 +501,21 @@ bool gemm_8pp_eligible(const GemmArgs& a) { return gemm_8pp_supported(a); }
 // for three rounds) and finishes it sooner ALONE -- QKV 83 -> 74 us, fc2 91 -> 84, o_proj 31 -> 29 (profiles/r05_gemm_8pp_rows192.txt) -- but a
 // 192-row tile takes 0.89-0.93 of a 256-row tile's time for 0.75 of its work: ~20 % more CU-time per launch.  In the pipelined job the CUs a
 // 256-row launch leaves free are not idle (other calls' kernels, the decode steps), and the headline went 321-322 -> 317-318 utt/s with the
-// finer tiles while the family's own time fell 10.9 -> 10.6 ms per call.  So the launcher keeps 256 rows; OAVSR_GEMM_TILE_ROWS=192 selects
-// the other form where it exists (one call at a time on an otherwise idle chip).  Never a bit: both forms accumulate every element in the
+// finer tiles while the family's own time fell 10.9 -> 10.6 ms per call.  So the launcher keeps 256 rows while calls share the chip and takes
+// the 192-row form where it finishes sooner when ONE call runs at a time (GemmArgs::alone, oavsr_set_launch_objective); OAVSR_GEMM_TILE_ROWS
+// forces either.  Never a bit: both forms accumulate every element in the
 // same order (tests compare them).
 int gemm_8pp_rows(const GemmArgs& a) {
   static const int forced = knob("OAVSR_GEMM_TILE_ROWS");
   const bool has192 = !a.swiglu_pairs && (a.act == ACT_NONE || (a.act == ACT_GELU && !a.res_after_act && !a.residual));
-  return forced == 192 && has192 ? 192 : 256;
+  if (!has192) return 256;
+  if (forced == 192) return 192;
+  if (forced == 256 || !a.alone) return 256;
+  // one call at a time (oavsr_set_launch_objective): the form that finishes sooner -- rounds x tile time, a 192-row tile at 0.9
+  const int cap = ncu8() < 8 ? 8 : ncu8();
+  const int64_t ntn = ceil_div(a.N, 256), t256 = (int64_t)ceil_div(a.M, 256) * ntn, t192 = (int64_t)ceil_div(a.M, 192) * ntn;
+  const int64_t r256 = (t256 + cap - 1) / cap, r192 = (t192 + cap - 1) / cap;
+  return r192 * 90 < r256 * 100 ? 192 : 256;
 }
 
 int launch_gemm_8pp(const GemmArgs& a, hipStream_t st, int grid, int rows) {

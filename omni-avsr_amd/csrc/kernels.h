@@ -56,6 +56,7 @@ struct GemmArgs {
   int tile_order = 0;
   // parity tests / yardsticks (oavsr_op_gemm): 2 = the 16-wave 256 x 256 LDS-DMA kernel whatever the dispatcher would pick.  0 in the product.
   int force_tile = 0;
+  int alone = 0;             // 1: the call runs alone on the chip (oavsr_set_launch_objective): tiles chosen for the launch's own duration, not for CU-time.  Speed only.
   int decode_tiled = 0;      // decode-shaped launch (M <= 128): the 128-row LDS-DMA tiles at ANY row count (speed only: the tile shape never changes a bit)
 };
 constexpr int kSyncInts = 4096;      // GemmArgs::sync

@@ -18,6 +18,7 @@
 #include <unordered_map>
 #include <vector>
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 
 #include "../../include/omni_avsr.h"
@@ -41,7 +42,7 @@ static const KnobDef kKnobs[] = {
     {"OAVSR_PROF_SHAPES", 0, "profiling hook: one family per GEMM shape instead of per kernel"},
     {"OAVSR_DECODE_GRAPH", 1, "0: decode steps are launched eagerly instead of replayed from hipGraphs (same kernels, same bits)"},
     {"OAVSR_FUSED_REDUCE_ROWS", 32, "decode-shaped GEMMs with at most this many rows reduce their split-K slabs inside the launch, others in a second launch (same code, same bits)"},
-    {"OAVSR_GEMM_TILE_ROWS", 256, "persistent GEMM: 192 = the 192-row tiles wherever that form exists: shorter launches alone, ~20 % more CU-time (same bits)"},
+    {"OAVSR_GEMM_TILE_ROWS", 0, "persistent GEMM: 256 / 192 = that tile height wherever its form exists, 0 = the launcher's rule (256 while calls share the chip; alone: whichever finishes sooner); same bits"},
 };
 int knob(const char* name) {
   for (const KnobDef& k : kKnobs)
@@ -122,7 +123,10 @@ static const char* gemm_family(const GemmArgs& a) {
 // Split-K factors are STATIC per call site (functions of the layer's N and K, never of the row count), so that an utterance gets the same
 // bits whether it runs alone or inside a batch.  The only split-K call sites are the decode-shaped GEMMs (decode_gemm below); the narrow
 // encoder projections and the prefill's LoRA down projections run un-split on the small-GEMM tile (gemm2.hip).
-static int run_gemm(const GemmArgs& a, hipStream_t st) {
+static std::atomic<int> g_alone{0};            // oavsr_set_launch_objective
+static int run_gemm(const GemmArgs& a0, hipStream_t st) {
+  GemmArgs a = a0;
+  a.alone = g_alone.load(std::memory_order_relaxed);
   const double esz = a.dtype == DT_F32 ? 4 : 2;
   const double kk = (double)a.K + a.K2;
   const double flops = 2.0 * a.M * a.N * kk * a.groups;
@@ -1287,6 +1291,7 @@ void oavsr_model_destroy(oavsr_model* m) {
   delete m;
 }
 
+int oavsr_set_launch_objective(int32_t alone) { g_alone.store(alone ? 1 : 0, std::memory_order_relaxed); return 0; }
 int oavsr_model_serialize_encoders(oavsr_model* m, int32_t on) {
   OAVSR_REQUIRE(m, "serialize_encoders: null model");
   if (on && !m->enc_done) OAVSR_CHECK_HIP(hipEventCreateWithFlags(&m->enc_done, hipEventDisableTiming));

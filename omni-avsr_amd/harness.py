@@ -305,6 +305,9 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
         make = (lambda idxs: flat([samples[i][0] for i in idxs], modality, bos_id)) if raw else \
             (lambda idxs: collate_test([samples[i][0] for i in idxs], modality, bos_id))
         pool = None if raw else ThreadPoolExecutor(1)
+        eng0 = getattr(model, "engine", None)
+        if eng0 is not None and hasattr(eng0, "launch_objective"):
+            eng0.launch_objective(True)                       # one call at a time on an idle chip: tiles chosen for the launch's own duration (same bits)
         try:
             nxt = pool.submit(make, batches[0]) if pool else None
             for n, idxs in enumerate(batches):
@@ -320,12 +323,15 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
         finally:
             if pool:
                 pool.shutdown(wait=True)
+            if eng0 is not None and hasattr(eng0, "launch_objective"):
+                eng0.launch_objective(False)
             if decode_group > 1:
                 model.encoder_chunk = chunk_prev
         return meter
 
     eng = model.engine
     dev = eng.device
+    eng.launch_objective(False)                               # several calls share the chip: least CU-time per launch
     # one workspace per slot, sized for the longest owned clip: nothing is re-created while other slots are busy
     tv_max = max([int(samples[i][0][vkey(samples[i][0])].shape[0]) for i in owned if vkey(samples[i][0]) in samples[i][0]] or [1])
     u8_shape = tuple(samples[owned[0]][0]["video_u8"].shape[1:]) if owned and "video_u8" in samples[owned[0]][0] else None

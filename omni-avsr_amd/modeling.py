@@ -134,6 +134,13 @@ class OmniEngine:
         L.check(self.lib.oavsr_workspace_create(self._model, B, max(Tv, 1), max(Ts, 1), beams, max_new, C.byref(self._ws)))
         self._ws_key = (B, Tv, Ts, beams, max_new)
 
+    def launch_objective(self, alone: bool):
+        """What the GEMM dispatcher optimises (process-wide; include/omni_avsr.h: oavsr_set_launch_objective).  False (default): calls share
+        the chip -- coarse tiles on as many CUs as they have tiles, least CU-time.  True: one call at a time on an idle chip (the reference's
+        evaluation protocol) -- finer tiles that finish sooner.  Same bits either way."""
+        L.check(self.lib.oavsr_set_launch_objective(int(bool(alone))))
+        return self
+
     def serialize_encoders(self, on: bool = True):
         """Several generate() calls in flight (slots): run their encoder + prefill phases back to back, overlap only decode."""
         L.check(self.lib.oavsr_model_serialize_encoders(self._model, int(on)))

@@ -1126,6 +1126,27 @@ def test_gemm_under_filled_launches_same_bits_on_every_tile(M, N, K, K2):
     assert torch.equal(auto, t256)
 
 
+@pytest.mark.parametrize("M,N,K,res", [(2504, 2048, 8192, True), (2504, 3072, 2048, False), (12000, 1024, 1024, True), (3200, 3072, 1088, False), (12000, 3072, 1024, False)])
+def test_launch_objective_changes_tiles_not_bits(M, N, K, res):
+    """oavsr_set_launch_objective: calls sharing the chip keep launches of 64 .. 255 coarse tiles on the persistent 256 x 256 kernel (least
+    CU-time), one call at a time takes finer tiles / the 192-row form (soonest finish) -- the same bits, and the bits of the 256 x 128 tile."""
+    lib = L.load()
+    dtype = "bf16"
+    a, ar = q(rnd(M, K, seed=1), dtype)
+    w, wr = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
+    bias = rnd(N, seed=7)
+    r = q(rnd(M, N, seed=5), dtype)[0] if res else None
+    try:
+        L.check(lib.oavsr_set_launch_objective(0))
+        shared = gemm(dtype, a, w, bias=bias.to(DEV), residual=r)
+        L.check(lib.oavsr_set_launch_objective(1))
+        alone = gemm(dtype, a, w, bias=bias.to(DEV), residual=r)
+    finally:
+        L.check(lib.oavsr_set_launch_objective(0))
+    t256 = gemm(dtype, a, w, bias=bias.to(DEV), residual=r, kernel=7)
+    assert torch.equal(shared, alone) and torch.equal(shared, t256)
+
+
 @pytest.mark.parametrize("dtype,M,N,K,K2", [("bf16", 3200, 3072, 1024, 64), ("bf16", 1000, 3072, 1024, 64), ("f32", 700, 384, 128, 32)])
 def test_gemm_lora_segment_equals_one_concatenated_k_range(dtype, M, N, K, K2):
     """model.hip: run_encoder_layers hands the video encoder's QKV + LoRA GEMM over as ONE K range -- A = [h | t] (row stride K + K2),
