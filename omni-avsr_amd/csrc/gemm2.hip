@@ -714,7 +714,7 @@ static int dma_tile_choice(const GemmArgs& a) {
   // The 160 x 128 tile is gone with its last caller.
   // (256 x 192 / 192 x 256 tiles against the ragged last round were built in round 1 and dropped in round 4 for the same reason: alone
   // they won 10 %, with several calls in flight they cost 2 %; round 5's 192-row form of the persistent kernel repeated the lesson.)
-  if (a.amode == A_DENSE && a.N >= 256 && n256 >= (a.alone ? 144 : 64)) return 2;      // (one call at a time: the latency rule)
+  if (a.amode == A_DENSE && a.N >= 256 && n256 >= (launch_alone() ? 144 : 64)) return 2;      // (one call at a time: the latency rule)
   if (n128 >= 144) return 1;
   return 0;
 }

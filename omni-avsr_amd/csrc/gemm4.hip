@@ -502,7 +502,7 @@ bool gemm_8pp_eligible(const GemmArgs& a) { return gemm_8pp_supported(a); }
 // 192-row tile takes 0.89-0.93 of a 256-row tile's time for 0.75 of its work: ~20 % more CU-time per launch.  In the pipelined job the CUs a
 // 256-row launch leaves free are not idle (other calls' kernels, the decode steps), and the headline went 321-322 -> 317-318 utt/s with the
 // finer tiles while the family's own time fell 10.9 -> 10.6 ms per call.  So the launcher keeps 256 rows while calls share the chip and takes
-// the 192-row form where it finishes sooner when ONE call runs at a time (GemmArgs::alone, oavsr_set_launch_objective); OAVSR_GEMM_TILE_ROWS
+// the 192-row form where it finishes sooner when ONE call runs at a time (launch_alone(), oavsr_set_launch_objective); OAVSR_GEMM_TILE_ROWS
 // forces either.  Never a bit: both forms accumulate every element in the
 // same order (tests compare them).
 int gemm_8pp_rows(const GemmArgs& a) {
@@ -510,7 +510,7 @@ int gemm_8pp_rows(const GemmArgs& a) {
   const bool has192 = !a.swiglu_pairs && (a.act == ACT_NONE || (a.act == ACT_GELU && !a.res_after_act && !a.residual));
   if (!has192) return 256;
   if (forced == 192) return 192;
-  if (forced == 256 || !a.alone) return 256;
+  if (forced == 256 || !launch_alone()) return 256;
   // one call at a time (oavsr_set_launch_objective): the form that finishes sooner -- rounds x tile time, a 192-row tile at 0.9
   const int cap = ncu8() < 8 ? 8 : ncu8();
   const int64_t ntn = ceil_div(a.N, 256), t256 = (int64_t)ceil_div(a.M, 256) * ntn, t192 = (int64_t)ceil_div(a.M, 192) * ntn;

@@ -56,7 +56,6 @@ struct GemmArgs {
   int tile_order = 0;
   // parity tests / yardsticks (oavsr_op_gemm): 2 = the 16-wave 256 x 256 LDS-DMA kernel whatever the dispatcher would pick.  0 in the product.
   int force_tile = 0;
-  int alone = 0;             // 1: the call runs alone on the chip (oavsr_set_launch_objective): tiles chosen for the launch's own duration, not for CU-time.  Speed only.
   int decode_tiled = 0;      // decode-shaped launch (M <= 128): the 128-row LDS-DMA tiles at ANY row count (speed only: the tile shape never changes a bit)
 };
 constexpr int kSyncInts = 4096;      // GemmArgs::sync
@@ -93,6 +92,9 @@ bool gemm_8pp_eligible(const GemmArgs& a);     // the dispatcher's rule (support
 bool gemm_8pp_supported(const GemmArgs& a);
 int gemm_8pp_grid(int64_t ntiles);             // workgroups the launcher uses for `ntiles` tiles
 // grid: workgroups (multiple of 8; 0 = gemm_8pp_grid); rows: tile rows, 256 / 192 (0 = gemm_8pp_rows: the cheaper form for the shape; same bits)
+// 1: ONE call at a time on an otherwise idle chip (oavsr_set_launch_objective): tiles chosen for a launch's own duration, not for CU-time.
+// Read by the dispatcher's rules directly (process-wide), so that every eligibility query and the launch itself agree.  Speed only.
+int launch_alone();
 int gemm_8pp_rows(const GemmArgs& a);
 double gemm_cu_share(const GemmArgs& a);     // fraction of the CUs the launch can occupy (profiling: CU-time = duration x share)
 int launch_gemm_8pp(const GemmArgs& a, hipStream_t st, int grid = 0, int rows = 0);

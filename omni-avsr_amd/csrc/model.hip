@@ -124,9 +124,8 @@ static const char* gemm_family(const GemmArgs& a) {
 // bits whether it runs alone or inside a batch.  The only split-K call sites are the decode-shaped GEMMs (decode_gemm below); the narrow
 // encoder projections and the prefill's LoRA down projections run un-split on the small-GEMM tile (gemm2.hip).
 static std::atomic<int> g_alone{0};            // oavsr_set_launch_objective
-static int run_gemm(const GemmArgs& a0, hipStream_t st) {
-  GemmArgs a = a0;
-  a.alone = g_alone.load(std::memory_order_relaxed);
+int launch_alone() { return g_alone.load(std::memory_order_relaxed); }
+static int run_gemm(const GemmArgs& a, hipStream_t st) {
   const double esz = a.dtype == DT_F32 ? 4 : 2;
   const double kk = (double)a.K + a.K2;
   const double flops = 2.0 * a.M * a.N * kk * a.groups;

@@ -96,6 +96,26 @@ def test_fullsize_batch_invariance_and_determinism(bf16_engine):
         assert ids12[b].tolist() == ids_b[b].tolist(), f"utterance {b} decodes differently inside a batch of 12"
 
 
+def test_fullsize_launch_objective_changes_no_result(bf16_engine):
+    """oavsr_set_launch_objective (harness.evaluate sets it: several batches in flight vs one call at a time) moves launches between tile
+    shapes -- incl. prefill GEMMs that lose their fused SwiGLU epilogue under the other rule (a ragged batch: 2 x 16 s, a short batch: 2 short
+    clips, one utterance) -- and never a bit: same ids, same video encoder output."""
+    eng = bf16_engine
+    for Tv in ([400, 400], [100, 61], [250], [400, 250, 100, 61, 61, 40, 33, 27]):
+        video, audio, Ts = clips(Tv, seed=21)
+        got = {}
+        try:
+            for alone in (False, True):
+                eng.launch_objective(alone)
+                ids, _ = eng.generate("audiovisual", video, Tv, audio, Ts, 4, 4, beams=1, max_new=16, force_len=True)
+                _, venc, _ = eng.encode_video(video, Tv, 4, return_enc=True)
+                got[alone] = (ids.clone(), venc.clone())
+        finally:
+            eng.launch_objective(False)
+        assert torch.equal(got[False][0], got[True][0]), f"T_v={Tv}: ids depend on the launch objective"
+        assert torch.equal(got[False][1], got[True][1]), f"T_v={Tv}: video encoder output depends on the launch objective"
+
+
 def test_fullsize_grouped_decode_equals_separate_calls(bf16_engine):
     """harness decode_group / bench --decode-group: 24 utterances in one call (encoders / prefill in chunks of 8, ONE decode loop over 24 rows)
     decode the ids of three separate calls of 8."""
