@@ -829,6 +829,8 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnAr
   float m_run = -INFINITY, l_run = 0.f;
   char* svw = sv + wave * (64 * RB);
 
+  // (requesting tile i + 1 before computing tile i -- a second register set for the K fragments and the V row -- was measured for the 2-wave
+  // form: nothing at 8 rows, 20 -> 26 us at 97 rows through the lost occupancy; the other workgroups of the CU hide the latency instead)
   for (; kt0 < ctx; kt0 += NW * 64) {
     if (kt0 != wave * 64) load_tile(kt0, kf, vr);         // later tiles (contexts longer than NW * 64 keys)
     if (newkey >= kt0 && newkey < kt0 + 64) {             // wave-uniform: this tile holds the token being appended
@@ -1277,7 +1279,11 @@ int launch_decode_attention(const DecodeAttnArgs& a, hipStream_t st) {
     if (a.n_heads == 4 * a.n_kv_heads && a.step && !a.rowmap && a.rows % a.beams == 0 && a.max_tail <= 64) return launch_dec_beam4(a, st);
     return launch_dec_t<bf16_t, 64, 4>(a, st);
   }
-  return a.head_dim == 64 ? launch_dec_t<bf16_t, 64>(a, st) : launch_dec_t<bf16_t, 128>(a, st);
+  // greedy rows: TWO waves per workgroup (a wave walks every second 64-key tile; up to eight workgroups per CU).  Alone a launch of few rows
+  // is slower that way (8 rows x 16 s clips: 7.3 -> 8-9 us) and a full one faster (97 rows: 28 -> 20 us, head_dim 128: 50 -> 43 us), and the
+  // CU-time falls with the LDS footprint: headline 327 -> 330 utt/s, Llama-3.1-8B 164 -> 166 (round 5, same box).  Like every wave layout
+  // here it is a property of (model, decode mode) -- the key -> wave partition fixes the fp32 merge order of a row -- never of the row count.
+  return a.head_dim == 64 ? launch_dec_t<bf16_t, 64, 2>(a, st) : launch_dec_t<bf16_t, 128, 2>(a, st);
 }
 
 }  // namespace oavsr
