@@ -207,7 +207,8 @@ int launch_swiglu(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, i
 // scratch: optional [rows][64] float2 for the two-stage variant
 int launch_argmax(const float* logits, int64_t ld, int rows, int V, int banned, int* out, void* scratch, hipStream_t st);
 // per-utterance 64-bit digest of rows [cu[b], cu[b + 1]) (cu == nullptr: row b) of `words_per_row` 32-bit words each -> out[b * out_stride + out_col]
-int launch_digest(const void* base, const int* cu, int64_t words_per_row, int n_utts, uint64_t* out, int out_stride, int out_col, hipStream_t st);
+int launch_digest(const void* base, const int* cu, int64_t words_per_row, int n_utts, uint64_t* out, int out_stride, int out_col, hipStream_t st,
+                  int64_t row_stride = 0);      // row_stride (words, cu == nullptr only): rows further apart than they are long (padded logits rows)
 // segment metadata
 int launch_build_rowinfo(const int* cu_out, const int* cu_in, int n_seqs, int stride, int4* rowinfo, int rows,
                          hipStream_t st);

@@ -1015,11 +1015,16 @@ static int llm_prefill_layers(const oavsr_model* m, oavsr_workspace* ws, int tas
 
 // logits[rows][vocab] (fp32, Llama_LoRA.py:372-373) of decode-shaped rows: A = ws->lh rows (T(x * norm.w), written by the last
 // down_proj's reduce), accumulator x 1 / rms(x) from the same reduce's sums of squares
+// Row stride of the engine's own logits buffers: the vocabulary rounded up to 16 floats, so that every row starts on a 64-byte boundary and
+// lm_head's epilogue stores 16-byte vectors (Llama-3's 128 261 = 128 256 + 5 added tokens is odd: rows at a stride of V floats are only
+// 4-byte aligned and went out as sixteen scalar stores per lane and slab -- lm_head at 97 rows 183 -> 140 us).  Callers' logits buffers
+// (oavsr_prefill) stay dense [B][V]: copied row by row.
+static inline int64_t vstride(const oavsr_config& c) { return ((int64_t)c.llm_vocab + 15) & ~(int64_t)15; }
 static int lm_head_rows(const oavsr_model* m, oavsr_workspace* ws, int rows, float* logits, hipStream_t st) {
   const oavsr_config& c = m->cfg;
   const int d = c.llm_hidden;
   GemmArgs g; g.dtype = m->dtype; g.M = rows; g.N = c.llm_vocab; g.K = d; g.W = m->lm_head; g.ldw = d;
-  g.A = ws->lh; g.lda = d; g.C = logits; g.ldc = c.llm_vocab; g.out_f32 = 1;
+  g.A = ws->lh; g.lda = d; g.C = logits; g.ldc = vstride(c); g.out_f32 = 1;
   // (N = the vocabulary: the column tiles alone fill the chip; decode_split gives 1)
   return decode_gemm(m, ws, g, st, ceil_div(d, 64));
 }
@@ -1060,10 +1065,10 @@ static int prefill_impl(const oavsr_model* m, oavsr_workspace* ws, int task, int
   OAVSR_TRY(h2d(ws->cu_b, cul, sizeof(int) * (B + 1), st));   // cu_b: encoder scratch, idle during prefill
   // logits of every utterance's last position only (the reference materialises all positions, Llama_LoRA.py:372-373)
   OAVSR_TRY(llm_prefill_layers(m, ws, task, total, B, maxS, ws->pos, ws->cpos, ws->last_rows, ws->cu_b, st));
-  float* lg = dest ? dest->logits + (size_t)dest->slot0 * c.llm_vocab : ws->logits + (size_t)utt0 * c.llm_vocab;
+  float* lg = dest ? dest->logits + (size_t)dest->slot0 * vstride(c) : ws->logits + (size_t)utt0 * vstride(c);
   OAVSR_TRY(lm_head_rows(m, ws, B, lg, st));
-  if (ws->digests) OAVSR_TRY(launch_digest(lg, nullptr, c.llm_vocab, B, ws->digests + (size_t)utt0 * 2, 2, 1, st));      // the first step's logits row
-  if (logits_out) OAVSR_CHECK_HIP(hipMemcpyAsync(logits_out, lg, (size_t)B * c.llm_vocab * 4, hipMemcpyDeviceToDevice, st));
+  if (ws->digests) OAVSR_TRY(launch_digest(lg, nullptr, c.llm_vocab, B, ws->digests + (size_t)utt0 * 2, 2, 1, st, vstride(c)));      // the first step's logits row
+  if (logits_out) OAVSR_CHECK_HIP(hipMemcpy2DAsync(logits_out, (size_t)c.llm_vocab * 4, lg, (size_t)vstride(c) * 4, (size_t)c.llm_vocab * 4, (size_t)B, hipMemcpyDeviceToDevice, st));
   return 0;
 }
 
@@ -1099,13 +1104,13 @@ static int decode_greedy(const oavsr_model* m, oavsr_workspace* ws, int task, in
   for (int b = 0; b < B; ++b) slot[b] = b;
   OAVSR_TRY(h2d(ws->slot, slot, sizeof(int) * B, st));
   const int banned = force_len ? c.id_eos : -1;
-  OAVSR_TRY(launch_argmax(ws->logits, c.llm_vocab, B, c.llm_vocab, banned, ws->amax, ws->amax_scratch, st));
+  OAVSR_TRY(launch_argmax(ws->logits, vstride(c), B, c.llm_vocab, banned, ws->amax, ws->amax_scratch, st));
   OAVSR_TRY(launch_greedy_update(ws->amax, gs, B, max_new, c.id_eos, c.id_pad, st));
   auto one_step = [&]() -> int {
     OAVSR_TRY(launch_embed(m->dtype, m->embed, c.llm_hidden, gs.tok, ws->lx, c.llm_hidden, B, c.llm_hidden, st));
     OAVSR_TRY(llm_decode_layers(m, ws, task, B, 1, maxS + max_new, gs.pos, gs.cpos, nullptr, gs.step, st, gs.rope_cs));
     OAVSR_TRY(lm_head_rows(m, ws, B, ws->logits, st));
-    OAVSR_TRY(launch_argmax(ws->logits, c.llm_vocab, B, c.llm_vocab, banned, ws->amax, ws->amax_scratch, st));
+    OAVSR_TRY(launch_argmax(ws->logits, vstride(c), B, c.llm_vocab, banned, ws->amax, ws->amax_scratch, st));
     return launch_greedy_update(ws->amax, gs, B, max_new, c.id_eos, c.id_pad, st);
   };
   // The decode step is identical every iteration (all step-dependent values live in device memory), so it is captured
@@ -1162,7 +1167,7 @@ static int decode_beam(const oavsr_model* m, oavsr_workspace* ws, int task, int 
   int* anc[2] = {ws->anc[0], ws->anc[1]};
   // step 0: candidates from the prefill logits (one row per utterance; beam_scores = [0, -1e9, ...] <=> only beam 0 counts)
   { ProfScope ps("beam_search", 0, (double)B * c.llm_vocab * 16, st);
-    OAVSR_TRY(launch_beam_topk(ws->logits, c.llm_vocab, B, c.llm_vocab, K, nullptr, ws->cand_val, ws->cand_tok, ws->topk_flag, st));
+    OAVSR_TRY(launch_beam_topk(ws->logits, vstride(c), B, c.llm_vocab, K, nullptr, ws->cand_val, ws->cand_tok, ws->topk_flag, st));
     OAVSR_TRY(launch_beam_step(a, 1, seq[0], anc[0], seq[1], anc[1], st)); }
   // one step reads ping-pong side `cur` of the sequence / ancestry tables and writes the other one
   auto one_step = [&](int cur) -> int {
@@ -1170,7 +1175,7 @@ static int decode_beam(const oavsr_model* m, oavsr_workspace* ws, int task, int 
     OAVSR_TRY(llm_decode_layers(m, ws, task, R, K, maxS + max_new, ws->gs.pos, ws->gs.cpos, anc[cur], ws->gs.step, st));
     OAVSR_TRY(lm_head_rows(m, ws, R, ws->logits, st));
     ProfScope ps("beam_search", 0, (double)R * c.llm_vocab * 16, st);
-    OAVSR_TRY(launch_beam_topk(ws->logits, c.llm_vocab, R, c.llm_vocab, K, ws->beam_scores, ws->cand_val, ws->cand_tok, ws->topk_flag, st));
+    OAVSR_TRY(launch_beam_topk(ws->logits, vstride(c), R, c.llm_vocab, K, ws->beam_scores, ws->cand_val, ws->cand_tok, ws->topk_flag, st));
     return launch_beam_step(a, 0, seq[cur], anc[cur], seq[cur ^ 1], anc[cur ^ 1], st);
   };
   // Every step-dependent value lives in device memory, so a PAIR of steps (side 0 -> 1 -> 0) is one hipGraph, captured once per
@@ -1357,7 +1362,7 @@ int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, 
   WANT(embeds, ST * d * e); WANT(maps, ST * 4 * sizeof(int));
   WANT(lx, Rl * d * e); WANT(lh, Rl * d * e); WANT(lqkv, Rl * nqkv * e); WANT(lattn, Rl * (size_t)H * hd * e);
   WANT(lgu, Rl * 2 * I * e); WANT(lact, Rl * (size_t)I * e); WANT(llora, Rl * (size_t)std::max(64, c.lora_k2) * e);
-  WANT(lastx, rows_dec * d * e); WANT(logits, rows_dec * (size_t)c.llm_vocab * 4);
+  WANT(lastx, rows_dec * d * e); WANT(logits, rows_dec * (size_t)vstride(c) * 4);
   ws->kpre_layer = (size_t)max_B * KV * ws->max_prefix * hd * e;
   ws->ktail_layer = rows_dec * KV * (size_t)max_new * hd * e;
   WANT(kpre, ws->kpre_layer * c.llm_layers); WANT(vpre, ws->kpre_layer * c.llm_layers);
@@ -1590,7 +1595,7 @@ static int sched_one_step(oavsr_scheduler* s, SchedLane& l, int R, int task, int
   OAVSR_TRY(llm_decode_layers(m, w, task, R, 1, s->max_prefix + s->max_new, s->ss.pos, s->ss.cpos, nullptr, nullptr, l.st, s->ss.rope_cs));
   OAVSR_TRY(lm_head_rows(m, w, R, w->logits, l.st));
   { ProfScope ps("argmax_partial", 0, (double)R * c.llm_vocab * 4, l.st);
-    OAVSR_TRY(launch_argmax_partial(w->logits, c.llm_vocab, R, c.llm_vocab, banned, l.partials, l.st)); }
+    OAVSR_TRY(launch_argmax_partial(w->logits, vstride(c), R, c.llm_vocab, banned, l.partials, l.st)); }
   ProfScope ps("sched_tail", 0, 2.0 * R * c.llm_hidden * m->esz, l.st);
   return launch_sched_tail(l.partials, s->ss, l.rowmap, 0, R, c.id_eos, c.id_pad, m->dtype, m->embed, c.llm_hidden, w->lx, c.llm_hidden, c.llm_hidden, l.st);
 }
@@ -1704,7 +1709,7 @@ int oavsr_scheduler_create(const oavsr_model* m, int32_t n_slots, int32_t max_ro
   WANT(w->kpre, w->kpre_layer * c.llm_layers); WANT(w->vpre, w->kpre_layer * c.llm_layers);
   WANT(w->ktail, w->ktail_layer * c.llm_layers); WANT(w->vtail, w->ktail_layer * c.llm_layers);
   WANT(w->prefix_len, NS * 4);
-  WANT(s->logits_pre, (size_t)n_slots * c.llm_vocab * 4);
+  WANT(s->logits_pre, (size_t)n_slots * vstride(c) * 4);
   WANT(s->ss.tok, NS * 4); WANT(s->ss.finished, NS * 4); WANT(s->ss.out_ids, NS * (size_t)max_new * 4); WANT(s->ss.out_len, NS * 4);
   WANT(s->ss.nstep, NS * 4); WANT(s->ss.limit, NS * 4); WANT(s->ss.pos, NS * 4); WANT(s->ss.cpos, NS * 4);
   WANT(s->ss.rope_cs, NS * (size_t)(hd / 2) * sizeof(float2));
@@ -1712,7 +1717,7 @@ int oavsr_scheduler_create(const oavsr_model* m, int32_t n_slots, int32_t max_ro
     l.dws = new oavsr_workspace();
     oavsr_workspace* lw = l.dws;
     WANT(lw->lx, R * d * e); WANT(lw->lh, R * d * e); WANT(lw->lqkv, R * nqkv * e); WANT(lw->lattn, R * (size_t)H * hd * e);
-    WANT(lw->lact, R * (size_t)I * e); WANT(lw->llora, R * (size_t)std::max(64, c.lora_k2) * e); WANT(lw->logits, R * (size_t)c.llm_vocab * 4);
+    WANT(lw->lact, R * (size_t)I * e); WANT(lw->llora, R * (size_t)std::max(64, c.lora_k2) * e); WANT(lw->logits, R * (size_t)vstride(c) * 4);
     WANT(l.partials, R * 64 * 8); WANT(l.rowmap, 128 * 4);
     {   // the decode-shaped GEMMs' split-K slabs, arrival counters, deferred-norm scratch and (when SwiGLU is not fused) the [rows][2I] gate / up tensor
       const int sites[5][3] = {{c.lora_k2, d, 1}, {(int)nqkv, d + c.lora_k2, 1}, {d, H * hd, 2}, {2 * I, d, 1}, {d, I, 2}};
@@ -1889,7 +1894,7 @@ int oavsr_generate_submit(const oavsr_model* m, oavsr_scheduler* s, oavsr_worksp
     IntPack128 Sp;
     for (int b = 0; b < B; ++b) Sp.v[b] = S[b];
     OAVSR_TRY(launch_sched_init_slots(s->ss, slot0, B, Sp, max_new, c.id_pad, l.st));
-    OAVSR_TRY(launch_argmax_partial(s->logits_pre + (size_t)slot0 * c.llm_vocab, c.llm_vocab, B, c.llm_vocab, banned, l.partials, l.st));
+    OAVSR_TRY(launch_argmax_partial(s->logits_pre + (size_t)slot0 * vstride(c), vstride(c), B, c.llm_vocab, banned, l.partials, l.st));
     OAVSR_TRY(launch_sched_tail(l.partials, s->ss, nullptr, slot0, B, c.id_eos, c.id_pad, m->dtype, m->embed, c.llm_hidden, nullptr, 0, c.llm_hidden, l.st));
     return 0;
   };

@@ -539,11 +539,11 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
   return z;
 }
 __global__ __launch_bounds__(kThreads) void digest_kernel(const unsigned* __restrict__ base, const int* __restrict__ cu, long long words_per_row,
-                                                           unsigned long long* __restrict__ out, int out_stride, int out_col) {
+                                                           unsigned long long* __restrict__ out, int out_stride, int out_col, long long row_stride) {
   __shared__ unsigned long long part[kWavesPerBlock];
   const int b = blockIdx.x;
   const long long r0 = cu ? cu[b] : b, r1 = cu ? cu[b + 1] : b + 1;
-  const unsigned* p = base + r0 * words_per_row;
+  const unsigned* p = base + r0 * row_stride;      // (row_stride != words_per_row only with cu == nullptr: one padded row per utterance)
   const long long n = (r1 - r0) * words_per_row;
   // blockIdx.y owns one contiguous share of the utterance's words; the shares meet in an integer atomic add (any order: same value)
   const long long per = (n + gridDim.y - 1) / gridDim.y, i0 = blockIdx.y * per, i1 = i0 + per < n ? i0 + per : n;
@@ -748,11 +748,12 @@ int launch_greedy_update(const int* amax, GreedyState s, int B, int max_new, int
   return 0;
 }
 
-int launch_digest(const void* base, const int* cu, int64_t words_per_row, int n_utts, uint64_t* out, int out_stride, int out_col, hipStream_t st) {
+int launch_digest(const void* base, const int* cu, int64_t words_per_row, int n_utts, uint64_t* out, int out_stride, int out_col, hipStream_t st, int64_t row_stride) {
   if (n_utts <= 0) return 0;
   // the utterances' slots of this column start from zero (a strided 8-byte clear), then 64 shares per utterance add into them
   OAVSR_CHECK_HIP(hipMemset2DAsync(out + out_col, (size_t)out_stride * 8, 0, 8, (size_t)n_utts, st));
-  hipLaunchKernelGGL(digest_kernel, dim3(n_utts, 64), dim3(kThreads), 0, st, (const unsigned*)base, cu, (long long)words_per_row, (unsigned long long*)out, out_stride, out_col);
+  hipLaunchKernelGGL(digest_kernel, dim3(n_utts, 64), dim3(kThreads), 0, st, (const unsigned*)base, cu, (long long)words_per_row, (unsigned long long*)out, out_stride, out_col,
+                     (long long)(row_stride > 0 ? row_stride : words_per_row));
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;
 }
