@@ -199,6 +199,7 @@ def parse_args():
     ap.add_argument("--sched-slots", type=int, default=None, help="row slots of the scheduler's pool (default: the engine's)")
     ap.add_argument("--sched-stride", type=int, default=0, help="steps per admission (0 = automatic)")
     ap.add_argument("--sched-lanes", type=int, default=None, help="independent step loops of the scheduler (default: the engine's)")
+    ap.add_argument("--pending-per-lane", type=int, default=8, help="submitted calls the loop leaves uncollected: 2 x streams + this x lanes (a stream-side wait beyond that)")
     ap.add_argument("--no-stagger", action="store_true", help="let the encoder phases of in-flight batches share the chip (default: chained)")
     ap.add_argument("--testset", type=int, default=0,
                     help="N > 0: the test-set-shaped run instead of the step loop (BASELINE.json configs[4] / SURVEY.md 8d C5: N synthetic utterances, "
@@ -439,7 +440,7 @@ def testset_run(args, rank, world, local, use_dist, affinity=None):
             "config": {"workload": f"test-set-shaped run (SURVEY.md 8d C5 / BASELINE.json configs[4] shape): {N} utterances, lengths U[1 s, {args.frames / 25:.0f} s], "
                                    f"{task}, {llm_name} (Omni-LoRA ST r32/a4), batches of {B}, rates ({ra}, {rv}), greedy <= {args.max_new} tokens (natural EOS), "
                                    f"HOST inputs (collation + host-to-device copies timed), preset {args.preset} (NOT the headline configuration)",
-                       "utterances": N, "audio_seconds": round(secs, 1), "batch_per_call": B, "in_flight": 3,
+                       "utterances": N, "audio_seconds": round(secs, 1), "batch_per_call": B, "in_flight": 4,
                        "parallelism": f"utterance-sharded dp{world}, duration-sorted round-robin", "utterances_per_rank": per_rank,
                        "rank_busy_s": [round(b, 3) for b in busy_all], "imbalance": round(max(busy_all) / max(1e-9, min(busy_all)), 4),
                        "host_ms_per_batch": {k: round(tm[k] / max(1, tm["batches"]) * 1e3, 2) for k in ("wait_collate", "submit", "collect")},
@@ -626,7 +627,7 @@ def main():
                 ids_, lens_, ticket = eng.submit(task, video, Tvs, audio if use_a else None, Ts if use_a else None, ra, rv, max_new=args.max_new,
                                                  force_len=True, video_is_flat=True, slot=s, digests=dg)
                 pending.append((s, ticket))
-                if len(pending) > 2 * nstream + 8 * args.sched_lanes:            # every step of that call was issued long ago: a stream-side wait, no host sync
+                if len(pending) > 2 * nstream + args.pending_per_lane * args.sched_lanes:            # every step of that call was issued long ago: a stream-side wait, no host sync
                     s0, t0_ = pending.pop(0)
                     with torch.cuda.stream(streams[s0]):
                         eng.wait(t0_)
