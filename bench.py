@@ -199,9 +199,9 @@ def parse_args():
     ap.add_argument("--sched-slots", type=int, default=None, help="row slots of the scheduler's pool (default: the engine's)")
     ap.add_argument("--sched-stride", type=int, default=0, help="steps per admission (0 = automatic)")
     ap.add_argument("--sched-lanes", type=int, default=None, help="independent step loops of the scheduler (default: the engine's)")
-    ap.add_argument("--pending-per-lane", type=int, default=16,
+    ap.add_argument("--pending-per-lane", type=int, default=24,
                     help="submitted calls the loop leaves uncollected: 2 x streams + this x lanes (a stream-side wait beyond that).  8 (rounds 3-4) kept the "
-                         "lanes' steps at 74-78 rows; 16: 91-107 rows per step, +2.5-3.8 %% utt/s; more changes nothing (round 5)")
+                         "lanes' steps at 74-78 rows; 16: 91-107 rows per step, +2.5-3.8 %% utt/s; 24 with the 1024-slot pool: +2 %% more (round 5)")
     ap.add_argument("--no-stagger", action="store_true", help="let the encoder phases of in-flight batches share the chip (default: chained)")
     ap.add_argument("--testset", type=int, default=0,
                     help="N > 0: the test-set-shaped run instead of the step loop (BASELINE.json configs[4] / SURVEY.md 8d C5: N synthetic utterances, "

@@ -53,7 +53,9 @@ class OmniEngine:
         # rows per decode step (<= 128) / row slots of the pool / independent step loops sharing the pool.  Every decode-shaped GEMM runs on the
         # tiled LDS-DMA kernels (model.hip: llm_decode_layers): a step is ONE 128-row tile whatever its row count and streams every LLM weight
         # once, so the more rows share it the better -- 128-row steps, three lanes, for every model
-        self.sched_rows, self.sched_slots = 128, 512
+        # 1024 slots (round 5; 512 before): calls whose prefill is done wait in the pool for a lane -- with cheaper encoders 512 slots were the
+        # queue's limit (headline 337-340 -> 345-346 utt/s; Llama-3.2-1B at 16 s clips: 11.7 GB, Llama-3.1-8B: _fit_slots caps it at a quarter of the device)
+        self.sched_rows, self.sched_slots = 128, 1024
         self.sched_lanes = 3
         self.sched_stride = 0                           # steps per admission (0: automatic; oavsr_scheduler_set_stride)
         self._blob = None
@@ -358,7 +360,7 @@ class OmniEngine:
     def _fit_slots(self, max_prefix: int, max_new: int) -> int:
         """Row slots the pool is built with: `sched_slots`, cut down (never below one step's rows) so that the pool -- per slot the prefix and tail
         KV rows of every layer plus one fp32 logits row -- stays under a quarter of the device's memory (Llama-3.1-8B, 16 s clips: ~42 MB per
-        slot, 512 slots = 21 GB: fine on 288 GB, not on a small board or with several engines per process)."""
+        slot, 1024 slots = 43 GB: fine on 288 GB, not on a small board or with several engines per process)."""
         l = self.spec.llm
         esz = 2 if self.dtype == "bf16" else 4
         per_slot = 2 * l.layers * l.kv_heads * l.head_dim * (max_prefix + max_new) * esz + l.vocab * 4

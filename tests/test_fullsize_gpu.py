@@ -169,7 +169,7 @@ def test_headline_configuration_returns_the_ids_of_isolated_calls(bf16_engine):
     engine's caller streams, four input sets rotating -- 28 calls, and every one of them must return exactly the ids of ONE isolated
     oavsr_generate of its input set (what bench.py itself verifies after its timed region before it prints a line)."""
     eng = bf16_engine
-    assert (eng.sched_lanes, eng.sched_rows, eng.sched_slots) == (3, 128, 512), "this case pins the engine's default scheduler shape"
+    assert (eng.sched_lanes, eng.sched_rows, eng.sched_slots) == (3, 128, 1024), "this case pins the engine's default scheduler shape"
     B, Tv = 8, 400
     sets = []
     for s_ in range(4):
