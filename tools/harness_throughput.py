@@ -39,7 +39,8 @@ to_text = lambda ids: [" ".join(str(int(t)) for t in row) for row in ids.cpu()] 
 out = {}
 for name, smp, k in (("float samples, sequential", samples[:48], 1), ("float samples, 3 in flight (cold)", samples, 3), ("float samples, 3 in flight", samples, 3),
                      ("uint8 frames, 3 in flight (cold)", samples_u8, 3), ("uint8 frames, 3 in flight", samples_u8, 3), ("uint8 frames, 3 in flight", samples_u8, 3),
-                     ("float samples, 3 in flight", samples, 3), ("float samples, 4 in flight", samples, 4), ("uint8 frames, 4 in flight", samples_u8, 4)):
+                     ("float samples, 3 in flight", samples, 3), ("float samples, 4 in flight", samples, 4), ("uint8 frames, 4 in flight", samples_u8, 4)) + tuple(
+                         (f"uint8 frames, {int(k)} in flight", samples_u8, int(k)) for k in os.environ.get("HT_EXTRA_IN_FLIGHT", "").split(",") if k):
     torch.cuda.synchronize()
     s0 = eng.scheduler_stats()
     t0 = time.perf_counter()
