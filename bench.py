@@ -249,7 +249,15 @@ def latency_leg(eng, args, pre, task, use_a, first_set):
     ra, rv = pre["rates"][0]
     out = {"unit": "ms per utterance", "clip_s": round(t1 / 25.0, 2), "calls": 10,
            "note": "B = 1, one call at a time on an idle chip, device-synchronised per call, median of 10 (the reference's evaluation protocol, data_module.py:238-242)"}
-    eng.launch_objective(True)              # one call at a time on an idle chip: the dispatcher's latency rule (same bits)
+    prev_obj = eng.launch_objective(True)   # one call at a time on an idle chip: the dispatcher's latency rule (same bits); restored in `finally`
+    try:
+        _latency_calls(eng, args, out, task, v1, t1, a1, use_a, ra, rv)
+    finally:
+        eng.launch_objective(prev_obj)
+    return out
+
+
+def _latency_calls(eng, args, out, task, v1, t1, a1, use_a, ra, rv):
     for name, beams in (("greedy", 1), ("beam15", 15)):
         ts = []
         for k in range(13):
@@ -263,8 +271,6 @@ def latency_leg(eng, args, pre, task, use_a, first_set):
         ts.sort()
         out[name] = round(ts[len(ts) // 2], 3)
         out[name + "_min"] = round(ts[0], 3)
-    eng.launch_objective(False)
-    return out
 
 
 def schedule_summary(recs, skip_calls):

@@ -83,6 +83,8 @@ int oavsr_env_report(char* buf, int32_t nbytes);
  * other CUs are not idle.  1: ONE call at a time on an otherwise idle chip (the reference's evaluation protocol, data_module.py:238-242) --
  * such launches take finer tiles that cover more CUs and finish sooner.  Never a bit: every tile shape accumulates in the same order. */
 int oavsr_set_launch_objective(int32_t alone);
+/* the current objective (0 / 1): it is GLOBAL to the process -- a caller that changes it for a phase reads it first and restores it after */
+int oavsr_get_launch_objective(void);
 
 /* weights: one device blob + manifest (replaces AVSR_LLMs.load_state_dict, lightning_OmniAVSR.py:148-150) */
 int oavsr_model_create(const oavsr_config* cfg, const void* blob_dev, uint64_t blob_bytes, const oavsr_tensor* tensors,

@@ -313,6 +313,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   if (a.amode == A_CONV1D) OAVSR_REQUIRE(a.Cin % vec == 0 && a.rowinfo && a.Kvalid == a.taps * a.Cin && a.Kvalid <= a.K, "gemm/conv1d: bad geometry");
   if (a.amode == A_STEM) OAVSR_REQUIRE(a.frameinfo && a.K == 256 && a.M % 1936 == 0, "gemm/stem: bad geometry");
   OAVSR_REQUIRE(a.act != ACT_PRELU || a.prelu, "gemm: PReLU needs slopes");
+  OAVSR_REQUIRE(!a.row_sumsq || (a.amode == A_DENSE && a.groups == 1 && a.M <= 128 && a.N >= 64 && a.row_sumsq_tiles >= 1 && a.row_dim > 0 && (a.ksplit > 1 || a.decode_tiled)),
+                "gemm: the row factor (row_sumsq) is an epilogue of the decode-shaped launches (dense, M <= 128, N >= 64, decode_tiled)");
+  OAVSR_REQUIRE(!a.ng_out || a.ksplit > 1, "gemm: the next-norm outputs (ng_out) are written by the split-K reduce only");
   if (a.ksplit > 1) {
     // split-K: the 128 x 64 LDS-DMA tile only -- the decode-shaped GEMMs, <= 128 rows per launch -- with the reduce inside the launch (a.sync:
     // arrival counters) or as a second launch of the same reduce code (gemm2.hip)
@@ -330,8 +333,6 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     }
     return launch_gemm_dma(a, st);
   }
-  OAVSR_REQUIRE(!a.row_sumsq || (a.amode == A_DENSE && a.groups == 1 && a.M <= 128 && a.N >= 64 && a.row_sumsq_tiles >= 1 && a.row_dim > 0 && (a.ksplit > 1 || a.decode_tiled)),
-                "gemm: the row factor (row_sumsq) is an epilogue of the decode-shaped launches (dense, M <= 128, N >= 64, decode_tiled)");
   if (a.swiglu_pairs) OAVSR_REQUIRE(gemm_dma_swiglu_ok(a), "gemm: fused SwiGLU epilogue unavailable for this shape (check gemm_dma_swiglu_ok)");
   if (gemm_dma_eligible(a)) return launch_gemm_dma(a, st);
   return a.dtype == DT_F32 ? launch_mode<float>(a, st) : launch_mode<bf16_t>(a, st);

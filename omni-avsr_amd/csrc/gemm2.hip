@@ -654,7 +654,12 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
       __syncthreads();
       if (tid == 0) {
         const int old = __hip_atomic_fetch_add(p.sync + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *sflag = old == (int)gridDim.y - 1;
+        const bool last = old == (int)gridDim.y - 1;
+        // The measured sc1-only hand-off (guide, first table row) holds at ONE workgroup per CU; this tile shares a CU with a second
+        // workgroup and with other streams' kernels, so the last arriver also takes the agent-scope acquire (invalidate this CU's L1,
+        // wait for it) before the barrier that releases the other waves' loads: ~1.7 us on one workgroup per tile.
+        if (last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        *sflag = last;
       }
       __syncthreads();
       if (!*sflag) return;

@@ -31,6 +31,8 @@
 // 256 x 256-tile launch it supports: with one tile per workgroup it still beats the 16-wave and the ping-pong kernel (leaner prologue and
 // epilogue; RES variant for o_proj / fc2 / down_proj); the LoRA-segment GEMMs stay on gemm2.hip / gemm3.hip.
 #include <stdlib.h>
+#include <mutex>
+#include <set>
 #include <type_traits>
 #include "kernels.h"
 
@@ -532,10 +534,15 @@ int launch_gemm_8pp(const GemmArgs& a, hipStream_t st, int grid, int rows) {
   GemmArgs b = a;
   b.tile_order = 1;
   auto go = [&](auto kern) -> int {
-    static bool attr_set = false;
-    if (!attr_set) {
-      OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem8pp));
-      attr_set = true;
+    // every instantiation has the same function-pointer type (one lambda instance): the attribute is remembered per kernel POINTER
+    static std::mutex mu;
+    static std::set<const void*> attr_set;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!attr_set.count(reinterpret_cast<const void*>(kern))) {
+        OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kSmem8pp));
+        attr_set.insert(reinterpret_cast<const void*>(kern));
+      }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), kSmem8pp, st, b, (int)ntiles);
     OAVSR_CHECK_HIP(hipGetLastError());

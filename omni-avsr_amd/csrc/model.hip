@@ -1296,6 +1296,7 @@ void oavsr_model_destroy(oavsr_model* m) {
 }
 
 int oavsr_set_launch_objective(int32_t alone) { g_alone.store(alone ? 1 : 0, std::memory_order_relaxed); return 0; }
+int oavsr_get_launch_objective(void) { return g_alone.load(std::memory_order_relaxed); }
 int oavsr_model_serialize_encoders(oavsr_model* m, int32_t on) {
   OAVSR_REQUIRE(m, "serialize_encoders: null model");
   if (on && !m->enc_done) OAVSR_CHECK_HIP(hipEventCreateWithFlags(&m->enc_done, hipEventDisableTiming));

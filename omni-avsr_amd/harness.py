@@ -304,10 +304,15 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
         from concurrent.futures import ThreadPoolExecutor
         make = (lambda idxs: flat([samples[i][0] for i in idxs], modality, bos_id)) if raw else \
             (lambda idxs: collate_test([samples[i][0] for i in idxs], modality, bos_id))
+        if not batches:      # a rank that owns nothing (world > utterances) or an empty sample list: an empty meter, and on to the collectives
+            if decode_group > 1:
+                model.encoder_chunk = chunk_prev
+            return meter
         pool = None if raw else ThreadPoolExecutor(1)
         eng0 = getattr(model, "engine", None)
+        prev_obj = None      # the dispatcher's objective is global to the process: what was found is put back
         if eng0 is not None and hasattr(eng0, "launch_objective"):
-            eng0.launch_objective(True)                       # one call at a time on an idle chip: tiles chosen for the launch's own duration (same bits)
+            prev_obj = eng0.launch_objective(True)            # one call at a time on an idle chip: tiles chosen for the launch's own duration (same bits)
         try:
             nxt = pool.submit(make, batches[0]) if pool else None
             for n, idxs in enumerate(batches):
@@ -323,15 +328,15 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
         finally:
             if pool:
                 pool.shutdown(wait=True)
-            if eng0 is not None and hasattr(eng0, "launch_objective"):
-                eng0.launch_objective(False)
+            if prev_obj is not None:
+                eng0.launch_objective(bool(prev_obj))
             if decode_group > 1:
                 model.encoder_chunk = chunk_prev
         return meter
 
     eng = model.engine
     dev = eng.device
-    eng.launch_objective(False)                               # several calls share the chip: least CU-time per launch
+    prev_obj = eng.launch_objective(False)                    # several calls share the chip: least CU-time per launch (restored below)
     # one workspace per slot, sized for the longest owned clip: nothing is re-created while other slots are busy
     tv_max = max([int(samples[i][0][vkey(samples[i][0])].shape[0]) for i in owned if vkey(samples[i][0]) in samples[i][0]] or [1])
     u8_shape = tuple(samples[owned[0]][0]["video_u8"].shape[1:]) if owned and "video_u8" in samples[owned[0]][0] else None
@@ -435,6 +440,7 @@ def evaluate(model, samples: Sequence[Tuple[Dict[str, torch.Tensor], str]], moda
         pool.shutdown(wait=True)
         torch.cuda.synchronize(dev)
         eng.serialize_encoders(False)
+        eng.launch_objective(bool(prev_obj))
         if decode_group > 1:
             model.encoder_chunk = chunk_prev
     return meter

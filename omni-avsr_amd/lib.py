@@ -97,6 +97,7 @@ SYMBOLS = {
     "oavsr_last_error": (C.c_char_p, []),
     "oavsr_env_report": (C.c_int, [C.c_char_p, _I]),
     "oavsr_set_launch_objective": (C.c_int, [C.c_int32]),
+    "oavsr_get_launch_objective": (C.c_int, []),
     "oavsr_model_create": (C.c_int, [C.POINTER(OavsrConfig), _P, C.c_uint64, C.POINTER(OavsrTensor), _I, C.POINTER(_P)]),
     "oavsr_model_destroy": (None, [_P]),
     "oavsr_model_serialize_encoders": (C.c_int, [_P, C.c_int32]),

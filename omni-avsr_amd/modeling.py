@@ -139,9 +139,11 @@ class OmniEngine:
     def launch_objective(self, alone: bool):
         """What the GEMM dispatcher optimises (process-wide; include/omni_avsr.h: oavsr_set_launch_objective).  False (default): calls share
         the chip -- coarse tiles on as many CUs as they have tiles, least CU-time.  True: one call at a time on an idle chip (the reference's
-        evaluation protocol) -- finer tiles that finish sooner.  Same bits either way."""
+        evaluation protocol) -- finer tiles that finish sooner.  Same bits either way.  Returns the PREVIOUS objective: the setting is global
+        to the process, so a caller that changes it for a phase restores what it found (`prev = launch_objective(True) ... launch_objective(prev)`)."""
+        prev = bool(self.lib.oavsr_get_launch_objective())
         L.check(self.lib.oavsr_set_launch_objective(int(bool(alone))))
-        return self
+        return prev
 
     def serialize_encoders(self, on: bool = True):
         """Several generate() calls in flight (slots): run their encoder + prefill phases back to back, overlap only decode."""

@@ -136,6 +136,39 @@ def test_evaluate_reports_failed_batches():
         H.evaluate(Sticky(), samples, "video", lambda ids: ["w1 w2"] * ids.shape[0], batch_size=1, allow_failures=True)
 
 
+def test_evaluate_with_an_empty_shard_returns_an_empty_meter():
+    """A rank that owns no utterance (world > utterances) or an empty sample list must come back with an empty meter -- it still has to
+    reach the collectives behind evaluate() -- and the process-wide launch objective must be what the caller had set."""
+    class Obj:
+        def __init__(self):
+            self.alone, self.calls = False, []
+
+        def launch_objective(self, alone):
+            prev, self.alone = self.alone, bool(alone)
+            self.calls.append(bool(alone))
+            return prev
+
+    class M:
+        is_task_specific = False
+
+        def __init__(self):
+            self.engine = Obj()
+
+        def __call__(self, batch, **kw):
+            return torch.tensor([[1, 2]] * batch["video"].shape[0])
+
+    m = M()
+    meter = H.evaluate(m, [], "video", lambda ids: ["w1 w2"] * ids.shape[0], batch_size=2)
+    assert meter.total_length == 0 and meter.total_edit_distance == 0 and meter.per_utt == {} or len(meter.per_utt) == 0
+    samples = [({"video": torch.zeros(5, 1, 88, 88)}, "w1 w2")]
+    meter = H.evaluate(m, samples, "video", lambda ids: ["w1 w2"] * ids.shape[0], batch_size=2, rank=1, world=2)      # rank 1 of 2 owns nothing
+    assert meter.total_length == 0 and len(meter.per_utt) == 0
+    # the owning rank scores it, and restores the objective it found (here: "alone" set by the caller)
+    m.engine.alone = True
+    meter = H.evaluate(m, samples, "video", lambda ids: ["w1 w2"] * ids.shape[0], batch_size=2, rank=0, world=2)
+    assert meter.total_length == 2 and m.engine.alone is True
+
+
 def test_reduce_wer_counters_carries_the_failed_count():
     from omni_avsr_amd.dist import reduce_wer_counters
     assert reduce_wer_counters(3, 10) == (3, 10) and reduce_wer_counters(3, 10, failed=2) == (3, 10, 2)
