@@ -24,8 +24,10 @@ extern "C" {
  * points (oavsr_scheduler_*, oavsr_generate_submit / _wait / _poll) and oavsr_trace_rec were added.
  * 3 (round 5): oavsr_gemm_desc follows the single decode regime (weight-streaming decode kernels removed: no `skinny` / norm_gain / rn_* /
  * shared_chip; `kernel`, decode_tiled, sync, row_scale, ng_* added); oavsr_generate / _submit take optional per-utterance digest buffers.
+ * 4 (round 6): oavsr_gemm_desc gained rowsq_strips / row_sumsq_form (the <= 32-row strip kernels' layout of the deferred RMSNorm's sums of
+ * squares); oavsr_get_launch_objective added.
  * A binding built against an older version must not load. */
-#define OAVSR_ABI_VERSION 3
+#define OAVSR_ABI_VERSION 4
 #define OAVSR_DT_F32 0  /* parity mode: exact-f32 MFMA */
 #define OAVSR_DT_BF16 1 /* throughput mode: bf16 storage, f32 accumulate (reference: bf16-true, eval_OmniAVSR.py:19) */
 #define OAVSR_MAX_RATES 8
@@ -280,6 +282,10 @@ typedef struct oavsr_gemm_desc {
   const float* ng_gain;
   float* ng_rowsq;
   int32_t grid;        /* persistent kernel only: workgroups (multiple of 8); 0 = the launcher's rule */
+  /* <= 32 rows (csrc/decode_strip.hip): rowsq_strips = 1: ng_rowsq is written per 16-column STRIP, [N / 16][M] (needs M <= 32); row_sumsq_form = 1:
+     row_sumsq is read in that layout -- row_sumsq_tiles tiles = 4 x as many entries, a tile's sum formed as (s0 + s1) + (s2 + s3), the tiles added
+     in order: the bits of the tiled layout */
+  int32_t rowsq_strips, row_sumsq_form;
 } oavsr_gemm_desc;
 #define OAVSR_GEMM_SYNC_INTS 4096
 int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream);

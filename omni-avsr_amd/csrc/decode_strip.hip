@@ -1,0 +1,339 @@
+// Decode-shaped GEMMs of FEW rows (<= kStripRows = 16: the reference's own protocol -- one utterance, one row per step, 15 with beam
+// search, Llama_LoRA.py:246-259,314,372,587-655 -- and every call-private decode loop of <= 16 rows):  C[M,N] = epi(A1.W1^T + A2.W2^T).
+//
+// The 128-row LDS-DMA tiles (gemm2.hip) serve these launches with the arithmetic of a 128-row batch: 2 / 3 of a k-tile's LDS traffic is
+// the zero page, the K split lives in separate workgroups whose fp32 slabs go through memory, an arrival counter and a second pass -- a
+// launch costs 12-14 us to move 1-14 MB (profiles/r05_decode_mix_timing.txt), 8-9 us of it fixed.  Here the same arithmetic is laid out for the
+// weights, which are all that moves:
+//   * a WAVE owns one item = one 16-column strip of W x one k-slice (the slices are the tiled kernels': slice s = k-tiles [s per, (s + 1) per),
+//     per = ceil(k-tiles / ksplit), the LoRA segment's k-tiles behind the main segment's) and streams its weights through a wave-PRIVATE FIFO of D
+//     k-tiles in LDS (LDS-DMA, non-temporal: every byte is read once per step; lane l reads back the 16 bytes lane l fetched); its <= 16 activation
+//     rows come from L2 the same way.  No barrier and no waiting on another wave inside the k loop, counted waits only; the MFMAs are the tiled
+//     kernels' (Mma2: activations as the A operand, k-tile by k-tile, chunk 0 then 1), so an item's 16 x 16 partial sums have the bits of the
+//     corresponding slab entries
+//   * the items of a strip sit in ONE workgroup: their partial sums meet in LDS and are added in slab order (0.f + s0 + s1 + ...: what
+//     splitk_reduce_tile does with the slabs), then the shared epilogue (epilogue.h: segment_finish) -- no slabs in memory, no arrival
+//     counter, no reduce launch.  ksplit stays what it is on the tiled path: a function of (N, K) that defines the summation order; here it only
+//     says how many waves share a strip
+//   * the deferred RMSNorm's per-row sums of squares are kept per 16-column strip (GemmArgs::rowsq_strips); a consumer forms the tiled
+//     producer's 64-column butterfly (s0 + s1) + (s2 + s3) from them and adds the tiles in order (row_sumsq_form = 1): same bits as the tiled path
+// => a row decodes to the same bits at 1 row and inside a 128-row step (tests/test_kernels_gpu.py::test_decode_shaped_gemm_rows_*).
+#include "kernels.h"
+#include "epilogue.h"
+
+namespace oavsr {
+namespace {
+
+constexpr int kStripRowBytes = 128;
+constexpr int kStripMaxTiles = 128;      // row_sumsq_tiles the kernel can take (hidden <= 8192)
+// one k-tile of a wave's ring: W chunk 0 | W chunk 1 (1 KiB each: 16 weight rows x 64 bytes) | A: MA activation rows x 128 bytes (MA = 8 or 16)
+constexpr int slot_bytes(int MA) { return 2048 + MA * 128; }
+
+template <typename T> __device__ __forceinline__ Chunk16 ld16(const T* p) { return *reinterpret_cast<const Chunk16*>(p); }
+
+// HBM -> LDS without a register destination: lane l's 16 bytes land at lds_wave_base + 16 l.  Nothing the compiler allocates is written
+// asynchronously (a first version streamed into registers from inline asm; the compiler split the ring's live ranges between the loop and
+// its tail and COPIED registers whose loads were still in flight).  aux 2 = nt: weights are read once per step.
+template <int AUX>
+__device__ __forceinline__ void strip_dma16(const void* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
+}
+template <int N> __device__ __forceinline__ void strip_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// D: k-tiles in flight per wave (ring slots); NW: waves per workgroup; MA: activation rows staged per k-tile (8: M <= 8, one DMA instruction; 16).
+// <= 16 rows: one MFMA row block.
+template <typename T, int D, int NW, int MA>
+__global__ __launch_bounds__(NW * 64) void decode_strip_kernel(const GemmArgs p, const int spw) {
+  constexpr int kSlotBytes = slot_bytes(MA);
+  constexpr int VEC = TypeInfo<T>::kVec;
+  constexpr int BKE = kStripRowBytes / (int)sizeof(T);
+  constexpr int kThreads = NW * 64;
+  constexpr int kRows = 16;
+  constexpr int JQ = 4;                                  // tile sums of the row factor a thread prepares from registers
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frow = lane & 15, fg = lane >> 4;
+  const int ks = p.ksplit < 1 ? 1 : p.ksplit;
+  const int nt1 = p.K / BKE, nall = nt1 + p.K2 / BKE;
+  const int per = (nall + ks - 1) / ks;
+  const int nstrips = (p.N + 15) >> 4;
+  const int strip0 = blockIdx.x * spw;
+  const int items = spw * ks;
+  const int nT = p.row_sumsq ? p.row_sumsq_tiles : 0;
+  char* ring = smem + wave * (D * kSlotBytes);            // this wave's FIFO
+  float* slab = reinterpret_cast<float*>(smem + NW * D * kSlotBytes);      // [items][16][16] partial sums
+  float* tsum = slab + (size_t)items * kRows * 16;        // [rows][nT] tile sums of squares (row factor)
+  const T* A1 = reinterpret_cast<const T*>(p.A);
+  const T* A2 = reinterpret_cast<const T*>(p.A2);
+  const T* W1 = reinterpret_cast<const T*>(p.W);
+  const T* W2 = reinterpret_cast<const T*>(p.W2);
+
+  // ---- what the finish needs from memory goes out FIRST (the oldest loads: landed long before anything waits for them)
+  // finish thread -> (strip sl of the workgroup, row): 16 columns of one row; fused SwiGLU: (pair of strips, row)
+  const bool swi = p.swiglu_pairs != 0;
+  const int fsl = tid / kRows, frw = tid % kRows;
+  const int fstrip = strip0 + (swi ? 2 * fsl : fsl);
+  const bool flive = fsl < (swi ? spw / 2 : spw) && frw < p.M && fstrip < nstrips;
+  const int fnc = fstrip * 16;
+  Chunk16 rraw[16 / VEC];
+  if (flive && p.residual) {
+    const T* Rr = reinterpret_cast<const T*>(p.residual) + (int64_t)frw * p.ldr + fnc;
+#pragma unroll
+    for (int e = 0; e < 16; e += VEC) rraw[e / VEC] = ld16(Rr + e);
+  }
+  float tq[JQ][4];
+  const int ntq = p.M * nT;                              // tile sums this workgroup needs: [t][row], row fastest (coalesced)
+  if (nT > 0) {
+#pragma unroll
+    for (int j = 0; j < JQ; ++j) {
+      const int idx = tid + j * kThreads;
+      if (idx < ntq) {
+        const int t = idx / p.M, r = idx - t * p.M;
+        if (p.row_sumsq_form) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) tq[j][q] = p.row_sumsq[(int64_t)(4 * t + q) * p.M + r];
+        } else {
+          tq[j][0] = p.row_sumsq[(int64_t)t * p.M + r];
+        }
+      }
+    }
+  }
+
+  // ---- the items of this wave.  Rows past M read row M - 1: an output row depends on its own activation row only and rows >= M are never
+  //      stored, so there is no zero fill and no branch between the loads of the ring
+  // Activations: lane l of an A instruction fetches chunk (l & 7) ^ (l >> 3) of row 8 j + (l >> 3) (j: the instruction; 8 rows x 128 bytes each), so
+  // the k-tile's rows sit in LDS as [row][chunk ^ (row & 7)] -- the MFMA fragment reads (row = lane & 15, chunk = 4 kb + lane / 16) are conflict-free
+  const int arow_l = lane >> 3, achunk_l = (lane & 7) ^ (lane >> 3);
+  const T* a1row[MA / 8];
+  const T* a2row[MA / 8];
+#pragma unroll
+  for (int j = 0; j < MA / 8; ++j) {
+    const int mr = min(j * 8 + arow_l, p.M - 1);
+    a1row[j] = A1 + (int64_t)mr * p.lda + achunk_l * VEC;
+    a2row[j] = A2 ? A2 + (int64_t)mr * p.lda2 + achunk_l * VEC : nullptr;
+  }
+  const int fr_a = frow & (MA - 1);                        // (MA = 8: lanes of rows 8..15 re-read rows 0..7 -- rows >= M are never stored)
+  const int a_off0 = (fr_a * 8 + (fg ^ (fr_a & 7))) * 16, a_off1 = (fr_a * 8 + ((4 + fg) ^ (fr_a & 7))) * 16;
+  for (int it = wave; it < items; it += NW) {
+    const int sl = it / ks, s = it - sl * ks;
+    const int strip = strip0 + sl;
+    if (strip >= nstrips) continue;
+    const int wr = min(strip * 16 + frow, p.N - 1);       // ragged last strip (lm_head's vocabulary): the row is read, its column never stored
+    const T* w1row = W1 + (int64_t)wr * p.ldw + fg * VEC;
+    const T* w2row = W2 ? W2 + (int64_t)wr * p.ldw2 + fg * VEC : nullptr;
+    const int tb = s * per;
+    const int n = tb + per <= nall ? per : (nall - tb > 0 ? nall - tb : 0);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto loadk = [&](int t, int slot) {                   // L LDS-DMA instructions: the k-tile's two 16-byte chunks of W per lane, MA rows of A
+      const bool s1 = t < nt1;                            // wave-uniform
+      const int k = (s1 ? t : t - nt1) * BKE;
+      const T* wp = (s1 ? w1row : w2row) + k;
+      char* dst = ring + slot * kSlotBytes;
+      strip_dma16<2>(wp, dst);
+      strip_dma16<2>(wp + 4 * VEC, dst + 1024);
+#pragma unroll
+      for (int j = 0; j < MA / 8; ++j) strip_dma16<0>((s1 ? a1row[j] : a2row[j]) + k, dst + 2048 + j * 1024);
+    };
+    auto mma = [&](int slot) {                            // W: each lane reads back exactly what it fetched; A: the swizzled row-major tile
+      const char* src = ring + slot * kSlotBytes;
+      const Chunk16 w0 = *reinterpret_cast<const Chunk16*>(src + lane * 16), w1 = *reinterpret_cast<const Chunk16*>(src + 1024 + lane * 16);
+      const Chunk16 a0 = *reinterpret_cast<const Chunk16*>(src + 2048 + a_off0), a1 = *reinterpret_cast<const Chunk16*>(src + 2048 + a_off1);
+      Mma2<T>::run(a0, w0, acc);
+      Mma2<T>::run(a1, w1, acc);
+      asm volatile("" ::: "memory");                      // the slot is read before anything below refills it
+    };
+
+    // L DMA instructions per k-tile; a slot's are the oldest outstanding when it is consumed.  Steady state: D L outstanding before a slot is
+    // consumed -> vmcnt((D - 1) L); the drain uses counts that are exact or smaller (a smaller count only waits longer).
+    // (the previous item's last LDS reads are done: its MFMAs took their operands before its slab entry was written)
+    constexpr int L = 2 + MA / 8;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+      if (i < n) loadk(tb + i, i);
+    int done = 0;
+    for (; done + 2 * D <= n; done += D) {                // steady state: every slot is consumed and refilled, no branch in the body
+      static_for<0, D>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        strip_wait<(D - 1) * L>();
+        mma(i);
+        loadk(tb + done + D + i, i);
+      });
+    }
+    const int rem = n - done;                             // < 2 D k-tiles left, the first min(rem, D) of them in the ring
+    if (rem >= D) {
+      static_for<0, D>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        strip_wait<(D - 1 - i) * L>();                    // the slots behind i are outstanding (+ the refills: waited for early)
+        mma(i);
+        if (i + D < rem) loadk(tb + done + D + i, i);
+      });
+      strip_wait<0>();
+      static_for<0, D>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if (i + D < rem) mma(i);
+      });
+    } else {
+      strip_wait<0>();
+      static_for<0, D>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if (i < rem) mma(i);
+      });
+    }
+
+    float* sp = slab + (size_t)it * kRows * 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sp[(fg * 4 + r) * 16 + frow] = acc[r];
+  }
+
+  // ---- row factor: the tile sums (the tiled producer's butterfly over a tile's four strips, or the producer's own tile sums) into LDS
+  if (nT > 0) {
+#pragma unroll
+    for (int j = 0; j < JQ; ++j) {
+      const int idx = tid + j * kThreads;
+      if (idx < ntq) {
+        const int t = idx / p.M, r = idx - t * p.M;
+        tsum[r * nT + t] = p.row_sumsq_form ? (tq[j][0] + tq[j][1]) + (tq[j][2] + tq[j][3]) : tq[j][0];
+      }
+    }
+    for (int idx = tid + JQ * kThreads; idx < ntq; idx += kThreads) {      // (more tile sums than the register set holds: very wide models)
+      const int t = idx / p.M, r = idx - t * p.M;
+      float v;
+      if (p.row_sumsq_form) {
+        const float q0 = p.row_sumsq[(int64_t)(4 * t) * p.M + r], q1 = p.row_sumsq[(int64_t)(4 * t + 1) * p.M + r];
+        const float q2 = p.row_sumsq[(int64_t)(4 * t + 2) * p.M + r], q3 = p.row_sumsq[(int64_t)(4 * t + 3) * p.M + r];
+        v = (q0 + q1) + (q2 + q3);
+      } else {
+        v = p.row_sumsq[(int64_t)t * p.M + r];
+      }
+      tsum[r * nT + t] = v;
+    }
+  }
+  __syncthreads();
+  if (!flive) return;
+
+  // ---- finish: the strip's slices in slab order, then the shared epilogue
+  float rs = 1.f;
+  if (nT > 0) {
+    float tot = 0.f;
+    for (int t = 0; t < nT; ++t) tot += tsum[frw * nT + t];
+    rs = rsqrtf(tot / (float)p.row_dim + p.row_eps);
+  }
+  auto strip_sum = [&](int sl, float (&y)[16]) {
+    const float* sp = slab + ((size_t)sl * ks * kRows + frw) * 16;
+    if (ks == 1) {
+#pragma unroll
+      for (int e = 0; e < 16; e += 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(sp + e); y[e] = v[0]; y[e + 1] = v[1]; y[e + 2] = v[2]; y[e + 3] = v[3]; }
+      return;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) y[e] = 0.f;
+    for (int s = 0; s < ks; ++s) {
+#pragma unroll
+      for (int e = 0; e < 16; e += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sp + (size_t)s * kRows * 16 + e);
+        y[e] += v[0]; y[e + 1] += v[1]; y[e + 2] += v[2]; y[e + 3] += v[3];
+      }
+    }
+  };
+  float y[16];
+  if (!swi) {
+    strip_sum(fsl, y);
+    segment_finish<T>(p, frw, fnc, fnc >> 6, true, y, rraw, rs, tid);
+    return;
+  }
+  // fused SwiGLU (gate / up weight rows interleaved in blocks of 16: strip 2j = gate block j, strip 2j + 1 = its up block): the un-split
+  // epilogue of the tiled kernel -- row factor, fma(y, 1, 0) + 0, both halves rounded to T, silu(gate) * up
+  float u[16], o[16];
+  strip_sum(2 * fsl, y);
+  strip_sum(2 * fsl + 1, u);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    float g = y[e], v = u[e];
+    if (nT > 0) { g *= rs; v *= rs; }
+    g = fmaf(g, 1.f, 0.f) + 0.f; v = fmaf(v, 1.f, 0.f) + 0.f;
+    o[e] = silu(to_f32(from_f32<T>(g))) * to_f32(from_f32<T>(v));
+  }
+  const int64_t oc = (int64_t)frw * p.ldc + (fnc >> 5) * 16;
+  if (p.out_f32) {
+    float* Cf = reinterpret_cast<float*>(p.C) + oc;
+#pragma unroll
+    for (int e = 0; e < 16; e += 4) *reinterpret_cast<f32x4*>(Cf + e) = f32x4{o[e], o[e + 1], o[e + 2], o[e + 3]};
+  } else {
+    T* Ct = reinterpret_cast<T*>(p.C) + oc;
+#pragma unroll
+    for (int e = 0; e < 16; e += VEC) *reinterpret_cast<Chunk16*>(Ct + e) = chunk_from_f32<T>(o + e);
+  }
+}
+
+template <typename T, int D, int NW, int MA>
+int launch_strip(const GemmArgs& a, int spw, size_t smem, hipStream_t st) {
+  auto kern = decode_strip_kernel<T, D, NW, MA>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const int nstrips = ceil_div(a.N, 16);
+  hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(nstrips, spw)), dim3(NW * 64), smem, st, a, spw);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// Ring depth: what the CU's 160 KiB of LDS hold.  Launches of at most one workgroup per CU (every GEMM of a layer) get 32 KiB of ring per
+// wave at 4 waves -- the short k-slices of the narrow projections (8-9 k-tiles) are then ONE round trip to memory, and gate / up keeps 64 KiB
+// of weights in flight per CU; more workgroups than CUs (two per CU) and the 8-wave form: 16 KiB per wave.
+template <typename T>
+int launch_strip_t(const GemmArgs& a, hipStream_t st) {
+  static const int ncu = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
+  const int ks = a.ksplit < 1 ? 1 : a.ksplit;
+  const int nw = ks >= 8 ? 8 : 4;
+  int spw = nw / ks < 1 ? 1 : nw / ks;
+  if (a.swiglu_pairs && (spw & 1)) spw += 1;
+  const bool deep = nw == 4 && ceil_div(ceil_div(a.N, 16), spw) <= ncu;
+  const int ma = a.M <= 8 ? 8 : 16;
+  const int d = deep ? (ma == 8 ? 10 : 8) : (ma == 8 ? 5 : 4);
+  const size_t smem = (size_t)nw * d * slot_bytes(ma) + (size_t)spw * ks * 16 * 16 * 4 + (size_t)a.M * (a.row_sumsq ? a.row_sumsq_tiles : 0) * 4 + 16;
+  OAVSR_REQUIRE(smem <= 160 * 1024, "decode strips: %zu bytes of LDS (ksplit %d)", smem, ks);
+  if (nw == 8) return ma == 8 ? launch_strip<T, 5, 8, 8>(a, spw, smem, st) : launch_strip<T, 4, 8, 16>(a, spw, smem, st);
+  if (deep) return ma == 8 ? launch_strip<T, 10, 4, 8>(a, spw, smem, st) : launch_strip<T, 8, 4, 16>(a, spw, smem, st);
+  return ma == 8 ? launch_strip<T, 5, 4, 8>(a, spw, smem, st) : launch_strip<T, 4, 4, 16>(a, spw, smem, st);
+}
+
+}  // namespace
+
+// What the strips can serve: dense decode-shaped launches of <= kStripRows rows.  Next-norm outputs only in the strip layout
+// (GemmArgs::rowsq_strips) -- a caller that asks for the tiled layout gets the tiled kernel.
+bool gemm_strip_eligible(const GemmArgs& a) {
+  if (a.amode != A_DENSE || a.groups != 1 || a.M < 1 || a.M > kStripRows || a.force_tile) return false;
+  if (!(a.decode_tiled || a.ksplit > 1 || a.row_sumsq)) return false;
+  if (a.ng_out && !a.rowsq_strips) return false;
+  if (a.row_sumsq && a.row_sumsq_tiles > kStripMaxTiles) return false;
+  if (a.ksplit > 64) return false;
+  // the vocabulary-sized launch (lm_head): at 1-2 rows the strips stream it as fast as the 128 x 256 tile (step 1.13 vs 1.18 ms at one row), from a few
+  // rows on the tile shares the activation rows between 256 columns and wins (8 rows: 104 vs 129 us, 16 rows: 121 vs 153; profiles/r06_decode_sites_by_rows.txt)
+  // -- same bits, so the faster form
+  if (a.N >= 65536 && a.M > 2) return false;
+  const int vec = a.dtype == DT_F32 ? 4 : 8;
+  if (a.swiglu_pairs && (a.ksplit > 1 || a.N % 32 != 0 || a.residual || a.act != ACT_NONE || a.col_scale || a.col_bias || a.ldc % vec != 0 || ((uintptr_t)a.C & 15) != 0))
+    return false;
+  return true;
+}
+
+int launch_gemm_strip(const GemmArgs& a, hipStream_t st) {
+  OAVSR_REQUIRE(gemm_strip_eligible(a), "decode strips: launch %d x %d x %d not eligible", a.M, a.N, a.K + a.K2);
+  const int vec_t = a.dtype == DT_F32 ? 4 : 8;
+  if (a.ksplit > 1 || a.ng_out)
+    OAVSR_REQUIRE(a.N % 16 == 0 && ((uintptr_t)a.C & 15) == 0 && a.ldc % (a.out_f32 ? 4 : vec_t) == 0 &&
+                  (!a.residual || (a.ldr % vec_t == 0 && ((uintptr_t)a.residual & 15) == 0)), "decode strips: a split launch needs N %% 16 == 0 and 16-byte rows");
+  if (a.residual) OAVSR_REQUIRE(a.N % 16 == 0 && a.ldr % vec_t == 0 && ((uintptr_t)a.residual & 15) == 0, "decode strips: the residual needs N %% 16 == 0 and 16-byte rows");
+  if (a.ng_out)
+    OAVSR_REQUIRE(a.ng_gain && a.ng_rowsq && !a.out_f32 && a.act == ACT_NONE && a.N % 64 == 0 && a.ng_ld % vec_t == 0 && ((uintptr_t)a.ng_out & 15) == 0,
+                  "decode strips: next-norm outputs need a plain epilogue, whole column tiles and 16-byte rows");
+  OAVSR_REQUIRE(!a.row_sumsq || (a.row_sumsq_tiles >= 1 && a.row_dim > 0), "decode strips: the row factor needs row_sumsq_tiles >= 1 and row_dim > 0");
+  GemmArgs b = a;
+  b.rowsq_strips = a.ng_out ? 1 : 0;
+  return a.dtype == DT_F32 ? launch_strip_t<float>(b, st) : launch_strip_t<bf16_t>(b, st);
+}
+
+}  // namespace oavsr

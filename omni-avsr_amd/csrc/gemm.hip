@@ -294,6 +294,12 @@ int launch_mode(const GemmArgs& a, hipStream_t st) {
 
 }  // namespace
 
+bool gemm_strip_rows(int M) {
+  static const bool on = knob("OAVSR_DECODE_STRIPS") != 0;
+  return on && M >= 1 && M <= kStripRows;
+}
+bool gemm_strip_selected(const GemmArgs& a) { return gemm_strip_rows(a.M) && gemm_strip_eligible(a); }
+
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0) return 0;
   const int esz = a.dtype == DT_F32 ? 4 : 2;
@@ -316,6 +322,12 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   OAVSR_REQUIRE(!a.row_sumsq || (a.amode == A_DENSE && a.groups == 1 && a.M <= 128 && a.N >= 64 && a.row_sumsq_tiles >= 1 && a.row_dim > 0 && (a.ksplit > 1 || a.decode_tiled)),
                 "gemm: the row factor (row_sumsq) is an epilogue of the decode-shaped launches (dense, M <= 128, N >= 64, decode_tiled)");
   OAVSR_REQUIRE(!a.ng_out || a.ksplit > 1, "gemm: the next-norm outputs (ng_out) are written by the split-K reduce only");
+  // <= 16 rows: the weight-streaming strips (decode_strip.hip) -- the tiled kernels' arithmetic without slabs, counters or a reduce launch
+  if (gemm_strip_selected(a)) return launch_gemm_strip(a, st);
+  // the strip layout of the sums of squares: written by the strips only; read by the strips and by the un-split vocabulary-sized tiles (128 x 128 / 128 x 256)
+  OAVSR_REQUIRE(!a.rowsq_strips, "gemm: the strip layout of the sums of squares is written by the <= %d-row strip kernels (M = %d)", kStripRows, a.M);
+  OAVSR_REQUIRE(!a.row_sumsq_form || (a.M <= kStripRows && a.ksplit <= 1 && a.amode == A_DENSE && a.groups == 1 && a.N >= 256 * 128 && a.row_sumsq_tiles <= 128),
+                "gemm: the strip layout of the sums of squares is read by the strips and by the vocabulary-sized tiles (M = %d, N = %d)", a.M, a.N);
   if (a.ksplit > 1) {
     // split-K: the 128 x 64 LDS-DMA tile only -- the decode-shaped GEMMs, <= 128 rows per launch -- with the reduce inside the launch (a.sync:
     // arrival counters) or as a second launch of the same reduce code (gemm2.hip)

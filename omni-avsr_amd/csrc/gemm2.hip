@@ -10,6 +10,7 @@
 //   * out-of-range rows / conv padding read a 16-byte zero page instead of branching
 #include <stdlib.h>
 #include "kernels.h"
+#include "epilogue.h"
 
 namespace oavsr {
 namespace {
@@ -17,20 +18,6 @@ namespace {
 constexpr int kRowBytes = 128;
 
 __device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];
-
-template <typename T> struct Mma2;
-template <> struct Mma2<bf16_t> {
-  static __device__ __forceinline__ void run(const Chunk16& a, const Chunk16& b, f32x4& c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a.v), __builtin_bit_cast(bf16x8, b.v), c, 0, 0, 0);
-  }
-};
-template <> struct Mma2<float> {
-  static __device__ __forceinline__ void run(const Chunk16& a, const Chunk16& b, f32x4& c) {
-    f32x4 fa = __builtin_bit_cast(f32x4, a.v), fb = __builtin_bit_cast(f32x4, b.v);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s], fb[s], c, 0, 0, 0);
-  }
-};
 
 struct ARow2 {
   int valid;
@@ -110,92 +97,6 @@ __device__ __forceinline__ f32x4 ld16_sc1f(__amdgpu_buffer_rsrc_t rsrc, unsigned
 __device__ __forceinline__ void dma16(const void* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-// The epilogue of ONE finished 16-column row segment of a decode-shaped GEMM (yy: the fp32 sums): row factor, col_scale / bias, residual,
-// activation, store; optionally the consumer's RMSNorm operands (GemmArgs::ng_*).  The four lanes tid % 4 = 0..3 hold the four segments of
-// one row of a 64-column tile; every lane of the wave must call (the sum of squares crosses those lanes).  The one place where the results
-// of a split decode-shaped GEMM are formed (the reduce inside the GEMM launch and the stand-alone reduce kernel both end here).
-template <typename T>
-__device__ __forceinline__ void segment_finish(const GemmArgs& p, int m, int nc, int nt_, bool live, float (&yy)[16],
-                                               const Chunk16 (&rraw)[16 / TypeInfo<T>::kVec], float rsv, int tid) {
-  constexpr int VEC = TypeInfo<T>::kVec;
-  constexpr int SEG = 4;
-  const T* Rr = reinterpret_cast<const T*>(p.residual);
-  const bool want_ng = p.ng_out != nullptr;
-  float ss = 0.f;
-  if (live) {
-    if (p.row_sumsq) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) yy[e] *= rsv;
-    }
-    float res[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) res[e] = 0.f;
-    if (Rr) {
-#pragma unroll
-      for (int e = 0; e < 16; e += VEC) chunk_to_f32<T>(rraw[e / VEC], res + e);
-    }
-    const bool whole = nc + 16 <= p.N;                        // (a ragged last segment: un-split launches only, e.g. lm_head's vocabulary)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const bool in = whole || nc + e < p.N;
-      float v = fmaf(yy[e], (p.col_scale && in) ? p.col_scale[nc + e] : 1.f, (p.col_bias && in) ? p.col_bias[nc + e] : 0.f);
-      if (!p.res_after_act) v += res[e];
-      switch (p.act) {
-        case ACT_GELU: v = gelu_act<T>(v); break;
-        case ACT_RELU: v = fmaxf(v, 0.f); break;
-        case ACT_PRELU: v = v >= 0.f ? v : (in ? p.prelu[nc + e] : 0.f) * v; break;
-        case ACT_SILU: v = silu(v); break;
-        default: break;
-      }
-      yy[e] = p.res_after_act ? v + res[e] : v;
-    }
-    if (p.out_f32) {
-      float* Cf = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + nc;
-      if (whole && (p.ldc % 4) == 0 && ((uintptr_t)p.C & 15) == 0 && (nc % 4) == 0) {
-#pragma unroll
-        for (int e = 0; e < 16; e += 4) *reinterpret_cast<f32x4*>(Cf + e) = f32x4{yy[e], yy[e + 1], yy[e + 2], yy[e + 3]};
-      } else {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) if (nc + e < p.N) Cf[e] = yy[e];
-      }
-    } else if (!(whole && (p.ldc % VEC) == 0 && ((uintptr_t)p.C & 15) == 0)) {
-      T* Ct = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + nc;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) if (nc + e < p.N) Ct[e] = from_f32<T>(yy[e]);
-    } else {
-      T* Ct = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + nc;
-      Chunk16 oc[16 / VEC];
-#pragma unroll
-      for (int e = 0; e < 16; e += VEC) { oc[e / VEC] = chunk_from_f32<T>(yy + e); *reinterpret_cast<Chunk16*>(Ct + e) = oc[e / VEC]; }
-      if (want_ng) {      // the consumer's RMSNorm: x * gain now (x as stored), the row's sum of squares per column tile
-        float xr[16], xg[16];
-#pragma unroll
-        for (int e = 0; e < 16; e += VEC) chunk_to_f32<T>(oc[e / VEC], xr + e);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { xg[e] = xr[e] * p.ng_gain[nc + e]; ss = fmaf(xr[e], xr[e], ss); }
-        T* Gt = reinterpret_cast<T*>(p.ng_out) + (int64_t)m * p.ng_ld + nc;
-#pragma unroll
-        for (int e = 0; e < 16; e += VEC) *reinterpret_cast<Chunk16*>(Gt + e) = chunk_from_f32<T>(xg + e);
-      }
-    }
-  }
-  if (want_ng) {      // the row's sum of squares over this tile's 64 columns: the row's four adjacent lanes, fixed butterfly
-#pragma unroll
-    for (int o = 1; o < SEG; o <<= 1) ss += __shfl_xor(ss, o, 64);
-    if (live && (tid % SEG) == 0) p.ng_rowsq[(int64_t)nt_ * p.M + m] = ss;
-  }
-}
-
-// 1 / rms of a row from the producer's per-tile sums of squares (GemmArgs::row_sumsq), tile by tile, in order
-__device__ __forceinline__ float row_factor(const GemmArgs& p, int m) {
-  float tot = 0.f;
-  if (m < p.M) {
-#pragma unroll 8
-    for (int t = 0; t < p.row_sumsq_tiles; ++t) tot += p.row_sumsq[(int64_t)t * p.M + m];
-  }
-  return rsqrtf(tot / (float)p.row_dim + p.row_eps);
 }
 
 // ---- split-K reduce of ONE 64-column tile strip: rows [m0, m0 + NI * nthr / 4) x columns [n0, n0 + 64) of C.  A thread owns NI segments of
@@ -400,7 +301,28 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
   constexpr bool kRowScale = AMODE == A_DENSE && BM == 128;
   float* rs_lds = reinterpret_cast<float*>(smem + kStages * kStageBytes);
   if constexpr (kRowScale) {
-    if (p.row_sumsq && tid < BM) {
+    if constexpr (BN >= 128) {
+      // the vocabulary-sized launch behind a <= 16-row strip producer (lm_head of a small decode step): the rows' sums of squares come per
+      // 16-column strip (GemmArgs::row_sumsq_form); all threads form the tile sums (s0 + s1) + (s2 + s3), one thread per row adds the tiles in order
+      if (p.row_sumsq && p.row_sumsq_form) {
+        float* ts = rs_lds + 256;                            // [M <= 16][tiles <= 128]
+        const int nT = p.row_sumsq_tiles, ntq = p.M * nT;
+        for (int idx = tid; idx < ntq; idx += kThreads) {
+          const int t = idx / p.M, r = idx - t * p.M;
+          const float q0 = p.row_sumsq[(int64_t)(4 * t) * p.M + r], q1 = p.row_sumsq[(int64_t)(4 * t + 1) * p.M + r];
+          const float q2 = p.row_sumsq[(int64_t)(4 * t + 2) * p.M + r], q3 = p.row_sumsq[(int64_t)(4 * t + 3) * p.M + r];
+          ts[r * nT + t] = (q0 + q1) + (q2 + q3);
+        }
+        __syncthreads();
+        if (tid < p.M) {
+          float tot = 0.f;
+          for (int t = 0; t < nT; ++t) tot += ts[tid * nT + t];
+          rs_lds[tid] = rsqrtf(tot / (float)p.row_dim + p.row_eps);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+    if (p.row_sumsq && !p.row_sumsq_form && tid < BM) {
       rs_lds[tid] = row_factor(p, m0 + tid);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -672,7 +594,8 @@ __global__ __launch_bounds__(NWAVES * 64) void gemm_dma_kernel(const GemmArgs p)
 template <typename T, int AMODE, int BM, int BN, int kStages, int WAVES_M, int NWAVES, int DW = NWAVES>
 int launch_dma(const GemmArgs& a, hipStream_t st) {
   auto kern = gemm_dma_kernel<T, AMODE, BM, BN, kStages, WAVES_M, NWAVES, DW>;
-  constexpr int smem = kStages * (BM + BN) * kRowBytes + ((AMODE == A_DENSE && BM == 128) ? 1024 : 0);      // + the rows' 1 / rms (decode-shaped launches)
+  // + the rows' 1 / rms (decode-shaped launches); the wide tiles (lm_head) also stage the strip layout's tile sums: 16 rows x 128 tiles
+  constexpr int smem = kStages * (BM + BN) * kRowBytes + ((AMODE == A_DENSE && BM == 128) ? (BN >= 128 ? 1024 + 8192 : 1024) : 0);
   static bool attr_set = false;
   if (!attr_set) {
     OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));

@@ -49,6 +49,10 @@ struct GemmArgs {
   // ng_out[m][n] = T(x[m][n] * ng_gain[n]), ng_rowsq[nt * M + m] = sum over column tile nt of x[m][n]^2 (x as rounded to T; 16 columns per
   // lane in column order, then a fixed butterfly over the row's 4 lanes) -- the consumer's row_sumsq with ceil(N / 64) tiles.
   void* ng_out = nullptr; int64_t ng_ld = 0; const float* ng_gain = nullptr; float* ng_rowsq = nullptr;
+  // The <= 16-row form of the decode-shaped GEMMs (decode_strip.hip) keeps a 64-column tile's sum of squares as its four 16-column STRIP sums
+  // ([N / 16][M]); whoever consumes them forms (s0 + s1) + (s2 + s3) per tile -- the butterfly of the tiled producer -- then adds the tiles in order:
+  // rowsq_strips: this launch WRITES ng_rowsq in that layout; row_sumsq_form = 1: this launch READS row_sumsq in it (row_sumsq_tiles tiles = 4 x as many entries)
+  int rowsq_strips = 0, row_sumsq_form = 0;
   int* sync = nullptr;       // [kSyncInts] arrival counters, one per output tile (zero between launches)
   // LDS-DMA kernels: order in which an XCD's contiguous range of workgroups walks the output tiles.  0: row-major (or column-major when
   // M < N); 1: blocks of 8 M-tiles x 4 N-tiles, so the 32 tiles an XCD's CUs work on at one time share 8 A panels and 4 W panels in
@@ -81,6 +85,14 @@ bool gemm_small_tile(const GemmArgs& a);       // small dense GEMM: 128 x 64 til
 bool gemm_dma_swiglu_ok(const GemmArgs& a);
 const char* gemm_dma_variant(const GemmArgs& a);
 int launch_gemm_dma(const GemmArgs& a, hipStream_t st);
+// Decode-shaped GEMMs of <= kStripRows rows (decode_strip.hip): a wave streams one 16-column strip x one k-slice of the weights through a
+// wave-private LDS FIFO (no barrier in the k loop), the k-slices of a strip -- GemmArgs::ksplit of them, the SAME slices the tiled kernels
+// split over workgroups -- are summed in slab order inside the workgroup.  Same bits as the tiled kernels, no slabs, no arrival counters.
+constexpr int kStripRows = 16;
+bool gemm_strip_eligible(const GemmArgs& a);
+bool gemm_strip_rows(int M);                    // the decode path takes the strips for a chunk of M rows (M <= kStripRows and the developer switch is on)
+bool gemm_strip_selected(const GemmArgs& a);    // launch_gemm will run the strips for this launch
+int launch_gemm_strip(const GemmArgs& a, hipStream_t st);
 // 256 x 256 tile with the 8-wave ping-pong k loop (gemm3.hip): dense bf16, no split-K / groups; picked by launch_gemm_dma
 bool gemm_8p_eligible(const GemmArgs& a);      // the dispatcher's rule (deep K)
 bool gemm_8p_supported(const GemmArgs& a);     // what the kernel can compute at all

@@ -41,6 +41,7 @@ struct KnobDef { const char* name; int dflt; const char* what; };
 static const KnobDef kKnobs[] = {
     {"OAVSR_PROF_SHAPES", 0, "profiling hook: one family per GEMM shape instead of per kernel"},
     {"OAVSR_DECODE_GRAPH", 1, "0: decode steps are launched eagerly instead of replayed from hipGraphs (same kernels, same bits)"},
+    {"OAVSR_DECODE_STRIPS", 1, "0: decode-shaped GEMMs of <= 16 rows run on the 128-row LDS-DMA tiles like larger launches instead of the register-streaming strips (same bits)"},
     {"OAVSR_FUSED_REDUCE_ROWS", 32, "decode-shaped GEMMs with at most this many rows reduce their split-K slabs inside the launch, others in a second launch (same code, same bits)"},
     {"OAVSR_GEMM_TILE_ROWS", 0, "persistent GEMM: 256 / 192 = that tile height wherever its form exists, 0 = the launcher's rule (256 while calls share the chip; alone: whichever finishes sooner); same bits"},
 };
@@ -111,7 +112,7 @@ static const char* gemm_family(const GemmArgs& a) {
   static thread_local char buf[64];
   const char* dt = a.dtype == DT_F32 ? "f32" : "bf16";
   const char* mode = a.amode == A_DENSE ? "gemm" : a.amode == A_CONV2D ? "conv2d_gemm" : a.amode == A_CONV1D ? "conv1d_gemm" : "stem_gemm";
-  const char* tile = gemm_dma_eligible(a) ? gemm_dma_variant(a) : (a.N <= 64 ? "128x64" : "128x128");
+  const char* tile = gemm_strip_selected(a) ? (a.M <= 16 ? "strip16" : "strip32") : gemm_dma_eligible(a) ? gemm_dma_variant(a) : (a.N <= 64 ? "128x64" : "128x128");
   static const bool shapes = knob("OAVSR_PROF_SHAPES") != 0;      // developer aid: one family per GEMM shape
   if (shapes) { snprintf(buf, sizeof(buf), "%s%c%s %dx%dx%d", a.decode_tiled ? "decode_" : "", mode[0], tile, a.M, a.N, a.K + a.K2); buf[31] = 0; return buf; }
   // decode-shaped GEMMs: a family of their own ("decode_..."), so that bench.py keeps the decode side apart from the encoder / prefill
@@ -841,6 +842,7 @@ static size_t rowsq_chunk(int d) { return (size_t)(ceil_div(d, 64) + 1) * 128; }
 // sq_tiles > 0: A is T(x * gain) of a deferred RMSNorm; the accumulator is multiplied by 1 / rms(x) from the `sq_tiles` partial sums per row
 //   that the producer of A left in ws->rowsq (rms_prep: 1; the reduce of o_proj / down_proj: d / 64).
 // next_gain: the GEMM's output is the residual stream; also write T(x * next_gain) to `ng_out` and the rows' partial sums to ws->rowsq.
+constexpr int kSqPrep = -1;      // decode_gemm's sq_tiles: ONE sum of squares per row, left by rms_prep (not by a reduce)
 static int decode_gemm(const oavsr_model* m, oavsr_workspace* ws, const GemmArgs& g0, hipStream_t st, int sq_tiles = 0, const float* next_gain = nullptr,
                        void* ng_out = nullptr) {
   const size_t e = m->esz;
@@ -855,17 +857,26 @@ static int decode_gemm(const oavsr_model* m, oavsr_workspace* ws, const GemmArgs
     g.A = adv(g0.A, g0.lda, e); g.A2 = adv(g0.A2, g0.lda2, e); g.residual = adv(g0.residual, g0.ldr, e);
     g.C = (void*)adv(g0.C, g0.ldc, g0.out_f32 ? 4 : e);
     float* sq = ws->rowsq + (size_t)(r0 / 128) * rowsq_chunk(d);
-    if (sq_tiles > 0) { g.row_sumsq = sq; g.row_sumsq_tiles = sq_tiles; g.row_dim = d; g.row_eps = m->cfg.llm_rms_eps; }
-    OAVSR_REQUIRE(gemm_dma_eligible(g), "decode GEMM %d x %d x %d: no LDS-DMA tile (N >= 64 needed)", g.M, g.N, g.K + g.K2);
+    // <= kStripRows rows of a chunk: the register-streaming strips (decode_strip.hip) -- every GEMM of the step sees the same chunk sizes, so
+    // producer and consumer of a chunk's sums of squares agree on their layout (per 16-column strip there, per 64-column tile on the tiled path)
+    const bool strips = gemm_strip_rows(g.M);
+    if (sq_tiles != 0) {
+      g.row_sumsq = sq; g.row_sumsq_tiles = sq_tiles == kSqPrep ? 1 : sq_tiles; g.row_dim = d; g.row_eps = m->cfg.llm_rms_eps;
+      g.row_sumsq_form = (strips && sq_tiles != kSqPrep) ? 1 : 0;
+    }
     if (ks > 1) {
-      OAVSR_REQUIRE((size_t)ks * g.M * g.N * 4 <= ws->partial_bytes, "decode GEMM: split-K slabs (%d x %d x %d) exceed the workspace", ks, g.M, g.N);
       // up to kFusedRows rows the tile's last-arriving workgroup reduces the slabs inside the launch (one launch instead of two: what
       // counts when a launch is mostly fixed cost); above, that workgroup would be a serial tail -- the same reduce runs as a launch of
-      // its own over ~4 x the workgroups.  Same code either way: never a different bit (tests compare them).
+      // its own over ~4 x the workgroups.  Same code either way: never a different bit (tests compare them).  (The strips need neither.)
       static const int kFusedRows = knob("OAVSR_FUSED_REDUCE_ROWS");
-      g.ksplit = ks; g.partial = ws->partial; g.sync = g.M <= kFusedRows ? ws->gsync : nullptr;
-      if (next_gain) { g.ng_out = (char*)ng_out + (size_t)r0 * g.N * e; g.ng_ld = g.N; g.ng_gain = next_gain; g.ng_rowsq = sq; }
+      g.ksplit = ks;
+      if (!strips) {
+        OAVSR_REQUIRE((size_t)ks * g.M * g.N * 4 <= ws->partial_bytes, "decode GEMM: split-K slabs (%d x %d x %d) exceed the workspace", ks, g.M, g.N);
+        g.partial = ws->partial; g.sync = g.M <= kFusedRows ? ws->gsync : nullptr;
+      }
+      if (next_gain) { g.ng_out = (char*)ng_out + (size_t)r0 * g.N * e; g.ng_ld = g.N; g.ng_gain = next_gain; g.ng_rowsq = sq; g.rowsq_strips = strips ? 1 : 0; }
     }
+    if (!strips) OAVSR_REQUIRE(gemm_dma_eligible(g), "decode GEMM %d x %d x %d: no LDS-DMA tile (N >= 64 needed)", g.M, g.N, g.K + g.K2);
     OAVSR_TRY(run_gemm(g, st));
   }
   return 0;
@@ -918,7 +929,7 @@ static int llm_decode_layers(const oavsr_model* m, oavsr_workspace* ws, int task
   const int nq = H * hd, nqkv = (H + 2 * KV) * hd;
   const int tl = c.lora_task_specific ? task : 0;
   OAVSR_TRY(decode_rms_prep(m, ws, ws->lx, ws->lh, m->llayers[0].ln1w, rows, st));
-  int sq_tiles = 1;                            // partial sums per row in ws->rowsq: 1 behind rms_prep, d / 64 behind a reduce
+  int sq_tiles = kSqPrep;                      // partial sums per row in ws->rowsq: one behind rms_prep, d / 64 tiles behind a reduce
   for (int li = 0; li < c.llm_layers; ++li) {
     const LlmLayer& L = m->llayers[li];
     GemmArgs g;
@@ -2032,6 +2043,7 @@ int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream) {
   g.ksplit = d->ksplit < 1 ? 1 : d->ksplit; g.partial = d->partial; g.sync = d->sync;
   g.row_sumsq = d->row_sumsq; g.row_sumsq_tiles = d->row_sumsq_tiles; g.row_dim = d->row_dim; g.row_eps = d->row_eps;
   g.ng_out = d->ng_out; g.ng_ld = d->ng_ld; g.ng_gain = d->ng_gain; g.ng_rowsq = d->ng_rowsq;
+  g.rowsq_strips = d->rowsq_strips; g.row_sumsq_form = d->row_sumsq_form;
   OAVSR_REQUIRE(!g.ng_out || g.ksplit > 1, "op_gemm: the next-norm outputs need split-K (ksplit > 1)");
   OAVSR_REQUIRE(!g.row_sumsq || d->kernel == 0, "op_gemm: the row factor is an epilogue of the decode-shaped launches (kernel selector 0)");
   if (g.row_sumsq) g.decode_tiled = 1;

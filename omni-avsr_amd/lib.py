@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # OAVSR_LIB points the binding at another build of the same library (A/B timing of kernel variants on one box)
 LIB_PATH = os.environ.get("OAVSR_LIB") or os.path.join(_HERE, "libomniavsr_hip.so")
 
-ABI_VERSION = 3      # OAVSR_ABI_VERSION of include/omni_avsr.h this binding's structures and argument lists follow
+ABI_VERSION = 4      # OAVSR_ABI_VERSION of include/omni_avsr.h this binding's structures and argument lists follow
 MAX_RATES = 8
 GEMM_SYNC_INTS = 4096      # OAVSR_GEMM_SYNC_INTS: zeroed ints a split-K oavsr_op_gemm launch needs (GemmDesc.sync)
 DT_F32, DT_BF16 = 0, 1
@@ -65,7 +65,7 @@ class GemmDesc(C.Structure):
         ("ksplit", C.c_int32), ("partial", C.c_void_p), ("sync", C.c_void_p),
         ("row_sumsq", C.c_void_p), ("row_sumsq_tiles", C.c_int32), ("row_dim", C.c_int32), ("row_eps", C.c_float),
         ("ng_out", C.c_void_p), ("ng_ld", C.c_int64), ("ng_gain", C.c_void_p), ("ng_rowsq", C.c_void_p),
-        ("grid", C.c_int32),
+        ("grid", C.c_int32), ("rowsq_strips", C.c_int32), ("row_sumsq_form", C.c_int32),
     ]
 
 

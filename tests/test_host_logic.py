@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/omni_avsr.h but not exported"
     assert declared == set(L.SYMBOLS), f"ctypes table out of sync: {declared ^ set(L.SYMBOLS)}"
-    assert lib.oavsr_abi_version() == L.ABI_VERSION == 3
+    assert lib.oavsr_abi_version() == L.ABI_VERSION == 4
     assert ctypes.sizeof(L.OavsrConfig) % 4 == 0
 
 

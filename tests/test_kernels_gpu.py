@@ -150,6 +150,56 @@ def test_decode_shaped_gemm_rows_do_not_depend_on_the_row_count(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,K,K2,S", [(2048, 2048, 0, 8), (256, 2048, 0, 4), (3072, 2048, 256, 4), (2048, 8192, 0, 8), (512, 1024, 128, 5), (1024, 4096, 0, 16), (128, 512, 0, 3)])
+def test_decode_strips_equal_the_tiled_kernels(dtype, N, K, K2, S):
+    """<= 16 rows run on the weight-streaming strips (csrc/decode_strip.hip): a wave per (16-column strip, k-slice), the slices summed in slab order
+    inside the workgroup -- no slabs, no arrival counters.  Against the SAME rows inside a 128-row launch of the tiled kernels (split-K over
+    workgroups, reduce in a second launch): C, T(x * gain), the per-tile sums of squares rebuilt from the strip sums as (s0 + s1) + (s2 + s3),
+    and a consumer that reads the strip layout (row_sumsq_form = 1) -- all bit-identical."""
+    D = 4096
+    a, _ = q(rnd(128, K, seed=1), dtype)
+    w, _ = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
+    r, _ = q(rnd(128, N, seed=5), dtype)
+    bias = rnd(N, seed=9).to(DEV)
+    gain = (rnd(N, seed=6) * 0.1 + 1).to(DEV)
+    kw = {}
+    if K2:
+        a2, _ = q(rnd(128, K2, seed=3), dtype)
+        w2, _ = q(rnd(N, K2, seed=4) / math.sqrt(K2), dtype)
+        kw.update(W2=w2)
+    part = torch.empty(S * 128 * N, dtype=torch.float32, device=DEV)
+    sq_in = ((rnd(128, seed=8).abs() + 0.5) * D).to(DEV)         # one sum of squares per row (rms_prep's layout)
+    tiles = N // 64
+    # the tiled kernels at 128 rows (reduce as its own launch)
+    xg_t = torch.empty(128, N, dtype=tdt(dtype), device=DEV)
+    rowsq_t = torch.empty(tiles * 128, dtype=torch.float32, device=DEV)
+    c_t = gemm(dtype, a, w, residual=r.clone(), bias=bias, ksplit=S, partial=part, ng_out=xg_t, ng_ld=N, ng_gain=gain, ng_rowsq=rowsq_t,
+               row_sumsq=sq_in, row_sumsq_tiles=1, row_dim=D, row_eps=1e-5, **(dict(A2=a2, **kw) if K2 else {})).clone()
+    rowsq_t = rowsq_t.view(tiles, 128)
+    # a consumer of those sums on the tiled path: 128 rows, tile layout
+    wc, _ = q(rnd(192, N, seed=12) / math.sqrt(N), dtype)
+    cons_t = gemm(dtype, xg_t, wc, out_f32=True, decode_tiled=1, row_sumsq=rowsq_t.contiguous(), row_sumsq_tiles=tiles, row_dim=N, row_eps=1e-6).clone()
+    for M in (16, 9, 8, 1):
+        xg = torch.full((M, N), float("nan"), dtype=tdt(dtype), device=DEV)
+        rowsq = torch.full((N // 16 * M,), float("nan"), dtype=torch.float32, device=DEV)
+        more = dict(A2=a2[:M], **kw) if K2 else {}
+        c = gemm(dtype, a[:M], w, residual=r[:M].clone(), bias=bias, ksplit=S, ng_out=xg, ng_ld=N, ng_gain=gain, ng_rowsq=rowsq, rowsq_strips=1,
+                 row_sumsq=sq_in[:M].contiguous(), row_sumsq_tiles=1, row_dim=D, row_eps=1e-5, **more)
+        assert torch.equal(c, c_t[:M]), f"{dtype} M={M}: C of the strips differs from the tiled kernels'"
+        assert torch.equal(xg, xg_t[:M]), f"{dtype} M={M}: T(x * gain) differs"
+        st = rowsq.view(N // 16, M)
+        tile_sums = (st[0::4] + st[1::4]) + (st[2::4] + st[3::4])
+        assert torch.equal(tile_sums, rowsq_t[:, :M]), f"{dtype} M={M}: (s0 + s1) + (s2 + s3) of the strip sums != the tiled producer's tile sums"
+        cons = gemm(dtype, xg, wc, out_f32=True, decode_tiled=1, row_sumsq=rowsq, row_sumsq_tiles=tiles, row_dim=N, row_eps=1e-6, row_sumsq_form=1)
+        assert torch.equal(cons, cons_t[:M]), f"{dtype} M={M}: a consumer of the strip layout differs from the tiled consumer"
+        # in place on the residual rows, as the decoder runs it
+        r2 = r[:M].clone()
+        gemm(dtype, a[:M], w, residual=r2, C_out=r2, bias=bias, ksplit=S, ng_out=xg, ng_ld=N, ng_gain=gain, ng_rowsq=rowsq, rowsq_strips=1,
+             row_sumsq=sq_in[:M].contiguous(), row_sumsq_tiles=1, row_dim=D, row_eps=1e-5, **more)
+        assert torch.equal(r2, c_t[:M])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_rms_prep_and_row_scale_equal_rmsnorm_then_gemm(dtype):
     """oavsr_op_rms_prep (the rows of a decode step's first layer: y = T(x * gain), the row's sum of squares) followed by a GEMM with the row
     factor computes RMSNorm(x) W^T (Llama_LoRA.py:587-655) -- against fp32 torch."""

@@ -53,7 +53,9 @@ qkv = torch.empty(R, nqkv, device=DEV, dtype=td)
 logits = torch.empty(R, V, device=DEV, dtype=torch.float32)
 gain = torch.ones(d, device=DEV)
 rowsq = torch.rand((d // 64 + 2) * 128, device=DEV) * 64
-RS = dict(row_sumsq=rowsq, row_sumsq_tiles=d // 64, row_dim=d, row_eps=1e-5)
+STRIP = R <= 32 and os.environ.get("OAVSR_DECODE_STRIPS", "1") != "0"      # model.hip: decode_gemm takes the strips (decode_strip.hip) for <= 32 rows
+RS = dict(row_sumsq=rowsq, row_sumsq_tiles=d // 64, row_dim=d, row_eps=1e-5, row_sumsq_form=int(STRIP))
+NG = dict(rowsq_strips=1) if STRIP else {}
 part = torch.empty(16 * 128 * max(nqkv, d, k2), device=DEV, dtype=torch.float32)
 sync = torch.zeros(L.GEMM_SYNC_INTS, dtype=torch.int32, device=DEV) if R <= 32 else None      # model.hip: OAVSR_FUSED_REDUCE_ROWS
 
@@ -93,11 +95,11 @@ def launch(name, i):
         kw = dict(ksplit=ks, partial=part, sync=sync) if ks > 1 else dict(decode_tiled=1)
         gemm("bf16", xg, w, A2=t, W2=W2[i % ncopy], C_out=qkv, **RS, **kw)
     elif name == "o_proj":
-        gemm("bf16", attn, w, residual=x, C_out=x, ksplit=split(d, nq, 2), partial=part, sync=sync, ng_out=xg, ng_ld=d, ng_gain=gain, ng_rowsq=rowsq)
+        gemm("bf16", attn, w, residual=x, C_out=x, ksplit=split(d, nq, 2), partial=part, sync=sync, ng_out=xg, ng_ld=d, ng_gain=gain, ng_rowsq=rowsq, **NG)
     elif name == "gate_up":
         gemm("bf16", xg, w, swiglu_pairs=1, C_out=act, decode_tiled=1, **RS)
     elif name == "down":
-        gemm("bf16", act, w, residual=x, C_out=x, ksplit=split(d, I2 // 2, 2), partial=part, sync=sync, ng_out=xg, ng_ld=d, ng_gain=gain, ng_rowsq=rowsq)
+        gemm("bf16", act, w, residual=x, C_out=x, ksplit=split(d, I2 // 2, 2), partial=part, sync=sync, ng_out=xg, ng_ld=d, ng_gain=gain, ng_rowsq=rowsq, **NG)
     else:
         gemm("bf16", xg, w, out_f32=True, C_out=logits, decode_tiled=1, **RS)
 
