@@ -53,7 +53,7 @@ qkv = torch.empty(R, nqkv, device=DEV, dtype=td)
 logits = torch.empty(R, V, device=DEV, dtype=torch.float32)
 gain = torch.ones(d, device=DEV)
 rowsq = torch.rand((d // 64 + 2) * 128, device=DEV) * 64
-STRIP = R <= 32 and os.environ.get("OAVSR_DECODE_STRIPS", "1") != "0"      # model.hip: decode_gemm takes the strips (decode_strip.hip) for <= 32 rows
+STRIP = R <= 16 and os.environ.get("OAVSR_DECODE_STRIPS", "1") != "0"      # model.hip: decode_gemm takes the strips (decode_strip.hip) for <= 32 rows
 RS = dict(row_sumsq=rowsq, row_sumsq_tiles=d // 64, row_dim=d, row_eps=1e-5, row_sumsq_form=int(STRIP))
 NG = dict(rowsq_strips=1) if STRIP else {}
 part = torch.empty(16 * 128 * max(nqkv, d, k2), device=DEV, dtype=torch.float32)
