@@ -334,6 +334,9 @@ int oavsr_op_stem_pool(int32_t dtype, const void* video, int32_t channels, int32
  * residual may alias out. */
 int oavsr_op_conv3x3_c64(const void* x, int32_t imgs, int32_t H, int32_t W, const void* w, const float* scale, const float* shift,
                          const float* slope, const void* residual, void* out, oavsr_stream stream);
+/* the 128-channel twin (trunk layer2, 11 x 11 maps): groups of images resident in LDS, weights streamed tap by tap; bit-identical to the implicit GEMM */
+int oavsr_op_conv3x3_c128(const void* x, int32_t imgs, int32_t H, int32_t W, const void* w, const float* scale, const float* shift,
+                         const float* slope, const void* residual, void* out, oavsr_stream stream);
 /* Row-wise candidates of one HF beam-search step (`_beam_search`: log_softmax + beam score, top 2K per row, ties by lower
  * token id): cand_val / cand_tok [rows][2K], sorted.  need_exact: rows int32 of scratch for the certified fast path
  * (NULL = exact radix-select kernel only). */

@@ -668,6 +668,12 @@ int launch_dma_mode(const GemmArgs& a, hipStream_t st) {
     return launch_dma<T, A_DENSE, 128, 64, 3, 4, 4>(a, st);
   }
   if (dma_tile_choice(a) == 5) return launch_dma<T, A_CONV1D, 128, 64, 3, 4, 4>(a, st);
+  // implicit-GEMM convolutions with >= 256 output channels (trunk layer3 / layer4, resnet.py:61-74): the 16-wave 256 x 256 tile gathers every
+  // input row once per 256 columns instead of once per 128 -- the gather (9 taps re-read from L2) is what bounds these launches.  Same k order and
+  // epilogue expressions as the 256 x 128 tile: same bits.
+  static const bool conv256 = knob("OAVSR_CONV_TILE256") != 0;
+  if (conv256 && a.amode == A_CONV2D && a.N >= 256 && a.N % 256 == 0 && a.groups == 1 && a.ksplit <= 1 && sizeof(T) == 2)
+    return launch_dma<T, A_CONV2D, 256, 256, 2, 4, 16>(a, st);
   switch (a.amode) {
     case A_DENSE: return launch_dma<T, A_DENSE, 256, 128, 3, 4, 8>(a, st);
     case A_CONV2D: return launch_dma<T, A_CONV2D, 256, 128, 3, 4, 8>(a, st);

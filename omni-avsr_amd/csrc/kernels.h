@@ -187,6 +187,10 @@ int launch_stem_pool(int dtype, const void* video, const int2* frameinfo, int F,
 bool conv3x3_c64_eligible(int dtype, int H, int W, int Cin, int Cout, int ks, int stride);
 int launch_conv3x3_c64(const void* x, int imgs, int H, int W, const void* w, const float* scale, const float* shift, const float* slope,
                        const void* residual, void* out, hipStream_t st);
+// ... and 128 -> 128 channels on small maps (layer2: 11 x 11): groups of images resident, weights streamed tap by tap.  Bit-identical to the implicit GEMM.
+bool conv3x3_c128_eligible(int dtype, int H, int W, int Cin, int Cout, int ks, int stride);
+int launch_conv3x3_c128(const void* x, int imgs, int H, int W, const void* w, const float* scale, const float* shift, const float* slope,
+                        const void* residual, void* out, hipStream_t st);
 // 3x3 stride-2 pad-1 max pool, NHWC
 int launch_maxpool3x3s2(int dtype, const void* x, void* y, int imgs, int H, int W, int C, hipStream_t st);
 // global average pool over HW, NHWC -> [imgs][C]

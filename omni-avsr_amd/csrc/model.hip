@@ -42,6 +42,8 @@ static const KnobDef kKnobs[] = {
     {"OAVSR_PROF_SHAPES", 0, "profiling hook: one family per GEMM shape instead of per kernel"},
     {"OAVSR_DECODE_GRAPH", 1, "0: decode steps are launched eagerly instead of replayed from hipGraphs (same kernels, same bits)"},
     {"OAVSR_DECODE_STRIPS", 1, "0: decode-shaped GEMMs of <= 16 rows run on the 128-row LDS-DMA tiles like larger launches instead of the register-streaming strips (same bits)"},
+    {"OAVSR_CONV_C128", 1, "0: the 128-channel 3x3 convolutions of the trunk as implicit GEMMs instead of the image-resident kernel (same bits)"},
+    {"OAVSR_CONV_TILE256", 1, "0: implicit-GEMM convolutions with >= 256 output channels on the 256 x 128 tile instead of the 16-wave 256 x 256 tile (same bits)"},
     {"OAVSR_FUSED_REDUCE_ROWS", 32, "decode-shaped GEMMs with at most this many rows reduce their split-K slabs inside the launch, others in a second launch (same code, same bits)"},
     {"OAVSR_GEMM_TILE_ROWS", 0, "persistent GEMM: 256 / 192 = that tile height wherever its form exists, 0 = the launcher's rule (256 while calls share the chip; alone: whichever finishes sooner); same bits"},
 };
@@ -595,6 +597,10 @@ static int conv2d_gemm(const oavsr_model* m, const void* x, int imgs, int H, int
   if (conv3x3_c64_eligible(m->dtype, H, W, Cin, Cout, ks, stride)) {
     ProfScope ps("conv3x3_c64_bf16", 2.0 * imgs * H * W * 9.0 * Cin * Cout, 2.0 * imgs * H * W * (Cin + Cout * (residual ? 2 : 1)), st);
     return launch_conv3x3_c64(x, imgs, H, W, c.w, c.scale, c.shift, prelu ? c.slope : nullptr, residual, out, st);
+  }
+  if (conv3x3_c128_eligible(m->dtype, H, W, Cin, Cout, ks, stride)) {
+    ProfScope ps("conv3x3_c128_bf16", 2.0 * imgs * H * W * 9.0 * Cin * Cout, 2.0 * imgs * H * W * (Cin + Cout * (residual ? 2 : 1)), st);
+    return launch_conv3x3_c128(x, imgs, H, W, c.w, c.scale, c.shift, prelu ? c.slope : nullptr, residual, out, st);
   }
   GemmArgs g; g.dtype = m->dtype; g.amode = A_CONV2D; g.H = H; g.Wd = W; g.Cin = Cin; g.ksize = ks; g.stride = stride; g.pad = ks / 2;
   g.OH = (H + 2 * g.pad - ks) / stride + 1; g.OW = (W + 2 * g.pad - ks) / stride + 1;
@@ -2078,6 +2084,13 @@ int oavsr_op_conv3x3_c64(const void* x, int32_t imgs, int32_t H, int32_t W, cons
   OAVSR_REQUIRE(x && w && scale && shift && out, "op_conv3x3_c64: null argument");
   OAVSR_REQUIRE(conv3x3_c64_eligible(DT_BF16, H, W, 64, 64, 3, 1), "op_conv3x3_c64: %dx%d image does not fit", H, W);
   return launch_conv3x3_c64(x, imgs, H, W, w, scale, shift, slope, residual, out, (hipStream_t)stream);
+}
+
+int oavsr_op_conv3x3_c128(const void* x, int32_t imgs, int32_t H, int32_t W, const void* w, const float* scale, const float* shift,
+                          const float* slope, const void* residual, void* out, oavsr_stream stream) {
+  OAVSR_REQUIRE(x && w && scale && shift && out, "op_conv3x3_c128: null argument");
+  OAVSR_REQUIRE(H * W <= 128 && H * W >= 16, "op_conv3x3_c128: %dx%d image does not fit (16 .. 128 pixels)", H, W);
+  return launch_conv3x3_c128(x, imgs, H, W, w, scale, shift, slope, residual, out, (hipStream_t)stream);
 }
 
 int oavsr_op_beam_topk(const float* logits, int64_t ld, int32_t rows, int32_t V, int32_t K, const float* beam_scores, float* cand_val,

@@ -136,6 +136,7 @@ SYMBOLS = {
     "oavsr_op_rms_prep": (C.c_int, [_I, _P, _L, _P, _L, _P, _P, _I, _I, _P]),
     "oavsr_op_stem_pool": (C.c_int, [_I, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "oavsr_op_conv3x3_c64": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "oavsr_op_conv3x3_c128": (C.c_int, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "oavsr_op_beam_topk": (C.c_int, [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P]),
     "oavsr_op_maxpool3x3s2": (C.c_int, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "oavsr_op_avgpool_hw": (C.c_int, [_I, _P, _P, _I, _I, _I, _P]),

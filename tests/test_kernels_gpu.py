@@ -373,6 +373,42 @@ def test_conv3x3_c64_image_resident(imgs, H, with_res, with_prelu):
     close(out, y, tol(dtype) * 2, what="direct conv")
 
 
+@pytest.mark.parametrize("imgs,H,with_res,with_prelu", [(7, 11, True, True), (601, 11, False, True), (2, 11, True, False), (1, 11, False, False), (5, 8, True, True), (33, 6, True, True)])
+def test_conv3x3_c128_image_resident(imgs, H, with_res, with_prelu):
+    """conv.hip, 128 channels (trunk layer2, resnet.py:61-74): groups of images resident in LDS, the weights streamed tap by tap; must equal the
+    implicit-GEMM path bit for bit (same k order, same epilogue) and match torch conv2d + BN + residual + PReLU; odd image counts (a last partial
+    group), several groups per workgroup (601 images on 256 CUs), residual aliasing the output as in the trunk's in-place update."""
+    dtype, Cn = "bf16", 128
+    x = rnd(imgs, Cn, H, H, seed=1)
+    w = rnd(Cn, Cn, 3, 3, seed=2) / math.sqrt(9 * Cn)
+    xd, xr = q(x.permute(0, 2, 3, 1).contiguous(), dtype)
+    wd, wr = q(w.permute(0, 2, 3, 1).reshape(Cn, -1), dtype)
+    scale, shift, slope = rnd(Cn, seed=3) * 0.1 + 1, rnd(Cn, seed=4) * 0.1, rnd(Cn, seed=5) * 0.05 + 0.25
+    res, resr = q(rnd(imgs * H * H, Cn, seed=6), dtype)
+    sc, sh, sl = scale.to(DEV), shift.to(DEV), slope.to(DEV)
+    kw = dict(scale=sc, bias=sh)
+    if with_prelu:
+        kw.update(prelu=sl, act=3)
+    if with_res:
+        kw.update(residual=res)
+    import os
+    assert os.environ.get("OAVSR_CONV_C128", "1") != "0"
+    # the implicit GEMM of the same convolution (Cin = 127 + 1 would change the math; the GEMM entry point never takes the image-resident kernel)
+    want = gemm(dtype, xd, wd, M=imgs * H * H, amode=1, H=H, W_=H, Cin=Cn, OH=H, OW=H, stride=1, pad=1, ksize=3, lda=0, **kw)
+    out = res.clone() if with_res else torch.empty(imgs * H * H, Cn, dtype=tdt(dtype), device=DEV)      # residual aliases the output
+    L.check(L.load().oavsr_op_conv3x3_c128(P(xd), imgs, H, H, P(wd), P(sc), P(sh), P(sl) if with_prelu else None,
+                                           P(out) if with_res else None, P(out), stream()))
+    assert torch.equal(out, want), f"image-resident conv differs from implicit GEMM: max {(out.float() - want.float()).abs().max().item():.3e}"
+    y = F.conv2d(xr.permute(0, 3, 1, 2), wr.reshape(Cn, 3, 3, Cn).permute(0, 3, 1, 2), padding=1)
+    y = y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    y = y.permute(0, 2, 3, 1).reshape(imgs * H * H, Cn)
+    if with_res:
+        y = y + resr
+    if with_prelu:
+        y = torch.where(y >= 0, y, slope.view(1, -1) * y)
+    close(out, y, tol(dtype) * 2, what="image-resident conv, 128 channels")
+
+
 def _rowinfo(cu_out, cu_in, stride):
     lib = L.load()
     n = len(cu_out) - 1
