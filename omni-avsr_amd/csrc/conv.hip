@@ -150,7 +150,7 @@ __global__ __launch_bounds__(kConvThreads) void conv3x3_c64_kernel(const bf16_t*
 // Image-resident instead: a GROUP of G = 256 / (H W) images (2 x 121 pixels x 256 B = 61 KB) stays in LDS while the weights stream past it one TAP
 // at a time (128 x 128 x 2 B = 32 KB from L2, double-buffered through registers: the next tap's rows are requested before the current tap's MFMAs
 // and committed after them) -- memory sees each input byte once and 295 KB of weights per group.  Persistent workgroups of 8 waves walk the
-// groups; the next group's pixels are prefetched into registers during the current one.  A wave owns 2 pixel tiles x all 128 channels; K runs
+// groups; the next group's pixels are prefetched into registers during the current one.  A wave owns 4 pixel tiles x 4 channel tiles; K runs
 // tap-major then channels and the epilogue is the implicit GEMM's, so the result is BIT-IDENTICAL to that path (tests).
 constexpr int kC2 = 128;
 constexpr int kKW2 = 9 * kC2;                  // 1152
@@ -199,11 +199,13 @@ __global__ __launch_bounds__(kConvThreads) void conv3x3_c128_kernel(const bf16_t
     *reinterpret_cast<u32x4*>(sw + (BUF) * (kC2 * 256) + n_ * 256 + ((c_ ^ (n_ & 15)) << 4)) = wpre[j];               \
   }
 
-  // the 2 pixel tiles of this wave: group pixel q = (wave * 2 + i) * 16 + r16 -> (image in group, y, x)
-  int qb[2], qy[2], qx[2], qin[2];
+  // a wave owns 4 pixel tiles x 4 channel tiles (waves 0-3: channels 0..63, waves 4-7: 64..127): 8 fragment reads feed 16 MFMAs
+  // group pixel q = ((wave & 3) * 4 + i) * 16 + r16 -> (image in group, y, x)
+  const int pg = wave & 3, ng = wave >> 2;
+  int qb[4], qy[4], qx[4], qin[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int q = (wave * 2 + i) * 16 + r16;
+  for (int i = 0; i < 4; ++i) {
+    const int q = (pg * 4 + i) * 16 + r16;
     qin[i] = q < HWg;
     const int qq = qin[i] ? q : 0;
     const int im = qq / HW, pos = qq - im * HW;
@@ -222,19 +224,19 @@ __global__ __launch_bounds__(kConvThreads) void conv3x3_c128_kernel(const bf16_t
     if (grp + (int)gridDim.x < ngroups) OAVSR_C128_IMG_PREFETCH(grp + gridDim.x)
     const int npix = min(G, imgs - grp * G) * HW;             // valid pixels of this group
 
-    f32x4 acc[2][8];
+    f32x4 acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
       // the next tap's weights (tap 0 of the next group behind tap 8) into registers while this tap computes
       OAVSR_C128_W_PREFETCH(tap == 8 ? 0 : tap + 1)
       const int ky = tap / 3 - 1, kx = tap - (tap / 3) * 3 - 1;
-      int pin[2];
+      int pin[4];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < 4; ++i) {
         const int iy = qy[i] + ky, ix = qx[i] + kx;
         pin[i] = (qin[i] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? qb[i] + iy * W + ix : HWg;
       }
@@ -242,31 +244,33 @@ __global__ __launch_bounds__(kConvThreads) void conv3x3_c128_kernel(const bf16_t
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
         const int c = kb * 4 + g;                             // 16-byte chunk of the 128 channels
-        Chunk16 pf[2];
+        Chunk16 pf[4], wf[4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) pf[i] = *reinterpret_cast<const Chunk16*>(simg + pin[i] * 256 + ((c ^ (pin[i] & 15)) << 4));
+        for (int i = 0; i < 4; ++i) pf[i] = *reinterpret_cast<const Chunk16*>(simg + pin[i] * 256 + ((c ^ (pin[i] & 15)) << 4));
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int n = j * 16 + r16;
-          const Chunk16 wf = *reinterpret_cast<const Chunk16*>(swt + n * 256 + ((c ^ (n & 15)) << 4));
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf.v), __builtin_bit_cast(bf16x8, pf[i].v), acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+          const int n = (ng * 4 + j) * 16 + r16;
+          wf[j] = *reinterpret_cast<const Chunk16*>(swt + n * 256 + ((c ^ (n & 15)) << 4));
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[j].v), __builtin_bit_cast(bf16x8, pf[i].v), acc[i][j], 0, 0, 0);
       }
       OAVSR_C128_W_COMMIT((stage + 1) & 1)                    // (that buffer's readers passed the barrier that ended the previous tap)
       ++stage;
       __syncthreads();
     }
-    // D[channel = 16 j + 4 g + r][pixel = r16]
+    // D[channel = 16 (4 ng + j) + 4 g + r][pixel = r16]
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int q = (wave * 2 + i) * 16 + r16;
+    for (int i = 0; i < 4; ++i) {
+      const int q = (pg * 4 + i) * 16 + r16;
       if (q >= npix) continue;
       const size_t o = ((size_t)grp * HWg + q) * kC2;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int c0 = j * 16 + 4 * g;
+      for (int j = 0; j < 4; ++j) {
+        const int c0 = (ng * 4 + j) * 16 + 4 * g;
         const f32x4 sc = *reinterpret_cast<const f32x4*>(spar + c0);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(spar + kC2 + c0);
         const f32x4 sl = *reinterpret_cast<const f32x4*>(spar + 2 * kC2 + c0);
