@@ -24,6 +24,9 @@ FAMILY = [  # rocprof kernel-name pattern -> bench.py family name
     (r"gemm_dma_kernelIDF16bLi0ELi256ELi128E|gemm_dma_kernel<[^>]*0, 256, 128", "gemm_dma_256x128_bf16"),
     (r"gemm_dma_kernelIDF16bLi0ELi128ELi64E|gemm_dma_kernel<[^>]*0, 128, 64", "decode_gemm_dma_128x64_bf16"),        # (tools/decode_mix.py passes: split-K launches, reduce inside)
     (r"gemm_dma_kernelIDF16bLi0ELi128ELi256E|gemm_dma_kernel<[^>]*0, 128, 256", "decode_gemm_dma_128x256_bf16"),     # lm_head
+    (r"decode_strip_kernel", "decode_gemm_strip16_bf16"),                                                             # <= 16 rows: the weight-streaming strips (decode_strip.hip)
+    (r"conv3x3_c128_kernel", "conv3x3_c128_bf16"),
+    (r"conv3x3_c64_kernel", "conv3x3_c64_bf16"),
     (r"decode_attn_beam4_kernel", "decode_attention_beam4"),
     (r"splitk_reduce_kernel", "decode_splitk_reduce"),
     (r"decode_attn_kernel", "decode_attention"),
@@ -72,7 +75,8 @@ for f in sorted(set(fa) | set(sa)):
     write = wa[f].get("WRITE_SIZE", 0.0) / max(wc[f].get("WRITE_SIZE", 0), 1)
     ns = max(sc[f].get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0), 1)
     mops = sa[f].get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) / ns
-    what = "tools/decode_mix.py 8 1b (8 rows: the split-K reduce inside the launch)" if "decode_r8" in tag else "tools/decode_mix.py 97 8b (97 rows, Llama-3.1-8B widths)" if "decode8b" in tag else "tools/decode_mix.py 97 1b (97 rows, Llama-3.2-1B widths)" if "decode" in tag else "tools/gemm_mix.py" if "gemm" in tag else \
+    what = "bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-grouped (the JOB's own launches: scheduler on, 4 caller streams)" if "job" in tag else \
+        "tools/decode_mix.py 1 1b (one row: the weight-streaming strips)" if "decode_r1" in tag else "tools/decode_mix.py 8 1b (8 rows: the weight-streaming strips; lm_head on the 128 x 256 tile)" if "decode_r8" in tag else "tools/decode_mix.py 97 8b (97 rows, Llama-3.1-8B widths)" if "decode8b" in tag else "tools/decode_mix.py 97 1b (97 rows, Llama-3.2-1B widths)" if "decode" in tag else "tools/gemm_mix.py" if "gemm" in tag else \
         "bench.py --streams 1 --steps 1 --warmup 1 --calls-per-step 2 --no-cpu-baseline --no-roofline"
     d = dict(note="rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*; separate runs, each with --kernel-trace) over `" + what + "`; traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B (gfx950 read-side "
                   "correction; the counters sit on the L2's memory side, Infinity-Cache hits included); mfma flops = SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512; "
