@@ -75,7 +75,7 @@ for f in sorted(set(fa) | set(sa)):
     write = wa[f].get("WRITE_SIZE", 0.0) / max(wc[f].get("WRITE_SIZE", 0), 1)
     ns = max(sc[f].get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0), 1)
     mops = sa[f].get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) / ns
-    what = "bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-grouped (the JOB's own launches: scheduler on, 4 caller streams)" if "job" in tag else \
+    what = "bench.py --gpus 1 --steps 1 --warmup 1 --calls-per-step 2 --no-cpu-baseline --no-roofline --no-grouped (the JOB's own launches: scheduler on, engine-owned caller streams)" if "job" in tag else \
         "tools/decode_mix.py 1 1b (one row: the weight-streaming strips)" if "decode_r1" in tag else "tools/decode_mix.py 8 1b (8 rows: the weight-streaming strips; lm_head on the 128 x 256 tile)" if "decode_r8" in tag else "tools/decode_mix.py 97 8b (97 rows, Llama-3.1-8B widths)" if "decode8b" in tag else "tools/decode_mix.py 97 1b (97 rows, Llama-3.2-1B widths)" if "decode" in tag else "tools/gemm_mix.py" if "gemm" in tag else \
         "bench.py --streams 1 --steps 1 --warmup 1 --calls-per-step 2 --no-cpu-baseline --no-roofline"
     d = dict(note="rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*; separate runs, each with --kernel-trace) over `" + what + "`; traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B (gfx950 read-side "
