@@ -499,10 +499,6 @@ __device__ __forceinline__ float xor_max_32(float x) {
   return a;
 }
 
-#ifndef OAVSR_ATTN_PRIO
-#define OAVSR_ATTN_PRIO 0
-#endif
-constexpr bool kAttnPrio = OAVSR_ATTN_PRIO != 0;      // probe builds: raised wave priority over the P V MFMA groups
 template <int NW>
 __device__ __forceinline__ void attn_dma32_body(const AttnArgs& p) {
   constexpr int HD = 64, RB = 128, NSTAGE = 3;
@@ -682,7 +678,6 @@ __device__ __forceinline__ void attn_dma32_body(const AttnArgs& p) {
         for (int r = 0; r < 4; ++r) { pf[sl][r] = (bf16_t)s[t2][8 * sl + r]; pf[sl][4 + r] = (bf16_t)s[t2][8 * sl + 4 + r]; }
       asm volatile("s_waitcnt lgkmcnt(0)"
                    : "+v"(vt[0][0]), "+v"(vt[0][1]), "+v"(vt[1][0]), "+v"(vt[1][1]), "+v"(vt[2][0]), "+v"(vt[2][1]), "+v"(vt[3][0]), "+v"(vt[3][1]));
-      if (kAttnPrio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl)
 #pragma unroll
@@ -690,7 +685,6 @@ __device__ __forceinline__ void attn_dma32_body(const AttnArgs& p) {
           const u32x4 vv = u32x4{vt[dt * 2 + sl][0][0], vt[dt * 2 + sl][0][1], vt[dt * 2 + sl][1][0], vt[dt * 2 + sl][1][1]};
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[sl], o[dt], 0, 0, 0);
         }
-      if (kAttnPrio) __builtin_amdgcn_s_setprio(0);
     });
     l_run = l_run * alpha + (lsum2[0] + lsum2[1]);
     m_run = m_new;
