@@ -199,6 +199,42 @@ def test_decode_strips_equal_the_tiled_kernels(dtype, N, K, K2, S):
         assert torch.equal(r2, c_t[:M])
 
 
+def test_decode_strips_under_load_are_deterministic():
+    """The strips' counted waits (wave-private LDS-DMA FIFO) only ever assume FEWER outstanding operations than there are, and a slot is refilled only after
+    its fragments were read: with a second stream hammering HBM and a third one running the strips on other operands -- DMA arrivals late and out of step,
+    other workgroups sharing the CUs -- every launch must return the bits of an undisturbed one.  All ring depths: 1 / 8 / 9 / 16 rows, short and long k-slices."""
+    dtype = "bf16"
+    shapes = [(2048, 2048, 0, 4), (3072, 2048, 256, 4), (2048, 8192, 0, 8), (16384, 2048, 0, 1), (256, 2048, 0, 4)]
+    cases = []
+    for N, K, K2, S in shapes:
+        a, _ = q(rnd(16, K, seed=1), dtype)
+        w, _ = q(rnd(N, K, seed=2) / math.sqrt(K), dtype)
+        a2 = w2 = None
+        if K2:
+            a2, _ = q(rnd(16, K2, seed=3), dtype)
+            w2, _ = q(rnd(N, K2, seed=4) / math.sqrt(K2), dtype)
+        for M in (1, 8, 9, 16):
+            kw = dict(A2=a2[:M], W2=w2) if K2 else {}
+            kw.update(dict(swiglu_pairs=1, decode_tiled=1) if S == 1 else dict(ksplit=S))
+            cases.append((a[:M], w, kw, gemm(dtype, a[:M], w, **kw).clone()))
+    torch.cuda.synchronize()
+    side, third = torch.cuda.Stream(), torch.cuda.Stream()
+    junk = torch.empty(256 << 20, dtype=torch.uint8, device=DEV)
+    wb, _ = q(rnd(4096, 4096, seed=9) / 64, dtype)
+    ab, _ = q(rnd(16, 4096, seed=10), dtype)
+    for rep in range(4):
+        with torch.cuda.stream(side):
+            for _ in range(30):
+                junk.add_(1)
+        with torch.cuda.stream(third):
+            for _ in range(60):
+                gemm(dtype, ab, wb, ksplit=4)
+        for a_, w_, kw, ref in cases:
+            out = gemm(dtype, a_, w_, **kw)
+            assert torch.equal(out, ref), f"strips under load: {a_.shape[0]} x {w_.shape[0]} x {w_.shape[1]} differs from an undisturbed launch (repeat {rep})"
+        torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_rms_prep_and_row_scale_equal_rmsnorm_then_gemm(dtype):
     """oavsr_op_rms_prep (the rows of a decode step's first layer: y = T(x * gain), the row's sum of squares) followed by a GEMM with the row
