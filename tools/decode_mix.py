@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The decode-shaped launches of ONE decode step (llm_decode_layers + lm_head, model.hip) at R rows for a model's widths, through the C ABI:
 per layer LoRA-down, QKV (+ LoRA segment, row_scale), o_proj (+ residual, next-norm outputs), gate / up (+ SwiGLU, row_scale), down_proj
-(+ residual, next-norm outputs) -- split-K exactly as decode_gemm sizes it (reduce inside the launch up to 32 rows, as a second launch above) --, the
+(+ residual, next-norm outputs) -- split-K exactly as decode_gemm sizes it (<= 16 rows: the weight-streaming strips; reduce inside the launch up to 32 rows, as a second launch above) --, the
 decode attention on the same rows, then lm_head (fp32 logits).
 Weight copies rotate beyond the 256 MiB Infinity Cache.  For `rocprofv3 --pmc` / `--kernel-trace` passes over the decode kernels that
 ship (tools/pmc_round.py tags "decode..."), and with `--time` a per-site timing table.
@@ -53,7 +53,7 @@ qkv = torch.empty(R, nqkv, device=DEV, dtype=td)
 logits = torch.empty(R, V, device=DEV, dtype=torch.float32)
 gain = torch.ones(d, device=DEV)
 rowsq = torch.rand((d // 64 + 2) * 128, device=DEV) * 64
-STRIP = R <= 16 and os.environ.get("OAVSR_DECODE_STRIPS", "1") != "0"      # model.hip: decode_gemm takes the strips (decode_strip.hip) for <= 32 rows
+STRIP = R <= 16 and os.environ.get("OAVSR_DECODE_STRIPS", "1") != "0"      # model.hip: decode_gemm takes the strips (decode_strip.hip) for <= 16 rows
 RS = dict(row_sumsq=rowsq, row_sumsq_tiles=d // 64, row_dim=d, row_eps=1e-5, row_sumsq_form=int(STRIP))
 NG = dict(rowsq_strips=1) if STRIP else {}
 part = torch.empty(16 * 128 * max(nqkv, d, k2), device=DEV, dtype=torch.float32)
