@@ -143,13 +143,15 @@ __global__ __launch_bounds__(kTopkThreads) void beam_topk_exact_kernel(const flo
   }
 }
 
-// ---- fast path of the row top-2K (same outputs, bit for bit): no histogram atomics ----
-// Sweep 1 keeps, per thread, the kTopT best of its strided elements in registers plus the best element it had to drop; sweep 2 is
-// the same sum of exp as the exact kernel (same element -> thread mapping, same reduction order => identical logZ bits).  The
-// 1024 x kTopT survivors are reduced to the top 2K by max-extraction (per wave, then one wave over the 16 x 2K finalists), with
-// the tie rule (value desc, index asc).  A row is CERTIFIED exact when no thread dropped an element that beats the 2K-th
-// survivor; otherwise need_exact[row] is set and beam_topk_exact_kernel redoes the row (probability ~ C(2K, T+1) / 1024^T).
-constexpr int kTopT = 6;
+// ---- fast path of the row top-2K (same outputs, bit for bit): two sweeps, no histogram atomics, no per-element insertion ----
+// Sweep 1 is a plain max per thread (round 5 kept a sorted top-6 per thread in registers: with 64 lanes some lane inserts on nearly every
+// element, so every wave ran the ~40-instruction insertion path all the time -- half of the kernel's 109 us at 120 x 128 261).  The 2K-th largest
+// of the 1024 thread maxima is a LOWER BOUND tau of the row's 2K-th largest element (those 2K maxima are 2K distinct elements >= tau), and a tight
+// one (~2K .. 1.5 x 2K elements of the row reach it).  Sweep 2 is the exact kernel's sum of exp (same element -> thread mapping, same reduction
+// order => identical logZ bits) and, on the way, appends every element >= tau to a candidate list in LDS; the candidates are rank-sorted with the
+// tie rule (value desc, index asc).  EXACT for every row whose candidates fit the list (kCandMax); otherwise -- a row with >= kCandMax elements
+// tied at its 2K-th value -- need_exact[row] is set and beam_topk_exact_kernel redoes the row.
+constexpr int kCandMax = 1024;
 
 struct Cand { float v; int i; };
 __device__ __forceinline__ bool beats(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
@@ -159,121 +161,110 @@ __global__ __launch_bounds__(kTopkThreads) void beam_topk_fast_kernel(const floa
                                                                        int* __restrict__ cand_tok, int* __restrict__ need_exact) {
   constexpr int NW = kTopkThreads / 64;
   __shared__ float red[NW];
-  __shared__ float fin_v[NW * kMax2K];
-  __shared__ int fin_i[NW * kMax2K];
-  __shared__ float sel_v[kMax2K];
-  __shared__ int sel_i[kMax2K];
-  __shared__ int s_bad;
+  __shared__ float fin_v[NW * 64];                  // per wave: its 64 thread maxima, sorted descending
+  __shared__ float c_v[kCandMax];
+  __shared__ int c_i[kCandMax];
+  __shared__ int c_n;
+  __shared__ float s_tau;
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* x = logits + (int64_t)row * ld;
-  if (tid == 0) s_bad = 0;
-  // ---- sweep 1: max + local top-T (sorted descending) + best dropped element ----
-  float tv[kTopT]; int tix[kTopT];
-#pragma unroll
-  for (int k = 0; k < kTopT; ++k) { tv[k] = -INFINITY; tix[k] = 0x7fffffff; }
-  float dv = -INFINITY; int di = 0x7fffffff;     // best dropped
-  float m = -INFINITY;
-  auto consider = [&](float v, int i) {
-    m = fmaxf(m, v);
-    if (beats(v, i, tv[kTopT - 1], tix[kTopT - 1])) {
-      // the current last is dropped (if it was a real element)
-      if (tix[kTopT - 1] != 0x7fffffff && beats(tv[kTopT - 1], tix[kTopT - 1], dv, di)) { dv = tv[kTopT - 1]; di = tix[kTopT - 1]; }
-      tv[kTopT - 1] = v; tix[kTopT - 1] = i;
-#pragma unroll
-      for (int k = kTopT - 1; k > 0; --k) {
-        if (beats(tv[k], tix[k], tv[k - 1], tix[k - 1])) {
-          const float fv = tv[k]; tv[k] = tv[k - 1]; tv[k - 1] = fv;
-          const int fi = tix[k]; tix[k] = tix[k - 1]; tix[k - 1] = fi;
-        }
-      }
-    } else if (beats(v, i, dv, di)) { dv = v; di = i; }
-  };
+  if (tid == 0) c_n = 0;
+  const int need = twoK < V ? twoK : V;
+  // ---- sweep 1: the thread's max ----
+  float tm = -INFINITY;
   constexpr int UL = 16;                          // loads in flight per thread (the row is streamed from HBM / L2)
   for (int i0 = tid; i0 < V; i0 += kTopkThreads * UL) {
     float buf[UL];
 #pragma unroll
     for (int u = 0; u < UL; ++u) { const int i = i0 + u * kTopkThreads; buf[u] = i < V ? x[i] : -INFINITY; }
 #pragma unroll
-    for (int u = 0; u < UL; ++u) { const int i = i0 + u * kTopkThreads; if (i < V) consider(buf[u], i); }
+    for (int u = 0; u < UL; ++u) tm = fmaxf(tm, buf[u]);
   }
-  m = wave_max(m);
+  float m = wave_max(tm);
   if (lane == 0) red[wave] = m;
+  // the wave's 64 maxima sorted descending (bitonic network over the lanes)
+  float sv = tm;
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const float ov = __shfl_xor(sv, j, 64);
+      const bool up = ((lane & k) == 0);            // this k-block sorts descending (up) or ascending
+      const bool lower = ((lane & j) == 0);
+      const float hi = fmaxf(sv, ov), lo = fminf(sv, ov);
+      sv = (up == lower) ? hi : lo;
+    }
+  fin_v[wave * 64 + lane] = sv;
   __syncthreads();
   m = red[0];
   for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w]);
+  // ---- wave 0: the need-th largest of the 1024 maxima = merge of the NW sorted lists (lane w < NW walks list w) ----
+  if (wave == 0) {
+    int pos = 0;
+    float tau = -INFINITY;
+    for (int r = 0; r < need; ++r) {
+      const float bv = (lane < NW && pos < 64) ? fin_v[lane * 64 + pos] : -INFINITY;
+      float wv = bv; int wl = lane;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(wv, o, 64); const int ol = __shfl_xor(wl, o, 64);
+        if (ov > wv || (ov == wv && ol < wl)) { wv = ov; wl = ol; }
+      }
+      tau = wv;
+      if (lane == wl) ++pos;
+    }
+    if (lane == 0) s_tau = tau;                     // (-inf when the row has fewer than `need` non-empty threads: everything is a candidate)
+  }
   __syncthreads();
-  // ---- sweep 2: sum of exp, identical order to the exact kernel ----
+  const float tau = s_tau;
+  // ---- sweep 2: sum of exp, identical order to the exact kernel; candidates >= tau on the way ----
   float s = 0.f;
   for (int i0 = tid; i0 < V; i0 += kTopkThreads * UL) {    // same element order per thread as the exact kernel
     float buf[UL];
 #pragma unroll
     for (int u = 0; u < UL; ++u) { const int i = i0 + u * kTopkThreads; buf[u] = i < V ? x[i] : 0.f; }
 #pragma unroll
-    for (int u = 0; u < UL; ++u) { const int i = i0 + u * kTopkThreads; if (i < V) s += expf(buf[u] - m); }
+    for (int u = 0; u < UL; ++u) {
+      const int i = i0 + u * kTopkThreads;
+      if (i < V) {
+        s += expf(buf[u] - m);
+        if (buf[u] >= tau) { const int p = atomicAdd(&c_n, 1); if (p < kCandMax) { c_v[p] = buf[u]; c_i[p] = i; } }
+      }
+    }
   }
   s = wave_sum(s);
+  __syncthreads();                                   // (red[] is read above by every thread before it is rewritten)
   if (lane == 0) red[wave] = s;
   __syncthreads();
   s = 0.f;
   for (int w = 0; w < NW; ++w) s += red[w];
   const float logz = logf(s);
-  // ---- per wave: extract the best `twoK` of its 64 x T survivors (each lane's list is sorted: only its head competes) ----
-  const int need = twoK < V ? twoK : V;
-  int head = 0;
-  for (int r = 0; r < need; ++r) {
-    float bv = head < kTopT ? tv[0] : -INFINITY; int bi = head < kTopT ? tix[0] : 0x7fffffff;
-    float wv = bv; int wi = bi;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(wv, o, 64); const int oi = __shfl_xor(wi, o, 64);
-      if (beats(ov, oi, wv, wi)) { wv = ov; wi = oi; }
-    }
-    if (lane == 0) { fin_v[wave * kMax2K + r] = wv; fin_i[wave * kMax2K + r] = wi; }
-    if (bi == wi && wi != 0x7fffffff) {            // this lane's head won: pop it
-#pragma unroll
-      for (int k = 0; k < kTopT - 1; ++k) { tv[k] = tv[k + 1]; tix[k] = tix[k + 1]; }
-      tv[kTopT - 1] = -INFINITY; tix[kTopT - 1] = 0x7fffffff;
-      ++head;
-    }
-  }
-  __syncthreads();
-  // ---- wave 0: merge the NW sorted lists of finalists (lane w < NW walks list w) ----
-  if (wave == 0) {
-    int pos = 0;
-    for (int r = 0; r < need; ++r) {
-      float bv = (lane < NW && pos < need) ? fin_v[lane * kMax2K + pos] : -INFINITY;
-      int bi = (lane < NW && pos < need) ? fin_i[lane * kMax2K + pos] : 0x7fffffff;
-      float wv = bv; int wi = bi;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(wv, o, 64); const int oi = __shfl_xor(wi, o, 64);
-        if (beats(ov, oi, wv, wi)) { wv = ov; wi = oi; }
-      }
-      if (lane == 0) { sel_v[r] = wv; sel_i[r] = wi; }
-      if (bi == wi && wi != 0x7fffffff) ++pos;
-    }
-  }
-  __syncthreads();
-  // ---- certify: nothing that was dropped beats the last selected element; a popped-out list (head == T) must not either ----
-  const float lv = sel_v[need - 1]; const int li = sel_i[need - 1];
-  bool bad = beats(dv, di, lv, li) && di != 0x7fffffff;
-  if (bad) s_bad = 1;
-  __syncthreads();
-  if (tid == 0) need_exact[row] = s_bad;
-  if (s_bad) return;
+  const int n = c_n;
+  if (tid == 0) need_exact[row] = n > kCandMax ? 1 : 0;
+  if (n > kCandMax) return;
+  // ---- rank sort of the candidates (value desc, index asc); the first `need` ranks are the row's top 2K ----
   const float bs = beam_scores ? beam_scores[row] : 0.f;
-  if (tid < need) {
-    cand_val[(int64_t)row * twoK + tid] = ((sel_v[tid] - m) - logz) + bs;
-    cand_tok[(int64_t)row * twoK + tid] = sel_i[tid];
+  if (tid < n) {
+    const float v = c_v[tid]; const int idx = c_i[tid];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += beats(c_v[j], c_i[j], v, idx) ? 1 : 0;
+    if (rank < need) {
+      cand_val[(int64_t)row * twoK + rank] = ((v - m) - logz) + bs;
+      cand_tok[(int64_t)row * twoK + rank] = idx;
+    }
   }
 }
 
-// One wave per utterance.
-__global__ __launch_bounds__(64) void beam_step_kernel(BeamArgs a, int Kr /* rows per utterance holding candidates: 1 at step 0, else K */,
-                                                        const int* seq_old, const int* anc_old, int* seq_new, int* anc_new) {
+// One workgroup per utterance.  The utterance's top 2K of its K x 2K row candidates by RANK: every candidate counts the candidates that beat it
+// (value desc, then flat index beam * V + token asc -- torch.topk's order over the flattened [K V] scores; flat indices are distinct, so ranks
+// are too), 2 048 candidates at most on 512 threads (round 5: 2K rounds of a 64-lane arg-max with a barrier each, 70 us per step at K = 15).
+constexpr int kStepThreads = 512;
+__global__ __launch_bounds__(kStepThreads) void beam_step_kernel(BeamArgs a, int Kr /* rows per utterance holding candidates: 1 at step 0, else K */,
+                                                                  const int* seq_old, const int* anc_old, int* seq_new, int* anc_new) {
   __shared__ float cv[kMaxK * kMax2K];
   __shared__ int cflat_b[kMaxK * kMax2K];
   __shared__ int ctok[kMaxK * kMax2K];
+  __shared__ long cflat[kMaxK * kMax2K];         // beam * V + token: torch.topk's flat index
   __shared__ float top_v[kMax2K];
   __shared__ int top_b[kMax2K], top_t[kMax2K];
   __shared__ int nb_parent[kMaxK], nb_tok[kMaxK];
@@ -283,28 +274,24 @@ __global__ __launch_bounds__(64) void beam_step_kernel(BeamArgs a, int Kr /* row
   const int cur_len = *a.step;                 // tokens generated so far (== input_ids.shape[-1] in HF's process())
   const int row0 = u * K;
   const int n = Kr * twoK;
-  for (int i = lane; i < n; i += 64) {
+  for (int i = lane; i < n; i += kStepThreads) {
     int b = i / twoK, j = i - b * twoK;
     int64_t src = (int64_t)((Kr == 1 ? u : row0 + b)) * twoK + j;
-    cv[i] = a.cand_val[src]; ctok[i] = a.cand_tok[src]; cflat_b[i] = b;
+    const int tok = a.cand_tok[src];
+    cv[i] = a.cand_val[src]; ctok[i] = tok; cflat_b[i] = b; cflat[i] = (long)b * V + tok;
   }
   __syncthreads();
-  // global top-2K of the utterance (torch.topk over the flattened [K*V] scores; ties -> lower flat index)
-  for (int r = 0; r < twoK; ++r) {
-    float bv = -INFINITY; int bi = -1; long bf = 0x7fffffffffffffffL;
-    for (int i = lane; i < n; i += 64) {
-      float v = cv[i];
-      long flat = (long)cflat_b[i] * V + ctok[i];
-      if (ctok[i] >= 0 && (v > bv || (v == bv && flat < bf))) { bv = v; bi = i; bf = flat; }
+  for (int i = lane; i < n; i += kStepThreads) {
+    const float v = cv[i];
+    const long flat = cflat[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const float w = cv[j];
+      rank += (w > v || (w == v && cflat[j] < flat)) ? 1 : 0;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      float ov = __shfl_xor(bv, o, 64); int oi = __shfl_xor(bi, o, 64); long of = __shfl_xor(bf, o, 64);
-      if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && of < bf))) { bv = ov; bi = oi; bf = of; }
-    }
-    if (lane == 0) { top_v[r] = bv; top_b[r] = cflat_b[bi]; top_t[r] = ctok[bi]; ctok[bi] = -1; }
-    __syncthreads();
+    if (rank < twoK) { top_v[rank] = v; top_b[rank] = cflat_b[i]; top_t[rank] = ctok[i]; }
   }
+  __syncthreads();
   // ---- BeamSearchScorer.process for this batch element (sequential, lane 0) ----
   if (lane == 0) {
     int nnew = 0;
@@ -356,20 +343,20 @@ __global__ __launch_bounds__(64) void beam_step_kernel(BeamArgs a, int Kr /* row
   }
   __syncthreads();
   // ---- reorder histories / ancestry, publish the next step's inputs ----
-  for (int b = 0; b < K; ++b) {
+  for (int i = lane; i < K * cur_len; i += kStepThreads) {
+    const int b = i / cur_len, t = i - b * cur_len;
     const int prow = row0 + (Kr == 1 ? 0 : nb_parent[b]);
     const int row = row0 + b;
-    for (int t = lane; t < cur_len; t += 64) {
-      seq_new[(int64_t)row * a.max_new + t] = seq_old[(int64_t)prow * a.max_new + t];
-      anc_new[(int64_t)row * a.max_new + t] = anc_old[(int64_t)prow * a.max_new + t];
-    }
-    if (lane == 0) {
-      if (cur_len < a.max_new) { seq_new[(int64_t)row * a.max_new + cur_len] = nb_tok[b]; anc_new[(int64_t)row * a.max_new + cur_len] = row; }
-      a.beam_scores[row] = nb_score[b];
-      a.next_tok[row] = nb_tok[b];
-      a.pos[row] = a.prefix_len[u] + cur_len;      // absolute position of the token just chosen
-      a.cpos[row] = cur_len;                       // its tail-cache index
-    }
+    seq_new[(int64_t)row * a.max_new + t] = seq_old[(int64_t)prow * a.max_new + t];
+    anc_new[(int64_t)row * a.max_new + t] = anc_old[(int64_t)prow * a.max_new + t];
+  }
+  if (lane < K) {
+    const int b = lane, row = row0 + b;
+    if (cur_len < a.max_new) { seq_new[(int64_t)row * a.max_new + cur_len] = nb_tok[b]; anc_new[(int64_t)row * a.max_new + cur_len] = row; }
+    a.beam_scores[row] = nb_score[b];
+    a.next_tok[row] = nb_tok[b];
+    a.pos[row] = a.prefix_len[u] + cur_len;      // absolute position of the token just chosen
+    a.cpos[row] = cur_len;                       // its tail-cache index
   }
 }
 
@@ -423,7 +410,7 @@ int launch_beam_topk(const float* logits, int64_t ld, int rows, int V, int K, co
                      int* need_exact, hipStream_t st) {
   OAVSR_REQUIRE(K >= 1 && K <= kMaxK, "beam search: num_beams=%d unsupported (max %d)", K, kMaxK);
   if (rows <= 0) return 0;
-  const bool fast = true;      // certified register top-2K first; rows it cannot certify fall through to the exact radix select
+  const bool fast = true;      // threshold + candidate list first; rows whose candidates overflow the list fall through to the exact radix select
   if (fast && need_exact)
     hipLaunchKernelGGL(beam_topk_fast_kernel, dim3(rows), dim3(kTopkThreads), 0, st, logits, ld, V, 2 * K, beam_scores, cand_val, cand_tok, need_exact);
   hipLaunchKernelGGL(beam_topk_exact_kernel, dim3(rows), dim3(kTopkThreads), 0, st, logits, ld, V, 2 * K, beam_scores, cand_val, cand_tok,
@@ -434,7 +421,7 @@ int launch_beam_topk(const float* logits, int64_t ld, int rows, int V, int K, co
 
 int launch_beam_step(const BeamArgs& a, int first, const int* seq_old, const int* anc_old, int* seq_new, int* anc_new, hipStream_t st) {
   OAVSR_REQUIRE(a.K >= 1 && a.K <= kMaxK, "beam search: num_beams=%d unsupported (max %d)", a.K, kMaxK);
-  hipLaunchKernelGGL(beam_step_kernel, dim3(a.B), dim3(64), 0, st, a, first ? 1 : a.K, seq_old, anc_old, seq_new, anc_new);
+  hipLaunchKernelGGL(beam_step_kernel, dim3(a.B), dim3(kStepThreads), 0, st, a, first ? 1 : a.K, seq_old, anc_old, seq_new, anc_new);
   hipLaunchKernelGGL(beam_bump_step_kernel, dim3(1), dim3(1), 0, st, a.step);
   OAVSR_CHECK_HIP(hipGetLastError());
   return 0;

@@ -1006,10 +1006,11 @@ def test_gemm_dma_fused_swiglu_prefill(dtype, M, I, K):
 
 # ------------------------------------------------------------------------------------------------ beam-search candidates
 @pytest.mark.parametrize("rows,V,K,mode", [(120, 128256, 15, "random"), (7, 128256, 15, "clustered"), (5, 151936, 4, "ties"), (3, 1000, 32, "random"),
-                                           (2, 40, 15, "random")])
+                                           (2, 40, 15, "random"), (4, 128261, 15, "flat"), (3, 128261, 15, "plateau")])
 def test_beam_topk_fast_and_fallback(rows, V, K, mode):
-    """Top-2K of log_softmax(logits) + beam score per row.  "clustered" puts the whole top-2K on indices that one thread of the
-    fast kernel owns (stride 1024), which it cannot certify -> exact fallback; "ties" checks the lower-index-first rule."""
+    """Top-2K of log_softmax(logits) + beam score per row.  "clustered" puts the whole top-2K on indices that ONE thread of the fast kernel owns
+    (stride 1024: its threshold comes from the other threads' maxima, the candidates are still complete); "ties" checks the lower-index-first
+    rule; "flat" (all logits equal) and "plateau" (2 000 elements tied at the 2K-th value) overflow the candidate list -> exact fallback."""
     g = torch.Generator().manual_seed(7)
     x = torch.randn(rows, V, generator=g) * 3
     if mode == "clustered":
@@ -1017,6 +1018,12 @@ def test_beam_topk_fast_and_fallback(rows, V, K, mode):
             x[r, (torch.arange(40) * 1024 + 5 + r) % V] = 20.0 + torch.arange(40).float()
     if mode == "ties":
         x = torch.round(x * 2) / 2               # many exact ties
+    if mode == "flat":
+        x = torch.zeros(rows, V)
+    if mode == "plateau":
+        for r in range(rows):
+            x[r, torch.randperm(V, generator=g)[:2000]] = 15.0
+            x[r, torch.randperm(V, generator=g)[:7]] = 30.0 + r
     bs = torch.randn(rows, generator=g)
     xd, bsd = x.to(DEV), bs.to(DEV)
     twoK = min(2 * K, V)
@@ -1029,10 +1036,10 @@ def test_beam_topk_fast_and_fallback(rows, V, K, mode):
         outs.append((val.cpu(), tok.cpu(), flag.cpu()))
     (vf, tf, ff), (ve, te, _) = outs
     assert torch.equal(tf[:, :twoK], te[:, :twoK]) and torch.equal(vf[:, :twoK], ve[:, :twoK]), "fast path differs from the exact kernel"
-    if mode == "clustered":
-        assert int(ff.sum()) == rows, "the clustered rows must have taken the fallback"
-    if mode == "random" and V > 100000:
-        assert int(ff.sum()) == 0, "random rows should be certified by the fast path"
+    if mode in ("flat", "plateau"):
+        assert int(ff.sum()) == rows, "rows with more ties at the 2K-th value than the candidate list holds must have taken the fallback"
+    if mode in ("random", "clustered", "ties") and V > 100000:
+        assert int(ff.sum()) == 0, "these rows should be served by the fast path"
     lp = torch.log_softmax(x, -1) + bs[:, None]
     order = torch.argsort(torch.stack([-x, torch.arange(V).expand(rows, V).float()], -1)[..., 0], dim=-1, stable=True)[:, :twoK]
     assert torch.equal(te[:, :twoK].long(), order), "candidate tokens differ from a stable descending sort"
