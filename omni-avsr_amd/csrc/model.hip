@@ -44,6 +44,7 @@ static const KnobDef kKnobs[] = {
     {"OAVSR_DECODE_STRIPS", 1, "0: decode-shaped GEMMs of <= 16 rows run on the 128-row LDS-DMA tiles like larger launches instead of the register-streaming strips (same bits)"},
     {"OAVSR_CONV_C128", 1, "0: the 128-channel 3x3 convolutions of the trunk as implicit GEMMs instead of the image-resident kernel (same bits)"},
     {"OAVSR_CONV_TILE256", 1, "0: implicit-GEMM convolutions with >= 256 output channels on the 256 x 128 tile instead of the 16-wave 256 x 256 tile (same bits)"},
+    {"OAVSR_ENC_SIDE_BY_SIDE", 1, "0: an audio-visual call made alone (the latency objective) runs its two encoders one after the other instead of side by side on two streams (same launches, same bits)"},
     {"OAVSR_FUSED_REDUCE_ROWS", 32, "decode-shaped GEMMs with at most this many rows reduce their split-K slabs inside the launch, others in a second launch (same code, same bits)"},
     {"OAVSR_GEMM_TILE_ROWS", 0, "persistent GEMM: 256 / 192 = that tile height wherever its form exists, 0 = the launcher's rule (256 while calls share the chip; alone: whichever finishes sooner); same bits"},
 };
@@ -205,6 +206,12 @@ struct DecodeGraphKey {
   bool operator==(const DecodeGraphKey& o) const { return B == o.B && task == o.task && max_new == o.max_new && banned == o.banned; }
 };
 
+// Activations of one encoder's transformer stack + the small index tables its launches read.
+struct EncScratch {
+  void *x = nullptr, *h = nullptr, *qkv = nullptr, *attn = nullptr, *ffn = nullptr, *lora = nullptr, *hcat = nullptr;
+  int4* rowinfo = nullptr; int* cu = nullptr; int4* seg = nullptr;
+};
+
 struct oavsr_workspace {
   const oavsr_model* m = nullptr;
   std::vector<std::pair<DecodeGraphKey, hipGraphExec_t>> graphs;   // captured greedy decode steps
@@ -212,12 +219,13 @@ struct oavsr_workspace {
   char* arena = nullptr; size_t arena_bytes = 0, used = 0;
   char* host_base = nullptr; char* host = nullptr; size_t host_bytes = 0, host_used = 0;   // pinned staging (2 halves)
   hipEvent_t host_ev[2] = {nullptr, nullptr}; unsigned call_idx = 0;
-  // encoder scratch (shared by both encoders)
-  void *enc_x, *enc_h, *enc_qkv, *enc_attn, *enc_ffn, *enc_lora, *enc_out_v, *enc_out_a;
-  void* enc_hcat = nullptr;      // [rows][D + k2]: LayerNorm output next to the LoRA-down output (run_encoder_layers; video encoder only)
+  // encoder scratch: one set per encoder, so that the two encoders of an audio-visual call may run side by side (encode_prefill)
+  EncScratch esa, esv;           // Whisper's / AV-HuBERT's (esv.hcat [rows][D + k2]: LayerNorm output next to the LoRA-down output, run_encoder_layers)
+  void *enc_out_v, *enc_out_a;
+  hipStream_t enc2 = nullptr; hipEvent_t enc2_fork = nullptr, enc2_join = nullptr;      // the video encoder's stream when the two run side by side
   // video front
   void *pool_out, *trunk[2], *feat512, *featproj, *ln2d;
-  int2* frameinfo; int4* rowinfo; int4* rowinfo2; int* cu_a; int* cu_b; int4* seg;
+  int2* frameinfo; int4* rowinfo2; int* cu_b;
   // audio front
   void *mel, *conv1_out, *pos_rep; float *mel_ws, *max_ws; int* lens_dev;
   // projector / prompt
@@ -546,47 +554,47 @@ static int resolve_model(oavsr_model* m) {
 // of 128 bytes on both sides, so the k-tile sequence -- hence every bit -- is that of the two-segment launch.
 static bool enc_cat_ok(int D, int k2, size_t esz) { return k2 > 0 && (D * esz) % 128 == 0 && (k2 * esz) % 128 == 0; }
 
-static int run_encoder_layers(const oavsr_model* m, oavsr_workspace* ws, const std::vector<EncLayer>& layers, int rows, int D,
+static int run_encoder_layers(const oavsr_model* m, const EncScratch& es, const std::vector<EncLayer>& layers, int rows, int D,
                               int heads, int ffn, int lora_k2, const int* cu_dev, int n_seqs, int max_len, hipStream_t st, int attn_form = 0) {
   const int dt = m->dtype;
   const int hd = D / heads;
   for (const EncLayer& L : layers) {
-    const bool cat = lora_k2 > 0 && L.qkvw_cat && ws->enc_hcat;
+    const bool cat = lora_k2 > 0 && L.qkvw_cat && es.hcat;
     const int ldh = cat ? D + lora_k2 : D;
-    void* h = cat ? ws->enc_hcat : ws->enc_h;
+    void* h = cat ? es.hcat : es.h;
     { ProfScope ps("layernorm", 0, 2.0 * rows * D * m->esz, st);
-      OAVSR_TRY(launch_layernorm(dt, ws->enc_x, D, h, ldh, L.ln1w, L.ln1b, rows, D, 1e-5f, st)); }
+      OAVSR_TRY(launch_layernorm(dt, es.x, D, h, ldh, L.ln1w, L.ln1b, rows, D, 1e-5f, st)); }
     GemmArgs g;
     if (lora_k2 > 0) {   // t = h . [A_q; A_v]^T
       g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = lora_k2; g.K = D; g.A = h; g.lda = ldh; g.W = L.lora_dn; g.ldw = D;
-      g.C = cat ? (void*)((char*)h + (size_t)D * m->esz) : ws->enc_lora; g.ldc = cat ? ldh : lora_k2;
+      g.C = cat ? (void*)((char*)h + (size_t)D * m->esz) : es.lora; g.ldc = cat ? ldh : lora_k2;
       OAVSR_TRY(run_gemm(g, st));
     }
     g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = 3 * D; g.A = h; g.lda = ldh;
     if (cat) { g.K = D + lora_k2; g.W = L.qkvw_cat; g.ldw = D + lora_k2; }
     else {
       g.K = D; g.W = L.qkvw; g.ldw = D;
-      if (lora_k2 > 0) { g.A2 = ws->enc_lora; g.lda2 = lora_k2; g.W2 = L.lora_up; g.ldw2 = lora_k2; g.K2 = lora_k2; }
+      if (lora_k2 > 0) { g.A2 = es.lora; g.lda2 = lora_k2; g.W2 = L.lora_up; g.ldw2 = lora_k2; g.K2 = lora_k2; }
     }
-    g.col_bias = L.qkvb; g.C = ws->enc_qkv; g.ldc = 3 * D;
+    g.col_bias = L.qkvb; g.C = es.qkv; g.ldc = 3 * D;
     OAVSR_TRY(run_gemm(g, st));
     AttnArgs a; a.dtype = dt; a.head_dim = hd; a.n_heads = heads; a.n_kv_heads = heads; a.n_seqs = n_seqs;
-    a.Q = ws->enc_qkv; a.K = (const char*)ws->enc_qkv + (size_t)D * m->esz; a.V = (const char*)ws->enc_qkv + (size_t)2 * D * m->esz;
-    a.ldq = a.ldk = a.ldv = 3 * D; a.O = ws->enc_attn; a.ldo = D; a.cu_q = cu_dev; a.cu_k = cu_dev; a.max_q = max_len;
+    a.Q = es.qkv; a.K = (const char*)es.qkv + (size_t)D * m->esz; a.V = (const char*)es.qkv + (size_t)2 * D * m->esz;
+    a.ldq = a.ldk = a.ldv = 3 * D; a.O = es.attn; a.ldo = D; a.cu_q = cu_dev; a.cu_k = cu_dev; a.max_q = max_len;
     a.scale = 1.0f / sqrtf((float)hd); a.causal = 0; a.form = attn_form;
     { double fl = 0; /* 4*T*T*D per sequence, upper bound with max_len */ fl = 4.0 * (double)rows * max_len * D;
       ProfScope ps(dt == DT_F32 ? "attention_f32" : "attention_bf16", fl, 4.0 * rows * D * m->esz, st);
       OAVSR_TRY(launch_attention(a, st)); }
-    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = D; g.K = D; g.A = ws->enc_attn; g.lda = D; g.W = L.ow; g.ldw = D; g.col_bias = L.ob;
-    g.residual = ws->enc_x; g.ldr = D; g.C = ws->enc_x; g.ldc = D;
+    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = D; g.K = D; g.A = es.attn; g.lda = D; g.W = L.ow; g.ldw = D; g.col_bias = L.ob;
+    g.residual = es.x; g.ldr = D; g.C = es.x; g.ldc = D;
     OAVSR_TRY(run_gemm(g, st));
     { ProfScope ps("layernorm", 0, 2.0 * rows * D * m->esz, st);
-      OAVSR_TRY(launch_layernorm(dt, ws->enc_x, D, ws->enc_h, D, L.ln2w, L.ln2b, rows, D, 1e-5f, st)); }
-    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = ffn; g.K = D; g.A = ws->enc_h; g.lda = D; g.W = L.fc1w; g.ldw = D; g.col_bias = L.fc1b;
-    g.act = ACT_GELU; g.C = ws->enc_ffn; g.ldc = ffn;
+      OAVSR_TRY(launch_layernorm(dt, es.x, D, es.h, D, L.ln2w, L.ln2b, rows, D, 1e-5f, st)); }
+    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = ffn; g.K = D; g.A = es.h; g.lda = D; g.W = L.fc1w; g.ldw = D; g.col_bias = L.fc1b;
+    g.act = ACT_GELU; g.C = es.ffn; g.ldc = ffn;
     OAVSR_TRY(run_gemm(g, st));
-    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = D; g.K = ffn; g.A = ws->enc_ffn; g.lda = ffn; g.W = L.fc2w; g.ldw = ffn; g.col_bias = L.fc2b;
-    g.residual = ws->enc_x; g.ldr = D; g.C = ws->enc_x; g.ldc = D;
+    g = GemmArgs(); g.dtype = dt; g.M = rows; g.N = D; g.K = ffn; g.A = es.ffn; g.lda = ffn; g.W = L.fc2w; g.ldw = ffn; g.col_bias = L.fc2b;
+    g.residual = es.x; g.ldr = D; g.C = es.x; g.ldc = D;
     OAVSR_TRY(run_gemm(g, st));
   }
   return 0;
@@ -611,7 +619,7 @@ static int conv2d_gemm(const oavsr_model* m, const void* x, int imgs, int H, int
   return run_gemm(g, st);
 }
 
-static int time_compress(const oavsr_model* m, oavsr_workspace* ws, const void* x, int D, const std::vector<int>& in_off,
+static int time_compress(const oavsr_model* m, oavsr_workspace* ws, const EncScratch& es, const void* x, int D, const std::vector<int>& in_off,
                          const std::vector<int>& n_in, int rate, void* out, int* total_out, hipStream_t st) {
   const int B = (int)in_off.size();
   int4* seg_h = ws->stage<int4>(B);
@@ -619,13 +627,13 @@ static int time_compress(const oavsr_model* m, oavsr_workspace* ws, const void* 
   int off = 0, mx = 0;
   for (int b = 0; b < B; ++b) { int n = n_in[b] / rate; seg_h[b] = make_int4(in_off[b], off, n, 0); off += n; mx = std::max(mx, n); }
   *total_out = off;
-  OAVSR_TRY(h2d(ws->seg, seg_h, sizeof(int4) * B, st));
+  OAVSR_TRY(h2d(es.seg, seg_h, sizeof(int4) * B, st));
   const int stack = m->cfg.compression_stack;
   ProfScope ps("time_compress", 0, (double)off * D * (rate + 1) * m->esz, st);
   if (rate == 1 && !stack) {
     // identity compress still goes through the kernel (rate 1 mean == copy)
   }
-  return launch_time_compress(m->dtype, x, D, out, stack ? (int64_t)D * rate : D, ws->seg, B, mx, rate, D, stack, st);
+  return launch_time_compress(m->dtype, x, D, out, stack ? (int64_t)D * rate : D, es.seg, B, mx, rate, D, stack, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -637,6 +645,7 @@ static int encode_video_impl(const oavsr_model* m, oavsr_workspace* ws, const vo
   OAVSR_REQUIRE(B >= 1 && B <= ws->max_B, "encode_video: B=%d exceeds workspace (%d)", B, ws->max_B);
   const oavsr_config& c = m->cfg;
   const int dt = m->dtype, D = c.av_dim;
+  const EncScratch& es = ws->esv;
   int F = 0, maxT = 0;
   for (int b = 0; b < B; ++b) { OAVSR_REQUIRE(Tv[b] >= 1 && Tv[b] <= ws->max_Tv, "encode_video: Tv[%d]=%d out of range", b, Tv[b]); F += Tv[b]; maxT = std::max(maxT, Tv[b]); }
   int2* fi = ws->stage<int2>(F); int* cu = ws->stage<int>(B + 1);
@@ -644,7 +653,7 @@ static int encode_video_impl(const oavsr_model* m, oavsr_workspace* ws, const vo
   { int f = 0; cu[0] = 0;
     for (int b = 0; b < B; ++b) { for (int t = 0; t < Tv[b]; ++t) fi[f++] = make_int2(t, Tv[b]); cu[b + 1] = f; } }
   OAVSR_TRY(h2d(ws->frameinfo, fi, sizeof(int2) * F, st));
-  OAVSR_TRY(h2d(ws->cu_a, cu, sizeof(int) * (B + 1), st));
+  OAVSR_TRY(h2d(es.cu, cu, sizeof(int) * (B + 1), st));
   // K1: stem conv3d + BN + PReLU + MaxPool3d (resnet.py:137-141), one fused kernel (stem.hip)
   { const double in_bytes = ws->vsrc.C ? (double)ws->vsrc.C * ws->vsrc.H * ws->vsrc.W : 7744.0 * 4;
     ProfScope ps(dt == DT_F32 ? "stem_conv_pool_f32" : "stem_conv_pool_bf16", 2.0 * F * 1936 * 245 * 64, (double)F * (in_bytes + 484 * 64 * m->esz), st);
@@ -674,24 +683,24 @@ static int encode_video_impl(const oavsr_model* m, oavsr_workspace* ws, const vo
   { ProfScope ps("layernorm", 0, 3.0 * F * D * m->esz, st);
     OAVSR_TRY(launch_layernorm_zero_prefix(dt, ws->featproj, D, ws->ln2d, 2 * D, m->vln_w, m->vln_b, F, D, 1e-5f, st)); }
   g = GemmArgs(); g.dtype = dt; g.M = F; g.N = D; g.K = 2 * D; g.A = ws->ln2d; g.lda = 2 * D; g.W = m->vpost_w; g.ldw = 2 * D; g.col_bias = m->vpost_b;
-  g.C = ws->enc_h; g.ldc = D;   // x0 in enc_h
+  g.C = es.h; g.ldc = D;   // x0 in enc_h
   OAVSR_TRY(run_gemm(g, st));
   // K4: x = x0 + GELU(pos_conv(x0))  (wav2vec2.py:875-877)
-  OAVSR_TRY(launch_build_rowinfo(ws->cu_a, ws->cu_a, B, 1, ws->rowinfo, F, st));
+  OAVSR_TRY(launch_build_rowinfo(es.cu, es.cu, B, 1, es.rowinfo, F, st));
   const int G = c.av_conv_groups, Cg = D / G, taps = c.av_conv_pos;
   g = GemmArgs(); g.dtype = dt; g.amode = A_CONV1D; g.M = F; g.N = Cg; g.K = taps * Cg; g.Kvalid = taps * Cg; g.taps = taps; g.pad = taps / 2;
-  g.Cin = Cg; g.A = ws->enc_h; g.lda = D; g.groups = G; g.a_goff = Cg; g.rowinfo = ws->rowinfo; g.W = m->vpos_w; g.ldw = g.K;
-  g.col_bias = m->vpos_b; g.act = ACT_GELU; g.residual = ws->enc_h; g.ldr = D; g.res_after_act = 1; g.C = ws->enc_x; g.ldc = D;
+  g.Cin = Cg; g.A = es.h; g.lda = D; g.groups = G; g.a_goff = Cg; g.rowinfo = es.rowinfo; g.W = m->vpos_w; g.ldw = g.K;
+  g.col_bias = m->vpos_b; g.act = ACT_GELU; g.residual = es.h; g.ldr = D; g.res_after_act = 1; g.C = es.x; g.ldc = D;
   OAVSR_TRY(run_gemm(g, st));
-  OAVSR_TRY(run_encoder_layers(m, ws, m->vlayers, F, D, c.av_heads, c.av_ffn, c.av_lora_k2, ws->cu_a, B, maxT, st, 32));      // attention: the 32x32x16-MFMA kernel, like the Whisper encoder (VSR B = 16: 0.90 -> 0.72 ms per call)
+  OAVSR_TRY(run_encoder_layers(m, es, m->vlayers, F, D, c.av_heads, c.av_ffn, c.av_lora_k2, es.cu, B, maxT, st, 32));      // attention: the 32x32x16-MFMA kernel, like the Whisper encoder (VSR B = 16: 0.90 -> 0.72 ms per call)
   void* enc = ws->enc_out_v;
   { ProfScope ps("layernorm", 0, 2.0 * F * D * m->esz, st);
-    OAVSR_TRY(launch_layernorm(dt, ws->enc_x, D, enc, D, m->vlnf_w, m->vlnf_b, F, D, 1e-5f, st)); }
+    OAVSR_TRY(launch_layernorm(dt, es.x, D, enc, D, m->vlnf_w, m->vlnf_b, F, D, 1e-5f, st)); }
   if (enc_dev) OAVSR_CHECK_HIP(hipMemcpyAsync(enc_dev, enc, (size_t)F * D * m->esz, hipMemcpyDeviceToDevice, st));
   std::vector<int> in_off(B), n_in(B);
   for (int b = 0; b < B; ++b) { in_off[b] = cu[b]; n_in[b] = Tv[b]; }
   int total = 0;
-  OAVSR_TRY(time_compress(m, ws, enc, D, in_off, n_in, rate, ws->comp_v, &total, st));
+  OAVSR_TRY(time_compress(m, ws, es, enc, D, in_off, n_in, rate, ws->comp_v, &total, st));
   const int Dout = c.compression_stack ? D * rate : D;
   if (out_dev) OAVSR_CHECK_HIP(hipMemcpyAsync(out_dev, ws->comp_v, (size_t)total * Dout * m->esz, hipMemcpyDeviceToDevice, st));
   if (n_out_host) for (int b = 0; b < B; ++b) n_out_host[b] = Tv[b] / rate;
@@ -707,6 +716,7 @@ static int encode_audio_impl(const oavsr_model* m, oavsr_workspace* ws, const fl
   OAVSR_REQUIRE(B >= 1 && B <= ws->max_B, "encode_audio: B=%d exceeds workspace (%d)", B, ws->max_B);
   const oavsr_config& c = m->cfg;
   const int dt = m->dtype, D = c.wh_dim;
+  const EncScratch& es = ws->esa;
   int* lens = ws->stage<int>(B); int* cu3000 = ws->stage<int>(B + 1); int* cu1500 = ws->stage<int>(B + 1);
   OAVSR_REQUIRE(lens && cu3000 && cu1500, "host staging exhausted");
   for (int b = 0; b < B; ++b) {
@@ -716,32 +726,32 @@ static int encode_audio_impl(const oavsr_model* m, oavsr_workspace* ws, const fl
   }
   cu3000[B] = B * 3000; cu1500[B] = B * 1500;
   OAVSR_TRY(h2d(ws->lens_dev, lens, sizeof(int) * B, st));
-  OAVSR_TRY(h2d(ws->cu_a, cu3000, sizeof(int) * (B + 1), st));
+  OAVSR_TRY(h2d(es.cu, cu3000, sizeof(int) * (B + 1), st));
   OAVSR_TRY(h2d(ws->cu_b, cu1500, sizeof(int) * (B + 1), st));
   { ProfScope ps("logmel", 2.0 * B * 3000.0 * 201 * 400 * 2, (double)B * 480000 * 4, st);
     OAVSR_TRY(launch_logmel(dt, wav, ld, ws->lens_dev, B, m->twiddle, m->melfb, ws->mel_ws, ws->max_ws, ws->mel, 80, st)); }
   if (mel_dev) OAVSR_CHECK_HIP(hipMemcpyAsync(mel_dev, ws->mel, (size_t)B * 3000 * 80 * m->esz, hipMemcpyDeviceToDevice, st));
   // K9: conv1 (k3,p1)+GELU ; conv2 (k3,s2,p1)+GELU ; + embed_positions   (transformers WhisperEncoder.forward)
-  OAVSR_TRY(launch_build_rowinfo(ws->cu_a, ws->cu_a, B, 1, ws->rowinfo, B * 3000, st));
+  OAVSR_TRY(launch_build_rowinfo(es.cu, es.cu, B, 1, es.rowinfo, B * 3000, st));
   GemmArgs g; g.dtype = dt; g.amode = A_CONV1D; g.M = B * 3000; g.N = D; g.K = 256; g.Kvalid = 240; g.taps = 3; g.pad = 1; g.Cin = 80;
-  g.A = ws->mel; g.lda = 80; g.rowinfo = ws->rowinfo; g.W = m->aconv1_w; g.ldw = 256; g.col_bias = m->aconv1_b; g.act = ACT_GELU;
+  g.A = ws->mel; g.lda = 80; g.rowinfo = es.rowinfo; g.W = m->aconv1_w; g.ldw = 256; g.col_bias = m->aconv1_b; g.act = ACT_GELU;
   g.C = ws->conv1_out; g.ldc = D;
   OAVSR_TRY(run_gemm(g, st));
-  OAVSR_TRY(launch_build_rowinfo(ws->cu_b, ws->cu_a, B, 2, ws->rowinfo2, B * 1500, st));
+  OAVSR_TRY(launch_build_rowinfo(ws->cu_b, es.cu, B, 2, ws->rowinfo2, B * 1500, st));
   g = GemmArgs(); g.dtype = dt; g.amode = A_CONV1D; g.M = B * 1500; g.N = D; g.K = 3 * D; g.Kvalid = 3 * D; g.taps = 3; g.pad = 1; g.Cin = D;
   g.A = ws->conv1_out; g.lda = D; g.rowinfo = ws->rowinfo2; g.W = m->aconv2_w; g.ldw = 3 * D; g.col_bias = m->aconv2_b; g.act = ACT_GELU;
-  g.residual = ws->pos_rep; g.ldr = D; g.res_after_act = 1; g.C = ws->enc_x; g.ldc = D;
+  g.residual = ws->pos_rep; g.ldr = D; g.res_after_act = 1; g.C = es.x; g.ldc = D;
   OAVSR_TRY(run_gemm(g, st));
   // attention on the 32x32x16-MFMA kernel: chosen by the call site (the encoders), so the choice never depends on a batch
-  OAVSR_TRY(run_encoder_layers(m, ws, m->alayers, B * 1500, D, c.wh_heads, c.wh_ffn, 0, ws->cu_b, B, 1500, st, 32));
+  OAVSR_TRY(run_encoder_layers(m, es, m->alayers, B * 1500, D, c.wh_heads, c.wh_ffn, 0, ws->cu_b, B, 1500, st, 32));
   void* enc = ws->enc_out_a;
   { ProfScope ps("layernorm", 0, 2.0 * B * 1500 * D * m->esz, st);
-    OAVSR_TRY(launch_layernorm(dt, ws->enc_x, D, enc, D, m->alnf_w, m->alnf_b, B * 1500, D, 1e-5f, st)); }
+    OAVSR_TRY(launch_layernorm(dt, es.x, D, enc, D, m->alnf_w, m->alnf_b, B * 1500, D, 1e-5f, st)); }
   if (enc_dev) OAVSR_CHECK_HIP(hipMemcpyAsync(enc_dev, enc, (size_t)B * 1500 * D * m->esz, hipMemcpyDeviceToDevice, st));
   std::vector<int> in_off(B), n_in(B);
   for (int b = 0; b < B; ++b) { in_off[b] = b * 1500; n_in[b] = keep[b]; }   // truncation modeling_OmniAVSR.py:537
   int total = 0;
-  OAVSR_TRY(time_compress(m, ws, enc, D, in_off, n_in, rate, ws->comp_a, &total, st));
+  OAVSR_TRY(time_compress(m, ws, es, enc, D, in_off, n_in, rate, ws->comp_a, &total, st));
   const int Dout = c.compression_stack ? D * rate : D;
   if (out_dev) OAVSR_CHECK_HIP(hipMemcpyAsync(out_dev, ws->comp_a, (size_t)total * Dout * m->esz, hipMemcpyDeviceToDevice, st));
   if (n_out_host) for (int b = 0; b < B; ++b) n_out_host[b] = keep[b] / rate;
@@ -1358,10 +1368,19 @@ int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, 
 #define WANT(field, bytes) want((void**)&ws->field, (bytes))
   const int stackmul_a = c.compression_stack ? 1 : 1;
   (void)stackmul_a;
-  WANT(enc_x, NT * De * e); WANT(enc_h, NT * De * e); WANT(enc_qkv, NT * 3 * De * e); WANT(enc_attn, NT * De * e);
-  WANT(enc_ffn, NT * Fe * e); WANT(enc_lora, NT * (size_t)std::max(64, c.av_lora_k2) * e);
+  // One scratch set sized for either encoder; a model with both gets a second one of the video encoder's size, so that the two encoders of
+  // one call can be in flight together (encode_prefill).  F x (6 Dv + ffn) elements: 65 MB at 8 x 400 frames.
+  const bool two_sets = m->has_video && m->has_audio;
+  WANT(esa.x, NT * De * e); WANT(esa.h, NT * De * e); WANT(esa.qkv, NT * 3 * De * e); WANT(esa.attn, NT * De * e);
+  WANT(esa.ffn, NT * Fe * e); WANT(esa.lora, NT * (size_t)std::max(64, c.av_lora_k2) * e);
+  WANT(esa.rowinfo, std::max(F, (size_t)max_B * 3000) * sizeof(int4)); WANT(esa.cu, (max_B + 1) * sizeof(int)); WANT(esa.seg, max_B * sizeof(int4));
+  if (two_sets) {
+    WANT(esv.x, F * Dv * e); WANT(esv.h, F * Dv * e); WANT(esv.qkv, F * 3 * Dv * e); WANT(esv.attn, F * Dv * e);
+    WANT(esv.ffn, F * (size_t)c.av_ffn * e); WANT(esv.lora, F * (size_t)std::max(64, c.av_lora_k2) * e);
+    WANT(esv.rowinfo, F * sizeof(int4)); WANT(esv.cu, (max_B + 1) * sizeof(int)); WANT(esv.seg, max_B * sizeof(int4));
+  }
+  if (m->has_video && m->enc_cat) WANT(esv.hcat, F * (size_t)(Dv + c.av_lora_k2) * e);
   WANT(enc_out_v, F * Dv * e); WANT(enc_out_a, TA * Da * e);
-  if (m->has_video && m->enc_cat) WANT(enc_hcat, F * (size_t)(Dv + c.av_lora_k2) * e);
   if (m->has_video) {
     WANT(pool_out, F * 484 * 64 * e);
     for (int i = 0; i < 2; ++i) WANT(trunk[i], F * 484 * 64 * e);
@@ -1369,8 +1388,7 @@ int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, 
     WANT(frameinfo, F * sizeof(int2));
     WANT(comp_v, F * Dv * e); WANT(tok_v, F * (size_t)d * e);
   }
-  WANT(rowinfo, std::max(F, (size_t)max_B * 3000) * sizeof(int4)); WANT(rowinfo2, ((size_t)max_B * 1500 + 16) * sizeof(int4));
-  WANT(cu_a, (max_B + 1) * sizeof(int)); WANT(cu_b, (max_B + 1) * sizeof(int)); WANT(seg, max_B * sizeof(int4));
+  WANT(rowinfo2, ((size_t)max_B * 1500 + 16) * sizeof(int4)); WANT(cu_b, (max_B + 1) * sizeof(int));
   if (m->has_audio) {
     WANT(mel, (size_t)max_B * 3000 * 80 * e); WANT(mel_ws, (size_t)max_B * 3000 * 80 * 4); WANT(max_ws, max_B * 4); WANT(lens_dev, max_B * 4);
     WANT(conv1_out, (size_t)max_B * 3000 * Da * e); WANT(pos_rep, TA * Da * e);
@@ -1414,6 +1432,13 @@ int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, 
   // keeps a missed guard from turning into run-to-run differences).
   if (hipMemset(ws->arena, 0, total) != hipSuccess) { set_last_error("workspace_create: hipMemset failed"); hipFree(ws->arena); delete ws; return -2; }
   for (auto& r : reqs) { *r.p = ws->take(std::max<size_t>(r.bytes, 256)); if (!*r.p) { set_last_error("workspace arena overflow"); hipFree(ws->arena); delete ws; return -1; } }
+  if (!two_sets) { void* hcat = ws->esv.hcat; ws->esv = ws->esa; ws->esv.hcat = hcat; }      // one encoder: one set
+  else {
+    if (hipStreamCreateWithFlags(&ws->enc2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ws->enc2_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ws->enc2_join, hipEventDisableTiming) != hipSuccess) {
+      set_last_error("workspace_create: stream / event creation failed"); hipFree(ws->arena); delete ws; return -2;
+    }
+  }
   // decode uses gs.pos / gs.cpos as the row position arrays of the layer stack
   ws->host_bytes = (size_t)(F * sizeof(int2) + ST * 8 * sizeof(int) + rows_dec * (size_t)(max_new + 16) * sizeof(int) + 1 * 1024 * 1024);
   if (hipHostMalloc((void**)&ws->host_base, 2 * ws->host_bytes) != hipSuccess) { set_last_error("workspace_create: hipHostMalloc failed"); hipFree(ws->arena); delete ws; return -2; }
@@ -1436,6 +1461,9 @@ void oavsr_workspace_destroy(oavsr_workspace* ws) {
   if (!ws) return;
   for (auto& e : ws->graphs) hipGraphExecDestroy(e.second);
   if (ws->own_stream) { hipStreamSynchronize(ws->own_stream); hipStreamDestroy(ws->own_stream); }
+  if (ws->enc2) { hipStreamSynchronize(ws->enc2); hipStreamDestroy(ws->enc2); }
+  if (ws->enc2_fork) hipEventDestroy(ws->enc2_fork);
+  if (ws->enc2_join) hipEventDestroy(ws->enc2_join);
   if (ws->own_in) hipEventDestroy(ws->own_in);
   if (ws->own_out) hipEventDestroy(ws->own_out);
   if (ws->arena) hipFree(ws->arena);
@@ -1525,18 +1553,36 @@ static int encode_prefill(const oavsr_model* m, oavsr_workspace* ws, int32_t tas
     const int Bc = std::min<int>(chunk_B, B - b0);
     std::vector<int> na(Bc), nv(Bc);
     int tot_a = 0, tot_v = 0;
-    if (use_a) {
-      OAVSR_TRY(encode_audio_impl(m, ws, wav_dev + (int64_t)b0 * wav_ld, wav_ld, Ts_host + b0, keep_host + b0, Bc, rate_audio, nullptr, nullptr, nullptr,
-                                  na.data(), st));
-      for (int b = 0; b < Bc; ++b) tot_a += na[b];
-      OAVSR_TRY(project_impl(m, ws, 0, rate_audio, ws->comp_a, tot_a, ws->tok_a, st));
+    // One call at a time (the latency objective): neither encoder fills the chip at a request-sized batch (Whisper at 1500 rows: 60
+    // workgroups per GEMM), so the video encoder of an audio-visual call runs on a second stream beside the audio encoder, each on its
+    // own scratch set; the projectors follow on the call's stream.  Same launches, same bits.  Calls that overlap each other (the
+    // pipelined job) already fill the chip with the next call's encoders and keep the one-stream order.
+    const bool side = use_a && use_v && ws->enc2 && launch_alone() && !g_prof.on && knob("OAVSR_ENC_SIDE_BY_SIDE");
+    hipStream_t sv = st;
+    if (side) {
+      OAVSR_CHECK_HIP(hipEventRecord(ws->enc2_fork, st));
+      OAVSR_CHECK_HIP(hipStreamWaitEvent(ws->enc2, ws->enc2_fork, 0));
+      sv = ws->enc2;
     }
     if (use_v) {
       const int64_t frame_bytes = ws->vsrc.C ? (int64_t)ws->vsrc.C * ws->vsrc.H * ws->vsrc.W : (int64_t)7744 * 4;
-      OAVSR_TRY(encode_video_impl(m, ws, (const char*)video_dev + frames_before * frame_bytes, Tv_host + b0, Bc, rate_video, nullptr, nullptr, nv.data(), st));
+      const int rc = encode_video_impl(m, ws, (const char*)video_dev + frames_before * frame_bytes, Tv_host + b0, Bc, rate_video, nullptr, nullptr, nv.data(), sv);
+      if (side) {      // joined on every path: the caller's stream never runs ahead of work on the second stream
+        hipEventRecord(ws->enc2_join, ws->enc2);
+        if (rc) hipStreamWaitEvent(st, ws->enc2_join, 0);
+      }
+      if (rc) return rc;
       for (int b = 0; b < Bc; ++b) { tot_v += nv[b]; frames_before += Tv_host[b0 + b]; }
-      OAVSR_TRY(project_impl(m, ws, 1, rate_video, ws->comp_v, tot_v, ws->tok_v, st));
     }
+    if (use_a) {
+      const int rc = encode_audio_impl(m, ws, wav_dev + (int64_t)b0 * wav_ld, wav_ld, Ts_host + b0, keep_host + b0, Bc, rate_audio, nullptr, nullptr, nullptr,
+                                       na.data(), st);
+      if (rc) { if (side) hipStreamWaitEvent(st, ws->enc2_join, 0); return rc; }
+      for (int b = 0; b < Bc; ++b) tot_a += na[b];
+      OAVSR_TRY(project_impl(m, ws, 0, rate_audio, ws->comp_a, tot_a, ws->tok_a, st));
+    }
+    if (side) OAVSR_CHECK_HIP(hipStreamWaitEvent(st, ws->enc2_join, 0));
+    if (use_v) OAVSR_TRY(project_impl(m, ws, 1, rate_video, ws->comp_v, tot_v, ws->tok_v, st));
     std::vector<int> S(Bc);
     OAVSR_TRY(build_prompt_impl(m, ws, task, Bc, use_a ? na.data() : nullptr, ws->tok_a, use_v ? nv.data() : nullptr, ws->tok_v, ws->lx, S.data(), st));
     PrefillDest d;

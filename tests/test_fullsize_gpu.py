@@ -116,6 +116,38 @@ def test_fullsize_launch_objective_changes_no_result(bf16_engine):
         assert torch.equal(got[False][1], got[True][1]), f"T_v={Tv}: video encoder output depends on the launch objective"
 
 
+def test_fullsize_encoders_side_by_side_change_no_bit(bf16_engine):
+    """One call at a time (the latency objective), an audio-visual call runs its video encoder on a second stream beside the audio
+    encoder, each on its own scratch set (model.hip: encode_prefill).  Same launches: the ids and the digests of inputs_embeds / first-step
+    logits are those of the one-stream order (OAVSR_ENC_SIDE_BY_SIDE=0) and of the pipelined objective, call after call."""
+    import os
+    eng = bf16_engine
+    for Tv in ([250], [400, 61], [100, 400, 33, 250, 61, 61, 400, 27]):
+        video, audio, Ts = clips(Tv, seed=33)
+        B = len(Tv)
+
+        def run():
+            dg = torch.zeros(B, 2, dtype=torch.int64, device="cuda:0")
+            ids, _ = eng.generate("audiovisual", video, Tv, audio, Ts, 4, 4, beams=1, max_new=8, force_len=True, digests=dg)
+            torch.cuda.synchronize()
+            return ids.clone(), dg.clone()
+
+        ref = run()      # calls share the chip: one stream
+        prev = eng.launch_objective(True)
+        try:
+            os.environ["OAVSR_ENC_SIDE_BY_SIDE"] = "0"
+            one = run()
+            os.environ["OAVSR_ENC_SIDE_BY_SIDE"] = "1"
+            for rep in range(4):
+                two = run()
+                assert torch.equal(two[0], one[0]) and torch.equal(two[1], one[1]), f"T_v={Tv} run {rep}: side-by-side encoders changed a result"
+        finally:
+            os.environ.pop("OAVSR_ENC_SIDE_BY_SIDE", None)
+            eng.launch_objective(prev)
+        assert torch.equal(ref[0], one[0]) and torch.equal(ref[1], one[1]), f"T_v={Tv}: results depend on the launch objective"
+        assert (ref[1] != 0).all()
+
+
 def test_fullsize_grouped_decode_equals_separate_calls(bf16_engine):
     """harness decode_group / bench --decode-group: 24 utterances in one call (encoders / prefill in chunks of 8, ONE decode loop over 24 rows)
     decode the ids of three separate calls of 8."""
