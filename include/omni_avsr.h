@@ -282,13 +282,20 @@ typedef struct oavsr_gemm_desc {
   const float* ng_gain;
   float* ng_rowsq;
   int32_t grid;        /* persistent kernel only: workgroups (multiple of 8); 0 = the launcher's rule */
-  /* <= 32 rows (csrc/decode_strip.hip): rowsq_strips = 1: ng_rowsq is written per 16-column STRIP, [N / 16][M] (needs M <= 32); row_sumsq_form = 1:
+  /* <= 16 rows (csrc/decode_strip.hip): rowsq_strips = 1: ng_rowsq is written per 16-column STRIP, [N / 16][M] (needs M <= 16); row_sumsq_form = 1:
      row_sumsq is read in that layout -- row_sumsq_tiles tiles = 4 x as many entries, a tile's sum formed as (s0 + s1) + (s2 + s3), the tiles added
      in order: the bits of the tiled layout */
   int32_t rowsq_strips, row_sumsq_form;
 } oavsr_gemm_desc;
 #define OAVSR_GEMM_SYNC_INTS 4096
 int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream);
+/* n (2 .. 6) decode-shaped launches of <= 16 rows (same M, same dtype; each one oavsr_op_gemm would give to the strips of
+   csrc/decode_strip.hip), launch i + 1 consuming what launch i produced, as the PHASES OF ONE LAUNCH: the workgroups of a phase request their
+   first weights, wait until every workgroup of the phase before has released its outputs, then read them.  The bits of n oavsr_op_gemm calls
+   (what a decode step issues between two attention launches: o_proj, gate / up, down_proj, the next layer's LoRA-down and QKV; the reference
+   runs them as separate modules, Llama_LoRA.py:246-259,314,587-655).  counters: n + 1 ints, zero before the first launch; the launch leaves
+   them zero (counters[n] != 0 afterwards: a wait was given up -- never on a correct schedule). */
+int oavsr_op_gemm_chain(const oavsr_gemm_desc* d, int32_t n, int32_t* counters, oavsr_stream stream);
 
 typedef struct oavsr_attn_desc {
   int32_t dtype, head_dim, n_heads, n_kv_heads, n_seqs, max_q, causal;

@@ -42,22 +42,48 @@ template <int N> __device__ __forceinline__ void strip_wait() { asm volatile("s_
 
 // D: k-tiles in flight per wave (ring slots); NW: waves per workgroup; MA: activation rows staged per k-tile (8: M <= 8, one DMA instruction; 16).
 // <= 16 rows: one MFMA row block.
-template <typename T, int D, int NW, int MA>
-__global__ __launch_bounds__(NW * 64) void decode_strip_kernel(const GemmArgs p, const int spw) {
+//
+// CHAIN (decode_chain_kernel below): the launch is one PHASE of several GEMMs that feed each other, its workgroups behind the producer's in
+// block order.  A wave requests the weights of its first D k-tiles, THEN waits for the producer phase (wait_ctr == wait_n workgroups done,
+// agent-scope acquire), and only then touches what the producer wrote: activations, residual, sums of squares.  At the end every wave
+// releases its stores and the workgroup counts itself done (done_ctr).  Same items, same MFMA order, same finish: same bits.
+// (a macro, not a lambda: captured by reference, tq[][] stayed in scratch memory)
+#define OAVSR_STRIP_FIN_LOADS() \
+  do { \
+    if (flive && p.residual) { \
+      const T* Rr = reinterpret_cast<const T*>(p.residual) + (int64_t)frw * p.ldr + fnc; \
+      _Pragma("unroll") for (int e = 0; e < 16; e += VEC) rraw[e / VEC] = ld16(Rr + e); \
+    } \
+    if (nT > 0) { \
+      _Pragma("unroll") for (int j = 0; j < JQ; ++j) { \
+        const int idx = tid + j * kThreads; \
+        if (idx < ntq) { \
+          const int t = idx / p.M, r = idx - t * p.M; \
+          if (p.row_sumsq_form) { \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) tq[j][q] = p.row_sumsq[(int64_t)(4 * t + q) * p.M + r]; \
+          } else { \
+            tq[j][0] = p.row_sumsq[(int64_t)t * p.M + r]; \
+          } \
+        } \
+      } \
+    } \
+  } while (0)
+template <typename T, int D, int NW, int MA, bool CHAIN>
+__device__ __forceinline__ void strip_body(const GemmArgs& p, const int spw, const int wg, char* smem, const int* wait_ctr, const int wait_n,
+                                           int* done_ctr, int* err, int* clean_ctr = nullptr, const int clean_n = 0, const int nwg = 0) {
   constexpr int kSlotBytes = slot_bytes(MA);
   constexpr int VEC = TypeInfo<T>::kVec;
   constexpr int BKE = kStripRowBytes / (int)sizeof(T);
   constexpr int kThreads = NW * 64;
   constexpr int kRows = 16;
   constexpr int JQ = 4;                                  // tile sums of the row factor a thread prepares from registers
-  extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 15, fg = lane >> 4;
   const int ks = p.ksplit < 1 ? 1 : p.ksplit;
   const int nt1 = p.K / BKE, nall = nt1 + p.K2 / BKE;
   const int per = (nall + ks - 1) / ks;
   const int nstrips = (p.N + 15) >> 4;
-  const int strip0 = blockIdx.x * spw;
+  const int strip0 = wg * spw;
   const int items = spw * ks;
   const int nT = p.row_sumsq ? p.row_sumsq_tiles : 0;
   char* ring = smem + wave * (D * kSlotBytes);            // this wave's FIFO
@@ -76,28 +102,29 @@ __global__ __launch_bounds__(NW * 64) void decode_strip_kernel(const GemmArgs p,
   const bool flive = fsl < (swi ? spw / 2 : spw) && frw < p.M && fstrip < nstrips;
   const int fnc = fstrip * 16;
   Chunk16 rraw[16 / VEC];
-  if (flive && p.residual) {
-    const T* Rr = reinterpret_cast<const T*>(p.residual) + (int64_t)frw * p.ldr + fnc;
-#pragma unroll
-    for (int e = 0; e < 16; e += VEC) rraw[e / VEC] = ld16(Rr + e);
-  }
   float tq[JQ][4];
   const int ntq = p.M * nT;                              // tile sums this workgroup needs: [t][row], row fastest (coalesced)
-  if (nT > 0) {
-#pragma unroll
-    for (int j = 0; j < JQ; ++j) {
-      const int idx = tid + j * kThreads;
-      if (idx < ntq) {
-        const int t = idx / p.M, r = idx - t * p.M;
-        if (p.row_sumsq_form) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) tq[j][q] = p.row_sumsq[(int64_t)(4 * t + q) * p.M + r];
-        } else {
-          tq[j][0] = p.row_sumsq[(int64_t)t * p.M + r];
-        }
-      }
-    }
-  }
+  if constexpr (!CHAIN) OAVSR_STRIP_FIN_LOADS();
+  // CHAIN: the producer phase is complete when its workgroups have all counted themselves done.  Bounded: a phase that never completes (a
+  // bug, never a legal schedule: producers sit in lower blocks, which the hardware dispatches first and which wait for nothing younger)
+  // flags `err` instead of hanging the device.
+  bool waited = !CHAIN;
+#define OAVSR_STRIP_CHAIN_WAIT() \
+  do { \
+    if (wait_ctr) {      /* ONE wave polls and acquires for the workgroup (the acquire invalidates the CU's L1); the others join at the barrier */ \
+      if (wave == 0) { \
+        int spins = 0; \
+        while (__hip_atomic_load(wait_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < wait_n) { \
+          __builtin_amdgcn_s_sleep(4); \
+          if (++spins > (1 << 20)) { if (lane == 0) atomicAdd(err, 1); break; } \
+        } \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); \
+      } \
+      __syncthreads(); \
+    } \
+    waited = true; \
+    OAVSR_STRIP_FIN_LOADS(); \
+  } while (0)
 
   // ---- the items of this wave.  Rows past M read row M - 1: an output row depends on its own activation row only and rows >= M are never
   //      stored, so there is no zero fill and no branch between the loads of the ring
@@ -125,16 +152,22 @@ __global__ __launch_bounds__(NW * 64) void decode_strip_kernel(const GemmArgs p,
     const int n = tb + per <= nall ? per : (nall - tb > 0 ? nall - tb : 0);
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto loadk = [&](int t, int slot) {                   // L LDS-DMA instructions: the k-tile's two 16-byte chunks of W per lane, MA rows of A
+    auto loadw = [&](int t, int slot) {                   // the k-tile's two 16-byte chunks of W per lane
       const bool s1 = t < nt1;                            // wave-uniform
       const int k = (s1 ? t : t - nt1) * BKE;
       const T* wp = (s1 ? w1row : w2row) + k;
       char* dst = ring + slot * kSlotBytes;
       strip_dma16<2>(wp, dst);
       strip_dma16<2>(wp + 4 * VEC, dst + 1024);
+    };
+    auto loada = [&](int t, int slot) {                   // MA rows of A
+      const bool s1 = t < nt1;
+      const int k = (s1 ? t : t - nt1) * BKE;
+      char* dst = ring + slot * kSlotBytes;
 #pragma unroll
       for (int j = 0; j < MA / 8; ++j) strip_dma16<0>((s1 ? a1row[j] : a2row[j]) + k, dst + 2048 + j * 1024);
     };
+    auto loadk = [&](int t, int slot) { loadw(t, slot); loada(t, slot); };      // L LDS-DMA instructions
     auto mma = [&](int slot) {                            // W: each lane reads back exactly what it fetched; A: the swizzled row-major tile
       const char* src = ring + slot * kSlotBytes;
       const Chunk16 w0 = *reinterpret_cast<const Chunk16*>(src + lane * 16), w1 = *reinterpret_cast<const Chunk16*>(src + 1024 + lane * 16);
@@ -148,9 +181,20 @@ __global__ __launch_bounds__(NW * 64) void decode_strip_kernel(const GemmArgs p,
     // consumed -> vmcnt((D - 1) L); the drain uses counts that are exact or smaller (a smaller count only waits longer).
     // (the previous item's last LDS reads are done: its MFMAs took their operands before its slab entry was written)
     constexpr int L = 2 + MA / 8;
+    if (CHAIN && !waited) {      // the wave's first item: weights, the producer, then what it wrote; everything has landed when the loop starts (its counts hold trivially)
 #pragma unroll
-    for (int i = 0; i < D; ++i)
-      if (i < n) loadk(tb + i, i);
+      for (int i = 0; i < D; ++i)
+        if (i < n) loadw(tb + i, i);
+      OAVSR_STRIP_CHAIN_WAIT();
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+        if (i < n) loada(tb + i, i);
+      strip_wait<0>();
+    } else {
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+        if (i < n) loadk(tb + i, i);
+    }
     int done = 0;
     for (; done + 2 * D <= n; done += D) {                // steady state: every slot is consumed and refilled, no branch in the body
       static_for<0, D>([&](auto ic) {
@@ -186,6 +230,7 @@ __global__ __launch_bounds__(NW * 64) void decode_strip_kernel(const GemmArgs p,
     for (int r = 0; r < 4; ++r) sp[(fg * 4 + r) * 16 + frow] = acc[r];
   }
 
+  if (CHAIN && !waited) OAVSR_STRIP_CHAIN_WAIT();      // (a wave without an item)
   // ---- row factor: the tile sums (the tiled producer's butterfly over a tile's four strips, or the producer's own tile sums) into LDS
   if (nT > 0) {
 #pragma unroll
@@ -210,9 +255,23 @@ __global__ __launch_bounds__(NW * 64) void decode_strip_kernel(const GemmArgs p,
     }
   }
   __syncthreads();
-  if (!flive) return;
-
+  auto signal_done = [&]() {      // CHAIN: every wave's stores are released before the workgroup counts itself done
+    if constexpr (CHAIN) {
+      // this wave's stores have reached the L2; ONE agent-scope release per workgroup then writes the L2's dirty lines back (the add carries it).
+      // (Measured and rejected: write-through (sc1) stores + a relaxed add, no write-back -- 0.2 ms per step faster, but a consumer behind an
+      // acquire read stale bytes: tests/test_kernels_gpu.py::test_decode_chain_equals_separate_launches failed.)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        const int before = __hip_atomic_fetch_add(done_ctr, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // the LAST workgroup of the LAST phase: every wait of the launch has been passed -- the counters go back to zero for the next launch
+        if (clean_ctr && before == nwg - 1)
+          for (int i = 0; i < clean_n; ++i) __hip_atomic_store(clean_ctr + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
   // ---- finish: the strip's slices in slab order, then the shared epilogue
+  if (flive) do {
   float rs = 1.f;
   if (nT > 0) {
     float tot = 0.f;
@@ -240,7 +299,7 @@ __global__ __launch_bounds__(NW * 64) void decode_strip_kernel(const GemmArgs p,
   if (!swi) {
     strip_sum(fsl, y);
     segment_finish<T>(p, frw, fnc, fnc >> 6, true, y, rraw, rs, tid);
-    return;
+    break;
   }
   // fused SwiGLU (gate / up weight rows interleaved in blocks of 16: strip 2j = gate block j, strip 2j + 1 = its up block): the un-split
   // epilogue of the tiled kernel -- row factor, fma(y, 1, 0) + 0, both halves rounded to T, silu(gate) * up
@@ -264,6 +323,37 @@ __global__ __launch_bounds__(NW * 64) void decode_strip_kernel(const GemmArgs p,
 #pragma unroll
     for (int e = 0; e < 16; e += VEC) *reinterpret_cast<Chunk16*>(Ct + e) = chunk_from_f32<T>(o + e);
   }
+  } while (0);
+  signal_done();      // (every thread of the workgroup: one barrier)
+}
+
+template <typename T, int D, int NW, int MA>
+__global__ __launch_bounds__(NW * 64) void decode_strip_kernel(const GemmArgs p, const int spw) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  strip_body<T, D, NW, MA, false>(p, spw, blockIdx.x, smem, nullptr, 0, nullptr, nullptr);
+}
+
+// Several decode-shaped GEMMs that feed each other (o_proj -> gate / up -> down_proj -> the next layer's LoRA-down -> QKV) as the phases of
+// ONE launch: phase i's workgroups are blocks wg0[i] .. wg0[i + 1]; each waits for phase i - 1 as described above.  What a launch boundary
+// costs these GEMMs is not the launch but the empty pipe behind it -- the first weights of a kernel are requested when its predecessor has
+// drained; here the waiting workgroups of the next phases sit on the CUs with their rings full.
+constexpr int kChainMax = 6;
+struct StripChain {
+  int n; int wg0[kChainMax + 1]; int spw[kChainMax];
+  int* ctr;      // [n] workgroups done per phase: zero at launch, zeroed again by the launch's last workgroup
+  int* err;      // counts waits given up (never, see strip_body)
+  GemmArgs g[kChainMax];
+};
+template <typename T, int D, int NW, int MA>
+__global__ __launch_bounds__(NW * 64) void decode_chain_kernel(const StripChain c) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  int ph = 0;
+#pragma unroll
+  for (int i = 1; i < kChainMax; ++i)
+    if (i < c.n && (int)blockIdx.x >= c.wg0[i]) ph = i;
+  ph = __builtin_amdgcn_readfirstlane(ph);
+  strip_body<T, D, NW, MA, true>(c.g[ph], c.spw[ph], (int)blockIdx.x - c.wg0[ph], smem, ph > 0 ? c.ctr + ph - 1 : nullptr,
+                                 ph > 0 ? c.wg0[ph] - c.wg0[ph - 1] : 0, c.ctr + ph, c.err, ph == c.n - 1 ? c.ctr : nullptr, c.n, c.wg0[ph + 1] - c.wg0[ph]);
 }
 
 template <typename T, int D, int NW, int MA>
@@ -300,6 +390,47 @@ int launch_strip_t(const GemmArgs& a, hipStream_t st) {
   return ma == 8 ? launch_strip<T, 5, 4, 8>(a, spw, smem, st) : launch_strip<T, 4, 4, 16>(a, spw, smem, st);
 }
 
+// The chain's form: 4 waves per workgroup for every phase (an item's bits do not depend on the wave that computes it), ring depth by the
+// knob: 2 = two workgroups per CU (half the ring each: more of the next phases resident and requesting), 1 = one.
+template <typename T, int D, int MA>
+int launch_chain(const StripChain& c, size_t smem, hipStream_t st) {
+  auto kern = decode_chain_kernel<T, D, 4, MA>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)c.wg0[c.n]), dim3(256), smem, st, c);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int prepare_strip(const GemmArgs& a, GemmArgs& b);
+
+template <typename T>
+int launch_chain_t(const GemmArgs* g, int n, int* ctr, int* err, hipStream_t st) {
+  const int per_cu = knob("OAVSR_DECODE_CHAIN_PER_CU");
+  StripChain c;
+  c.n = n; c.ctr = ctr; c.err = err; c.wg0[0] = 0;
+  const int ma = g[0].M <= 8 ? 8 : 16;
+  const int d = per_cu >= 2 ? (ma == 8 ? 5 : 4) : (ma == 8 ? 10 : 8);
+  size_t smem = 0;
+  for (int i = 0; i < n; ++i) {
+    OAVSR_TRY(prepare_strip(g[i], c.g[i]));
+    const GemmArgs& a = c.g[i];
+    const int ks = a.ksplit < 1 ? 1 : a.ksplit;
+    int spw = 4 / ks < 1 ? 1 : 4 / ks;
+    if (a.swiglu_pairs && (spw & 1)) spw += 1;
+    c.spw[i] = spw;
+    c.wg0[i + 1] = c.wg0[i] + ceil_div(ceil_div(a.N, 16), spw);
+    smem = std::max(smem, (size_t)4 * d * slot_bytes(ma) + (size_t)spw * ks * 16 * 16 * 4 + (size_t)a.M * (a.row_sumsq ? a.row_sumsq_tiles : 0) * 4 + 16);
+  }
+  for (int i = n; i < kChainMax; ++i) { c.spw[i] = 1; c.wg0[i + 1] = c.wg0[n]; }
+  OAVSR_REQUIRE(smem <= 160 * 1024, "decode chain: %zu bytes of LDS", smem);
+  if (per_cu >= 2) return ma == 8 ? launch_chain<T, 5, 8>(c, smem, st) : launch_chain<T, 4, 16>(c, smem, st);
+  return ma == 8 ? launch_chain<T, 10, 8>(c, smem, st) : launch_chain<T, 8, 16>(c, smem, st);
+}
+
 }  // namespace
 
 // What the strips can serve: dense decode-shaped launches of <= kStripRows rows.  Next-norm outputs only in the strip layout
@@ -320,7 +451,8 @@ bool gemm_strip_eligible(const GemmArgs& a) {
   return true;
 }
 
-int launch_gemm_strip(const GemmArgs& a, hipStream_t st) {
+namespace {
+int prepare_strip(const GemmArgs& a, GemmArgs& b) {
   OAVSR_REQUIRE(gemm_strip_eligible(a), "decode strips: launch %d x %d x %d not eligible", a.M, a.N, a.K + a.K2);
   const int vec_t = a.dtype == DT_F32 ? 4 : 8;
   if (a.ksplit > 1 || a.ng_out)
@@ -331,9 +463,24 @@ int launch_gemm_strip(const GemmArgs& a, hipStream_t st) {
     OAVSR_REQUIRE(a.ng_gain && a.ng_rowsq && !a.out_f32 && a.act == ACT_NONE && a.N % 64 == 0 && a.ng_ld % vec_t == 0 && ((uintptr_t)a.ng_out & 15) == 0,
                   "decode strips: next-norm outputs need a plain epilogue, whole column tiles and 16-byte rows");
   OAVSR_REQUIRE(!a.row_sumsq || (a.row_sumsq_tiles >= 1 && a.row_dim > 0), "decode strips: the row factor needs row_sumsq_tiles >= 1 and row_dim > 0");
-  GemmArgs b = a;
+  b = a;
   b.rowsq_strips = a.ng_out ? 1 : 0;
+  return 0;
+}
+}  // namespace
+
+int launch_gemm_strip(const GemmArgs& a, hipStream_t st) {
+  GemmArgs b;
+  OAVSR_TRY(prepare_strip(a, b));
   return a.dtype == DT_F32 ? launch_strip_t<float>(b, st) : launch_strip_t<bf16_t>(b, st);
+}
+
+// n >= 2 strip launches, each consuming what the one before it produced, as ONE launch (decode_chain_kernel).  Same M and element type;
+// ctr: n ints that are zero when the launch starts; err: one int that stays zero.
+int launch_gemm_strip_chain(const GemmArgs* g, int n, int* ctr, int* err, hipStream_t st) {
+  OAVSR_REQUIRE(g && n >= 1 && n <= kChainMax && ctr && err, "decode chain: bad arguments (n = %d)", n);
+  for (int i = 1; i < n; ++i) OAVSR_REQUIRE(g[i].M == g[0].M && g[i].dtype == g[0].dtype, "decode chain: phases of different shapes");
+  return g[0].dtype == DT_F32 ? launch_chain_t<float>(g, n, ctr, err, st) : launch_chain_t<bf16_t>(g, n, ctr, err, st);
 }
 
 }  // namespace oavsr

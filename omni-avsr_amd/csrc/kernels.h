@@ -93,6 +93,9 @@ bool gemm_strip_eligible(const GemmArgs& a);
 bool gemm_strip_rows(int M);                    // the decode path takes the strips for a chunk of M rows (M <= kStripRows and the developer switch is on)
 bool gemm_strip_selected(const GemmArgs& a);    // launch_gemm will run the strips for this launch
 int launch_gemm_strip(const GemmArgs& a, hipStream_t st);
+// Strip launches that feed each other, as the phases of one launch (decode_strip.hip: decode_chain_kernel; same bits as launching them one by one)
+constexpr int kStripChainMax = 6;
+int launch_gemm_strip_chain(const GemmArgs* g, int n, int* ctr, int* err, hipStream_t st);
 // 256 x 256 tile with the 8-wave ping-pong k loop (gemm3.hip): dense bf16, no split-K / groups; picked by launch_gemm_dma
 bool gemm_8p_eligible(const GemmArgs& a);      // the dispatcher's rule (deep K)
 bool gemm_8p_supported(const GemmArgs& a);     // what the kernel can compute at all

@@ -41,6 +41,8 @@ struct KnobDef { const char* name; int dflt; const char* what; };
 static const KnobDef kKnobs[] = {
     {"OAVSR_PROF_SHAPES", 0, "profiling hook: one family per GEMM shape instead of per kernel"},
     {"OAVSR_DECODE_GRAPH", 1, "0: decode steps are launched eagerly instead of replayed from hipGraphs (same kernels, same bits)"},
+    {"OAVSR_DECODE_CHAIN", 0, "1: the strip GEMMs between two attention launches of a decode step (o_proj, gate / up, down_proj, next LoRA-down, QKV) as the phases of ONE launch (decode_strip.hip: decode_chain_kernel; same bits).  Measured slower than the launches it replaces (1.56 vs 1.15 ms per step at 1 row): off"},
+    {"OAVSR_DECODE_CHAIN_PER_CU", 1, "workgroups of a chained strip launch per CU: 1 = the full ring depth, 2 = half the depth each (speed only)"},
     {"OAVSR_DECODE_STRIPS", 1, "0: decode-shaped GEMMs of <= 16 rows run on the 128-row LDS-DMA tiles like larger launches instead of the register-streaming strips (same bits)"},
     {"OAVSR_CONV_C128", 1, "0: the 128-channel 3x3 convolutions of the trunk as implicit GEMMs instead of the image-resident kernel (same bits)"},
     {"OAVSR_CONV_TILE256", 1, "0: implicit-GEMM convolutions with >= 256 output channels on the 256 x 128 tile instead of the 16-wave 256 x 256 tile (same bits)"},
@@ -201,9 +203,11 @@ struct oavsr_model {
   }
 };
 
+static int decode_form() { return knob("OAVSR_DECODE_CHAIN") | knob("OAVSR_DECODE_STRIPS") << 1 | knob("OAVSR_DECODE_CHAIN_PER_CU") << 2; }
 struct DecodeGraphKey {
   int B, task, max_new, banned;
-  bool operator==(const DecodeGraphKey& o) const { return B == o.B && task == o.task && max_new == o.max_new && banned == o.banned; }
+  int form = decode_form();      // the developer switches a captured step depends on: a graph captured under other settings is not replayed
+  bool operator==(const DecodeGraphKey& o) const { return B == o.B && task == o.task && max_new == o.max_new && banned == o.banned && form == o.form; }
 };
 
 // Activations of one encoder's transformer stack + the small index tables its launches read.
@@ -238,6 +242,10 @@ struct oavsr_workspace {
   int *amax; void* amax_scratch; GreedyState gs;
   // decode-shaped GEMMs: arrival counters of the split-K reduce (GemmArgs::sync), the deferred RMSNorm's 1 / rms per row and its per-tile sums
   int* gsync = nullptr; float* rowsq = nullptr;
+  // strip launches of a decode step that feed each other, collected between two attention launches and issued as the phases of one launch
+  // (decode_gemm / chain_flush); chain_ctr: the phases' done counters of one step (zero between launches) + the error word at kChainErr
+  struct { bool open = false; int n = 0, used = 0; GemmArgs g[kStripChainMax]; } chain;
+  int* chain_ctr = nullptr;
   // beam search state
   float *beam_scores, *cand_val, *partial; int *cand_tok, *topk_flag, *hyp_n, *hyp_len, *hyp_tok, *seq[2], *anc[2]; double* hyp_score; size_t partial_bytes = 0;
   int max_tok_enc = 0, max_S_total = 0;
@@ -842,6 +850,7 @@ static int build_prompt_impl(const oavsr_model* m, oavsr_workspace* ws, int task
 // last workgroup -- cost more than the extra workgroups stream (tools/decode_split_scan.py, 97 rows: o_proj 2048 x 2048 17.8 us at 4 slices,
 // 22.9 at 8, 33.8 at 16; QKV 3072 x 2304 20.0 / 32.3 / 56.3; 8 rows: within 1 us of the best choice everywhere).
 constexpr int kDecodeSplitTarget = 256, kDecodeMinKtiles = 8;
+constexpr int kChainInts = 1024, kChainErr = kChainInts - 1;      // oavsr_workspace::chain_ctr
 static int decode_split(int N, int Ktot, int esz, int min_ks = 1) {
   const int ktiles = Ktot / (128 / esz);
   int ks = kDecodeSplitTarget / std::max(1, ceil_div(N, 64));
@@ -859,6 +868,23 @@ static size_t rowsq_chunk(int d) { return (size_t)(ceil_div(d, 64) + 1) * 128; }
 //   that the producer of A left in ws->rowsq (rms_prep: 1; the reduce of o_proj / down_proj: d / 64).
 // next_gain: the GEMM's output is the residual stream; also write T(x * next_gain) to `ng_out` and the rows' partial sums to ws->rowsq.
 constexpr int kSqPrep = -1;      // decode_gemm's sq_tiles: ONE sum of squares per row, left by rms_prep (not by a reduce)
+
+// The collected strip launches go out: one launch with a phase per GEMM (a single one: the plain launch).
+static int chain_flush(oavsr_workspace* ws, hipStream_t st) {
+  auto& ch = ws->chain;
+  const int n = ch.n;
+  ch.n = 0;
+  if (n == 0) return 0;
+  if (n == 1) return run_gemm(ch.g[0], st);
+  OAVSR_REQUIRE(ch.used + n <= kChainErr, "decode chain: more phases in a step than counters");
+  int* ctr = ws->chain_ctr + ch.used;
+  ch.used += n;
+  return launch_gemm_strip_chain(ch.g, n, ctr, ws->chain_ctr + kChainErr, st);
+}
+struct ChainScope {      // a decode step's collection window: closed on every way out
+  oavsr_workspace* ws;
+  ~ChainScope() { ws->chain.open = false; ws->chain.n = 0; }
+};
 static int decode_gemm(const oavsr_model* m, oavsr_workspace* ws, const GemmArgs& g0, hipStream_t st, int sq_tiles = 0, const float* next_gain = nullptr,
                        void* ng_out = nullptr) {
   const size_t e = m->esz;
@@ -893,6 +919,12 @@ static int decode_gemm(const oavsr_model* m, oavsr_workspace* ws, const GemmArgs
       if (next_gain) { g.ng_out = (char*)ng_out + (size_t)r0 * g.N * e; g.ng_ld = g.N; g.ng_gain = next_gain; g.ng_rowsq = sq; g.rowsq_strips = strips ? 1 : 0; }
     }
     if (!strips) OAVSR_REQUIRE(gemm_dma_eligible(g), "decode GEMM %d x %d x %d: no LDS-DMA tile (N >= 64 needed)", g.M, g.N, g.K + g.K2);
+    if (ws->chain.open && gemm_strip_selected(g)) {      // one of a chain of strip launches: collected (chain_flush)
+      if (ws->chain.n == kStripChainMax) OAVSR_TRY(chain_flush(ws, st));
+      ws->chain.g[ws->chain.n++] = g;
+      continue;
+    }
+    if (ws->chain.n) OAVSR_TRY(chain_flush(ws, st));
     OAVSR_TRY(run_gemm(g, st));
   }
   return 0;
@@ -944,6 +976,11 @@ static int llm_decode_layers(const oavsr_model* m, oavsr_workspace* ws, int task
   const int dt = m->dtype, d = c.llm_hidden, H = c.llm_heads, KV = c.llm_kv_heads, hd = c.llm_head_dim;
   const int nq = H * hd, nqkv = (H + 2 * KV) * hd;
   const int tl = c.lora_task_specific ? task : 0;
+  // <= 16 rows (the strips): the GEMMs between two attention launches go out as the phases of one launch
+  ChainScope scope{ws};
+  if (gemm_strip_rows(rows) && !g_prof.on && knob("OAVSR_DECODE_CHAIN")) {
+    ws->chain.open = true; ws->chain.n = 0; ws->chain.used = 0;      // (the counters are zero: workspace creation, then every launch cleans up behind itself)
+  }
   OAVSR_TRY(decode_rms_prep(m, ws, ws->lx, ws->lh, m->llayers[0].ln1w, rows, st));
   int sq_tiles = kSqPrep;                      // partial sums per row in ws->rowsq: one behind rms_prep, d / 64 tiles behind a reduce
   for (int li = 0; li < c.llm_layers; ++li) {
@@ -964,13 +1001,14 @@ static int llm_decode_layers(const oavsr_model* m, oavsr_workspace* ws, int task
     a.Kt = (char*)ws->ktail + li * ws->ktail_layer; a.Vt = (char*)ws->vtail + li * ws->ktail_layer; a.max_tail = ws->max_new;
     a.prefix_len = ws->prefix_len; a.step = step; a.anc = anc; a.scale = 1.0f / sqrtf((float)hd);
     a.inv_freq = m->inv_freq; a.pos = pos; a.cpos = cpos; a.rope_cs = rope_cs; a.rowmap = ws->rowmap;
+    OAVSR_TRY(chain_flush(ws, st));
     { ProfScope ps("decode_attention", 0, 2.0 * rows * max_S * KV * hd * m->esz, st);
       OAVSR_TRY(launch_decode_attention(a, st)); }
     const float* next_gain = li + 1 < c.llm_layers ? m->llayers[li + 1].ln1w : m->norm_w;
     OAVSR_TRY(decode_layer_tail(m, ws, L, rows, ws->lx, ws->lattn, ws->lact, ws->lh, next_gain, st));
     sq_tiles = ceil_div(d, 64);
   }
-  return 0;
+  return chain_flush(ws, st);
 }
 
 // Prefill: all prompt rows of all utterances through the MFMA-bound GEMM families (var-len causal attention, prefix KV written by the RoPE
@@ -1112,7 +1150,7 @@ static int decode_greedy(const oavsr_model* m, oavsr_workspace* ws, int task, in
   for (int b = 0; b < B; ++b) { ipos[b] = ws->S_host[b] - 1; icpos[b] = -1; ifin[b] = 0; ilen[b] = 0; maxS = std::max(maxS, ws->S_host[b]); }
   *istep = 0;
   for (int i = 0; i < B * max_new; ++i) iout[i] = c.id_pad;
-  static const bool graphs_on = knob("OAVSR_DECODE_GRAPH") != 0;
+  const bool graphs_on = knob("OAVSR_DECODE_GRAPH") != 0;
   // hipGraph replay needs stable addresses -> results land in workspace buffers and are copied out at the end; the eager
   // path (profiling, legacy default stream which cannot be captured) writes the caller's buffers directly.
   const bool use_graph = graphs_on && !g_prof.on && max_new > 3 && st != nullptr;
@@ -1208,7 +1246,7 @@ static int decode_beam(const oavsr_model* m, oavsr_workspace* ws, int task, int 
   // Every step-dependent value lives in device memory, so a PAIR of steps (side 0 -> 1 -> 0) is one hipGraph, captured once per
   // (B, K, task, max_new) and replayed: one graph launch instead of ~450 kernel launches.  Step 1 always runs eagerly (it also
   // sets the kernels' attributes before the first capture) and leaves the tables on side 0.
-  static const bool graphs_on = knob("OAVSR_DECODE_GRAPH") != 0;
+  const bool graphs_on = knob("OAVSR_DECODE_GRAPH") != 0;
   const bool use_graph = graphs_on && !g_prof.on && max_new > 4 && st != nullptr;
   int t = 1, cur = 1;
   if (t < max_new) { OAVSR_TRY(one_step(cur)); cur ^= 1; ++t; }
@@ -1405,6 +1443,7 @@ int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, 
   WANT(ktail, ws->ktail_layer * c.llm_layers); WANT(vtail, ws->ktail_layer * c.llm_layers);
   WANT(pos, Rl * 4); WANT(slot, Rl * 4); WANT(cpos, Rl * 4); WANT(cu_s, (max_B + 1) * 4); WANT(prefix_len, max_B * 4); WANT(last_rows, max_B * 4);
   WANT(amax, rows_dec * 4); WANT(amax_scratch, rows_dec * 64 * 8);
+  WANT(chain_ctr, kChainInts * 4);
   WANT(gsync, kSyncInts * 4); WANT(rowsq, rowsq_chunk(d) * ceil_div64((int64_t)Rl, 128) * 4);
   WANT(gs.tok, rows_dec * 4); WANT(gs.finished, rows_dec * 4); WANT(gs.out_ids, rows_dec * (size_t)max_new * 4); WANT(gs.out_len, rows_dec * 4);
   WANT(gs.step, 256); WANT(gs.pos, rows_dec * 4); WANT(gs.cpos, rows_dec * 4); WANT(gs.rope_cs, rows_dec * (size_t)(hd / 2) * sizeof(float2));
@@ -1696,7 +1735,7 @@ static int sched_retire(oavsr_scheduler* s, SchedLane& l, int idx) {
 
 // issue up to n steps for the rows admitted to the lane; calls whose last step has been issued leave (result copy + `done` event) on the way
 static int sched_run(oavsr_scheduler* s, SchedLane& l, int n) {
-  static const bool graphs_on = knob("OAVSR_DECODE_GRAPH") != 0;
+  const bool graphs_on = knob("OAVSR_DECODE_GRAPH") != 0;
   while (n > 0 && !l.active.empty()) {
     const int k = std::min(n, lane_min_remaining(s, l));
     OAVSR_TRY(sched_sync_membership(s, l));
@@ -2083,8 +2122,7 @@ int oavsr_profile_read(oavsr_prof_entry* out, int32_t max_entries) {
 }
 
 // ---- single-kernel entry points --------------------------------------------------------------------
-int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream) {
-  OAVSR_REQUIRE(d, "op_gemm: null desc");
+static GemmArgs gemm_args_of(const oavsr_gemm_desc* d) {
   GemmArgs g; g.dtype = d->dtype; g.M = d->M; g.N = d->N; g.K = d->K; g.K2 = d->K2; g.A = d->A; g.W = d->W; g.A2 = d->A2; g.W2 = d->W2;
   g.lda = d->lda; g.ldw = d->ldw; g.lda2 = d->lda2; g.ldw2 = d->ldw2; g.C = d->C; g.ldc = d->ldc; g.out_f32 = d->out_f32;
   g.col_scale = d->col_scale; g.col_bias = d->col_bias; g.prelu = d->prelu; g.act = d->act; g.residual = d->residual; g.ldr = d->ldr;
@@ -2096,6 +2134,12 @@ int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream) {
   g.row_sumsq = d->row_sumsq; g.row_sumsq_tiles = d->row_sumsq_tiles; g.row_dim = d->row_dim; g.row_eps = d->row_eps;
   g.ng_out = d->ng_out; g.ng_ld = d->ng_ld; g.ng_gain = d->ng_gain; g.ng_rowsq = d->ng_rowsq;
   g.rowsq_strips = d->rowsq_strips; g.row_sumsq_form = d->row_sumsq_form;
+  return g;
+}
+
+int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream) {
+  OAVSR_REQUIRE(d, "op_gemm: null desc");
+  GemmArgs g = gemm_args_of(d);
   OAVSR_REQUIRE(!g.ng_out || g.ksplit > 1, "op_gemm: the next-norm outputs need split-K (ksplit > 1)");
   OAVSR_REQUIRE(!g.row_sumsq || d->kernel == 0, "op_gemm: the row factor is an epilogue of the decode-shaped launches (kernel selector 0)");
   if (g.row_sumsq) g.decode_tiled = 1;
@@ -2115,6 +2159,19 @@ int oavsr_op_gemm(const oavsr_gemm_desc* d, oavsr_stream stream) {
   }
   OAVSR_REQUIRE(d->kernel == 0, "op_gemm: unknown kernel selector %d", d->kernel);
   return launch_gemm(g, (hipStream_t)stream);
+}
+
+int oavsr_op_gemm_chain(const oavsr_gemm_desc* d, int32_t n, int32_t* counters, oavsr_stream stream) {
+  OAVSR_REQUIRE(d && counters && n >= 1 && n <= kStripChainMax, "op_gemm_chain: bad arguments (n = %d, at most %d launches)", n, kStripChainMax);
+  GemmArgs g[kStripChainMax];
+  for (int i = 0; i < n; ++i) {
+    OAVSR_REQUIRE(d[i].kernel == 0, "op_gemm_chain: kernel selector 0 only");
+    g[i] = gemm_args_of(&d[i]);
+    OAVSR_REQUIRE(!g[i].ng_out || g[i].ksplit > 1, "op_gemm_chain: the next-norm outputs need split-K (ksplit > 1)");
+    if (g[i].row_sumsq) g[i].decode_tiled = 1;
+    OAVSR_REQUIRE(gemm_strip_selected(g[i]), "op_gemm_chain: launch %d (%d x %d x %d) is not one the <= %d-row strips take", i, g[i].M, g[i].N, g[i].K + g[i].K2, kStripRows);
+  }
+  return launch_gemm_strip_chain(g, n, counters, counters + n, (hipStream_t)stream);
 }
 
 int oavsr_op_stem_pool(int32_t dtype, const void* video, int32_t channels, int32_t height, int32_t width, const int32_t* frameinfo_dev, int32_t F,

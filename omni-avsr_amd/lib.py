@@ -130,6 +130,7 @@ SYMBOLS = {
     "oavsr_profile_reset": (C.c_int, []),
     "oavsr_profile_read": (C.c_int, [C.POINTER(OavsrProfEntry), _I]),
     "oavsr_op_gemm": (C.c_int, [C.POINTER(GemmDesc), _P]),
+    "oavsr_op_gemm_chain": (C.c_int, [C.POINTER(GemmDesc), C.c_int32, _P, _P]),
     "oavsr_op_attention": (C.c_int, [C.POINTER(AttnDesc), _P]),
     "oavsr_op_decode_attention": (C.c_int, [C.POINTER(DecodeAttnDesc), _P]),
     "oavsr_op_norm": (C.c_int, [_I, _I, _P, _L, _P, _L, _P, _P, _I, _I, _F, _P]),

@@ -30,7 +30,8 @@ def tol(dtype, k=1):
 
 
 def gemm(dtype, A, W, *, A2=None, W2=None, scale=None, bias=None, prelu=None, act=0, residual=None, res_after_act=0,
-         out_f32=False, kernel=0, M=None, N=None, K=None, C_out=None, **geom):
+         out_f32=False, kernel=0, M=None, N=None, K=None, C_out=None, collect=None, **geom):
+    """One launch through oavsr_op_gemm.  collect: a list -- the descriptor is appended to it INSTEAD of being launched (oavsr_op_gemm_chain)."""
     lib = L.load()
     d = L.GemmDesc()
     d.dtype = dcode(dtype)
@@ -57,8 +58,17 @@ def gemm(dtype, A, W, *, A2=None, W2=None, scale=None, bias=None, prelu=None, ac
             setattr(d, k, P(v))
         elif k != "groups":
             setattr(d, k, v)
+    if collect is not None:
+        collect.append(d)
+        return out
     L.check(lib.oavsr_op_gemm(C.byref(d), stream()))
     return out
+
+
+def gemm_chain(descs, counters):
+    """oavsr_op_gemm_chain: the collected launches as the phases of one launch.  counters: int32 tensor of len(descs) + 1 zeros."""
+    arr = (L.GemmDesc * len(descs))(*descs)
+    L.check(L.load().oavsr_op_gemm_chain(arr, len(descs), P(counters), stream()))
 
 
 def digest_words(t):

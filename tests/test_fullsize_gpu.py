@@ -148,6 +148,34 @@ def test_fullsize_encoders_side_by_side_change_no_bit(bf16_engine):
         assert (ref[1] != 0).all()
 
 
+def test_fullsize_chained_decode_launches_change_no_id(bf16_engine):
+    """<= 16 decode rows: the strip GEMMs between two attention launches go out as the phases of one launch (model.hip: chain_flush;
+    OAVSR_DECODE_CHAIN=0: one by one).  Same ids from the captured graph and from eager launches, greedy (1 and 8 rows) and beam search
+    (15 rows).  (Against the tiled kernels of larger steps: the batch / scheduler invariance suites.)"""
+    import os
+    eng = bf16_engine
+    Tv = [100, 61, 250, 40, 33, 61, 50, 27]
+    video, audio, Ts = clips(Tv, seed=44)
+    got = {}
+    try:
+        for chain in ("0", "1"):
+            os.environ["OAVSR_DECODE_CHAIN"] = chain
+            for graph in ("1", "0"):
+                os.environ["OAVSR_DECODE_GRAPH"] = graph
+                a, _ = eng.generate("audiovisual", video, Tv, audio, Ts, 4, 4, beams=1, max_new=24, force_len=True)
+                b, _ = eng.generate("audiovisual", video[:1, :100], Tv[:1], audio[:1, :64000], Ts[:1], 4, 4, beams=1, max_new=24, force_len=True)
+                c, lc = eng.generate("audiovisual", video[:1, :100], Tv[:1], audio[:1, :64000], Ts[:1], 4, 4, beams=15, max_new=24)
+                got[(chain, graph)] = (a.clone(), b.clone(), c.clone(), lc.clone())
+    finally:
+        os.environ.pop("OAVSR_DECODE_CHAIN", None)
+        os.environ.pop("OAVSR_DECODE_GRAPH", None)
+    ref = got[("0", "1")]
+    for k, v in got.items():
+        for what, x, y in zip(("greedy, 8 rows", "greedy, 1 row", "beam 15", "beam 15 lengths"), v, ref):
+            assert torch.equal(x, y), f"OAVSR_DECODE_CHAIN={k[0]} OAVSR_DECODE_GRAPH={k[1]}: {what} differs"
+    assert torch.equal(ref[0][0], ref[1][0]), "an utterance decodes differently alone and in its batch"
+
+
 def test_fullsize_grouped_decode_equals_separate_calls(bf16_engine):
     """harness decode_group / bench --decode-group: 24 utterances in one call (encoders / prefill in chunks of 8, ONE decode loop over 24 rows)
     decode the ids of three separate calls of 8."""

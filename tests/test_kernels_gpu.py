@@ -199,6 +199,98 @@ def test_decode_strips_equal_the_tiled_kernels(dtype, N, K, K2, S):
         assert torch.equal(r2, c_t[:M])
 
 
+def _decode_chain_case(dtype, M, d=2048, nq=2048, I=8192, k2=256, nqkv=3072, seed=0):
+    """The five strip launches a decode step issues between two attention launches (model.hip: decode_layer_tail + the next layer's LoRA-down and
+    QKV; widths of Llama-3.2-1B by default), on M rows: o_proj (+ residual, next-norm outputs) -> gate / up (+ SwiGLU, row factor) -> down_proj
+    (+ residual, next-norm outputs) -> LoRA-down -> QKV (+ LoRA segment, row factor).  Returns (run, buffers): run(chain) re-initialises the
+    state, issues the launches -- one by one or as ONE chained launch -- and returns copies of everything they wrote."""
+    from gpu_util import gemm_chain
+    t = tdt(dtype)
+    W = dict(o=q(rnd(d, nq, seed=seed + 1) / math.sqrt(nq), dtype)[0], gu=q(rnd(2 * I, d, seed=seed + 2) / math.sqrt(d), dtype)[0],
+             dn=q(rnd(d, I, seed=seed + 3) / math.sqrt(I), dtype)[0], la=q(rnd(k2, d, seed=seed + 4) / math.sqrt(d), dtype)[0],
+             qkv=q(rnd(nqkv, d, seed=seed + 5) / math.sqrt(d), dtype)[0], lb=q(rnd(nqkv, k2, seed=seed + 6) / math.sqrt(k2), dtype)[0])
+    attn0, _ = q(rnd(M, nq, seed=seed + 7), dtype)
+    x0, _ = q(rnd(M, d, seed=seed + 8), dtype)
+    g1 = (rnd(d, seed=seed + 9) * 0.1 + 1).to(DEV)
+    g2 = (rnd(d, seed=seed + 10) * 0.1 + 1).to(DEV)
+    bias = rnd(nqkv, seed=seed + 11).to(DEV)
+    x = torch.empty(M, d, dtype=t, device=DEV)
+    xg = torch.empty(M, d, dtype=t, device=DEV)
+    rowsq = torch.empty(d // 16 * M, dtype=torch.float32, device=DEV)
+    act = torch.empty(M, I, dtype=t, device=DEV)
+    lo = torch.empty(M, k2, dtype=t, device=DEV)
+    qkv = torch.empty(M, nqkv, dtype=t, device=DEV)
+    outs = (x, xg, rowsq, act, lo, qkv)
+    ctr = torch.zeros(8, dtype=torch.int32, device=DEV)
+
+    def split(N, K, mn=1):      # model.hip: decode_split
+        kt = K // (64 if dtype == "bf16" else 32)
+        ks = min(256 // max(1, -(-N // 64)), max(1, kt // 8))
+        return max(max(1, min(ks, 16)), min(mn, max(1, kt)))
+
+    rs = dict(row_sumsq=rowsq, row_sumsq_tiles=d // 64, row_dim=d, row_eps=1e-5, row_sumsq_form=1)
+
+    def run(chain):
+        x.copy_(x0)
+        for o in outs[1:]:
+            o.fill_(float("nan"))
+        c = [] if chain else None
+        gemm(dtype, attn0, W["o"], residual=x, C_out=x, ksplit=split(d, nq, 2), ng_out=xg, ng_ld=d, ng_gain=g1, ng_rowsq=rowsq, rowsq_strips=1, collect=c)
+        gemm(dtype, xg, W["gu"], swiglu_pairs=1, C_out=act, decode_tiled=1, collect=c, **rs)
+        gemm(dtype, act, W["dn"], residual=x, C_out=x, ksplit=split(d, I, 2), ng_out=xg, ng_ld=d, ng_gain=g2, ng_rowsq=rowsq, rowsq_strips=1, collect=c)
+        gemm(dtype, xg, W["la"], C_out=lo, ksplit=split(k2, d), collect=c)
+        ks = split(nqkv, d + k2)
+        gemm(dtype, xg, W["qkv"], A2=lo, W2=W["lb"], bias=bias, C_out=qkv, collect=c, **rs, **(dict(ksplit=ks) if ks > 1 else dict(decode_tiled=1)))
+        if chain:
+            gemm_chain(c, ctr)
+        return [o.clone() for o in outs]
+
+    return run, ctr
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_decode_chain_equals_separate_launches(dtype):
+    """oavsr_op_gemm_chain (csrc/decode_strip.hip: decode_chain_kernel): the strip launches between two attention launches of a decode step as the
+    phases of ONE launch, each phase waiting -- weights already requested -- until the phase before has released its outputs.  Residual stream,
+    T(x * gain), strip sums of squares, SwiGLU output, LoRA-down output and QKV: the bits of the five separate launches, at every ring depth
+    (1 / 8 / 9 / 16 rows), launch after launch; the counters are back at zero and no wait was given up."""
+    names = ("x", "T(x * gain)", "sums of squares", "SwiGLU", "LoRA-down", "QKV")
+    for M in (1, 8, 9, 16):
+        kw = dict(d=1024, nq=1024, I=4096, k2=128, nqkv=1536) if dtype == "f32" else {}
+        run, ctr = _decode_chain_case(dtype, M, **kw)
+        ref = run(False)
+        assert not any(torch.isnan(o.float()).any() for o in ref)
+        for rep in range(6):
+            got = run(True)
+            for n, a, b in zip(names, got, ref):
+                assert torch.equal(a, b), f"{dtype} M={M} launch {rep}: {n} of the chained launch differs from the separate launches'"
+        assert ctr.tolist() == [0] * 8, f"{dtype} M={M}: counters after the launches: {ctr.tolist()}"
+
+
+def test_decode_chain_under_load_is_deterministic():
+    """The chain's hand-off (release by every wave of the producer, agent-scope acquire behind the counter) with the chip shared: a second stream hammers
+    HBM and a third runs other chains, so phases start late, spread over the XCDs and wait with their rings full."""
+    run, ctr = _decode_chain_case("bf16", 8)
+    run2, ctr2 = _decode_chain_case("bf16", 16, seed=50)
+    ref, ref2 = run(False), run2(False)
+    torch.cuda.synchronize()
+    side, third = torch.cuda.Stream(), torch.cuda.Stream()
+    junk = torch.empty(256 << 20, dtype=torch.uint8, device=DEV)
+    for rep in range(5):
+        with torch.cuda.stream(side):
+            for _ in range(20):
+                junk.add_(1)
+        with torch.cuda.stream(third):
+            others = [run2(True) for _ in range(3)]
+        mine = [run(True) for _ in range(3)]
+        torch.cuda.synchronize()
+        for got in mine:
+            assert all(torch.equal(a, b) for a, b in zip(got, ref)), f"round {rep}: a chained launch under load differs"
+        for got in others:
+            assert all(torch.equal(a, b) for a, b in zip(got, ref2)), f"round {rep}: a chained launch on the third stream differs"
+    assert ctr.tolist() == [0] * 8 and ctr2.tolist() == [0] * 8
+
+
 def test_decode_strips_under_load_are_deterministic():
     """The strips' counted waits (wave-private LDS-DMA FIFO) only ever assume FEWER outstanding operations than there are, and a slot is refilled only after
     its fragments were read: with a second stream hammering HBM and a third one running the strips on other operands -- DMA arrivals late and out of step,
