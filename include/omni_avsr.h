@@ -265,7 +265,9 @@ typedef struct oavsr_gemm_desc {
   int32_t decode_tiled;     /* 1: decode-shaped launch (M <= 128): the 128-row LDS-DMA tiles at any row count */
   /* decode-shaped launches (M <= 128): split-K with fp32 partial slabs [ksplit][M][N], summed in slab order -- by the tile's last-arriving
      workgroup INSIDE the launch (`sync`: OAVSR_GEMM_SYNC_INTS zeroed ints, the arrival counters; zero again when the launch ends) or, with
-     sync == NULL, by a reduce launch of its own that runs the same code (same bits) */
+     sync == NULL, by a reduce launch of its own that runs the same code (same bits).  <= 16 rows (the strips) need neither; given BOTH, a launch
+     of few long strips (<= half a workgroup per CU, >= 128 KiB of weights per strip: down_proj of a 2048-wide model) runs TWO workgroups per
+     strip, the second continuing the first's chain of additions from M x N fp32 sums in `partial` (same bits; counters zero again at the end) */
   int32_t ksplit;
   float* partial;
   int32_t* sync;

@@ -27,6 +27,7 @@ namespace {
 constexpr int kStripRowBytes = 128;
 constexpr int kStripMaxTiles = 128;      // row_sumsq_tiles the kernel can take (hidden <= 8192)
 // one k-tile of a wave's ring: W chunk 0 | W chunk 1 (1 KiB each: 16 weight rows x 64 bytes) | A: MA activation rows x 128 bytes (MA = 8 or 16)
+// (a 2-row form for M <= 2 -- 2.25 KiB per k-tile, rings a third deeper -- was measured: no change; a CU's streaming rate does not follow its ring depth)
 constexpr int slot_bytes(int MA) { return 2048 + MA * 128; }
 
 template <typename T> __device__ __forceinline__ Chunk16 ld16(const T* p) { return *reinterpret_cast<const Chunk16*>(p); }
@@ -37,6 +38,17 @@ template <typename T> __device__ __forceinline__ Chunk16 ld16(const T* p) { retu
 template <int AUX>
 __device__ __forceinline__ void strip_dma16(const void* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
+}
+// hand-off of 1 KiB between the two workgroups of a PAIR (below): the form of gemm2.hip's in-launch reduce -- write-through (sc1) 16-byte stores, drained,
+// an agent-scope add behind the workgroup's barrier; the reader polls with sc1 loads, acquires, and reads with sc1 loads behind a barrier
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t strip_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ void strip_st16_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, byte_off, 0, 16);      // aux bit 4 = sc1 on gfx950
+}
+__device__ __forceinline__ f32x4 strip_ld16_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 16));
 }
 template <int N> __device__ __forceinline__ void strip_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -68,7 +80,13 @@ template <int N> __device__ __forceinline__ void strip_wait() { asm volatile("s_
       } \
     } \
   } while (0)
-template <typename T, int D, int NW, int MA, bool CHAIN>
+//
+// PAIR: a launch of few strips with long k-slices (down_proj of a 2048-wide model: 128 strips x 8 slices of 1024) fills half the chip, and a CU
+// streams ~20 GB/s whatever the depth of its rings (measured: deeper rings change nothing, the per-CU rate of 128- and 256-workgroup launches
+// is the same) -- so TWO workgroups share a strip: block 2 i takes the first half of its k-slices, sums them in slab order (0.f + s0 + ...) and
+// hands the 16 x 16 fp32 sums over through memory; block 2 i + 1 takes the second half, CONTINUES that sum in slab order (+ s_h + ...) and
+// finishes.  The same chain of additions as one workgroup: same bits.  Block 2 i never waits and is dispatched first; the wait is bounded.
+template <typename T, int D, int NW, int MA, bool CHAIN, bool PAIR = false>
 __device__ __forceinline__ void strip_body(const GemmArgs& p, const int spw, const int wg, char* smem, const int* wait_ctr, const int wait_n,
                                            int* done_ctr, int* err, int* clean_ctr = nullptr, const int clean_n = 0, const int nwg = 0) {
   constexpr int kSlotBytes = slot_bytes(MA);
@@ -83,8 +101,10 @@ __device__ __forceinline__ void strip_body(const GemmArgs& p, const int spw, con
   const int nt1 = p.K / BKE, nall = nt1 + p.K2 / BKE;
   const int per = (nall + ks - 1) / ks;
   const int nstrips = (p.N + 15) >> 4;
-  const int strip0 = wg * spw;
-  const int items = spw * ks;
+  const int half = PAIR ? (wg & 1) : 0;                   // PAIR: spw == 1, this workgroup's k-slices are [half ksl, (half + 1) ksl)
+  const int ksl = PAIR ? ks / 2 : ks;
+  const int strip0 = PAIR ? (wg >> 1) : wg * spw;
+  const int items = spw * ksl;
   const int nT = p.row_sumsq ? p.row_sumsq_tiles : 0;
   char* ring = smem + wave * (D * kSlotBytes);            // this wave's FIFO
   float* slab = reinterpret_cast<float*>(smem + NW * D * kSlotBytes);      // [items][16][16] partial sums
@@ -131,10 +151,11 @@ __device__ __forceinline__ void strip_body(const GemmArgs& p, const int spw, con
   // Activations: lane l of an A instruction fetches chunk (l & 7) ^ (l >> 3) of row 8 j + (l >> 3) (j: the instruction; 8 rows x 128 bytes each), so
   // the k-tile's rows sit in LDS as [row][chunk ^ (row & 7)] -- the MFMA fragment reads (row = lane & 15, chunk = 4 kb + lane / 16) are conflict-free
   const int arow_l = lane >> 3, achunk_l = (lane & 7) ^ (lane >> 3);
-  const T* a1row[MA / 8];
-  const T* a2row[MA / 8];
+  constexpr int AJ = MA / 8;
+  const T* a1row[AJ];
+  const T* a2row[AJ];
 #pragma unroll
-  for (int j = 0; j < MA / 8; ++j) {
+  for (int j = 0; j < AJ; ++j) {
     const int mr = min(j * 8 + arow_l, p.M - 1);
     a1row[j] = A1 + (int64_t)mr * p.lda + achunk_l * VEC;
     a2row[j] = A2 ? A2 + (int64_t)mr * p.lda2 + achunk_l * VEC : nullptr;
@@ -142,7 +163,7 @@ __device__ __forceinline__ void strip_body(const GemmArgs& p, const int spw, con
   const int fr_a = frow & (MA - 1);                        // (MA = 8: lanes of rows 8..15 re-read rows 0..7 -- rows >= M are never stored)
   const int a_off0 = (fr_a * 8 + (fg ^ (fr_a & 7))) * 16, a_off1 = (fr_a * 8 + ((4 + fg) ^ (fr_a & 7))) * 16;
   for (int it = wave; it < items; it += NW) {
-    const int sl = it / ks, s = it - sl * ks;
+    const int sl = it / ksl, s = it - sl * ksl + half * ksl;
     const int strip = strip0 + sl;
     if (strip >= nstrips) continue;
     const int wr = min(strip * 16 + frow, p.N - 1);       // ragged last strip (lm_head's vocabulary): the row is read, its column never stored
@@ -165,7 +186,7 @@ __device__ __forceinline__ void strip_body(const GemmArgs& p, const int spw, con
       const int k = (s1 ? t : t - nt1) * BKE;
       char* dst = ring + slot * kSlotBytes;
 #pragma unroll
-      for (int j = 0; j < MA / 8; ++j) strip_dma16<0>((s1 ? a1row[j] : a2row[j]) + k, dst + 2048 + j * 1024);
+      for (int j = 0; j < AJ; ++j) strip_dma16<0>((s1 ? a1row[j] : a2row[j]) + k, dst + 2048 + j * 1024);
     };
     auto loadk = [&](int t, int slot) { loadw(t, slot); loada(t, slot); };      // L LDS-DMA instructions
     auto mma = [&](int slot) {                            // W: each lane reads back exactly what it fetched; A: the swizzled row-major tile
@@ -180,7 +201,7 @@ __device__ __forceinline__ void strip_body(const GemmArgs& p, const int spw, con
     // L DMA instructions per k-tile; a slot's are the oldest outstanding when it is consumed.  Steady state: D L outstanding before a slot is
     // consumed -> vmcnt((D - 1) L); the drain uses counts that are exact or smaller (a smaller count only waits longer).
     // (the previous item's last LDS reads are done: its MFMAs took their operands before its slab entry was written)
-    constexpr int L = 2 + MA / 8;
+    constexpr int L = 2 + AJ;
     if (CHAIN && !waited) {      // the wave's first item: weights, the producer, then what it wrote; everything has landed when the loop starts (its counts hold trivially)
 #pragma unroll
       for (int i = 0; i < D; ++i)
@@ -254,6 +275,17 @@ __device__ __forceinline__ void strip_body(const GemmArgs& p, const int spw, con
       tsum[r * nT + t] = v;
     }
   }
+  if constexpr (PAIR) {
+    if (half == 1 && wave == 0) {      // the first half's sums: polled by ONE wave (the one whose lanes will read them), behind its own items
+      int spins = 0;
+      while (__hip_atomic_load(p.sync + strip0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 1) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 20)) break;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
   __syncthreads();
   auto signal_done = [&]() {      // CHAIN: every wave's stores are released before the workgroup counts itself done
     if constexpr (CHAIN) {
@@ -270,6 +302,30 @@ __device__ __forceinline__ void strip_body(const GemmArgs& p, const int spw, con
       }
     }
   };
+  if constexpr (PAIR) {
+    if (half == 0) {      // 0.f + s0 + ... + s_{ksl - 1} of the M rows, handed to block wg + 1: [strip][j][row] x 16 bytes (M x N x 4 bytes: inside any split-K slab buffer)
+      if (tid < p.M) {
+        float y[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) y[e] = 0.f;
+        const float* sp = slab + (size_t)tid * 16;
+        for (int s = 0; s < ksl; ++s) {
+#pragma unroll
+          for (int e = 0; e < 16; e += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(sp + (size_t)s * kRows * 16 + e);
+            y[e] += v[0]; y[e + 1] += v[1]; y[e + 2] += v[2]; y[e + 3] += v[3];
+          }
+        }
+        const __amdgpu_buffer_rsrc_t prs = strip_rsrc(p.partial + (size_t)strip0 * (p.M * 16));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) strip_st16_sc1(prs, (unsigned)((j * p.M + tid) * 16), f32x4{y[4 * j], y[4 * j + 1], y[4 * j + 2], y[4 * j + 3]});
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(p.sync + strip0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  }
   // ---- finish: the strip's slices in slab order, then the shared epilogue
   if (flive) do {
   float rs = 1.f;
@@ -279,7 +335,23 @@ __device__ __forceinline__ void strip_body(const GemmArgs& p, const int spw, con
     rs = rsqrtf(tot / (float)p.row_dim + p.row_eps);
   }
   auto strip_sum = [&](int sl, float (&y)[16]) {
-    const float* sp = slab + ((size_t)sl * ks * kRows + frw) * 16;
+    const float* sp = slab + ((size_t)sl * ksl * kRows + frw) * 16;
+    if constexpr (PAIR) {      // continue the first half's chain of additions
+      const __amdgpu_buffer_rsrc_t prs = strip_rsrc(p.partial + (size_t)strip0 * (p.M * 16));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 v = strip_ld16_sc1(prs, (unsigned)((j * p.M + frw) * 16));
+        y[4 * j] = v[0]; y[4 * j + 1] = v[1]; y[4 * j + 2] = v[2]; y[4 * j + 3] = v[3];
+      }
+      for (int s = 0; s < ksl; ++s) {
+#pragma unroll
+        for (int e = 0; e < 16; e += 4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(sp + (size_t)s * kRows * 16 + e);
+          y[e] += v[0]; y[e + 1] += v[1]; y[e + 2] += v[2]; y[e + 3] += v[3];
+        }
+      }
+      return;
+    }
     if (ks == 1) {
 #pragma unroll
       for (int e = 0; e < 16; e += 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(sp + e); y[e] = v[0]; y[e + 1] = v[1]; y[e + 2] = v[2]; y[e + 3] = v[3]; }
@@ -324,6 +396,9 @@ __device__ __forceinline__ void strip_body(const GemmArgs& p, const int spw, con
     for (int e = 0; e < 16; e += VEC) *reinterpret_cast<Chunk16*>(Ct + e) = chunk_from_f32<T>(o + e);
   }
   } while (0);
+  if constexpr (PAIR) {
+    if (tid == 0) __hip_atomic_store(p.sync + strip0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (its only reader is done: ready for the next launch)
+  }
   signal_done();      // (every thread of the workgroup: one barrier)
 }
 
@@ -331,6 +406,12 @@ template <typename T, int D, int NW, int MA>
 __global__ __launch_bounds__(NW * 64) void decode_strip_kernel(const GemmArgs p, const int spw) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   strip_body<T, D, NW, MA, false>(p, spw, blockIdx.x, smem, nullptr, 0, nullptr, nullptr);
+}
+
+template <typename T, int D, int MA>
+__global__ __launch_bounds__(256) void decode_strip_pair_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  strip_body<T, D, 4, MA, false, true>(p, 1, blockIdx.x, smem, nullptr, 0, nullptr, nullptr);
 }
 
 // Several decode-shaped GEMMs that feed each other (o_proj -> gate / up -> down_proj -> the next layer's LoRA-down -> QKV) as the phases of
@@ -370,6 +451,19 @@ int launch_strip(const GemmArgs& a, int spw, size_t smem, hipStream_t st) {
   return 0;
 }
 
+template <typename T, int D, int MA>
+int launch_strip_pair(const GemmArgs& a, size_t smem, hipStream_t st) {
+  auto kern = decode_strip_pair_kernel<T, D, MA>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    OAVSR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(2 * ceil_div(a.N, 16))), dim3(256), smem, st, a);
+  OAVSR_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 // Ring depth: what the CU's 160 KiB of LDS hold.  Launches of at most one workgroup per CU (every GEMM of a layer) get 32 KiB of ring per
 // wave at 4 waves -- the short k-slices of the narrow projections (8-9 k-tiles) are then ONE round trip to memory, and gate / up keeps 64 KiB
 // of weights in flight per CU; more workgroups than CUs (two per CU) and the 8-wave form: 16 KiB per wave.
@@ -380,8 +474,17 @@ int launch_strip_t(const GemmArgs& a, hipStream_t st) {
   const int nw = ks >= 8 ? 8 : 4;
   int spw = nw / ks < 1 ? 1 : nw / ks;
   if (a.swiglu_pairs && (spw & 1)) spw += 1;
-  const bool deep = nw == 4 && ceil_div(ceil_div(a.N, 16), spw) <= ncu;
   const int ma = a.M <= 8 ? 8 : 16;
+  // two workgroups per strip (strip_body: PAIR) where one per strip leaves half the chip idle and the strips are long: >= 128 KiB of weights each
+  const int nstrips = ceil_div(a.N, 16);
+  if (a.partial && a.sync && !a.swiglu_pairs && ks >= 2 && ks % 2 == 0 && 2 * nstrips <= ncu && nstrips <= kSyncInts && a.N % 16 == 0 &&
+      (size_t)16 * (a.K + a.K2) * sizeof(T) >= 128 * 1024 && knob("OAVSR_STRIP_PAIRS")) {
+    const int d = ma == 8 ? 10 : 8;
+    const size_t smem = (size_t)4 * d * slot_bytes(ma) + (size_t)(ks / 2) * 16 * 16 * 4 + (size_t)a.M * (a.row_sumsq ? a.row_sumsq_tiles : 0) * 4 + 16;
+    OAVSR_REQUIRE(smem <= 160 * 1024, "decode strips: %zu bytes of LDS (ksplit %d, pairs)", smem, ks);
+    return ma == 8 ? launch_strip_pair<T, 10, 8>(a, smem, st) : launch_strip_pair<T, 8, 16>(a, smem, st);
+  }
+  const bool deep = nw == 4 && ceil_div(ceil_div(a.N, 16), spw) <= ncu;
   const int d = deep ? (ma == 8 ? 10 : 8) : (ma == 8 ? 5 : 4);
   const size_t smem = (size_t)nw * d * slot_bytes(ma) + (size_t)spw * ks * 16 * 16 * 4 + (size_t)a.M * (a.row_sumsq ? a.row_sumsq_tiles : 0) * 4 + 16;
   OAVSR_REQUIRE(smem <= 160 * 1024, "decode strips: %zu bytes of LDS (ksplit %d)", smem, ks);

@@ -43,6 +43,7 @@ static const KnobDef kKnobs[] = {
     {"OAVSR_DECODE_GRAPH", 1, "0: decode steps are launched eagerly instead of replayed from hipGraphs (same kernels, same bits)"},
     {"OAVSR_DECODE_CHAIN", 0, "1: the strip GEMMs between two attention launches of a decode step (o_proj, gate / up, down_proj, next LoRA-down, QKV) as the phases of ONE launch (decode_strip.hip: decode_chain_kernel; same bits).  Measured slower than the launches it replaces (1.56 vs 1.15 ms per step at 1 row): off"},
     {"OAVSR_DECODE_CHAIN_PER_CU", 1, "workgroups of a chained strip launch per CU: 1 = the full ring depth, 2 = half the depth each (speed only)"},
+    {"OAVSR_STRIP_PAIRS", 1, "0: a strip launch of few long strips (down_proj of a 2048-wide model at <= 16 rows) keeps one workgroup per strip instead of two that share its k-slices (same bits)"},
     {"OAVSR_DECODE_STRIPS", 1, "0: decode-shaped GEMMs of <= 16 rows run on the 128-row LDS-DMA tiles like larger launches instead of the register-streaming strips (same bits)"},
     {"OAVSR_CONV_C128", 1, "0: the 128-channel 3x3 convolutions of the trunk as implicit GEMMs instead of the image-resident kernel (same bits)"},
     {"OAVSR_CONV_TILE256", 1, "0: implicit-GEMM convolutions with >= 256 output channels on the 256 x 128 tile instead of the 16-wave 256 x 256 tile (same bits)"},
@@ -915,6 +916,8 @@ static int decode_gemm(const oavsr_model* m, oavsr_workspace* ws, const GemmArgs
       if (!strips) {
         OAVSR_REQUIRE((size_t)ks * g.M * g.N * 4 <= ws->partial_bytes, "decode GEMM: split-K slabs (%d x %d x %d) exceed the workspace", ks, g.M, g.N);
         g.partial = ws->partial; g.sync = g.M <= kFusedRows ? ws->gsync : nullptr;
+      } else if ((size_t)g.M * g.N * 4 <= ws->partial_bytes && ceil_div(g.N, 16) <= kSyncInts) {
+        g.partial = ws->partial; g.sync = ws->gsync;      // the strips' pairs (decode_strip.hip): M x 16 fp32 sums and a counter per strip
       }
       if (next_gain) { g.ng_out = (char*)ng_out + (size_t)r0 * g.N * e; g.ng_ld = g.N; g.ng_gain = next_gain; g.ng_rowsq = sq; g.rowsq_strips = strips ? 1 : 0; }
     }

@@ -179,7 +179,7 @@ def test_decode_strips_equal_the_tiled_kernels(dtype, N, K, K2, S):
     # a consumer of those sums on the tiled path: 128 rows, tile layout
     wc, _ = q(rnd(192, N, seed=12) / math.sqrt(N), dtype)
     cons_t = gemm(dtype, xg_t, wc, out_f32=True, decode_tiled=1, row_sumsq=rowsq_t.contiguous(), row_sumsq_tiles=tiles, row_dim=N, row_eps=1e-6).clone()
-    for M in (16, 9, 8, 1):
+    for M in (16, 9, 8, 2, 1):
         xg = torch.full((M, N), float("nan"), dtype=tdt(dtype), device=DEV)
         rowsq = torch.full((N // 16 * M,), float("nan"), dtype=torch.float32, device=DEV)
         more = dict(A2=a2[:M], **kw) if K2 else {}
@@ -192,6 +192,16 @@ def test_decode_strips_equal_the_tiled_kernels(dtype, N, K, K2, S):
         assert torch.equal(tile_sums, rowsq_t[:, :M]), f"{dtype} M={M}: (s0 + s1) + (s2 + s3) of the strip sums != the tiled producer's tile sums"
         cons = gemm(dtype, xg, wc, out_f32=True, decode_tiled=1, row_sumsq=rowsq, row_sumsq_tiles=tiles, row_dim=N, row_eps=1e-6, row_sumsq_form=1)
         assert torch.equal(cons, cons_t[:M]), f"{dtype} M={M}: a consumer of the strip layout differs from the tiled consumer"
+        # ... and with the workspace's slab buffer and counters at hand, as the decoder launches it: few long strips (2048 x 8192: 128 strips of 256 KiB) are
+        # then shared by PAIRS of workgroups -- the second continues the first's chain of additions (decode_strip.hip: PAIR) -- same bits, counters back at zero
+        sync = torch.zeros(L.GEMM_SYNC_INTS, dtype=torch.int32, device=DEV)
+        for rep in range(3):
+            xg2 = torch.full((M, N), float("nan"), dtype=tdt(dtype), device=DEV)
+            rowsq2 = torch.full((N // 16 * M,), float("nan"), dtype=torch.float32, device=DEV)
+            c2 = gemm(dtype, a[:M], w, residual=r[:M].clone(), bias=bias, ksplit=S, partial=part, sync=sync, ng_out=xg2, ng_ld=N, ng_gain=gain, ng_rowsq=rowsq2,
+                      rowsq_strips=1, row_sumsq=sq_in[:M].contiguous(), row_sumsq_tiles=1, row_dim=D, row_eps=1e-5, **more)
+            assert torch.equal(c2, c) and torch.equal(xg2, xg) and torch.equal(rowsq2, rowsq), f"{dtype} M={M}: the strips with slab buffer / counters at hand differ (launch {rep})"
+        assert int(sync.abs().sum()) == 0
         # in place on the residual rows, as the decoder runs it
         r2 = r[:M].clone()
         gemm(dtype, a[:M], w, residual=r2, C_out=r2, bias=bias, ksplit=S, ng_out=xg, ng_ld=N, ng_gain=gain, ng_rowsq=rowsq, rowsq_strips=1,
@@ -294,7 +304,8 @@ def test_decode_chain_under_load_is_deterministic():
 def test_decode_strips_under_load_are_deterministic():
     """The strips' counted waits (wave-private LDS-DMA FIFO) only ever assume FEWER outstanding operations than there are, and a slot is refilled only after
     its fragments were read: with a second stream hammering HBM and a third one running the strips on other operands -- DMA arrivals late and out of step,
-    other workgroups sharing the CUs -- every launch must return the bits of an undisturbed one.  All ring depths: 1 / 8 / 9 / 16 rows, short and long k-slices."""
+    other workgroups sharing the CUs -- every launch must return the bits of an undisturbed one.  All ring depths: 1 / 2 / 8 / 9 / 16 rows, short and long k-slices,
+    and the PAIR form of the long strips (two workgroups per strip, the first half's sums handed over through memory)."""
     dtype = "bf16"
     shapes = [(2048, 2048, 0, 4), (3072, 2048, 256, 4), (2048, 8192, 0, 8), (16384, 2048, 0, 1), (256, 2048, 0, 4)]
     cases = []
@@ -305,10 +316,13 @@ def test_decode_strips_under_load_are_deterministic():
         if K2:
             a2, _ = q(rnd(16, K2, seed=3), dtype)
             w2, _ = q(rnd(N, K2, seed=4) / math.sqrt(K2), dtype)
-        for M in (1, 8, 9, 16):
+        for M in (1, 2, 8, 9, 16):
             kw = dict(A2=a2[:M], W2=w2) if K2 else {}
             kw.update(dict(swiglu_pairs=1, decode_tiled=1) if S == 1 else dict(ksplit=S))
             cases.append((a[:M], w, kw, gemm(dtype, a[:M], w, **kw).clone()))
+            if N * 16 <= 2048 * 16 and K >= 8192:      # few long strips: with a slab buffer and counters at hand, PAIRS of workgroups share a strip (hand-off through memory)
+                pk = dict(kw, partial=torch.empty(S * M * N, dtype=torch.float32, device=DEV), sync=torch.zeros(L.GEMM_SYNC_INTS, dtype=torch.int32, device=DEV))
+                cases.append((a[:M], w, pk, cases[-1][3]))
     torch.cuda.synchronize()
     side, third = torch.cuda.Stream(), torch.cuda.Stream()
     junk = torch.empty(256 << 20, dtype=torch.uint8, device=DEV)
