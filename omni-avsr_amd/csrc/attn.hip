@@ -756,6 +756,8 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnAr
   // fused append: the new token's key index; its K/V come from LDS (sknew/svnew), never from the just-written cache row
   const int newkey = p.inv_freq ? plen + p.cpos[srow] : -1;
 
+  constexpr int RPI = 64 / NCH;                        // V rows per load instruction (load_tile)
+  const int vch = lane % NCH, vro = lane / NCH;
   auto kv_row = [&](const void* pre, const void* tail, int j) -> const char* {
     if (j < plen) return reinterpret_cast<const char*>(pre) + (((int64_t)utt * p.n_kv_heads + kvh) * p.max_prefix + j) * RB;
     const int t = j - plen;
@@ -774,11 +776,16 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnAr
         else kf[kt][b].v = u32x4{0u, 0u, 0u, 0u};
       }
     }
+    // V: lane l knows the row of key kt0 + l; instruction c fetches chunk (l % NCH) of rows c RPI + l / NCH -- whole 128-byte lines, RPI rows per
+    // instruction (one 16-byte piece of 64 different rows per instruction, as the row-per-lane form did, costs the texture path 64 lines per instruction)
     const int key = kt0 + lane;
     const char* vp = (key < ctx && key != newkey) ? kv_row(p.Vp, p.Vt, key) : nullptr;
+    const unsigned vlo = (unsigned)(uintptr_t)vp, vhi = (unsigned)((uintptr_t)vp >> 32);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      if (vp) vr[c] = *reinterpret_cast<const Chunk16*>(vp + c * 16);
+      const int r = c * RPI + vro;
+      const uintptr_t bp = (uintptr_t)(unsigned)__shfl((int)vlo, r, 64) | ((uintptr_t)(unsigned)__shfl((int)vhi, r, 64) << 32);
+      if (bp) vr[c] = *reinterpret_cast<const Chunk16*>(bp + vch * 16);
       else vr[c].v = u32x4{0u, 0u, 0u, 0u};
     }
   };
@@ -840,14 +847,16 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnAr
 #pragma unroll
           for (int b = 0; b < NBLK; ++b) kf[kt][b] = *reinterpret_cast<const Chunk16*>(sknew + (b * 4 + g) * 16);
         }
-      if (kt0 + lane == newkey) {
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) vr[c] = *reinterpret_cast<const Chunk16*>(svnew + c * 16);
-      }
+      for (int c = 0; c < NCH; ++c)
+        if (kt0 + c * RPI + vro == newkey) vr[c] = *reinterpret_cast<const Chunk16*>(svnew + vch * 16);
     }
-    // V tile -> this wave's LDS image (lane = key row)
+    // V tile -> this wave's LDS image [key row][chunk ^ (row & SWZ)]
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) *reinterpret_cast<Chunk16*>(svw + lane * RB + ((c ^ (lane & SWZ)) << 4)) = vr[c];
+    for (int c = 0; c < NCH; ++c) {
+      const int r = c * RPI + vro;
+      *reinterpret_cast<Chunk16*>(svw + r * RB + ((vch ^ (r & SWZ)) << 4)) = vr[c];
+    }
     f32x4 s[4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -978,6 +987,8 @@ __global__ __launch_bounds__(256) void decode_attn_beam4_kernel(const DecodeAttn
   T* Kt = reinterpret_cast<T*>(const_cast<void*>(p.Kt));
   T* Vt = reinterpret_cast<T*>(const_cast<void*>(p.Vt));
 
+  constexpr int RPI = 64 / NCH;
+  const int vch = lane % NCH, vro = lane / NCH;
   // K fragments straight from the caches (A operand row = key (lane & 15), 16-byte chunk blk * 4 + g); V row of key `lane`
   auto key_row = [&](const void* pre, const void* tail, int tile, int kk, bool& ok) -> const char* {
     if (tile < nP) {
@@ -1002,11 +1013,16 @@ __global__ __launch_bounds__(256) void decode_attn_beam4_kernel(const DecodeAttn
         else kf[kt][b].v = u32x4{0u, 0u, 0u, 0u};
       }
     }
+    // V: whole 128-byte lines per row, RPI rows per instruction (decode_attn_kernel: load_tile); lane l knows the row of key l
     bool okv;
     const char* vp = key_row(p.Vp, p.Vt, tile, lane, okv);
+    if (!okv) vp = nullptr;
+    const unsigned vlo = (unsigned)(uintptr_t)vp, vhi = (unsigned)((uintptr_t)vp >> 32);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      if (okv) vr[c] = *reinterpret_cast<const Chunk16*>(vp + c * 16);
+      const int r = c * RPI + vro;
+      const uintptr_t bp = (uintptr_t)(unsigned)__shfl((int)vlo, r, 64) | ((uintptr_t)(unsigned)__shfl((int)vhi, r, 64) << 32);
+      if (bp) vr[c] = *reinterpret_cast<const Chunk16*>(bp + vch * 16);
       else vr[c].v = u32x4{0u, 0u, 0u, 0u};
     }
   };
@@ -1077,13 +1093,15 @@ __global__ __launch_bounds__(256) void decode_attn_beam4_kernel(const DecodeAttn
 #pragma unroll
           for (int b = 0; b < NBLK; ++b) kf[kt][b] = *reinterpret_cast<const Chunk16*>(sknew + bi * RB + (b * 4 + g) * 16);
         }
-      if (lane == newpos) {
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) vr[c] = *reinterpret_cast<const Chunk16*>(svnew + bi * RB + c * 16);
-      }
+      for (int c = 0; c < NCH; ++c)
+        if (c * RPI + vro == newpos) vr[c] = *reinterpret_cast<const Chunk16*>(svnew + bi * RB + vch * 16);
     }
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) *reinterpret_cast<Chunk16*>(svw + lane * RB + ((c ^ (lane & SWZ)) << 4)) = vr[c];
+    for (int c = 0; c < NCH; ++c) {
+      const int r = c * RPI + vro;
+      *reinterpret_cast<Chunk16*>(svw + r * RB + ((vch ^ (r & SWZ)) << 4)) = vr[c];
+    }
     f32x4 s[4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {

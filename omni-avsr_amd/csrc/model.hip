@@ -227,7 +227,9 @@ struct oavsr_workspace {
   // encoder scratch: one set per encoder, so that the two encoders of an audio-visual call may run side by side (encode_prefill)
   EncScratch esa, esv;           // Whisper's / AV-HuBERT's (esv.hcat [rows][D + k2]: LayerNorm output next to the LoRA-down output, run_encoder_layers)
   void *enc_out_v, *enc_out_a;
-  hipStream_t enc2 = nullptr; hipEvent_t enc2_fork = nullptr, enc2_join = nullptr;      // the video encoder's stream when the two run side by side
+  // the video encoder's stream when the two run side by side: created by the FIRST such call, not with the workspace -- a stream that exists takes a share of
+  // the process's 8 hardware queues even when idle (one per workspace of a 4-stream pipeline: beam-15 throughput 157 -> 108 utt/s)
+  hipStream_t enc2 = nullptr; hipEvent_t enc2_fork = nullptr, enc2_join = nullptr; bool two_sets = false;
   // video front
   void *pool_out, *trunk[2], *feat512, *featproj, *ln2d;
   int2* frameinfo; int4* rowinfo2; int* cu_b;
@@ -1474,13 +1476,8 @@ int oavsr_workspace_create(const oavsr_model* m, int32_t max_B, int32_t max_Tv, 
   // keeps a missed guard from turning into run-to-run differences).
   if (hipMemset(ws->arena, 0, total) != hipSuccess) { set_last_error("workspace_create: hipMemset failed"); hipFree(ws->arena); delete ws; return -2; }
   for (auto& r : reqs) { *r.p = ws->take(std::max<size_t>(r.bytes, 256)); if (!*r.p) { set_last_error("workspace arena overflow"); hipFree(ws->arena); delete ws; return -1; } }
+  ws->two_sets = two_sets;
   if (!two_sets) { void* hcat = ws->esv.hcat; ws->esv = ws->esa; ws->esv.hcat = hcat; }      // one encoder: one set
-  else {
-    if (hipStreamCreateWithFlags(&ws->enc2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ws->enc2_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ws->enc2_join, hipEventDisableTiming) != hipSuccess) {
-      set_last_error("workspace_create: stream / event creation failed"); hipFree(ws->arena); delete ws; return -2;
-    }
-  }
   // decode uses gs.pos / gs.cpos as the row position arrays of the layer stack
   ws->host_bytes = (size_t)(F * sizeof(int2) + ST * 8 * sizeof(int) + rows_dec * (size_t)(max_new + 16) * sizeof(int) + 1 * 1024 * 1024);
   if (hipHostMalloc((void**)&ws->host_base, 2 * ws->host_bytes) != hipSuccess) { set_last_error("workspace_create: hipHostMalloc failed"); hipFree(ws->arena); delete ws; return -2; }
@@ -1599,8 +1596,13 @@ static int encode_prefill(const oavsr_model* m, oavsr_workspace* ws, int32_t tas
     // workgroups per GEMM), so the video encoder of an audio-visual call runs on a second stream beside the audio encoder, each on its
     // own scratch set; the projectors follow on the call's stream.  Same launches, same bits.  Calls that overlap each other (the
     // pipelined job) already fill the chip with the next call's encoders and keep the one-stream order.
-    const bool side = use_a && use_v && ws->enc2 && launch_alone() && !g_prof.on && knob("OAVSR_ENC_SIDE_BY_SIDE");
+    const bool side = use_a && use_v && ws->two_sets && launch_alone() && !g_prof.on && knob("OAVSR_ENC_SIDE_BY_SIDE");
     hipStream_t sv = st;
+    if (side && !ws->enc2) {
+      OAVSR_CHECK_HIP(hipStreamCreateWithFlags(&ws->enc2, hipStreamNonBlocking));
+      OAVSR_CHECK_HIP(hipEventCreateWithFlags(&ws->enc2_fork, hipEventDisableTiming));
+      OAVSR_CHECK_HIP(hipEventCreateWithFlags(&ws->enc2_join, hipEventDisableTiming));
+    }
     if (side) {
       OAVSR_CHECK_HIP(hipEventRecord(ws->enc2_fork, st));
       OAVSR_CHECK_HIP(hipStreamWaitEvent(ws->enc2, ws->enc2_fork, 0));
