@@ -725,6 +725,18 @@ __device__ __forceinline__ void attn_dma32_body(const AttnArgs& p) {
 //     is written to the tail cache first and then read back like any other key (workgroup-scope visibility via the barrier)
 //   * the 4 waves split the 64-key tiles; K fragments go HBM -> VGPR directly (A operand), V tiles go through a per-wave
 //     LDS image for the transposed reads; per-wave (m, l, O^T) partials are merged through LDS at the end.
+// The merge of two softmax partials (m, l, O): the ONE formula every decode-attention result is folded with, in registers (two waves) or from LDS (four /
+// eight waves) -- so a row's bits do not depend on how many waves shared its keys, and the wave count may follow the row count.
+constexpr int kDecSlots = 8;
+__device__ __forceinline__ float decode_merge_weights(float m1, float m2, float& w1, float& w2) {
+  const float m = fmaxf(m1, m2);
+  const float mu = (m == -INFINITY) ? 0.f : m;
+  w1 = exp2f(m1 - mu);
+  w2 = exp2f(m2 - mu);
+  return m;
+}
+__device__ __forceinline__ float decode_merge_val(float x1, float w1, float x2, float w2) { return __builtin_fmaf(x1, w1, x2 * w2); }
+
 template <typename T, int HD, int NW>
 __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnArgs p) {
   constexpr int kDecThreads = NW * 64;
@@ -750,6 +762,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnAr
   const int ctx = plen + ntail;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qi = lane & 15, g = lane >> 4;
+  char* svw = sv + wave * (64 * RB);                   // this wave's V image
   const T* qrow = reinterpret_cast<const T*>(p.Q) + (int64_t)row * p.ldq;
   T* Kt = reinterpret_cast<T*>(const_cast<void*>(p.Kt));
   T* Vt = reinterpret_cast<T*>(const_cast<void*>(p.Vt));
@@ -765,35 +778,57 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnAr
     return reinterpret_cast<const char*>(tail) + (((int64_t)src * p.n_kv_heads + kvh) * p.max_tail + t) * RB;
   };
   // K fragments straight from the cache (A operand row = key (lane & 15), 16-byte chunk blk*4 + g); V row of key kt0 + lane
-  auto load_tile = [&](int kt0, Chunk16 (&kf)[4][NBLK], Chunk16 (&vr)[NCH]) {
+  auto load_tile = [&](int kt0, Chunk16 (&kf)[4][NBLK]) {
+    // (wave-uniform) a tile inside the context that does not hold the token being appended: no per-lane predicates, no zero fill
+    const bool whole = kt0 + 64 <= ctx && !(newkey >= kt0 && newkey < kt0 + 64);
+    if (whole) {
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      const int key = kt0 + kt * 16 + qi;
-      const char* kr = (key < ctx && key != newkey) ? kv_row(p.Kp, p.Kt, key) : nullptr;
+      for (int kt = 0; kt < 4; ++kt) {
+        const char* kr = kv_row(p.Kp, p.Kt, kt0 + kt * 16 + qi);
 #pragma unroll
-      for (int b = 0; b < NBLK; ++b) {
-        if (kr) kf[kt][b] = *reinterpret_cast<const Chunk16*>(kr + (b * 4 + g) * 16);
-        else kf[kt][b].v = u32x4{0u, 0u, 0u, 0u};
+        for (int b = 0; b < NBLK; ++b) kf[kt][b] = *reinterpret_cast<const Chunk16*>(kr + (b * 4 + g) * 16);
+      }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const int key = kt0 + kt * 16 + qi;
+        const char* kr = (key < ctx && key != newkey) ? kv_row(p.Kp, p.Kt, key) : nullptr;
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+          if (kr) kf[kt][b] = *reinterpret_cast<const Chunk16*>(kr + (b * 4 + g) * 16);
+          else kf[kt][b].v = u32x4{0u, 0u, 0u, 0u};
+        }
       }
     }
-    // V: lane l knows the row of key kt0 + l; instruction c fetches chunk (l % NCH) of rows c RPI + l / NCH -- whole 128-byte lines, RPI rows per
-    // instruction (one 16-byte piece of 64 different rows per instruction, as the row-per-lane form did, costs the texture path 64 lines per instruction)
+    // V: straight into this wave's LDS image [key row][chunk ^ (row & SWZ)] by LDS-DMA, no registers.  Lane l knows the row of key kt0 + l; instruction c
+    // moves rows c RPI + l / NCH -- whole 128-byte lines -- and lane l's 16 bytes land at image offset 16 (64 c + l) = row RB + 16 (l % NCH): the swizzle is
+    // applied to the SOURCE chunk.  Rows past the context (and the row of the token being appended, patched from LDS in tile()) are zero-filled.
     const int key = kt0 + lane;
-    const char* vp = (key < ctx && key != newkey) ? kv_row(p.Vp, p.Vt, key) : nullptr;
+    const char* vp = (whole || (key < ctx && key != newkey)) ? kv_row(p.Vp, p.Vt, key) : nullptr;
     const unsigned vlo = (unsigned)(uintptr_t)vp, vhi = (unsigned)((uintptr_t)vp >> 32);
+    if (whole) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int r = c * RPI + vro;
-      const uintptr_t bp = (uintptr_t)(unsigned)__shfl((int)vlo, r, 64) | ((uintptr_t)(unsigned)__shfl((int)vhi, r, 64) << 32);
-      if (bp) vr[c] = *reinterpret_cast<const Chunk16*>(bp + vch * 16);
-      else vr[c].v = u32x4{0u, 0u, 0u, 0u};
+      for (int c = 0; c < NCH; ++c) {
+        const int r = c * RPI + vro;
+        const uintptr_t bp = (uintptr_t)(unsigned)__shfl((int)vlo, r, 64) | ((uintptr_t)(unsigned)__shfl((int)vhi, r, 64) << 32);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bp + ((vch ^ (r & SWZ)) << 4)), (__attribute__((address_space(3))) void*)(svw + c * 1024), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int r = c * RPI + vro;
+        const uintptr_t bp = (uintptr_t)(unsigned)__shfl((int)vlo, r, 64) | ((uintptr_t)(unsigned)__shfl((int)vhi, r, 64) << 32);
+        char* dst = svw + c * 1024;
+        if (bp) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bp + ((vch ^ (r & SWZ)) << 4)), (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        else reinterpret_cast<Chunk16*>(dst)[lane].v = u32x4{0u, 0u, 0u, 0u};
+      }
     }
   };
 
   // ---- the first K/V tile of every wave is requested before anything else: its latency hides the RoPE phase ----
-  Chunk16 kf[4][NBLK], vr[NCH];
+  Chunk16 kf[4][NBLK];
   int kt0 = wave * 64;
-  if (kt0 < ctx) load_tile(kt0, kf, vr);
+  if (kt0 < ctx) load_tile(kt0, kf);
 
   // ---- phase 0: queries (+ RoPE) into LDS; new k (+ RoPE) / v appended to the tail cache and kept in LDS ----
   for (int i = tid + G * HD; i < 16 * HD; i += kDecThreads) reinterpret_cast<T*>(sq)[i] = from_f32<T>(0.f);   // rows >= G
@@ -831,15 +866,13 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnAr
 
   const float sc = p.scale * 1.44269504088896340736f;
   f32x4 o[NDT];
-#pragma unroll
-  for (int i = 0; i < NDT; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_run = 0.f;
-  char* svw = sv + wave * (64 * RB);
+  float m_run, l_run;
 
+  // One 64-key tile into the running (m_run, l_run, o) of the current SLOT.
   // (requesting tile i + 1 before computing tile i -- a second register set for the K fragments and the V row -- was measured for the 2-wave
   // form: nothing at 8 rows, 20 -> 26 us at 97 rows through the lost occupancy; the other workgroups of the CU hide the latency instead)
-  for (; kt0 < ctx; kt0 += NW * 64) {
-    if (kt0 != wave * 64) load_tile(kt0, kf, vr);         // later tiles (contexts longer than NW * 64 keys)
+  auto tile = [&](int kt0, bool loaded) {
+    if (!loaded) load_tile(kt0, kf);
     if (newkey >= kt0 && newkey < kt0 + 64) {             // wave-uniform: this tile holds the token being appended
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
@@ -847,15 +880,11 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnAr
 #pragma unroll
           for (int b = 0; b < NBLK; ++b) kf[kt][b] = *reinterpret_cast<const Chunk16*>(sknew + (b * 4 + g) * 16);
         }
-#pragma unroll
-      for (int c = 0; c < NCH; ++c)
-        if (kt0 + c * RPI + vro == newkey) vr[c] = *reinterpret_cast<const Chunk16*>(svnew + vch * 16);
-    }
-    // V tile -> this wave's LDS image [key row][chunk ^ (row & SWZ)]
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int r = c * RPI + vro;
-      *reinterpret_cast<Chunk16*>(svw + r * RB + ((vch ^ (r & SWZ)) << 4)) = vr[c];
+      const int r = newkey - kt0;                         // its V row: from LDS into the image (the lanes that zero-filled it in load_tile)
+      if (lane / NCH == r % RPI) {
+        const int ch = lane % NCH;
+        *reinterpret_cast<Chunk16*>(svw + r * RB + (ch << 4)) = *reinterpret_cast<const Chunk16*>(svnew + ((ch ^ (r & SWZ)) << 4));
+      }
     }
     f32x4 s[4];
 #pragma unroll
@@ -888,7 +917,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnAr
     m_run = m_new;
 #pragma unroll
     for (int i = 0; i < NDT; ++i) o[i] *= alpha;
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's V tile writes have landed before its own reads
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's V tile (LDS-DMA, zero fill, patch) is in LDS before its own reads
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -925,34 +954,104 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnAr
           }
         }
     }
+  };
+  // A slot = the tiles slot, slot + kDecSlots, ... of the context, accumulated in that order (online softmax); its partial (m, l, O^T) with l summed over
+  // the lane groups.  What a row's result is made of does not depend on the wave that computes a slot: see decode_merge.
+  auto run_slot = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    m_run = -INFINITY; l_run = 0.f;
+    for (int kt0 = slot * 64; kt0 < ctx; kt0 += kDecSlots * 64) tile(kt0, kt0 == wave * 64);      // (the wave's first tile was requested before the RoPE phase)
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+  };
+
+  float* sm = reinterpret_cast<float*>(sv);            // after the barrier: [P][16] m, [P][16] l, [P][HD][16] O^T (P partials, reusing the V-tile region)
+  if constexpr (NW == 2) {
+    // Two waves: wave w owns the chain of slots w, w + 2, w + 4, w + 6, folded IN THAT ORDER in registers -- the fold the merge below applies to
+    // the same slots when eight waves leave them in LDS.  (An empty slot is folded too: x (+) empty = x exactly, but for the sign of a zero.)
+    constexpr int kSlotUnroll = HD == 64 ? kDecSlots / 2 : 1;
+    f32x4 oa[NDT];
+    float ma = 0.f, la = 0.f;
+#pragma unroll kSlotUnroll
+    for (int j = 0; j < kDecSlots / 2; ++j) {      // (head_dim 128 is at the register limit: one copy of the tile code there; 64: unrolled, 20.8 -> 20.1 us at 97 rows)
+      run_slot(wave + 2 * j);
+      if (j == 0) {
+#pragma unroll
+        for (int i = 0; i < NDT; ++i) oa[i] = o[i];
+        ma = m_run; la = l_run;
+        continue;
+      }
+      float w1, w2;
+      const float mm = decode_merge_weights(ma, m_run, w1, w2);
+      la = decode_merge_val(la, w1, l_run, w2);
+#pragma unroll
+      for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oa[i][r] = decode_merge_val(oa[i][r], w1, o[i][r], w2);
+      ma = mm;
+    }
+    __syncthreads();
+    float* sl = sm + 2 * 16;
+    float* so = sl + 2 * 16;
+    if (g == 0) { sm[wave * 16 + qi] = ma; sl[wave * 16 + qi] = la; }
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) so[(wave * HD + dt * 16 + 4 * g + r) * 16 + qi] = oa[dt][r];
+  } else {
+    // Four / eight waves: every slot's partial goes to LDS (a wave keeps its kDecSlots / NW partials in registers until all waves are done with their V images)
+    constexpr int PW = kDecSlots / NW;
+    f32x4 op[PW][NDT];
+    float mp[PW], lp[PW];
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      run_slot(wave + j * NW);
+#pragma unroll
+      for (int i = 0; i < NDT; ++i) op[j][i] = o[i];
+      mp[j] = m_run; lp[j] = l_run;
+    }
+    __syncthreads();
+    float* sl = sm + kDecSlots * 16;
+    float* so = sl + kDecSlots * 16;
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      const int slot = wave + j * NW;
+      if (g == 0) { sm[slot * 16 + qi] = mp[j]; sl[slot * 16 + qi] = lp[j]; }
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) so[(slot * HD + dt * 16 + 4 * g + r) * 16 + qi] = op[j][dt][r];
+    }
   }
-  // ---- merge the NW waves: partials (m, l, O^T[d][q]) through LDS (reusing the V-tile region) ----
-  l_run += __shfl_xor(l_run, 16, 64);
-  l_run += __shfl_xor(l_run, 32, 64);
   __syncthreads();
-  float* sm = reinterpret_cast<float*>(sv);            // [NW][16] m, [NW][16] l, [NW][HD][16] O^T
-  float* sl = sm + NW * 16;
-  float* so = sl + NW * 16;
-  if (g == 0) { sm[wave * 16 + qi] = m_run; sl[wave * 16 + qi] = l_run; }
-#pragma unroll
-  for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) so[(wave * HD + dt * 16 + 4 * g + r) * 16 + qi] = o[dt][r];
-  __syncthreads();
+  // ---- the canonical merge: (((s0 (+) s2) (+) s4) (+) s6) (+) (((s1 (+) s3) (+) s5) (+) s7), element by element ----
+  constexpr int P = NW == 2 ? 2 : kDecSlots;
+  const float* sl = sm + P * 16;
+  const float* so = sl + P * 16;
   T* O = reinterpret_cast<T*>(p.O) + (int64_t)row * p.ldo + (int64_t)kvh * G * HD;
   for (int i = tid; i < G * HD; i += kDecThreads) {
     const int h = i / HD, d = i - h * HD;
-    float mstar = -INFINITY;
+    float mc[2], lc[2], oc[2];
 #pragma unroll
-    for (int w = 0; w < NW; ++w) mstar = fmaxf(mstar, sm[w * 16 + h]);
-    if (mstar == -INFINITY) mstar = 0.f;
-    float num = 0.f, den = 0.f;
+    for (int c = 0; c < 2; ++c) {      // chain c: slots c, c + 2, ... (two waves: already folded by wave c)
+      mc[c] = sm[c * 16 + h]; lc[c] = sl[c * 16 + h]; oc[c] = so[(c * HD + d) * 16 + h];
+      if constexpr (NW != 2) {
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const float f = exp2f(sm[w * 16 + h] - mstar);
-      num += f * so[(w * HD + d) * 16 + h];
-      den += f * sl[w * 16 + h];
+        for (int j = 1; j < kDecSlots / 2; ++j) {
+          const int sidx = c + 2 * j;
+          float w1, w2;
+          const float mm = decode_merge_weights(mc[c], sm[sidx * 16 + h], w1, w2);
+          lc[c] = decode_merge_val(lc[c], w1, sl[sidx * 16 + h], w2);
+          oc[c] = decode_merge_val(oc[c], w1, so[(sidx * HD + d) * 16 + h], w2);
+          mc[c] = mm;
+        }
+      }
     }
+    float w1, w2;
+    (void)decode_merge_weights(mc[0], mc[1], w1, w2);
+    const float den = decode_merge_val(lc[0], w1, lc[1], w2);
+    const float num = decode_merge_val(oc[0], w1, oc[1], w2);
     O[i] = from_f32<T>(den > 0.f ? num / den : 0.f);
   }
 }
@@ -1245,7 +1344,8 @@ template <typename T, int HD, int NWF = 0>
 int launch_dec_t(const DecodeAttnArgs& a, hipStream_t st) {
   constexpr int RB = HD * (int)sizeof(T);
   constexpr int NW = NWF ? NWF : (8 * 64 * RB <= 128 * 1024) ? 8 : 4;      // waves per workgroup: 8 x 64 keys in one pass when the V tiles fit
-  constexpr size_t tiles = (size_t)NW * 64 * RB, merge = (size_t)(2 * NW * 16 + NW * HD * 16) * 4;
+  constexpr int P = NW == 2 ? 2 : kDecSlots;      // partials that meet in LDS (decode_attn_kernel: the canonical merge)
+  constexpr size_t tiles = (size_t)NW * 64 * RB, merge = (size_t)(2 * P * 16 + P * HD * 16) * 4;
   constexpr size_t smem = 18 * RB + (tiles > merge ? tiles : merge);
   static_assert(smem <= 160 * 1024, "LDS");
   auto kern = decode_attn_kernel<T, HD, NW>;
@@ -1297,10 +1397,12 @@ int launch_decode_attention(const DecodeAttnArgs& a, hipStream_t st) {
     if (a.n_heads == 4 * a.n_kv_heads && a.step && !a.rowmap && a.rows % a.beams == 0 && a.max_tail <= 64) return launch_dec_beam4(a, st);
     return launch_dec_t<bf16_t, 64, 4>(a, st);
   }
-  // greedy rows: TWO waves per workgroup (a wave walks every second 64-key tile; up to eight workgroups per CU).  Alone a launch of few rows
-  // is slower that way (8 rows x 16 s clips: 7.3 -> 8-9 us) and a full one faster (97 rows: 28 -> 20 us, head_dim 128: 50 -> 43 us), and the
-  // CU-time falls with the LDS footprint: headline 327 -> 330 utt/s, Llama-3.1-8B 164 -> 166 (round 5, same box).  Like every wave layout
-  // here it is a property of (model, decode mode) -- the key -> wave partition fixes the fp32 merge order of a row -- never of the row count.
+  // greedy rows: TWO waves per workgroup for full launches (a wave walks every second slot of 64-key tiles; up to four workgroups per CU): 97 rows 28 -> 20 us,
+  // head_dim 128 50 -> 45 us against eight waves, and the CU-time falls with the LDS footprint (round 5: headline 327 -> 330 utt/s, Llama-3.1-8B 164 -> 166).
+  // The merge order of a row is canonical (decode_attn_kernel: slots, decode_merge_*: round 6), so the wave count may follow the launch: up to two
+  // workgroups per CU take EIGHT waves -- a row's tiles in one pass: 10.1 -> 6.8 us at one row, 11.5 -> 7.4 at 8, 15.7 -> 12.4 at 48 (16 s clips); 97 rows: 20.1 vs 22.3
+  static const int ncu = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
+  if (a.rows * a.n_kv_heads <= 2 * ncu) return a.head_dim == 64 ? launch_dec_t<bf16_t, 64, 8>(a, st) : launch_dec_t<bf16_t, 128, 8>(a, st);
   return a.head_dim == 64 ? launch_dec_t<bf16_t, 64, 2>(a, st) : launch_dec_t<bf16_t, 128, 2>(a, st);
 }
 

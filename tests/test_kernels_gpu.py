@@ -902,6 +902,45 @@ def test_decode_attention_fused_rope_append(dtype, hd, H, KV):
     close(vt[:, :, step - 1], vn, 0.0, what="appended v")
 
 
+@pytest.mark.parametrize("hd,H,KV,maxp", [(64, 32, 8, 320), (128, 32, 8, 320), (64, 32, 8, 1216)])
+def test_decode_attention_wave_count_follows_the_rows_not_the_bits(hd, H, KV, maxp):
+    """Greedy bf16 rows: a launch of few rows (rows x kv heads <= the CU count) spreads a row's 64-key tiles over EIGHT waves, a full step over two
+    (csrc/attn.hip: launch_decode_attention).  A row's keys are accumulated per SLOT (tile mod 8) and the slots folded in one canonical order --
+    in registers by two waves, from LDS by eight -- so a row's output has the same bits in both: rows 0 .. 5 of a 70-row launch against a 6-row
+    launch, with the fused RoPE + append, contexts of 2 .. 6 tiles and (max_prefix 1216) of more than eight tiles, where a slot holds two."""
+    from omni_avsr_amd.weights import rope_inv_freq
+    dtype, R, maxt, step = "bf16", 70, 8, 4
+    ld = (H + 2 * KV) * hd
+    g = torch.Generator().manual_seed(11)
+    plen = [int(x) for x in torch.randint(70, maxp - 4, (R,), generator=g)]
+    plen[:6] = [maxp - 7, 65, 129, 313, 200, maxp - 64]
+    qkv, _ = q(rnd(R, ld, seed=1), dtype)
+    kp, _ = q(rnd(R, KV, maxp, hd, seed=2), dtype)
+    vp, _ = q(rnd(R, KV, maxp, hd, seed=3), dtype)
+    inv = rope_inv_freq(hd, 500000.0, None).to(DEV)
+    outs = []
+    for rows in (R, 6):
+        kt, _ = q(rnd(R, KV, maxt, hd, seed=4), dtype)
+        vt, _ = q(rnd(R, KV, maxt, hd, seed=5), dtype)
+        pos = torch.tensor([p_ + step - 1 for p_ in plen[:rows]], dtype=torch.int32, device=DEV)
+        cpos = torch.full((rows,), step - 1, dtype=torch.int32, device=DEV)
+        pl = torch.tensor(plen[:rows], dtype=torch.int32, device=DEV)
+        st = torch.tensor([step], dtype=torch.int32, device=DEV)
+        out = torch.empty(rows, H * hd, dtype=tdt(dtype), device=DEV)
+        d = L.DecodeAttnDesc()
+        d.dtype, d.head_dim, d.n_heads, d.n_kv_heads, d.rows, d.beams, d.max_prefix, d.max_tail = dcode(dtype), hd, H, KV, rows, 1, maxp, maxt
+        d.Q, d.Kp, d.Vp, d.Kt, d.Vt, d.O = qkv.data_ptr(), kp.data_ptr(), vp.data_ptr(), kt.data_ptr(), vt.data_ptr(), out.data_ptr()
+        d.ldq, d.ldo = ld, H * hd
+        d.prefix_len, d.step, d.anc, d.scale = pl.data_ptr(), st.data_ptr(), None, 1.0 / math.sqrt(hd)
+        d.inv_freq, d.pos, d.cpos = inv.data_ptr(), pos.data_ptr(), cpos.data_ptr()
+        L.check(L.load().oavsr_op_decode_attention(C.byref(d), stream()))
+        outs.append((out.clone(), kt[:rows, :, step - 1].clone(), vt[:rows, :, step - 1].clone()))
+    big, small = outs
+    assert torch.isfinite(big[0].float()).all()
+    for what, a, b in zip(("O", "appended k", "appended v"), big, small):
+        assert torch.equal(a[:6], b), f"head_dim {hd}: {what} of a row depends on how many rows share the launch"
+
+
 @pytest.mark.parametrize("beams,fused", [(15, True), (15, False), (6, True), (4, False)])
 def test_decode_attention_beam_groups_of_four(beams, fused):
     """decode_attn_beam4_kernel (bf16, head_dim 64, GQA group 4, beams > 1): four beams of an utterance per workgroup share the prefix K / V
