@@ -738,7 +738,7 @@ __device__ __forceinline__ float decode_merge_weights(float m1, float m2, float&
 __device__ __forceinline__ float decode_merge_val(float x1, float w1, float x2, float w2) { return __builtin_fmaf(x1, w1, x2 * w2); }
 
 template <typename T, int HD, int NW>
-__global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const DecodeAttnArgs p) {
+__global__ __launch_bounds__(NW * 64, NW == 2 ? 2 : 1) void decode_attn_kernel(const DecodeAttnArgs p) {      // (two waves: a full launch -- at least two waves per SIMD)
   constexpr int kDecThreads = NW * 64;
   constexpr int RB = HD * (int)sizeof(T);
   constexpr int NCH = RB / 16;
