@@ -24,6 +24,7 @@ FAMILY = [  # rocprof kernel-name pattern -> bench.py family name
     (r"gemm_dma_kernelIDF16bLi0ELi256ELi128E|gemm_dma_kernel<[^>]*0, 256, 128", "gemm_dma_256x128_bf16"),
     (r"gemm_dma_kernelIDF16bLi0ELi128ELi64E|gemm_dma_kernel<[^>]*0, 128, 64", "decode_gemm_dma_128x64_bf16"),        # (tools/decode_mix.py passes: split-K launches, reduce inside)
     (r"gemm_dma_kernelIDF16bLi0ELi128ELi256E|gemm_dma_kernel<[^>]*0, 128, 256", "decode_gemm_dma_128x256_bf16"),     # lm_head
+    (r"decode_strip_pair_kernel", "decode_gemm_strip16_bf16"),                                                        # ... two workgroups per strip (few long strips)
     (r"decode_strip_kernel", "decode_gemm_strip16_bf16"),                                                             # <= 16 rows: the weight-streaming strips (decode_strip.hip)
     (r"conv3x3_c128_kernel", "conv3x3_c128_bf16"),
     (r"conv3x3_c64_kernel", "conv3x3_c64_bf16"),
