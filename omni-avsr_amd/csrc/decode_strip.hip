@@ -477,8 +477,9 @@ int launch_strip_t(const GemmArgs& a, hipStream_t st) {
   const int ma = a.M <= 8 ? 8 : 16;
   // two workgroups per strip (strip_body: PAIR) where one per strip leaves half the chip idle and the strips are long: >= 128 KiB of weights each
   const int nstrips = ceil_div(a.N, 16);
-  if (a.partial && a.sync && !a.swiglu_pairs && ks >= 2 && ks % 2 == 0 && 2 * nstrips <= ncu && nstrips <= kSyncInts && a.N % 16 == 0 &&
-      (size_t)16 * (a.K + a.K2) * sizeof(T) >= 128 * 1024 && knob("OAVSR_STRIP_PAIRS")) {
+  static const bool pairs_on = knob("OAVSR_STRIP_PAIRS") != 0;
+  if (pairs_on && a.partial && a.sync && !a.swiglu_pairs && ks >= 2 && ks % 2 == 0 && 2 * nstrips <= ncu && nstrips <= kSyncInts && a.N % 16 == 0 &&
+      (size_t)16 * (a.K + a.K2) * sizeof(T) >= 128 * 1024) {
     const int d = ma == 8 ? 10 : 8;
     const size_t smem = (size_t)4 * d * slot_bytes(ma) + (size_t)(ks / 2) * 16 * 16 * 4 + (size_t)a.M * (a.row_sumsq ? a.row_sumsq_tiles : 0) * 4 + 16;
     OAVSR_REQUIRE(smem <= 160 * 1024, "decode strips: %zu bytes of LDS (ksplit %d, pairs)", smem, ks);
