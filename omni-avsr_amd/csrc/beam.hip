@@ -358,6 +358,15 @@ __global__ __launch_bounds__(kStepThreads) void beam_step_kernel(BeamArgs a, int
     a.pos[row] = a.prefix_len[u] + cur_len;      // absolute position of the token just chosen
     a.cpos[row] = cur_len;                       // its tail-cache index
   }
+  if (a.rope_cs) {      // the K rows of an utterance share the position: same expression as the attention kernels' inline path => same bits
+    const float pos = (float)(a.prefix_len[u] + cur_len);
+    for (int i = lane; i < K * a.rope_half; i += kStepThreads) {
+      const int b = i / a.rope_half, d = i - b * a.rope_half;
+      float sn, cs;
+      sincosf(pos * a.inv_freq[d], &sn, &cs);
+      a.rope_cs[(int64_t)(row0 + b) * a.rope_half + d] = make_float2(cs, sn);
+    }
+  }
 }
 
 __global__ void beam_bump_step_kernel(int* step) { *step += 1; }

@@ -300,6 +300,9 @@ struct BeamArgs {
   int* done = nullptr; int* hyp_n = nullptr;            // [B]
   double* hyp_score = nullptr; int* hyp_len = nullptr; int* hyp_tok = nullptr;   // [B][K], [B][K], [B][K][max_new]
   int* out_ids = nullptr; int* out_len = nullptr;
+  // optional: {cos, sin}(pos[row] * inv_freq[d]) of the rows' NEXT step, written with the positions (the decode-attention kernels then read the
+  // table instead of each running sincosf in every layer; the same expression, hence the same bits -- as the greedy update does)
+  float2* rope_cs = nullptr; const float* inv_freq = nullptr; int rope_half = 0;
 };
 // need_exact: rows ints of scratch (nullptr = always run the exact radix-select kernel)
 int launch_beam_topk(const float* logits, int64_t ld, int rows, int V, int K, const float* beam_scores, float* cand_val, int* cand_tok,

@@ -1228,6 +1228,7 @@ static int decode_beam(const oavsr_model* m, oavsr_workspace* ws, int task, int 
   BeamArgs a;
   a.B = B; a.K = K; a.V = c.llm_vocab; a.max_new = max_new; a.eos = c.id_eos; a.pad = c.id_pad;
   a.step = ws->gs.step; a.beam_scores = ws->beam_scores; a.next_tok = ws->gs.tok; a.pos = ws->gs.pos; a.cpos = ws->gs.cpos;
+  a.rope_cs = ws->gs.rope_cs; a.inv_freq = m->inv_freq; a.rope_half = c.llm_head_dim / 2;
   a.prefix_len = ws->prefix_len; a.cand_val = ws->cand_val; a.cand_tok = ws->cand_tok; a.done = ws->gs.finished; a.hyp_n = ws->hyp_n;
   a.hyp_score = ws->hyp_score; a.hyp_len = ws->hyp_len; a.hyp_tok = ws->hyp_tok; a.out_ids = out_ids; a.out_len = out_len;
   OAVSR_CHECK_HIP(hipMemsetAsync(ws->gs.step, 0, sizeof(int), st));
@@ -1242,7 +1243,7 @@ static int decode_beam(const oavsr_model* m, oavsr_workspace* ws, int task, int 
   // one step reads ping-pong side `cur` of the sequence / ancestry tables and writes the other one
   auto one_step = [&](int cur) -> int {
     OAVSR_TRY(launch_embed(m->dtype, m->embed, c.llm_hidden, ws->gs.tok, ws->lx, c.llm_hidden, R, c.llm_hidden, st));
-    OAVSR_TRY(llm_decode_layers(m, ws, task, R, K, maxS + max_new, ws->gs.pos, ws->gs.cpos, anc[cur], ws->gs.step, st));
+    OAVSR_TRY(llm_decode_layers(m, ws, task, R, K, maxS + max_new, ws->gs.pos, ws->gs.cpos, anc[cur], ws->gs.step, st, ws->gs.rope_cs));
     OAVSR_TRY(lm_head_rows(m, ws, R, ws->logits, st));
     ProfScope ps("beam_search", 0, (double)R * c.llm_vocab * 16, st);
     OAVSR_TRY(launch_beam_topk(ws->logits, vstride(c), R, c.llm_vocab, K, ws->beam_scores, ws->cand_val, ws->cand_tok, ws->topk_flag, st));
